@@ -1,0 +1,290 @@
+"""ctypes binding of the C-ABI in include/cilqr.h (cilqr_amd/lib/libcilqr_hip.so).
+
+Host-side mirror of the reference's ``planning::IlqrOptimizer`` (algorithm/ilqr/
+ilqr_optimizer.h:29-52) for a batch of problems.  There is no CPU path: if the HIP library is
+missing, or no MI355X is visible, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcilqr_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "cilqr.h")
+
+OK = 0
+ERR_NULL, ERR_CONSTRAINTS, ERR_KNOTS, ERR_CAPACITY, ERR_DEVICE, ERR_ARG, ERR_STATE = -1, -2, -3, -4, -5, -6, -7
+MEM_HOST, MEM_DEVICE = 0, 1
+ST_RUNNING, ST_CONVERGED_ABS, ST_CONVERGED_REL, ST_GNORM, ST_UNSOLVED, ST_MAX_ITER = range(6)
+
+T_GOALS, T_CORRIDOR, T_LANES, T_X, T_U, T_XCAND, T_UCAND, T_A, T_B, T_LX, T_LU, T_LXX, T_LUU, \
+    T_KFB, T_KFF, T_DV, T_GNORM = range(17)
+
+# dense fp64 scalars moved per problem-step / per problem by the backward pass
+DENSE_DOUBLES_PER_STEP = 110
+DENSE_DOUBLES_TERMINAL = 44
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("n_steps", C.c_int32), ("num_of_disc", C.c_int32), ("max_iter", C.c_int32),
+        ("reserved0", C.c_int32), ("dt", C.c_double), ("safe_margin", C.c_double),
+        ("w_jerk", C.c_double), ("w_delta_rate", C.c_double), ("w_x", C.c_double),
+        ("w_y", C.c_double), ("w_theta", C.c_double), ("w_v", C.c_double), ("w_a", C.c_double),
+        ("w_delta", C.c_double), ("abs_cost_tol", C.c_double), ("rel_cost_tol", C.c_double),
+        ("front_hang", C.c_double), ("wheel_base", C.c_double), ("rear_hang", C.c_double),
+        ("width", C.c_double), ("max_velocity", C.c_double), ("min_acceleration", C.c_double),
+        ("max_acceleration", C.c_double), ("jerk_min", C.c_double), ("jerk_max", C.c_double),
+        ("delta_min", C.c_double), ("delta_max", C.c_double), ("delta_rate_min", C.c_double),
+        ("delta_rate_max", C.c_double), ("barrier_t", C.c_double), ("barrier_eps", C.c_double),
+    ]
+
+
+class ProblemBatch(C.Structure):
+    _fields_ = [
+        ("batch", C.c_int32), ("n_knots", C.c_int32), ("cmax", C.c_int32), ("memory", C.c_int32),
+        ("start", C.c_void_p), ("coarse", C.c_void_p), ("corridor", C.c_void_p),
+        ("corridor_count", C.c_void_p), ("n_left", C.c_int32), ("n_right", C.c_int32),
+        ("left_lane", C.c_void_p), ("right_lane", C.c_void_p),
+    ]
+
+
+class SolutionBatch(C.Structure):
+    _fields_ = [
+        ("memory", C.c_int32), ("max_iter_trajs", C.c_int32), ("traj", C.c_void_p),
+        ("cost_hist", C.c_void_p), ("n_cost", C.c_void_p), ("status", C.c_void_p),
+        ("n_iter", C.c_void_p), ("iter_trajs", C.c_void_p), ("n_iter_trajs", C.c_void_p),
+    ]
+
+
+class Profile(C.Structure):
+    _fields_ = [
+        ("iterations", C.c_int32), ("backward_launches", C.c_int32), ("backward_ms", C.c_double),
+        ("quadratize_ms", C.c_double), ("linesearch_ms", C.c_double), ("other_ms", C.c_double),
+        ("total_ms", C.c_double), ("backward_problem_steps", C.c_int64),
+    ]
+
+
+EXPORTS = [
+    "cilqr_abi_version", "cilqr_default_config", "cilqr_create", "cilqr_destroy", "cilqr_set_stream",
+    "cilqr_set_profiling", "cilqr_get_profile", "cilqr_device_bytes", "cilqr_solve_batch",
+    "cilqr_stage_load", "cilqr_stage_init_guess", "cilqr_stage_set_trajectory",
+    "cilqr_stage_total_cost", "cilqr_stage_quadratize", "cilqr_stage_backward", "cilqr_stage_forward",
+    "cilqr_stage_read", "cilqr_open_loop_rollout", "cilqr_error_string",
+]
+
+_LIB = None
+
+
+class CilqrError(RuntimeError):
+    def __init__(self, code, what=""):
+        self.code = code
+        msg = lib().cilqr_error_string(code).decode() if _LIB is not None else str(code)
+        super().__init__(f"cilqr error {code} ({msg}) {what}")
+
+
+def lib():
+    """Load the HIP library; raises if it was not built (no fallback exists)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run __graft_entry__.build() "
+                               "(make -C cilqr_amd/csrc); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.cilqr_error_string.restype = C.c_char_p
+        L.cilqr_device_bytes.restype = C.c_int64
+        L.cilqr_device_bytes.argtypes = [C.c_void_p]
+        L.cilqr_create.argtypes = [C.POINTER(Config), C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                   C.POINTER(C.c_void_p)]
+        L.cilqr_destroy.argtypes = [C.c_void_p]
+        L.cilqr_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        L.cilqr_set_profiling.argtypes = [C.c_void_p, C.c_int32]
+        L.cilqr_get_profile.argtypes = [C.c_void_p, C.POINTER(Profile)]
+        L.cilqr_solve_batch.argtypes = [C.c_void_p, C.POINTER(ProblemBatch), C.POINTER(SolutionBatch)]
+        L.cilqr_stage_load.argtypes = [C.c_void_p, C.POINTER(ProblemBatch)]
+        L.cilqr_stage_init_guess.argtypes = [C.c_void_p]
+        L.cilqr_stage_set_trajectory.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+        L.cilqr_stage_total_cost.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        L.cilqr_stage_quadratize.argtypes = [C.c_void_p]
+        L.cilqr_stage_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        L.cilqr_stage_forward.argtypes = [C.c_void_p, C.c_double]
+        L.cilqr_stage_read.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
+        L.cilqr_open_loop_rollout.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_int32]
+        _LIB = L
+    return _LIB
+
+
+def default_config(n_steps: int = 50, **over) -> Config:
+    c = Config()
+    rc = lib().cilqr_default_config(C.byref(c), C.c_int32(n_steps))
+    if rc != OK:
+        raise CilqrError(rc)
+    for k, v in over.items():
+        setattr(c, k, v)
+    return c
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+class BatchIlqrOptimizer:
+    """Batched drop-in of IlqrOptimizer: ``plan`` = Plan + cost() for B problems on one GPU."""
+
+    def __init__(self, cfg: Config | None = None, n_steps: int = 50, device: int = 0,
+                 batch_capacity: int = 1, cmax: int = 16, max_lane_segments: int = 64):
+        self.cfg = cfg or default_config(n_steps)
+        self.N = self.cfg.n_steps
+        self.K = self.N + 1
+        self.cmax = cmax
+        self.capacity = batch_capacity
+        self.L = lib()
+        self.h = C.c_void_p()
+        rc = self.L.cilqr_create(C.byref(self.cfg), device, batch_capacity, cmax, max_lane_segments,
+                                 C.byref(self.h))
+        if rc != OK:
+            self.h = C.c_void_p()
+            raise CilqrError(rc, "in cilqr_create")
+        self.B = 0
+        self.nl = self.nr = 0
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            self.L.cilqr_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- raw-pointer interface (device or host memory) ----
+    def make_problem(self, B, start, coarse, corridor, ccount, cmax, left, right, n_left, n_right,
+                     memory) -> ProblemBatch:
+        return ProblemBatch(B, self.K, cmax, memory, start, coarse, corridor, ccount, n_left, n_right,
+                            left, right)
+
+    def set_stream(self, stream_ptr):
+        rc = self.L.cilqr_set_stream(self.h, C.c_void_p(stream_ptr))
+        if rc != OK:
+            raise CilqrError(rc)
+
+    def set_profiling(self, on: bool):
+        self.L.cilqr_set_profiling(self.h, 1 if on else 0)
+
+    def profile(self) -> Profile:
+        p = Profile()
+        self.L.cilqr_get_profile(self.h, C.byref(p))
+        return p
+
+    def device_bytes(self) -> int:
+        return int(self.L.cilqr_device_bytes(self.h))
+
+    def solve_raw(self, prob: ProblemBatch, sol: SolutionBatch) -> int:
+        return self.L.cilqr_solve_batch(self.h, C.byref(prob), C.byref(sol))
+
+    # ---- numpy (host memory) interface ----
+    def _host_problem(self, scene: dict):
+        a = dict(start=_f64(scene["start"]), coarse=_f64(scene["coarse"]),
+                 corridor=_f64(scene["corridor"]),
+                 ccount=np.ascontiguousarray(scene["ccount"], dtype=np.int32),
+                 left=_f64(scene["left"]), right=_f64(scene["right"]))
+        B = a["coarse"].shape[0]
+        K = a["coarse"].shape[1] if a["coarse"].ndim == 3 else 0
+        cmax = a["corridor"].shape[2] if a["corridor"].ndim == 4 else 0
+        prob = ProblemBatch(B, K, cmax, MEM_HOST, _ptr(a["start"]), _ptr(a["coarse"]),
+                            _ptr(a["corridor"]) if a["corridor"].size else None,
+                            _ptr(a["ccount"]) if a["ccount"].size else None,
+                            a["left"].shape[0], a["right"].shape[0],
+                            _ptr(a["left"]) if a["left"].size else None,
+                            _ptr(a["right"]) if a["right"].size else None)
+        return prob, a
+
+    def plan(self, scene: dict, max_iter_trajs: int = 0, check: bool = True):
+        """scene: dict from cilqr_amd.scenario.generate (problem-major numpy arrays)."""
+        prob, keep = self._host_problem(scene)
+        B, K, M = prob.batch, self.K, self.cfg.max_iter
+        traj = np.zeros((B, K, 10))
+        hist = np.zeros((B, M + 1, 5))
+        n_cost = np.zeros(B, np.int32)
+        status = np.zeros(B, np.int32)
+        n_iter = np.zeros(B, np.int32)
+        it = np.zeros((B, max_iter_trajs, K, 10)) if max_iter_trajs else None
+        n_it = np.zeros(B, np.int32) if max_iter_trajs else None
+        sol = SolutionBatch(MEM_HOST, max_iter_trajs, _ptr(traj), _ptr(hist), _ptr(n_cost), _ptr(status),
+                            _ptr(n_iter), _ptr(it), _ptr(n_it))
+        rc = self.solve_raw(prob, sol)
+        del keep
+        if rc != OK:
+            if check:
+                raise CilqrError(rc, "in cilqr_solve_batch")
+            return dict(rc=rc)
+        self.B = B
+        # rows >= n_cost are unspecified by the ABI: zero them for convenience
+        mask = np.arange(M + 1)[None, :] >= n_cost[:, None]
+        hist[mask] = 0.0
+        return dict(rc=rc, traj=traj, cost_hist=hist, n_cost=n_cost, status=status, n_iter=n_iter,
+                    iter_trajs=it, n_iter_trajs=n_it)
+
+    # ---- stages ----
+    def _chk(self, rc, what):
+        if rc != OK:
+            raise CilqrError(rc, what)
+
+    def stage_load(self, scene: dict):
+        prob, keep = self._host_problem(scene)
+        self._chk(self.L.cilqr_stage_load(self.h, C.byref(prob)), "stage_load")
+        self.B = prob.batch
+        self.nl, self.nr = prob.n_left, prob.n_right
+
+    def stage_init_guess(self):
+        self._chk(self.L.cilqr_stage_init_guess(self.h), "stage_init_guess")
+
+    def stage_set_trajectory(self, X, U):
+        X, U = _f64(X), _f64(U)
+        self._chk(self.L.cilqr_stage_set_trajectory(self.h, _ptr(X), _ptr(U), MEM_HOST), "set_trajectory")
+
+    def stage_total_cost(self):
+        c = np.zeros((self.B, 5))
+        self._chk(self.L.cilqr_stage_total_cost(self.h, _ptr(c), MEM_HOST), "total_cost")
+        return c
+
+    def stage_quadratize(self):
+        self._chk(self.L.cilqr_stage_quadratize(self.h), "quadratize")
+
+    def stage_backward(self, lam=None):
+        if lam is not None:
+            lam = _f64(np.broadcast_to(lam, (self.B,)))
+        self._chk(self.L.cilqr_stage_backward(self.h, _ptr(lam), MEM_HOST), "backward")
+
+    def stage_forward(self, alpha: float):
+        self._chk(self.L.cilqr_stage_forward(self.h, C.c_double(alpha)), "forward")
+
+    def read(self, tensor: int):
+        B, N, K = self.B, self.N, self.K
+        shape = {
+            T_GOALS: (B, K, 6), T_CORRIDOR: (B, K, self.cmax, 3), T_LANES: (self.nl + self.nr, 3),
+            T_X: (B, K, 6), T_U: (B, N, 2), T_XCAND: (B, K, 6), T_UCAND: (B, N, 2),
+            T_A: (B, N, 6, 6), T_B: (B, N, 6, 2), T_LX: (B, K, 6), T_LU: (B, N, 2),
+            T_LXX: (B, K, 6, 6), T_LUU: (B, N, 2, 2), T_KFB: (B, N, 2, 6), T_KFF: (B, N, 2),
+            T_DV: (B, 2), T_GNORM: (B,),
+        }[tensor]
+        out = np.zeros(shape)
+        self._chk(self.L.cilqr_stage_read(self.h, tensor, _ptr(out), MEM_HOST), f"read({tensor})")
+        return out
+
+    def open_loop_rollout(self, x0, U):
+        x0, U = _f64(x0), _f64(U)
+        B = x0.shape[0]
+        X = np.zeros((B, self.K, 6))
+        self._chk(self.L.cilqr_open_loop_rollout(self.h, B, _ptr(x0), _ptr(U), _ptr(X), MEM_HOST), "rollout")
+        return X

@@ -1,0 +1,204 @@
+// Device-side model functions: angle wrap, relaxed log barrier, kinematic-bicycle dynamics and
+// its Jacobian, nearest lane segment.  All IEEE fp64; built with -ffp-contract=off so every
+// product and sum is rounded once, as on the reference's CPU build.
+//
+// Behaviour follows (not copied from) the reference:
+//   NormalizeAngle            algorithm/math/math_utils.cpp:53-59
+//   RelaxBarrierFunction      algorithm/ilqr/barrier_function.h:82-147
+//   VehicleModel::Dynamics    algorithm/ilqr/vehicle_model.cc:88-138
+//   VehicleModel::DynamicsJacbian  vehicle_model.cc:21-86
+//   LineSegment2d::DistanceTo algorithm/math/line_segment2d.cpp:61-75
+//   FindNeastLaneSegment      algorithm/ilqr/ilqr_optimizer.cc:605-618
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <math.h>
+
+#include "state.hpp"
+
+namespace cilqr {
+
+#define CILQR_DEV __device__ __forceinline__
+
+constexpr double kPi = 3.14159265358979323846;
+constexpr double kTwoPi = 2.0 * kPi;
+constexpr double kMathEps = 1e-10;  // algorithm/math/vec2d.h:33
+
+// fmod(a + pi, 2 pi) with the IEEE-exact fast paths (fmod is always exact, so the short
+// branches return bit-identical values to the library call).
+CILQR_DEV double normalize_angle(double angle) {
+  const double t = angle + kPi;
+  double r;
+  if (t >= 0.0 && t < kTwoPi) {
+    r = t;
+  } else if (t >= kTwoPi && t < 2.0 * kTwoPi) {
+    r = t - kTwoPi;  // exact (Sterbenz)
+  } else if (t < 0.0 && t > -kTwoPi) {
+    r = t;
+  } else {
+    r = fmod(t, kTwoPi);
+  }
+  if (r < 0.0) r += kTwoPi;
+  return r - kPi;
+}
+
+// ---- relaxed log barrier, barrier_function.h:104-140 ----
+CILQR_DEV double bar_value(const Params& p, double g) {
+  if (g < -p.bar_eps) return -p.bar_r * log(-g);
+  const double q = (-g - 2.0 * p.bar_eps) / p.bar_eps;
+  return 0.5 * p.bar_r * (q * q - 1) - p.bar_rlogeps;
+}
+// coefficient multiplying the constraint gradient in Jacbian()
+CILQR_DEV double bar_jcoef(const Params& p, double g) {
+  if (g < -p.bar_eps) return -p.bar_r / g;
+  return p.bar_r * (g + 2.0 * p.bar_eps) / p.bar_eps / p.bar_eps;
+}
+// Hessian() = (c1 dg_i) dg_j - c2 ddg_ij; the relaxed branch reuses the gradient coefficient
+// and drops ddg (reference quirk, kept).
+CILQR_DEV void bar_hcoef(const Params& p, double g, double& c1, double& c2, bool& log_branch) {
+  if (g < -p.bar_eps) {
+    c1 = p.bar_r / g / g;
+    c2 = p.bar_r / g;
+    log_branch = true;
+  } else {
+    c1 = p.bar_r * (g + 2.0 * p.bar_eps) / p.bar_eps / p.bar_eps;
+    c2 = 0.0;
+    log_branch = false;
+  }
+}
+
+// ---- continuous dynamics f(x,u), vehicle_model.cc:123-138 ----
+CILQR_DEV void dyn_continuous(const Params& p, const double* s, const double* u, double* r) {
+  const double theta = normalize_angle(s[2]);
+  const double v = s[3];
+  const double delta = normalize_angle(s[5]);
+  double sn, cs;
+  sincos(theta, &sn, &cs);
+  r[0] = v * cs;
+  r[1] = v * sn;
+  r[2] = v * tan(delta) / p.wheel_base;
+  r[3] = s[4];
+  r[4] = u[0];
+  r[5] = u[1];
+}
+
+// ---- RK2 midpoint step, vehicle_model.cc:88-121 ----
+CILQR_DEV void dynamics(const Params& p, const double* s, const double* u, double* out) {
+  double k1[6], mid[6], k2[6];
+  dyn_continuous(p, s, u, k1);
+  const double h = 0.5 * p.dt;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) mid[i] = s[i] + h * k1[i];
+  dyn_continuous(p, mid, u, k2);
+  double o[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) o[i] = s[i] + p.dt * k2[i];
+  o[2] = normalize_angle(o[2]);
+  o[5] = normalize_angle(o[5]);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) out[i] = o[i];
+}
+
+// ---- analytic Jacobian of the midpoint map, vehicle_model.cc:21-86 ----
+// Only the state-dependent entries are produced; the rest of A/B is constant:
+//   A = I, A(3,4) = dt;  B(3,0) = dt^2/2, B(4,0) = dt, B(5,1) = dt.
+struct DynJac {
+  double a02, a03, a04, a05;
+  double a12, a13, a14, a15;
+  double a23, a24, a25;
+  double b21;
+};
+CILQR_DEV void dynamics_jacobian(const Params& p, const double* s, const double* u, DynJac& J) {
+  const double L = p.wheel_base, dt = p.dt;
+  const double v = s[3];
+  const double theta = normalize_angle(s[2]);
+  const double delta = normalize_angle(s[5]);
+  const double a = s[4];
+  const double delta_rate = u[1];
+  const double tan_delta = tan(delta);
+  const double theta_mid = theta + 0.5 * dt * v * tan_delta / L;
+  const double tan_dr = tan(delta + 0.5 * dt * delta_rate);
+  double sin_m, cos_m;
+  sincos(theta_mid, &sin_m, &cos_m);
+  const double td2 = tan_delta * tan_delta;
+  const double tdr2 = tan_dr * tan_dr;
+  const double v_tdr = v * (tdr2 + 1);
+  const double vm = 0.5 * a * dt + v;
+  J.a02 = -dt * vm * sin_m;
+  J.a03 = dt * cos_m - 0.5 * dt * dt * vm * sin_m * tan_delta / L;
+  J.a04 = 0.5 * dt * dt * cos_m;
+  J.a05 = -0.5 * dt * dt * v * vm * (td2 + 1) * sin_m / L;
+  J.a12 = dt * vm * cos_m;
+  J.a13 = dt * sin_m + 0.5 * dt * dt * vm * cos_m * tan_delta / L;
+  J.a14 = 0.5 * dt * dt * sin_m;
+  J.a15 = 0.5 * dt * dt * v * vm * (td2 + 1) * cos_m / L;
+  J.a23 = dt * tan_dr / L;
+  J.a24 = 0.5 * dt * dt * tan_dr / L;
+  J.a25 = dt * v_tdr / L;
+  J.b21 = 0.5 * dt * dt * v * (tdr2 + 1) / L;
+}
+
+// ---- nearest lane segment (first minimum wins), cc:605-618 + line_segment2d.cpp:61-75 ----
+// `tab` rows: a b c | sx sy | ux uy | len | ex ey.  The table pointer and loop index are
+// wave-uniform, so the rows come in through scalar loads.  Squared distances are compared
+// (sqrt is monotone; exact ties -- the shared end point of two segments -- stay ties).
+CILQR_DEV int nearest_segment(const double* __restrict__ tab, int n, double px, double py) {
+  double best = DBL_MAX;
+  int bi = 0;
+  for (int s = 0; s < n; ++s) {
+    const double* __restrict__ r = tab + s * kLaneFields;
+    const double sx = r[3], sy = r[4], ux = r[5], uy = r[6], len = r[7];
+    const double x0 = px - sx, y0 = py - sy;
+    double d2;
+    if (len <= kMathEps) {
+      d2 = x0 * x0 + y0 * y0;
+    } else {
+      const double proj = x0 * ux + y0 * uy;
+      if (proj <= 0.0) {
+        d2 = x0 * x0 + y0 * y0;
+      } else if (proj >= len) {
+        const double x1 = px - r[8], y1 = py - r[9];
+        d2 = x1 * x1 + y1 * y1;
+      } else {
+        const double c = x0 * uy - y0 * ux;
+        d2 = c * c;
+      }
+    }
+    if (d2 < best) {
+      best = d2;
+      bi = s;
+    }
+  }
+  return bi;
+}
+
+// small helpers for the batch-fastest pair layout
+CILQR_DEV double2 ld2(const double2* __restrict__ base, int row, int Bcap, int slot) {
+  return base[(size_t)row * Bcap + slot];
+}
+CILQR_DEV void st2(double2* __restrict__ base, int row, int Bcap, int slot, double a, double b) {
+  base[(size_t)row * Bcap + slot] = make_double2(a, b);
+}
+
+// current-iterate state/control of a slot
+CILQR_DEV void load_x(const DeviceState& s, int buf, int i, int slot, double* x) {
+  const double2* b = s.X + ((size_t)buf * s.p.K + i) * 3 * s.Bcap;
+  const double2 p0 = b[slot], p1 = b[(size_t)s.Bcap + slot], p2 = b[(size_t)2 * s.Bcap + slot];
+  x[0] = p0.x; x[1] = p0.y; x[2] = p1.x; x[3] = p1.y; x[4] = p2.x; x[5] = p2.y;
+}
+CILQR_DEV void store_x(const DeviceState& s, int buf, int i, int slot, const double* x) {
+  double2* b = s.X + ((size_t)buf * s.p.K + i) * 3 * s.Bcap;
+  b[slot] = make_double2(x[0], x[1]);
+  b[(size_t)s.Bcap + slot] = make_double2(x[2], x[3]);
+  b[(size_t)2 * s.Bcap + slot] = make_double2(x[4], x[5]);
+}
+CILQR_DEV void load_u(const DeviceState& s, int buf, int i, int slot, double* u) {
+  const double2 q = s.U[((size_t)buf * s.p.N + i) * s.Bcap + slot];
+  u[0] = q.x; u[1] = q.y;
+}
+CILQR_DEV void store_u(const DeviceState& s, int buf, int i, int slot, const double* u) {
+  s.U[((size_t)buf * s.p.N + i) * s.Bcap + slot] = make_double2(u[0], u[1]);
+}
+
+}  // namespace cilqr

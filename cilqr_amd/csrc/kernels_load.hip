@@ -1,0 +1,517 @@
+// Load / prepare / init-guess / export kernels.
+//
+// Reference behaviour implemented here (algorithm/ilqr/ilqr_optimizer.cc):
+//   TransformGoals cc:141-152, ShrinkConstraints cc:438-473, NormalizeHalfPlane cc:475-495,
+//   iqr (init guess) cc:793-842, TransformToTrajectory cc:771-791,
+//   OpenLoopRollout algorithm/slover/ilqr.h:363-370.
+#include "dev_model.hpp"
+
+namespace cilqr {
+
+// ---------------------------------------------------------------------------------------------
+// Corridor: problem-major [B][K][cmax_in][3] -> shrunk, normalised, batch-fastest
+// [K][cmax][3][Bcap].  One block = 64 problems x one knot, transposed through LDS so both the
+// HBM reads (runs of cmax_in*3 doubles) and the writes (64 consecutive slots) are contiguous.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_load_corridor(DeviceState s, int B, ProblemView in) {
+  extern __shared__ double tile[];  // [64][row + 1]
+  const int i = blockIdx.y;
+  const int b0 = blockIdx.x * 64;
+  const int row = in.cmax_in * 3;
+  const int ld = row + 1;
+  const int nb = min(64, B - b0);
+  for (int e = threadIdx.x; e < nb * row; e += blockDim.x) {
+    const int pb = e / row, off = e - pb * row;
+    tile[pb * ld + off] = in.corridor[((size_t)(b0 + pb) * s.p.K + i) * row + off];
+  }
+  __syncthreads();
+  const int pb = threadIdx.x & 63;
+  if (pb >= nb) return;
+  const int slot = b0 + pb;
+  const int cnt = min(in.ccount[(size_t)slot * s.p.K + i], s.cmax);
+  if ((threadIdx.x >> 6) == 0) s.ccnt[(size_t)i * s.Bcap + slot] = cnt;
+  for (int c = threadIdx.x >> 6; c < cnt; c += 4) {
+    double a = tile[pb * ld + c * 3 + 0];
+    double b = tile[pb * ld + c * 3 + 1];
+    double cc = tile[pb * ld + c * 3 + 2];
+    cc = cc - s.p.shrink_corridor * (a * a + b * b) / hypot(a, b);   // cc:448
+    const double nrm = hypot(hypot(a, b), cc);                       // cc:479
+    double* o = s.cor + ((size_t)(i * s.cmax + c) * 3) * s.Bcap + slot;
+    o[0] = a / nrm;
+    o[(size_t)s.Bcap] = b / nrm;
+    o[(size_t)2 * s.Bcap] = cc / nrm;
+  }
+}
+
+// goals_[i] from the coarse trajectory, goals_[0] from the start state (cc:141-152), and the
+// per-problem solver state of Optimize() (cc:180-186).
+__global__ __launch_bounds__(256) void k_load_goals(DeviceState s, int B, ProblemView in) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int K = s.p.K;
+  if (t >= B * K) return;
+  const int slot = t / K, i = t - slot * K;
+  double g[6];
+  if (i == 0) {
+    const double* st = in.start + (size_t)slot * 4;
+    g[0] = st[0]; g[1] = st[1]; g[2] = st[2]; g[3] = st[3]; g[4] = 0.0; g[5] = 0.0;
+    s.lambda[slot] = 1.0;
+    s.dlambda[slot] = 1.0;
+    s.cost_old[slot] = 0.0;
+    s.dcost[slot] = 0.0;
+    s.iter[slot] = 0;
+    s.status[slot] = 0;
+    s.n_cost[slot] = 0;
+    s.upd[slot] = 1;
+    s.acc_idx[slot] = -1;
+    s.cur[slot] = 0;
+    s.n_iter_trajs[slot] = 0;
+    s.emit[slot] = 0;
+    s.act[slot] = slot;
+  } else {
+    const double* c = in.coarse + ((size_t)slot * K + i) * 6;
+#pragma unroll
+    for (int e = 0; e < 6; ++e) g[e] = c[e];
+  }
+  double2* o = s.goals + (size_t)i * 3 * s.Bcap + slot;
+  o[0] = make_double2(g[0], g[1]);
+  o[(size_t)s.Bcap] = make_double2(g[2], g[3]);
+  o[(size_t)2 * s.Bcap] = make_double2(g[4], g[5]);
+}
+
+// Lane rows (a,b,c,sx,sy,ex,ey) -> shrunk/normalised plane + segment frame
+// (cc:458-472, 484-494; LineSegment2d ctor line_segment2d.cpp:38-48).
+__global__ void k_load_lanes(DeviceState s, const double* __restrict__ raw) {
+  const int t = threadIdx.x;
+  if (t >= s.nl + s.nr) return;
+  const double* r = raw + t * 7;
+  double a = r[0], b = r[1], c = r[2];
+  c = c - s.p.shrink_lane * (a * a + b * b) / hypot(a, b);
+  const double nrm = hypot(hypot(a, b), c);
+  const double sx = r[3], sy = r[4], ex = r[5], ey = r[6];
+  const double dx = ex - sx, dy = ey - sy;
+  const double len = hypot(dx, dy);
+  double* o = s.lanes + t * kLaneFields;
+  o[0] = a / nrm; o[1] = b / nrm; o[2] = c / nrm;
+  o[3] = sx; o[4] = sy;
+  o[5] = (len <= kMathEps) ? 0.0 : dx / len;
+  o[6] = (len <= kMathEps) ? 0.0 : dy / len;
+  o[7] = len;
+  o[8] = ex; o[9] = ey;
+}
+
+void launch_load(const DeviceState& s, int B, const ProblemView& in, const double* lanes_raw,
+                 hipStream_t st) {
+  const int ld = in.cmax_in * 3 + 1;
+  dim3 g((B + 63) / 64, s.p.K);
+  hipLaunchKernelGGL(k_load_corridor, g, dim3(256), 64 * ld * sizeof(double), st, s, B, in);
+  const int n = B * s.p.K;
+  hipLaunchKernelGGL(k_load_goals, dim3((n + 255) / 256), dim3(256), 0, st, s, B, in);
+  hipLaunchKernelGGL(k_load_lanes, dim3(1), dim3(512), 0, st, s, lanes_raw);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Init guess: time-varying LQR along the goals + clamped closed-loop rollout (iqr, cc:793-842).
+// One lane per problem: backward sweep stores K_i in the gains arena, forward sweep rolls out.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_init_guess(DeviceState s, int B) {
+  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= B) return;
+  const Params& p = s.p;
+  const int N = p.N, Bc = s.Bcap;
+  const double Qd[6] = {0.001, 0.001, 0.001, 0.001, 0.01, 0.005};  // cc:801-807
+  const double R0 = 0.2, R1 = 0.05;                                // cc:811-813 (off-diagonals: 0)
+  double P[36];
+#pragma unroll
+  for (int e = 0; e < 36; ++e) P[e] = 0.0;
+#pragma unroll
+  for (int e = 0; e < 6; ++e) P[e * 7] = Qd[e];
+  const double dt = p.dt;
+  const double zero_u[2] = {0.0, 0.0};
+  for (int i = N - 1; i >= 0; --i) {
+    double g[6];
+    {
+      const double2* gp = s.goals + (size_t)i * 3 * Bc + slot;
+      const double2 g0 = gp[0], g1 = gp[(size_t)Bc], g2 = gp[(size_t)2 * Bc];
+      g[0] = g0.x; g[1] = g0.y; g[2] = g1.x; g[3] = g1.y; g[4] = g2.x; g[5] = g2.y;
+    }
+    DynJac J;
+    dynamics_jacobian(p, g, zero_u, J);
+    double A[36], Bm[12];
+#pragma unroll
+    for (int e = 0; e < 36; ++e) A[e] = 0.0;
+#pragma unroll
+    for (int e = 0; e < 12; ++e) Bm[e] = 0.0;
+#pragma unroll
+    for (int e = 0; e < 6; ++e) A[e * 7] = 1.0;
+    A[2] = J.a02; A[3] = J.a03; A[4] = J.a04; A[5] = J.a05;
+    A[8] = J.a12; A[9] = J.a13; A[10] = J.a14; A[11] = J.a15;
+    A[15] = J.a23; A[16] = J.a24; A[17] = J.a25;
+    A[22] = dt;
+    Bm[5] = J.b21; Bm[6] = 0.5 * dt * dt; Bm[8] = dt; Bm[11] = dt;
+    // BtP = B^T P (2x6), sequential over the inner index
+    double BtP[12];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        double acc = Bm[0 * 2 + r] * P[0 * 6 + c];
+#pragma unroll
+        for (int k = 1; k < 6; ++k) acc += Bm[k * 2 + r] * P[k * 6 + c];
+        BtP[r * 6 + c] = acc;
+      }
+    double M[4], BtPA[12];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        double acc = BtP[r * 6 + 0] * Bm[0 * 2 + c];
+#pragma unroll
+        for (int k = 1; k < 6; ++k) acc += BtP[r * 6 + k] * Bm[k * 2 + c];
+        M[r * 2 + c] = acc;
+      }
+    M[0] = R0 + M[0]; M[1] = 0.0 + M[1]; M[2] = 0.0 + M[2]; M[3] = R1 + M[3];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        double acc = BtP[r * 6 + 0] * A[0 * 6 + c];
+#pragma unroll
+        for (int k = 1; k < 6; ++k) acc += BtP[r * 6 + k] * A[k * 6 + c];
+        BtPA[r * 6 + c] = acc;
+      }
+    const double invdet = 1.0 / (M[0] * M[3] - M[2] * M[1]);
+    const double inv[4] = {M[3] * invdet, -M[1] * invdet, -M[2] * invdet, M[0] * invdet};
+    double Kg[12];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) Kg[r * 6 + c] = inv[r * 2 + 0] * BtPA[c] + inv[r * 2 + 1] * BtPA[6 + c];
+    {
+      double2* gp = s.gains + (size_t)i * kGainPairs * Bc + slot;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) gp[(size_t)q * Bc] = make_double2(Kg[2 * q], Kg[2 * q + 1]);
+    }
+    // P = Q + (A^T P)(A - B K)     cc:823
+    double AmBK[36];
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = 0; c < 6; ++c)
+        AmBK[r * 6 + c] = A[r * 6 + c] - (Bm[r * 2 + 0] * Kg[c] + Bm[r * 2 + 1] * Kg[6 + c]);
+    double AtP[36];
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        double acc = A[0 * 6 + r] * P[0 * 6 + c];
+#pragma unroll
+        for (int k = 1; k < 6; ++k) acc += A[k * 6 + r] * P[k * 6 + c];
+        AtP[r * 6 + c] = acc;
+      }
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        double acc = AtP[r * 6 + 0] * AmBK[0 * 6 + c];
+#pragma unroll
+        for (int k = 1; k < 6; ++k) acc += AtP[r * 6 + k] * AmBK[k * 6 + c];
+        P[r * 6 + c] = ((r == c) ? Qd[r] : 0.0) + acc;
+      }
+  }
+  // closed-loop rollout with clamped controls   cc:830-841
+  double x[6];
+  {
+    const double2* gp = s.goals + slot;
+    const double2 g0 = gp[0], g1 = gp[(size_t)Bc], g2 = gp[(size_t)2 * Bc];
+    x[0] = g0.x; x[1] = g0.y; x[2] = g1.x; x[3] = g1.y; x[4] = g2.x; x[5] = g2.y;
+  }
+  store_x(s, 0, 0, slot, x);
+  for (int i = 0; i < N; ++i) {
+    const double2* gp = s.goals + (size_t)i * 3 * Bc + slot;
+    const double2 g0 = gp[0], g1 = gp[(size_t)Bc], g2 = gp[(size_t)2 * Bc];
+    const double dx[6] = {x[0] - g0.x, x[1] - g0.y, x[2] - g1.x, x[3] - g1.y, x[4] - g2.x, x[5] - g2.y};
+    const double2* kp = s.gains + (size_t)i * kGainPairs * Bc + slot;
+    double u[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const double2 k0 = kp[(size_t)(r * 3 + 0) * Bc], k1 = kp[(size_t)(r * 3 + 1) * Bc],
+                    k2 = kp[(size_t)(r * 3 + 2) * Bc];
+      double acc = (-k0.x) * dx[0];
+      acc += (-k0.y) * dx[1];
+      acc += (-k1.x) * dx[2];
+      acc += (-k1.y) * dx[3];
+      acc += (-k2.x) * dx[4];
+      acc += (-k2.y) * dx[5];
+      u[r] = acc;
+    }
+    u[0] = fmin(p.jerk_max, fmax(u[0], p.jerk_min));
+    u[1] = fmin(p.delta_rate_max, fmax(u[1], p.delta_rate_min));
+    store_u(s, 0, i, slot, u);
+    dynamics(p, x, u, x);
+    store_x(s, 0, i + 1, slot, x);
+  }
+}
+
+void launch_init_guess(const DeviceState& s, int B, hipStream_t st) {
+  hipLaunchKernelGGL(k_init_guess, dim3((B + 63) / 64), dim3(64), 0, st, s, B);
+}
+
+// ---------------------------------------------------------------------------------------------
+// set / gather the iterate (stage API)
+// ---------------------------------------------------------------------------------------------
+__global__ void k_set_trajectory(DeviceState s, int B, const double* __restrict__ X,
+                                 const double* __restrict__ U) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int K = s.p.K, N = s.p.N;
+  if (t >= B * K) return;
+  const int slot = t / K, i = t - slot * K;
+  const int buf = s.cur[slot];
+  store_x(s, buf, i, slot, X + ((size_t)slot * K + i) * 6);
+  if (i < N) store_u(s, buf, i, slot, U + ((size_t)slot * N + i) * 2);
+  if (i == 0) s.upd[slot] = 1;
+}
+void launch_set_trajectory(const DeviceState& s, int B, const double* X, const double* U, hipStream_t st) {
+  const int n = B * s.p.K;
+  hipLaunchKernelGGL(k_set_trajectory, dim3((n + 255) / 256), dim3(256), 0, st, s, B, X, U);
+}
+
+__global__ void k_gather_xu(DeviceState s, int B, int cand, double* __restrict__ X, double* __restrict__ U) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int K = s.p.K, N = s.p.N;
+  if (t >= B * K) return;
+  const int slot = t / K, i = t - slot * K;
+  const int buf = s.cur[slot] ^ cand;
+  double x[6], u[2];
+  load_x(s, buf, i, slot, x);
+  if (X) {
+#pragma unroll
+    for (int e = 0; e < 6; ++e) X[((size_t)slot * K + i) * 6 + e] = x[e];
+  }
+  if (U && i < N) {
+    load_u(s, buf, i, slot, u);
+    U[((size_t)slot * N + i) * 2 + 0] = u[0];
+    U[((size_t)slot * N + i) * 2 + 1] = u[1];
+  }
+}
+void launch_gather_xu(const DeviceState& s, int B, int cand, double* X, double* U, hipStream_t st) {
+  const int n = B * s.p.K;
+  hipLaunchKernelGGL(k_gather_xu, dim3((n + 255) / 256), dim3(256), 0, st, s, B, cand, X, U);
+}
+
+// dst[b*dst_stride + dst_off + 2*r + {0,1}] = src[r][b].{x,y}
+__global__ void k_gather_pairs(const double2* __restrict__ src, int rows, int Bcap, int B,
+                               double* __restrict__ dst, int dst_stride, int dst_off) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= B * rows) return;
+  const int b = t / rows, r = t - b * rows;
+  const double2 v = src[(size_t)r * Bcap + b];
+  dst[(size_t)b * dst_stride + dst_off + 2 * r] = v.x;
+  dst[(size_t)b * dst_stride + dst_off + 2 * r + 1] = v.y;
+}
+void launch_gather_pairs(const double2* src, int rows_pairs, int Bcap, int B, double* dst,
+                         int dst_stride, int dst_off, hipStream_t st) {
+  const int n = B * rows_pairs;
+  hipLaunchKernelGGL(k_gather_pairs, dim3((n + 255) / 256), dim3(256), 0, st, src, rows_pairs, Bcap, B,
+                     dst, dst_stride, dst_off);
+}
+__global__ void k_gather_scalar(const double* __restrict__ src, int rows, int Bcap, int B,
+                                double* __restrict__ dst, int dst_stride, int dst_off) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= B * rows) return;
+  const int b = t / rows, r = t - b * rows;
+  dst[(size_t)b * dst_stride + dst_off + r] = src[(size_t)r * Bcap + b];
+}
+void launch_gather_scalar(const double* src, int rows, int Bcap, int B, double* dst, int dst_stride,
+                          int dst_off, hipStream_t st) {
+  const int n = B * rows;
+  hipLaunchKernelGGL(k_gather_scalar, dim3((n + 255) / 256), dim3(256), 0, st, src, rows, Bcap, B, dst,
+                     dst_stride, dst_off);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Export: TransformToTrajectory (cc:771-791) into problem-major [B][K][10]
+// ---------------------------------------------------------------------------------------------
+CILQR_DEV void write_traj_point(const DeviceState& s, int buf, int i, int slot, double* __restrict__ o) {
+  double x[6], u[2] = {0.0, 0.0};
+  load_x(s, buf, i, slot, x);
+  if (i < s.p.N) load_u(s, buf, i, slot, u);
+  o[0] = i * s.p.dt;
+  o[1] = x[0]; o[2] = x[1]; o[3] = x[2]; o[4] = x[3]; o[5] = x[4]; o[6] = x[5];
+  o[7] = tan(x[5]) / s.p.wheel_base;
+  o[8] = u[0]; o[9] = u[1];
+}
+__global__ void k_export_traj(DeviceState s, int B, double* __restrict__ traj) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int K = s.p.K;
+  if (t >= B * K) return;
+  const int i = t / B, slot = t - i * B;  // slot fastest: coalesced reads
+  write_traj_point(s, s.cur[slot], i, slot, traj + ((size_t)slot * K + i) * 10);
+}
+void launch_export_traj(const DeviceState& s, int B, double* traj, hipStream_t st) {
+  const int n = B * s.p.K;
+  hipLaunchKernelGGL(k_export_traj, dim3((n + 255) / 256), dim3(256), 0, st, s, B, traj);
+}
+
+// iter_trajs: append the current iterate of every listed slot whose emit flag is set
+__global__ void k_export_iter_traj(DeviceState s, const int* __restrict__ list, int n,
+                                   double* __restrict__ out, int cap) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int K = s.p.K;
+  if (t >= n * K) return;
+  const int i = t / n, j = t - i * n;
+  const int slot = list ? list[j] : j;
+  if (!s.emit[slot]) return;
+  const int idx = s.n_iter_trajs[slot] - 1;  // already counted by the kernel that set emit
+  if (idx >= cap) return;
+  write_traj_point(s, s.cur[slot], i, slot, out + (((size_t)slot * cap + idx) * K + i) * 10);
+}
+void launch_export_iter_traj(const DeviceState& s, const int* list, int n, double* iter_trajs,
+                             int max_iter_trajs, hipStream_t st) {
+  const int tot = n * s.p.K;
+  if (tot == 0) return;
+  hipLaunchKernelGGL(k_export_iter_traj, dim3((tot + 255) / 256), dim3(256), 0, st, s, list, n,
+                     iter_trajs, max_iter_trajs);
+}
+
+// cost history + counters, problem-major.  Rows >= n_cost are left untouched.
+__global__ void k_export_hist(DeviceState s, int B, double* __restrict__ hist, int* __restrict__ n_cost,
+                              int* __restrict__ status, int* __restrict__ n_iter,
+                              int* __restrict__ n_iter_trajs) {
+  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= B) return;
+  const int nc = s.n_cost[slot];
+  if (n_cost) n_cost[slot] = nc;
+  if (status) status[slot] = s.status[slot];
+  if (n_iter) n_iter[slot] = s.iter[slot];
+  if (n_iter_trajs) n_iter_trajs[slot] = s.n_iter_trajs[slot];
+  if (hist) {
+    double* o = hist + (size_t)slot * (s.p.max_iter + 1) * 5;
+    for (int r = 0; r < nc; ++r)
+#pragma unroll
+      for (int c = 0; c < 5; ++c) o[r * 5 + c] = s.hist[((size_t)r * 5 + c) * s.Bcap + slot];
+  }
+}
+void launch_export_hist(const DeviceState& s, int B, double* cost_hist, int* n_cost, int* status,
+                        int* n_iter, int* n_iter_trajs, hipStream_t st) {
+  hipLaunchKernelGGL(k_export_hist, dim3((B + 255) / 256), dim3(256), 0, st, s, B, cost_hist, n_cost,
+                     status, n_iter, n_iter_trajs);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Open-loop rollout: x_{k+1} = f(x_k, u_k) for B independent (x0, U) pairs, problem-major I/O.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_rollout(Params p, int B, const double* __restrict__ x0,
+                                                const double* __restrict__ U, double* __restrict__ X) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double x[6];
+#pragma unroll
+  for (int e = 0; e < 6; ++e) x[e] = x0[(size_t)b * 6 + e];
+  double* xo = X + (size_t)b * p.K * 6;
+#pragma unroll
+  for (int e = 0; e < 6; ++e) xo[e] = x[e];
+  for (int i = 0; i < p.N; ++i) {
+    const double u[2] = {U[((size_t)b * p.N + i) * 2], U[((size_t)b * p.N + i) * 2 + 1]};
+    dynamics(p, x, u, x);
+#pragma unroll
+    for (int e = 0; e < 6; ++e) xo[(i + 1) * 6 + e] = x[e];
+  }
+}
+void launch_rollout(const Params& p, int B, const double* x0, const double* U, double* X, hipStream_t st) {
+  hipLaunchKernelGGL(k_rollout, dim3((B + 63) / 64), dim3(64), 0, st, p, B, x0, U, X);
+}
+
+}  // namespace cilqr
+
+namespace cilqr {
+
+// ---------------------------------------------------------------------------------------------
+// stage_read: expand the compact linearisation / gains into dense problem-major tensors
+// ---------------------------------------------------------------------------------------------
+__global__ void k_expand(DeviceState s, int B, int tensor, double* __restrict__ dst) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int K = s.p.K, N = s.p.N, Bc = s.Bcap;
+  if (t >= B * K) return;
+  const int slot = t / K, i = t - slot * K;
+  const double dt = s.p.dt;
+  const bool term = (i == N);
+  double2 w[kLinPairs];
+  if (!term) {
+    const double2* q = s.lin + (size_t)i * kLinPairs * Bc + slot;
+    for (int r = 0; r < kLinPairs; ++r) w[r] = q[(size_t)r * Bc];
+  } else {
+    const double2* q = s.term + slot;
+    for (int r = 0; r < 3; ++r) w[kRowLx + r] = q[(size_t)r * Bc];
+    for (int r = 0; r < 6; ++r) w[kRowH + r] = q[(size_t)(3 + r) * Bc];
+  }
+  switch (tensor) {
+    case 7: {  // A [B][N][6][6]
+      if (term) return;
+      double* o = dst + ((size_t)slot * N + i) * 36;
+      for (int e = 0; e < 36; ++e) o[e] = 0.0;
+      for (int e = 0; e < 6; ++e) o[e * 7] = 1.0;
+      o[2] = w[0].x; o[3] = w[0].y; o[4] = w[1].x; o[5] = w[1].y;
+      o[8] = w[2].x; o[9] = w[2].y; o[10] = w[3].x; o[11] = w[3].y;
+      o[15] = w[4].x; o[16] = w[4].y; o[17] = w[5].x;
+      o[22] = dt;
+      break;
+    }
+    case 8: {  // B [B][N][6][2]
+      if (term) return;
+      double* o = dst + ((size_t)slot * N + i) * 12;
+      for (int e = 0; e < 12; ++e) o[e] = 0.0;
+      o[5] = w[5].y; o[6] = 0.5 * dt * dt; o[8] = dt; o[11] = dt;
+      break;
+    }
+    case 9: {  // lx [B][K][6]
+      double* o = dst + ((size_t)slot * K + i) * 6;
+      o[0] = w[6].x; o[1] = w[6].y; o[2] = w[7].x; o[3] = w[7].y; o[4] = w[8].x; o[5] = w[8].y;
+      break;
+    }
+    case 10: {  // lu [B][N][2]
+      if (term) return;
+      double* o = dst + ((size_t)slot * N + i) * 2;
+      o[0] = w[9].x; o[1] = w[9].y;
+      break;
+    }
+    case 11: {  // lxx [B][K][6][6]
+      double* o = dst + ((size_t)slot * K + i) * 36;
+      for (int e = 0; e < 36; ++e) o[e] = 0.0;
+      o[0] = w[10].x; o[1] = w[10].y; o[2] = w[11].x;
+      o[6] = w[11].y; o[7] = w[12].x; o[8] = w[12].y;
+      o[12] = w[13].x; o[13] = w[13].y; o[14] = w[14].x;
+      o[21] = w[14].y; o[28] = w[15].x; o[35] = w[15].y;
+      break;
+    }
+    case 12: {  // luu [B][N][2][2]
+      if (term) return;
+      double* o = dst + ((size_t)slot * N + i) * 4;
+      o[0] = w[16].x; o[1] = 0.0; o[2] = 0.0; o[3] = w[16].y;
+      break;
+    }
+    case 13: {  // K [B][N][2][6]
+      if (term) return;
+      const double2* g = s.gains + (size_t)i * kGainPairs * Bc + slot;
+      double* o = dst + ((size_t)slot * N + i) * 12;
+      for (int r = 0; r < 6; ++r) {
+        const double2 v = g[(size_t)r * Bc];
+        o[2 * r] = v.x; o[2 * r + 1] = v.y;
+      }
+      break;
+    }
+    case 14: {  // k [B][N][2]
+      if (term) return;
+      const double2 v = s.gains[((size_t)i * kGainPairs + 6) * Bc + slot];
+      double* o = dst + ((size_t)slot * N + i) * 2;
+      o[0] = v.x; o[1] = v.y;
+      break;
+    }
+    default: break;
+  }
+}
+void launch_expand(const DeviceState& s, int B, int tensor, double* dst, hipStream_t st) {
+  const int n = B * s.p.K;
+  hipLaunchKernelGGL(k_expand, dim3((n + 255) / 256), dim3(256), 0, st, s, B, tensor, dst);
+}
+
+}  // namespace cilqr

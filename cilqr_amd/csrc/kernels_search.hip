@@ -1,0 +1,218 @@
+// Forward pass, 11-step line search and the per-problem state machine of Optimize().
+//
+// Reference behaviour (algorithm/ilqr/ilqr_optimizer.cc):
+//   Forward cc:392-415; line search + acceptance test cc:243-270 (alpha list cc:197,
+//   beta in (1e-4, 10), dcost > 0); regularisation schedule and exits cc:272-308, 312-319;
+//   gradient-norm exit cc:235-241.
+//
+// Lockstep design: every trial of the line search depends only on the pre-trial iterate, so
+// round r evaluates alpha_r for exactly the problems that rejected alpha_0..alpha_{r-1}:
+//   forward(alpha_0) on the active list -> cost (problem x knot threads) ->
+//   [reduce + accept test, or roll out alpha_{r+1} and join pending list r+1] -> cost -> ...
+// The first passing list index wins, as in the sequential loop.  Pending lists are compacted
+// with wave-aggregated atomics; their order only affects coalescing, never results.
+#include "dev_model.hpp"
+
+namespace cilqr {
+
+__device__ const double kAlpha[kNumAlpha] = {1.0000, 0.5012, 0.2512, 0.1259, 0.0631, 0.0316,
+                                             0.0158, 0.0079, 0.0040, 0.0020, 0.0010};
+
+
+// roll the closed-loop policy out from goals_[0] into the candidate buffers (cc:392-415)
+CILQR_DEV void forward_problem(const DeviceState& s, int slot, double alpha) {
+  const Params& p = s.p;
+  const int Bc = s.Bcap, N = p.N;
+  const int buf = s.cur[slot], nb = buf ^ 1;
+  double x[6];
+  {
+    const double2* gp = s.goals + slot;
+    const double2 g0 = gp[0], g1 = gp[(size_t)Bc], g2 = gp[(size_t)2 * Bc];
+    x[0] = g0.x; x[1] = g0.y; x[2] = g1.x; x[3] = g1.y; x[4] = g2.x; x[5] = g2.y;
+  }
+  store_x(s, nb, 0, slot, x);
+  for (int i = 0; i < N; ++i) {
+    double xs[6], us[2];
+    load_x(s, buf, i, slot, xs);
+    load_u(s, buf, i, slot, us);
+    const double2* g = s.gains + (size_t)i * kGainPairs * Bc + slot;
+    double2 kk[kGainPairs];
+#pragma unroll
+    for (int r = 0; r < kGainPairs; ++r) kk[r] = g[(size_t)r * Bc];
+    double dx[6];
+#pragma unroll
+    for (int e = 0; e < 6; ++e) dx[e] = x[e] - xs[e];
+    double u[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      double acc = kk[r * 3].x * dx[0];
+      acc += kk[r * 3].y * dx[1];
+      acc += kk[r * 3 + 1].x * dx[2];
+      acc += kk[r * 3 + 1].y * dx[3];
+      acc += kk[r * 3 + 2].x * dx[4];
+      acc += kk[r * 3 + 2].y * dx[5];
+      const double kff = (r == 0) ? kk[6].x : kk[6].y;
+      u[r] = (us[r] + acc) + alpha * kff;                           // cc:407
+    }
+    u[1] = normalize_angle(u[1]);                                     // cc:408
+    store_u(s, nb, i, slot, u);
+    dynamics(p, x, u, x);
+    store_x(s, nb, i + 1, slot, x);
+  }
+}
+
+// stage API: plain rollout of the listed slots with one alpha
+__global__ __launch_bounds__(64) void k_forward(DeviceState s, const int* __restrict__ list, int n,
+                                                double alpha, int skip_done) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int slot = list ? list[j] : j;
+  if (skip_done && s.acc_idx[slot] != -1) return;
+  forward_problem(s, slot, alpha);
+}
+void launch_forward(const DeviceState& s, const int* list, int n, double alpha, int skip_done,
+                    hipStream_t st) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_forward, dim3((n + 63) / 64), dim3(64), 0, st, s, list, n, alpha, skip_done);
+}
+
+// round 0 opener: gradient-norm exit (cc:235-241), else roll out alpha_0
+__global__ __launch_bounds__(64) void k_search_open(DeviceState s, int n) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int slot = s.act[j];
+  if (s.gnorm[slot] < 1e-6 && s.lambda[slot] < 1e-5) {
+    s.status[slot] = 3;   // CILQR_ST_GNORM
+    s.acc_idx[slot] = -2;
+    return;
+  }
+  s.acc_idx[slot] = -1;
+  forward_problem(s, slot, kAlpha[0]);
+}
+
+CILQR_DEV void reduce_cost_ls(const DeviceState& s, int slot, double* c5) {
+  const int Bc = s.Bcap, K = s.p.K, N = s.p.N;
+  double j = 0.0, dx = 0.0, du = 0.0, cc = 0.0, lc = 0.0;
+  for (int i = 0; i < K; ++i) {
+    const double2* o = s.part + (size_t)i * kPartPairs * Bc + slot;
+    const double2 a = o[0], b = o[(size_t)Bc], c = o[(size_t)2 * Bc];
+    j += a.x;
+    dx += b.x;
+    cc += c.x;
+    lc += c.y;
+  }
+  for (int i = 0; i < N; ++i) {
+    const double2* o = s.part + (size_t)i * kPartPairs * Bc + slot;
+    j += o[0].y;
+    du += o[(size_t)Bc].y;
+  }
+  const double dyn = dx + du;
+  c5[0] = j + dyn + cc + lc;
+  c5[1] = j; c5[2] = dyn; c5[3] = cc; c5[4] = lc;
+}
+
+// round r: total cost of the alpha_r candidate, acceptance test (cc:252-261); on rejection roll
+// out alpha_{r+1} and queue the slot for the next round.
+__global__ __launch_bounds__(64) void k_search_round(DeviceState s, int r, int n_max) {
+  const int* __restrict__ list = (r == 0) ? s.act : s.pend + (size_t)r * s.Bcap;
+  const int n = (r == 0) ? n_max : min(s.counters[r], n_max);
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+    const int slot = list[j];
+    if (s.acc_idx[slot] != -1) continue;   // left at the gradient-norm exit
+    double c5[5];
+    reduce_cost_ls(s, slot, c5);
+    const double alpha = kAlpha[r];
+    const double dcost = s.cost_old[slot] - c5[0];                                  // cc:254
+    const double expected = -alpha * (s.dV[slot] + alpha * s.dV[(size_t)s.Bcap + slot]);  // cc:255
+    const double z = dcost / expected;                                              // cc:257
+#pragma unroll
+    for (int c = 0; c < 5; ++c) s.trial[(size_t)c * s.Bcap + slot] = c5[c];
+    if ((z > 1e-4 && z < 10.0) && dcost > 0.0) {                                    // cc:258
+      s.acc_idx[slot] = r;
+      s.dcost[slot] = dcost;
+      s.cur[slot] ^= 1;   // the candidate becomes the iterate
+    } else if (r + 1 < kNumAlpha) {
+      forward_problem(s, slot, kAlpha[r + 1]);
+      const int pos = atomicAdd(&s.counters[r + 1], 1);
+      s.pend[(size_t)(r + 1) * s.Bcap + pos] = slot;
+    }
+  }
+}
+
+void launch_linesearch(const DeviceState& s, int n_act, hipStream_t st) {
+  if (n_act == 0) return;
+  hipLaunchKernelGGL(k_search_open, dim3((n_act + 63) / 64), dim3(64), 0, st, s, n_act);
+  for (int r = 0; r < kNumAlpha; ++r) {
+    // later rounds carry a small fraction of the batch: shrink their grids, stride inside
+    const int shrink = (r == 0) ? 1 : (r == 1 ? 2 : 8);
+    const int n_grid = (n_act + shrink - 1) / shrink;
+    launch_cost_knots(s, (r == 0) ? (const int*)s.act : (const int*)(s.pend + (size_t)r * s.Bcap),
+                      (r == 0) ? (const int*)nullptr : (const int*)(s.counters + r), n_act, n_grid, 1, 1, st);
+    hipLaunchKernelGGL(k_search_round, dim3((n_grid + 63) / 64), dim3(64), 0, st, s, r, n_act);
+  }
+}
+
+// per-problem bookkeeping after the line search (cc:272-308, 312-319) + next active list
+__global__ __launch_bounds__(256) void k_update(DeviceState s, int n) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int slot = s.act[j];
+  const Params& p = s.p;
+  bool done = false;
+  int st = s.status[slot];
+  s.emit[slot] = 0;
+  if (st == 3) {
+    done = true;
+  } else {
+    const int a = s.acc_idx[slot];
+    const double lam = s.lambda[slot], dl = s.dlambda[slot];
+    if (a >= 0) {
+      const double ndl = fmin(dl / 1.6, 1.0 / 1.6);                                // cc:273
+      s.dlambda[slot] = ndl;
+      s.lambda[slot] = lam * ndl * ((lam > 1e-8) ? 1.0 : 0.0);                     // cc:275
+      s.upd[slot] = 1;
+      const double dc = s.dcost[slot], co = s.cost_old[slot];
+      const int nc = s.n_cost[slot];
+#pragma unroll
+      for (int c = 0; c < 5; ++c)
+        s.hist[((size_t)nc * 5 + c) * s.Bcap + slot] = s.trial[(size_t)c * s.Bcap + slot];
+      s.n_cost[slot] = nc + 1;
+      if (dc < p.abs_tol || dc / co < p.rel_tol) {                                 // cc:281-293
+        st = (dc < p.abs_tol) ? 1 : 2;
+        done = true;
+      } else {
+        s.n_iter_trajs[slot] += 1;                                                 // cc:294
+        s.emit[slot] = 1;
+        s.cost_old[slot] = s.trial[slot];                                          // cc:295
+      }
+    } else {
+      const double ndl = fmax(dl * 1.6, 1.6);                                      // cc:298
+      const double nl = fmax(lam * ndl, 1e-8);                                     // cc:299
+      s.dlambda[slot] = ndl;
+      s.lambda[slot] = nl;
+      s.upd[slot] = 0;
+      if (nl > 1e11) {                                                             // cc:302
+        st = 4;
+        done = true;
+      }
+    }
+  }
+  const int it = s.iter[slot] + 1;
+  s.iter[slot] = it;
+  if (!done && it >= p.max_iter) {                                                 // cc:312
+    st = 5;
+    done = true;
+  }
+  s.status[slot] = st;
+  s.acc_idx[slot] = -1;
+  if (!done) {
+    const int pos = atomicAdd(&s.counters[0], 1);
+    s.act_next[pos] = slot;
+  }
+}
+void launch_update(const DeviceState& s, int n_act, hipStream_t st) {
+  if (n_act == 0) return;
+  hipLaunchKernelGGL(k_update, dim3((n_act + 255) / 256), dim3(256), 0, st, s, n_act);
+}
+
+}  // namespace cilqr

@@ -1,0 +1,637 @@
+// Host side of the C-ABI (include/cilqr.h): HBM arena, lockstep driver of Optimize()
+// (algorithm/ilqr/ilqr_optimizer.cc:154-320) over the whole batch, stage entry points.
+//
+// Nothing here computes on the CPU: the host only sizes grids, launches kernels on one HIP
+// stream and reads back the active-problem count once per lockstep iteration.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/cilqr.h"
+#include "state.hpp"
+
+using namespace cilqr;
+
+#define HIP_TRY(expr)                                                              \
+  do {                                                                             \
+    hipError_t e_ = (expr);                                                        \
+    if (e_ != hipSuccess) {                                                        \
+      std::snprintf(g_last_hip_error, sizeof(g_last_hip_error), "%s -> %s", #expr, \
+                    hipGetErrorString(e_));                                        \
+      return CILQR_ERR_DEVICE;                                                     \
+    }                                                                              \
+  } while (0)
+
+static thread_local char g_last_hip_error[256] = "";
+
+struct cilqr_solver {
+  cilqr_config cfg;
+  int device = 0;
+  int Bcap = 0, cmax = 0, smax = 0;
+  DeviceState ds;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::vector<void*> allocs;
+  int64_t bytes = 0;
+  // staging (lazily grown): problem-major copies of host inputs / outputs on the device
+  void* in_stage = nullptr;
+  size_t in_stage_bytes = 0;
+  void* out_stage = nullptr;
+  size_t out_stage_bytes = 0;
+  double* lanes_raw = nullptr;  // device [2*smax][7]
+  double* lambda_stage = nullptr;
+  int* h_count = nullptr;  // pinned
+  int B = 0;               // problems loaded
+  int stage = 0;           // bit0 loaded, bit1 iterate, bit2 quadratized, bit3 gains
+  // profiling
+  bool profiling = false;
+  std::vector<hipEvent_t> ev;
+  cilqr_profile prof;
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(cilqr_solver* h, T** p, size_t count) {
+  void* q = nullptr;
+  const size_t bytes = count * sizeof(T);
+  HIP_TRY(hipMalloc(&q, bytes ? bytes : 256));
+  h->allocs.push_back(q);
+  h->bytes += (int64_t)bytes;
+  *p = static_cast<T*>(q);
+  return CILQR_OK;
+}
+
+int grow(void** p, size_t* have, size_t need) {
+  if (need <= *have) return CILQR_OK;
+  if (*p) HIP_TRY(hipFree(*p));
+  *p = nullptr;
+  *have = 0;
+  HIP_TRY(hipMalloc(p, need));
+  *have = need;
+  return CILQR_OK;
+}
+
+void fill_params(const cilqr_config& c, Params* p) {
+  std::memset(p, 0, sizeof(*p));
+  p->N = c.n_steps;
+  p->K = c.n_steps + 1;
+  p->num_of_disc = c.num_of_disc;
+  p->max_iter = c.max_iter;
+  p->dt = c.dt;
+  p->wheel_base = c.wheel_base;
+  p->w_jerk = c.w_jerk; p->w_delta_rate = c.w_delta_rate;
+  p->w_x = c.w_x; p->w_y = c.w_y; p->w_theta = c.w_theta;
+  p->w_v = c.w_v; p->w_a = c.w_a; p->w_delta = c.w_delta;
+  p->abs_tol = c.abs_cost_tol; p->rel_tol = c.rel_cost_tol;
+  p->max_velocity = c.max_velocity; p->min_acc = c.min_acceleration; p->max_acc = c.max_acceleration;
+  p->jerk_min = c.jerk_min; p->jerk_max = c.jerk_max;
+  p->delta_min = c.delta_min; p->delta_max = c.delta_max;
+  p->delta_rate_min = c.delta_rate_min; p->delta_rate_max = c.delta_rate_max;
+  p->bar_r = 1.0 / c.barrier_t;                       // barrier_function.h:85
+  p->bar_eps = c.barrier_eps;
+  p->bar_rlogeps = p->bar_r * std::log(c.barrier_eps);
+  // CalculateDiscRadius cc:97-104 and the disc offsets of cc:556-565
+  const double length = c.front_hang + c.wheel_base + c.rear_hang;
+  const double disc_radius = std::hypot(c.width / 2.0, length / 2.0 / c.num_of_disc);
+  const double L = (c.rear_hang + c.wheel_base + c.front_hang) / c.num_of_disc;
+  for (int j = 0; j < c.num_of_disc && j < kMaxDiscs; ++j) p->disc_off[j] = L * (j - 0.5) - c.rear_hang;
+  p->shrink_corridor = disc_radius + c.safe_margin;
+  p->shrink_lane = disc_radius;
+}
+
+int check_problem(const cilqr_solver* h, const cilqr_problem_batch* in) {
+  if (in == nullptr) return CILQR_ERR_NULL;
+  if (in->batch <= 0) return CILQR_ERR_ARG;
+  if (in->corridor == nullptr || in->corridor_count == nullptr || in->left_lane == nullptr ||
+      in->right_lane == nullptr || in->n_left <= 0 || in->n_right <= 0 || in->cmax <= 0)
+    return CILQR_ERR_CONSTRAINTS;                                 // cc:68-73
+  if (in->start == nullptr || in->coarse == nullptr) return CILQR_ERR_NULL;
+  if (in->n_knots != h->cfg.n_steps + 1) return CILQR_ERR_KNOTS;  // cc:75-78
+  if (in->batch > h->Bcap || in->cmax > h->cmax || in->n_left > h->smax || in->n_right > h->smax)
+    return CILQR_ERR_CAPACITY;
+  if (in->memory != CILQR_MEM_HOST && in->memory != CILQR_MEM_DEVICE) return CILQR_ERR_ARG;
+  return CILQR_OK;
+}
+
+// upload (if needed) + prepare kernels
+int do_load(cilqr_solver* h, const cilqr_problem_batch* in) {
+  const int rc = check_problem(h, in);
+  if (rc != CILQR_OK) return rc;
+  HIP_TRY(hipSetDevice(h->device));
+  const int B = in->batch, K = in->n_knots;
+  ProblemView pv;
+  pv.cmax_in = in->cmax;
+  const size_t n_start = (size_t)B * 4, n_coarse = (size_t)B * K * 6,
+               n_cor = (size_t)B * K * in->cmax * 3, n_cnt = (size_t)B * K;
+  if (in->memory == CILQR_MEM_HOST) {
+    const size_t bytes = (n_start + n_coarse + n_cor) * sizeof(double) + n_cnt * sizeof(int) + 1024;
+    const int g = grow(&h->in_stage, &h->in_stage_bytes, bytes);
+    if (g != CILQR_OK) return g;
+    double* d = static_cast<double*>(h->in_stage);
+    HIP_TRY(hipMemcpyAsync(d, in->start, n_start * 8, hipMemcpyHostToDevice, h->stream));
+    pv.start = d; d += n_start;
+    HIP_TRY(hipMemcpyAsync(d, in->coarse, n_coarse * 8, hipMemcpyHostToDevice, h->stream));
+    pv.coarse = d; d += n_coarse;
+    HIP_TRY(hipMemcpyAsync(d, in->corridor, n_cor * 8, hipMemcpyHostToDevice, h->stream));
+    pv.corridor = d; d += n_cor;
+    HIP_TRY(hipMemcpyAsync(d, in->corridor_count, n_cnt * 4, hipMemcpyHostToDevice, h->stream));
+    pv.ccount = reinterpret_cast<const int*>(d);
+  } else {
+    pv.start = in->start; pv.coarse = in->coarse; pv.corridor = in->corridor;
+    pv.ccount = in->corridor_count;
+  }
+  HIP_TRY(hipMemcpyAsync(h->lanes_raw, in->left_lane, (size_t)in->n_left * 7 * 8, hipMemcpyHostToDevice,
+                         h->stream));
+  HIP_TRY(hipMemcpyAsync(h->lanes_raw + (size_t)in->n_left * 7, in->right_lane,
+                         (size_t)in->n_right * 7 * 8, hipMemcpyHostToDevice, h->stream));
+  h->ds.nl = in->n_left;
+  h->ds.nr = in->n_right;
+  launch_load(h->ds, B, pv, h->lanes_raw, h->stream);
+  HIP_TRY(hipGetLastError());
+  h->B = B;
+  h->stage = 1;
+  return CILQR_OK;
+}
+
+struct Timer {  // event pairs, resolved after the final sync
+  cilqr_solver* h;
+  size_t next = 0;
+  std::vector<int> kind;  // 0 quad, 1 backward, 2 linesearch, 3 other
+  int begin(int k) {
+    if (!h->profiling) return 0;
+    if (next + 2 > h->ev.size()) {
+      const size_t old = h->ev.size();
+      h->ev.resize(old + 64);
+      for (size_t i = old; i < h->ev.size(); ++i)
+        if (hipEventCreate(&h->ev[i]) != hipSuccess) return -1;
+    }
+    kind.push_back(k);
+    return hipEventRecord(h->ev[next++], h->stream) == hipSuccess ? 0 : -1;
+  }
+  int end() {
+    if (!h->profiling) return 0;
+    return hipEventRecord(h->ev[next++], h->stream) == hipSuccess ? 0 : -1;
+  }
+  void resolve(cilqr_profile* p) {
+    if (!h->profiling) return;
+    for (size_t i = 0; i < kind.size(); ++i) {
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, h->ev[2 * i], h->ev[2 * i + 1]);
+      switch (kind[i]) {
+        case 0: p->quadratize_ms += ms; break;
+        case 1: p->backward_ms += ms; break;
+        case 2: p->linesearch_ms += ms; break;
+        default: p->other_ms += ms; break;
+      }
+    }
+    if (!kind.empty()) {
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, h->ev[0], h->ev[next - 1]);
+      p->total_ms = ms;
+    }
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+int cilqr_abi_version(void) { return CILQR_ABI_VERSION; }
+
+const char* cilqr_error_string(int code) {
+  switch (code) {
+    case CILQR_OK: return "ok";
+    case CILQR_ERR_NULL: return "null pointer";
+    case CILQR_ERR_CONSTRAINTS: return "ilqr input constraints error";
+    case CILQR_ERR_KNOTS: return "ilqr input coarse_traj error";
+    case CILQR_ERR_CAPACITY: return "batch / cmax / lane segments exceed the capacity given to cilqr_create";
+    case CILQR_ERR_DEVICE: return g_last_hip_error[0] ? g_last_hip_error : "HIP runtime error";
+    case CILQR_ERR_ARG: return "invalid argument";
+    case CILQR_ERR_STATE: return "stage called out of order";
+    default: return "unknown error";
+  }
+}
+
+int cilqr_default_config(cilqr_config* c, int32_t n_steps) {
+  if (c == nullptr) return CILQR_ERR_NULL;
+  std::memset(c, 0, sizeof(*c));
+  c->n_steps = n_steps;
+  c->num_of_disc = 5;       // planner_config.h:58
+  c->max_iter = 200;        // :63
+  c->dt = 0.1;              // :94
+  c->safe_margin = 0.2;     // :59
+  c->w_jerk = 1; c->w_delta_rate = 1;               // :46-47
+  c->w_x = 0.5; c->w_y = 0.5; c->w_theta = 1e-3;    // :49-51
+  c->w_v = 0.0; c->w_a = 0.0; c->w_delta = 0.0;     // :52-54
+  c->abs_cost_tol = 1e-2; c->rel_cost_tol = 1e-2;   // :65-66
+  c->front_hang = 0.96; c->wheel_base = 1.0; c->rear_hang = 0.929; c->width = 1.942;  // vehicle_param.h:26-41
+  c->max_velocity = 20.0;                           // :46
+  c->min_acceleration = -5.0; c->max_acceleration = 5.0;   // :51-52
+  c->jerk_min = -10.0; c->jerk_max = 10.0;          // :57-58
+  c->delta_min = -40.0 / 180 * M_PI; c->delta_max = 40.0 / 180 * M_PI;        // :60-61
+  c->delta_rate_min = c->delta_min / 3.0; c->delta_rate_max = c->delta_max / 3.0;  // :63-64
+  c->barrier_t = 5.0; c->barrier_eps = 0.01;        // barrier_function.h:144-145
+  return CILQR_OK;
+}
+
+int cilqr_create(const cilqr_config* cfg, int32_t device, int32_t batch_capacity, int32_t cmax,
+                 int32_t max_lane_segments, cilqr_handle* out) {
+  if (cfg == nullptr || out == nullptr) return CILQR_ERR_NULL;
+  *out = nullptr;
+  if (cfg->n_steps < 1 || cfg->num_of_disc < 1 || cfg->num_of_disc > CILQR_MAX_DISCS ||
+      cfg->max_iter < 1 || batch_capacity < 1 || cmax < 1 || max_lane_segments < 1 ||
+      max_lane_segments > CILQR_MAX_LANE_SEGMENTS || !(cfg->dt > 0.0) || !(cfg->barrier_t > 0.0) ||
+      !(cfg->barrier_eps > 0.0))
+    return CILQR_ERR_ARG;
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) {
+    std::snprintf(g_last_hip_error, sizeof(g_last_hip_error), "device %d not present (%d visible)", device, ndev);
+    return CILQR_ERR_DEVICE;
+  }
+  HIP_TRY(hipSetDevice(device));
+  cilqr_solver* h = new (std::nothrow) cilqr_solver();
+  if (h == nullptr) return CILQR_ERR_DEVICE;
+  h->cfg = *cfg;
+  h->device = device;
+  // slots are padded to a multiple of 64 so that every row of every tensor starts 512 B aligned
+  const int Bc = ((batch_capacity + 63) / 64) * 64;
+  h->Bcap = Bc;
+  h->cmax = cmax;
+  h->smax = max_lane_segments;
+  std::memset(&h->ds, 0, sizeof(h->ds));
+  std::memset(&h->prof, 0, sizeof(h->prof));
+  DeviceState& d = h->ds;
+  d.Bcap = Bc;
+  d.cmax = cmax;
+  fill_params(*cfg, &d.p);
+  const size_t N = cfg->n_steps, K = N + 1, B = Bc;
+  int rc = CILQR_OK;
+#define ALLOC(field, count) \
+  if (rc == CILQR_OK) rc = dev_alloc(h, &d.field, (size_t)(count))
+  ALLOC(X, 2 * K * 3 * B);
+  ALLOC(U, 2 * N * B);
+  ALLOC(cur, B);
+  ALLOC(goals, K * 3 * B);
+  ALLOC(cor, K * cmax * 3 * B);
+  ALLOC(ccnt, K * B);
+  ALLOC(lanes, (size_t)2 * max_lane_segments * kLaneFields);
+  ALLOC(lin, N * kLinPairs * B);
+  ALLOC(term, (size_t)kTermPairs * B);
+  ALLOC(gains, N * kGainPairs * B);
+  ALLOC(dV, 2 * B);
+  ALLOC(gnorm, B);
+  ALLOC(part, K * kPartPairs * B);
+  ALLOC(trial, 5 * B);
+  ALLOC(hist, (size_t)(cfg->max_iter + 1) * 5 * B);
+  ALLOC(lambda, B); ALLOC(dlambda, B); ALLOC(cost_old, B); ALLOC(dcost, B);
+  ALLOC(iter, B); ALLOC(status, B); ALLOC(n_cost, B); ALLOC(upd, B); ALLOC(acc_idx, B);
+  ALLOC(n_iter_trajs, B); ALLOC(emit, B);
+  ALLOC(act, B); ALLOC(act_next, B);
+  ALLOC(pend, (size_t)(kNumAlpha + 1) * B);
+  ALLOC(counters, 64);
+#undef ALLOC
+  if (rc == CILQR_OK) rc = dev_alloc(h, &h->lanes_raw, (size_t)2 * max_lane_segments * 7);
+  if (rc == CILQR_OK) rc = dev_alloc(h, &h->lambda_stage, B);
+  if (rc == CILQR_OK && hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess)
+    rc = CILQR_ERR_DEVICE;
+  if (rc == CILQR_OK && hipHostMalloc(reinterpret_cast<void**>(&h->h_count), 64 * sizeof(int)) != hipSuccess)
+    rc = CILQR_ERR_DEVICE;
+  if (rc == CILQR_OK && hipMemset(d.cor, 0, K * cmax * 3 * B * sizeof(double)) != hipSuccess)
+    rc = CILQR_ERR_DEVICE;
+  if (rc != CILQR_OK) {
+    cilqr_destroy(h);
+    return rc;
+  }
+  h->stream = h->own_stream;
+  *out = h;
+  return CILQR_OK;
+}
+
+int cilqr_destroy(cilqr_handle h) {
+  if (h == nullptr) return CILQR_ERR_NULL;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (void* p : h->allocs) (void)hipFree(p);
+  if (h->in_stage) (void)hipFree(h->in_stage);
+  if (h->out_stage) (void)hipFree(h->out_stage);
+  if (h->h_count) (void)hipHostFree(h->h_count);
+  for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  delete h;
+  return CILQR_OK;
+}
+
+int cilqr_set_stream(cilqr_handle h, void* hip_stream) {
+  if (h == nullptr) return CILQR_ERR_NULL;
+  h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
+  return CILQR_OK;
+}
+
+int cilqr_set_profiling(cilqr_handle h, int32_t enable) {
+  if (h == nullptr) return CILQR_ERR_NULL;
+  h->profiling = enable != 0;
+  return CILQR_OK;
+}
+
+int cilqr_get_profile(cilqr_handle h, cilqr_profile* out) {
+  if (h == nullptr || out == nullptr) return CILQR_ERR_NULL;
+  *out = h->prof;
+  return CILQR_OK;
+}
+
+int64_t cilqr_device_bytes(cilqr_handle h) {
+  if (h == nullptr) return 0;
+  return h->bytes + (int64_t)h->in_stage_bytes + (int64_t)h->out_stage_bytes;
+}
+
+int cilqr_solve_batch(cilqr_handle h, const cilqr_problem_batch* in, cilqr_solution_batch* out) {
+  if (h == nullptr || out == nullptr) return CILQR_ERR_NULL;
+  if (out->traj == nullptr || out->cost_hist == nullptr || out->n_cost == nullptr || out->status == nullptr)
+    return CILQR_ERR_NULL;                                                     // cc:64-66
+  if (out->memory != CILQR_MEM_HOST && out->memory != CILQR_MEM_DEVICE) return CILQR_ERR_ARG;
+  if (out->iter_trajs != nullptr && (out->max_iter_trajs <= 0 || out->n_iter_trajs == nullptr)) return CILQR_ERR_ARG;
+  HIP_TRY(hipSetDevice(h->device));
+  Timer tm{h};
+  std::memset(&h->prof, 0, sizeof(h->prof));
+  if (tm.begin(3)) return CILQR_ERR_DEVICE;
+  int rc = do_load(h, in);
+  if (rc != CILQR_OK) return rc;
+  const int B = in->batch, K = in->n_knots, M = h->cfg.max_iter;
+  DeviceState& d = h->ds;
+  hipStream_t st = h->stream;
+
+  // output staging when the caller's buffers live in host memory
+  double* o_traj = out->traj; double* o_hist = out->cost_hist; double* o_it = out->iter_trajs;
+  int* o_nc = out->n_cost; int* o_st = out->status; int* o_ni = out->n_iter; int* o_nit = out->n_iter_trajs;
+  const size_t n_traj = (size_t)B * K * 10, n_hist = (size_t)B * (M + 1) * 5;
+  const size_t n_it = out->iter_trajs ? (size_t)B * out->max_iter_trajs * K * 10 : 0;
+  if (out->memory == CILQR_MEM_HOST) {
+    const size_t bytes = (n_traj + n_hist + n_it) * 8 + (size_t)4 * B * 4 + 1024;
+    rc = grow(&h->out_stage, &h->out_stage_bytes, bytes);
+    if (rc != CILQR_OK) return rc;
+    double* p = static_cast<double*>(h->out_stage);
+    o_traj = p; p += n_traj;
+    o_hist = p; p += n_hist;
+    o_it = out->iter_trajs ? p : nullptr; p += n_it;
+    int* q = reinterpret_cast<int*>(p);
+    o_nc = q; o_st = q + B; o_ni = q + 2 * B; o_nit = q + 3 * B;
+  }
+
+  launch_init_guess(d, B, st);                         // cc:169
+  launch_cost_only(d, nullptr, B, 0, st);              // cc:172
+  launch_init_cost_commit(d, B, st);                   // cc:170,173
+  if (o_it) launch_export_iter_traj(d, nullptr, B, o_it, out->max_iter_trajs, st);
+  if (tm.end()) return CILQR_ERR_DEVICE;
+
+  int n_act = B;
+  int it = 0;
+  for (; it < M && n_act > 0; ++it) {                  // cc:201
+    HIP_TRY(hipMemsetAsync(d.counters, 0, 64 * sizeof(int), st));
+    if (tm.begin(0)) return CILQR_ERR_DEVICE;
+    launch_quadratize(d, d.act, n_act, 1, st);         // cc:203-214
+    if (tm.end() || tm.begin(1)) return CILQR_ERR_DEVICE;
+    launch_backward(d, d.act, n_act, nullptr, st);     // cc:218
+    if (tm.end() || tm.begin(2)) return CILQR_ERR_DEVICE;
+    h->prof.backward_launches += 1;
+    h->prof.backward_problem_steps += (int64_t)n_act * h->cfg.n_steps;
+    launch_linesearch(d, n_act, st);                   // cc:235-270
+    launch_update(d, n_act, st);                       // cc:272-308
+    if (o_it) launch_export_iter_traj(d, d.act, n_act, o_it, out->max_iter_trajs, st);
+    if (tm.end()) return CILQR_ERR_DEVICE;
+    HIP_TRY(hipMemcpyAsync(h->h_count, d.counters, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    n_act = h->h_count[0];
+    int* t = d.act; d.act = d.act_next; d.act_next = t;
+  }
+  h->prof.iterations = it;
+  if (tm.begin(3)) return CILQR_ERR_DEVICE;
+  launch_export_traj(d, B, o_traj, st);                // cc:319
+  launch_export_hist(d, B, o_hist, o_nc, o_st, o_ni, o_nit, st);
+  if (tm.end()) return CILQR_ERR_DEVICE;
+  HIP_TRY(hipGetLastError());
+  if (out->memory == CILQR_MEM_HOST) {
+    HIP_TRY(hipMemcpyAsync(out->traj, o_traj, n_traj * 8, hipMemcpyDeviceToHost, st));
+    // rows >= n_cost are unspecified on the device side; copy everything, the host masks
+    HIP_TRY(hipMemcpyAsync(out->cost_hist, o_hist, n_hist * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(out->n_cost, o_nc, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(out->status, o_st, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    if (out->n_iter) HIP_TRY(hipMemcpyAsync(out->n_iter, o_ni, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    if (out->iter_trajs) {
+      HIP_TRY(hipMemcpyAsync(out->iter_trajs, o_it, n_it * 8, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(out->n_iter_trajs, o_nit, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    }
+  }
+  HIP_TRY(hipStreamSynchronize(st));
+  tm.resolve(&h->prof);
+  h->stage = 1 | 2 | 4 | 8;
+  return CILQR_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// stages
+// ------------------------------------------------------------------------------------------
+int cilqr_stage_load(cilqr_handle h, const cilqr_problem_batch* in) {
+  if (h == nullptr) return CILQR_ERR_NULL;
+  const int rc = do_load(h, in);
+  if (rc != CILQR_OK) return rc;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return CILQR_OK;
+}
+
+int cilqr_stage_init_guess(cilqr_handle h) {
+  if (h == nullptr) return CILQR_ERR_NULL;
+  if (!(h->stage & 1)) return CILQR_ERR_STATE;
+  HIP_TRY(hipSetDevice(h->device));
+  launch_init_guess(h->ds, h->B, h->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->stage = 1 | 2;
+  return CILQR_OK;
+}
+
+static int to_device(cilqr_solver* h, const void* src, size_t bytes, int memory, void** tmp, const void** dev) {
+  *tmp = nullptr;
+  if (memory == CILQR_MEM_DEVICE) { *dev = src; return CILQR_OK; }
+  HIP_TRY(hipMalloc(tmp, bytes ? bytes : 256));
+  HIP_TRY(hipMemcpyAsync(*tmp, src, bytes, hipMemcpyHostToDevice, h->stream));
+  *dev = *tmp;
+  return CILQR_OK;
+}
+
+int cilqr_stage_set_trajectory(cilqr_handle h, const double* X, const double* U, int32_t memory) {
+  if (h == nullptr || X == nullptr || U == nullptr) return CILQR_ERR_NULL;
+  if (!(h->stage & 1)) return CILQR_ERR_STATE;
+  HIP_TRY(hipSetDevice(h->device));
+  const int B = h->B, K = h->cfg.n_steps + 1, N = h->cfg.n_steps;
+  void *tx = nullptr, *tu = nullptr;
+  const void *dx = nullptr, *du = nullptr;
+  int rc = to_device(h, X, (size_t)B * K * 6 * 8, memory, &tx, &dx);
+  if (rc == CILQR_OK) rc = to_device(h, U, (size_t)B * N * 2 * 8, memory, &tu, &du);
+  if (rc == CILQR_OK) {
+    launch_set_trajectory(h->ds, B, static_cast<const double*>(dx), static_cast<const double*>(du), h->stream);
+    if (hipStreamSynchronize(h->stream) != hipSuccess) rc = CILQR_ERR_DEVICE;
+  }
+  if (tx) (void)hipFree(tx);
+  if (tu) (void)hipFree(tu);
+  if (rc == CILQR_OK) h->stage = 1 | 2;
+  return rc;
+}
+
+static int from_device(cilqr_solver* h, double* dst, size_t count, int memory, double** dev, void** tmp) {
+  *tmp = nullptr;
+  if (memory == CILQR_MEM_DEVICE) { *dev = dst; return CILQR_OK; }
+  HIP_TRY(hipMalloc(tmp, count ? count * 8 : 256));
+  *dev = static_cast<double*>(*tmp);
+  (void)h;
+  return CILQR_OK;
+}
+static int finish_from_device(cilqr_solver* h, double* dst, size_t count, int memory, void* tmp) {
+  int rc = CILQR_OK;
+  if (memory == CILQR_MEM_HOST && tmp) {
+    if (hipMemcpyAsync(dst, tmp, count * 8, hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = CILQR_ERR_DEVICE;
+  }
+  if (hipStreamSynchronize(h->stream) != hipSuccess) rc = CILQR_ERR_DEVICE;
+  if (tmp) (void)hipFree(tmp);
+  if (rc == CILQR_OK && hipGetLastError() != hipSuccess) rc = CILQR_ERR_DEVICE;
+  return rc;
+}
+
+int cilqr_stage_total_cost(cilqr_handle h, double* cost5, int32_t memory) {
+  if (h == nullptr || cost5 == nullptr) return CILQR_ERR_NULL;
+  if (!(h->stage & 2)) return CILQR_ERR_STATE;
+  HIP_TRY(hipSetDevice(h->device));
+  const int B = h->B;
+  double* dev = nullptr;
+  void* tmp = nullptr;
+  int rc = from_device(h, cost5, (size_t)B * 5, memory, &dev, &tmp);
+  if (rc != CILQR_OK) return rc;
+  launch_cost_only(h->ds, nullptr, B, 0, h->stream);
+  launch_gather_scalar(h->ds.trial, 5, h->ds.Bcap, B, dev, 5, 0, h->stream);
+  return finish_from_device(h, cost5, (size_t)B * 5, memory, tmp);
+}
+
+int cilqr_stage_quadratize(cilqr_handle h) {
+  if (h == nullptr) return CILQR_ERR_NULL;
+  if (!(h->stage & 2)) return CILQR_ERR_STATE;
+  HIP_TRY(hipSetDevice(h->device));
+  launch_quadratize(h->ds, nullptr, h->B, 0, h->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->stage |= 4;
+  return CILQR_OK;
+}
+
+int cilqr_stage_backward(cilqr_handle h, const double* lambda, int32_t memory) {
+  if (h == nullptr) return CILQR_ERR_NULL;
+  if (!(h->stage & 4)) return CILQR_ERR_STATE;
+  HIP_TRY(hipSetDevice(h->device));
+  const double* dl = nullptr;
+  if (lambda != nullptr) {
+    if (memory == CILQR_MEM_HOST) {
+      HIP_TRY(hipMemcpyAsync(h->lambda_stage, lambda, (size_t)h->B * 8, hipMemcpyHostToDevice, h->stream));
+      dl = h->lambda_stage;
+    } else {
+      dl = lambda;
+    }
+  }
+  launch_backward(h->ds, nullptr, h->B, dl, h->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->stage |= 8;
+  return CILQR_OK;
+}
+
+int cilqr_stage_forward(cilqr_handle h, double alpha) {
+  if (h == nullptr) return CILQR_ERR_NULL;
+  if (!(h->stage & 8)) return CILQR_ERR_STATE;
+  HIP_TRY(hipSetDevice(h->device));
+  launch_forward(h->ds, nullptr, h->B, alpha, 0, h->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return CILQR_OK;
+}
+
+int cilqr_stage_read(cilqr_handle h, int32_t tensor, double* dst, int32_t memory) {
+  if (h == nullptr || dst == nullptr) return CILQR_ERR_NULL;
+  if (!(h->stage & 1)) return CILQR_ERR_STATE;
+  HIP_TRY(hipSetDevice(h->device));
+  const DeviceState& d = h->ds;
+  const int B = h->B, N = h->cfg.n_steps, K = N + 1, Bc = d.Bcap;
+  size_t count = 0;
+  switch (tensor) {
+    case CILQR_T_GOALS: count = (size_t)B * K * 6; break;
+    case CILQR_T_CORRIDOR: count = (size_t)B * K * d.cmax * 3; break;
+    case CILQR_T_LANES: count = (size_t)(d.nl + d.nr) * 3; break;
+    case CILQR_T_X: case CILQR_T_XCAND: case CILQR_T_LX: count = (size_t)B * K * 6; break;
+    case CILQR_T_U: case CILQR_T_UCAND: case CILQR_T_LU: case CILQR_T_KFF: count = (size_t)B * N * 2; break;
+    case CILQR_T_A: count = (size_t)B * N * 36; break;
+    case CILQR_T_B: case CILQR_T_KFB: count = (size_t)B * N * 12; break;
+    case CILQR_T_LXX: count = (size_t)B * K * 36; break;
+    case CILQR_T_LUU: count = (size_t)B * N * 4; break;
+    case CILQR_T_DV: count = (size_t)B * 2; break;
+    case CILQR_T_GNORM: count = (size_t)B; break;
+    default: return CILQR_ERR_ARG;
+  }
+  if (tensor >= CILQR_T_X && tensor <= CILQR_T_UCAND && !(h->stage & 2)) return CILQR_ERR_STATE;
+  if (tensor >= CILQR_T_A && tensor <= CILQR_T_LUU && !(h->stage & 4)) return CILQR_ERR_STATE;
+  if (tensor >= CILQR_T_KFB && !(h->stage & 8)) return CILQR_ERR_STATE;
+  if (tensor == CILQR_T_LANES) {
+    std::vector<double> tab((size_t)(d.nl + d.nr) * kLaneFields);
+    HIP_TRY(hipMemcpyAsync(tab.data(), d.lanes, tab.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    std::vector<double> abc((size_t)(d.nl + d.nr) * 3);
+    for (int s = 0; s < d.nl + d.nr; ++s)
+      for (int e = 0; e < 3; ++e) abc[(size_t)s * 3 + e] = tab[(size_t)s * kLaneFields + e];
+    if (memory == CILQR_MEM_HOST) std::memcpy(dst, abc.data(), abc.size() * 8);
+    else HIP_TRY(hipMemcpy(dst, abc.data(), abc.size() * 8, hipMemcpyHostToDevice));
+    return CILQR_OK;
+  }
+  double* dev = nullptr;
+  void* tmp = nullptr;
+  int rc = from_device(h, dst, count, memory, &dev, &tmp);
+  if (rc != CILQR_OK) return rc;
+  hipStream_t st = h->stream;
+  switch (tensor) {
+    case CILQR_T_GOALS: launch_gather_pairs(d.goals, K * 3, Bc, B, dev, K * 6, 0, st); break;
+    case CILQR_T_CORRIDOR: launch_gather_scalar(d.cor, K * d.cmax * 3, Bc, B, dev, K * d.cmax * 3, 0, st); break;
+    case CILQR_T_X: launch_gather_xu(d, B, 0, dev, nullptr, st); break;
+    case CILQR_T_U: launch_gather_xu(d, B, 0, nullptr, dev, st); break;
+    case CILQR_T_XCAND: launch_gather_xu(d, B, 1, dev, nullptr, st); break;
+    case CILQR_T_UCAND: launch_gather_xu(d, B, 1, nullptr, dev, st); break;
+    case CILQR_T_DV: launch_gather_scalar(d.dV, 2, Bc, B, dev, 2, 0, st); break;
+    case CILQR_T_GNORM: launch_gather_scalar(d.gnorm, 1, Bc, B, dev, 1, 0, st); break;
+    default: launch_expand(d, B, tensor, dev, st); break;
+  }
+  return finish_from_device(h, dst, count, memory, tmp);
+}
+
+int cilqr_open_loop_rollout(cilqr_handle h, int32_t batch, const double* x0, const double* U, double* X,
+                            int32_t memory) {
+  if (h == nullptr || x0 == nullptr || U == nullptr || X == nullptr) return CILQR_ERR_NULL;
+  if (batch <= 0) return CILQR_ERR_ARG;
+  HIP_TRY(hipSetDevice(h->device));
+  const int N = h->cfg.n_steps, K = N + 1;
+  void *t0 = nullptr, *tu = nullptr, *tx = nullptr;
+  const void *d0 = nullptr, *du = nullptr;
+  double* dx = nullptr;
+  int rc = to_device(h, x0, (size_t)batch * 6 * 8, memory, &t0, &d0);
+  if (rc == CILQR_OK) rc = to_device(h, U, (size_t)batch * N * 2 * 8, memory, &tu, &du);
+  if (rc == CILQR_OK) rc = from_device(h, X, (size_t)batch * K * 6, memory, &dx, &tx);
+  if (rc == CILQR_OK) {
+    launch_rollout(h->ds.p, batch, static_cast<const double*>(d0), static_cast<const double*>(du), dx, h->stream);
+    rc = finish_from_device(h, X, (size_t)batch * K * 6, memory, tx);
+    tx = nullptr;
+  }
+  if (t0) (void)hipFree(t0);
+  if (tu) (void)hipFree(tu);
+  if (tx) (void)hipFree(tx);
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,151 @@
+// Device-side state of the batched CILQR solver (gfx950).
+//
+// HBM layout: every per-problem tensor is batch-fastest ("slot" = position of a problem in
+// the arena, stride Bcap) so that a wavefront whose 64 lanes hold 64 consecutive problems
+// issues fully coalesced loads.  fp64 values are stored in pairs (double2 per slot) wherever
+// the row count is even, so a lane moves 16 B per load and a wave 1 KiB per instruction:
+//
+//   X      [2][K][3][Bcap] double2   (x,y) (theta,v) (a,delta); two buffers, `cur[slot]` selects
+//   U      [2][N][1][Bcap] double2   (jerk, delta_rate)
+//   goals  [K][3][Bcap]    double2
+//   cor    [K][cmax][3][Bcap] double shrunk+normalised planes;  ccnt [K][Bcap] int
+//   lin    [N][17][Bcap]   double2   per step, only the entries that are not structurally constant:
+//                                      A(0,2..5) A(1,2..5) A(2,3..5) B(2,1) | lx 6 | lu 2 |
+//                                      lxx(0..2,0..2) lxx(3,3) lxx(4,4) lxx(5,5) | luu(0,0) luu(1,1)
+//                                    (A = I + strictly-upper terms, A(3,4) = dt; B(3,0) = dt^2/2,
+//                                     B(4,0) = B(5,1) = dt; all other entries are exact zeros in the
+//                                     reference too: vehicle_model.cc:61-85, ilqr_optimizer.cc:642-650)
+//   term   [9][Bcap]       double2   lx_N 6 | lxx_N (3x3 block + 3 diagonal)
+//   gains  [N][7][Bcap]    double2   K (2x6 row-major) | k (2)
+//   part   [K][3][Bcap]    double2   per-knot cost partials (Jx, Ju) (dyn_x, dyn_u) (corridor, lane)
+//   hist   [max_iter+1][5][Bcap] double
+//
+// Lane tables are shared by the batch and read through wave-uniform (scalar) loads.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cilqr {
+
+constexpr int kNX = 6;
+constexpr int kNU = 2;
+constexpr int kLinPairs = 17;   // 34 stored doubles per step (of 96 dense)
+constexpr int kTermPairs = 9;   // 18 stored doubles (of 42 dense)
+constexpr int kGainPairs = 7;   // 14 doubles
+constexpr int kPartPairs = 3;
+constexpr int kNumAlpha = 11;
+constexpr int kMaxDiscs = 16;
+constexpr int kLaneFields = 10;  // a b c | sx sy | ux uy | len | ex ey
+
+// pair rows of a step inside `lin`
+//  0 (a02,a03) 1 (a04,a05) 2 (a12,a13) 3 (a14,a15) 4 (a23,a24) 5 (a25,b21)
+//  6 (lx0,lx1) 7 (lx2,lx3) 8 (lx4,lx5) 9 (lu0,lu1)
+// 10 (h00,h01) 11 (h02,h10) 12 (h11,h12) 13 (h20,h21) 14 (h22,h33) 15 (h44,h55) 16 (luu00,luu11)
+// pair rows of `term`: 0..2 lx_N, 3..8 = rows 10..15 above
+constexpr int kRowA = 0, kRowLx = 6, kRowLu = 9, kRowH = 10, kRowLuu = 16;
+// dense byte counts the roofline is quoted against: 96 read + 14 written doubles
+constexpr int kDenseDoublesPerStep = 110;
+constexpr int kDenseDoublesTerminal = 44;
+
+struct Params {
+  int N, K;
+  int num_of_disc;
+  int max_iter;
+  double dt;
+  double wheel_base;
+  double w_jerk, w_delta_rate, w_x, w_y, w_theta, w_v, w_a, w_delta;
+  double abs_tol, rel_tol;
+  double max_velocity, min_acc, max_acc, jerk_min, jerk_max, delta_min, delta_max;
+  double delta_rate_min, delta_rate_max;
+  double bar_r;        // 1 / t            (barrier_function.h:85)
+  double bar_eps;      // epsilon
+  double bar_rlogeps;  // r * log(eps), evaluated once on the host in fp64
+  double disc_off[kMaxDiscs];  // L*(j-0.5) - rf   (ilqr_optimizer.cc:564)
+  double shrink_corridor;      // disc_radius + safe_margin   (cc:448)
+  double shrink_lane;          // disc_radius                 (cc:463)
+};
+
+struct DeviceState {
+  int Bcap;  // arena capacity (slots)
+  int cmax;
+  int nl, nr;  // lane segments
+  Params p;
+
+  double2* X;      // [2][K][3][Bcap]
+  double2* U;      // [2][N][Bcap]
+  int* cur;        // [Bcap] which X/U buffer is the current iterate
+  double2* goals;  // [K][3][Bcap]
+  double* cor;     // [K][cmax][3][Bcap]
+  int* ccnt;       // [K][Bcap]
+  double* lanes;   // [nl+nr][kLaneFields]
+  double2* lin;    // [N][17][Bcap]
+  double2* term;   // [9][Bcap]
+  double2* gains;  // [N][7][Bcap]
+  double* dV;      // [2][Bcap]
+  double* gnorm;   // [Bcap]
+  double2* part;   // [K][3][Bcap]
+  double* trial;   // [5][Bcap] cost components of the last evaluated trajectory
+  double* hist;    // [max_iter+1][5][Bcap]
+
+  // per-problem solver state (ilqr_optimizer.cc:180-199)
+  double* lambda;
+  double* dlambda;
+  double* cost_old;
+  double* dcost;     // of the accepted trial
+  int* iter;
+  int* status;
+  int* n_cost;
+  int* upd;          // is_forward_pass_updated
+  int* acc_idx;      // accepted alpha index of this iteration, -1 = none yet, -2 = left the line search
+  int* n_iter_trajs;
+  int* emit;         // iterate to append to iter_trajs this iteration
+
+  // work lists
+  int* act;          // active slots
+  int* act_next;
+  int* pend;         // [kNumAlpha+1][Bcap] line-search pending lists (round r uses list r)
+  int* counters;     // [0] = n_act_next, [1..kNumAlpha] = pending counts of rounds 1..10
+};
+
+// ---- launchers (one per kernel family; all asynchronous on `st`) ----
+struct ProblemView {  // device pointers to the problem-major inputs
+  const double* start;
+  const double* coarse;
+  const double* corridor;
+  const int* ccount;
+  int cmax_in;
+};
+
+void launch_load(const DeviceState& s, int B, const ProblemView& in, const double* lanes_raw,
+                 hipStream_t st);
+void launch_init_guess(const DeviceState& s, int B, hipStream_t st);
+void launch_set_trajectory(const DeviceState& s, int B, const double* X, const double* U, hipStream_t st);
+// cost of buffer (cur ^ cand) for the n listed slots -> trial[], no accept logic
+void launch_cost_only(const DeviceState& s, const int* list, int n, int cand, hipStream_t st);
+void launch_cost_knots(const DeviceState& s, const int* list, const int* n_ptr, int n_max, int n_grid,
+                       int cand, int skip_done, hipStream_t st);
+void launch_init_cost_commit(const DeviceState& s, int n, hipStream_t st);
+void launch_quadratize(const DeviceState& s, const int* list, int n, int only_upd, hipStream_t st);
+void launch_backward(const DeviceState& s, const int* list, int n, const double* lambda_override,
+                     hipStream_t st);
+void launch_forward(const DeviceState& s, const int* list, int n, double alpha, int skip_done,
+                    hipStream_t st);
+// the 11-round line search of one lockstep iteration (forward/cost/accept with compaction)
+void launch_linesearch(const DeviceState& s, int n_act, hipStream_t st);
+void launch_update(const DeviceState& s, int n_act, hipStream_t st);
+void launch_export_traj(const DeviceState& s, int B, double* traj, hipStream_t st);
+void launch_export_iter_traj(const DeviceState& s, const int* list, int n, double* iter_trajs,
+                             int max_iter_trajs, hipStream_t st);
+void launch_export_hist(const DeviceState& s, int B, double* cost_hist, int* n_cost, int* status,
+                        int* n_iter, int* n_iter_trajs, hipStream_t st);
+void launch_rollout(const Params& p, int B, const double* x0, const double* U, double* X, hipStream_t st);
+// stage_read helpers: gather a batch-fastest tensor into problem-major order
+void launch_gather_pairs(const double2* src, int rows_pairs, int Bcap, int B, double* dst,
+                         int dst_stride, int dst_off, hipStream_t st);
+void launch_gather_scalar(const double* src, int rows, int Bcap, int B, double* dst, int dst_stride,
+                          int dst_off, hipStream_t st);
+void launch_expand(const DeviceState& s, int B, int tensor, double* dst, hipStream_t st);
+void launch_gather_xu(const DeviceState& s, int B, int cand, double* X, double* U, hipStream_t st);
+
+}  // namespace cilqr

@@ -1,0 +1,186 @@
+/*
+ * include/cilqr.h -- C-ABI of the MI355X-native batched CILQR trajectory optimiser.
+ *
+ * Drop-in boundary for the reference's `planning::IlqrOptimizer`
+ * (algorithm/ilqr/ilqr_optimizer.h:29-52) and its stages.  Plain pointers and sizes only; no
+ * C++/torch types cross this boundary.  Every entry point returns 0 (CILQR_OK) or a negative
+ * error code and never throws.
+ *
+ * The reference has no FFI/plugin layer; what each entry replaces:
+ *   cilqr_default_config    IlqrConfig/Weights/VehicleParam default member initialisers
+ *                           (algorithm/params/planner_config.h:45-73, vehicle_param.h:21-64),
+ *                           RelaxBarrierFunction t/epsilon (algorithm/ilqr/barrier_function.h:144-145)
+ *   cilqr_create/destroy    IlqrOptimizer::IlqrOptimizer / Init   (ilqr_optimizer.cc:13-51)
+ *   cilqr_solve_batch       IlqrOptimizer::Plan + cost()          (ilqr_optimizer.cc:53-95, .h:50-52),
+ *                           B independent problems per call
+ *   cilqr_stage_*           the private stages of Optimize()      (ilqr_optimizer.cc:154-320):
+ *       load            TransformGoals cc:141, ShrinkConstraints cc:438, NormalizeHalfPlane cc:475
+ *       init_guess      iqr cc:793-842
+ *       total_cost      TotalCost cc:417-436
+ *       quadratize      DynamicsJacbian vehicle_model.cc:21 + CostJacbian cc:620 + CostHessian cc:638
+ *       backward        Backward cc:334-390 (+ CalGradientNorm cc:322)
+ *       forward         Forward cc:392-415
+ *   cilqr_open_loop_rollout ilqr::iLQR::OpenLoopRollout (algorithm/slover/ilqr.h:363-370) on
+ *                           VehicleModel::Dynamics (vehicle_model.cc:88-121)
+ *
+ * Layout convention: every per-problem array is problem-major ("[B][...]"), IEEE fp64,
+ * in host or device memory as flagged by `memory`.
+ */
+#ifndef CILQR_H_
+#define CILQR_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CILQR_ABI_VERSION 1
+
+#define CILQR_NX 6  /* state  (x, y, theta, v, a, delta)   vehicle_model.h:11 */
+#define CILQR_NU 2  /* control (jerk, delta_rate)           vehicle_model.h:12 */
+#define CILQR_TRAJ_FIELDS 10 /* time,x,y,theta,v,a,delta,kappa,jerk,delta_rate  (cc:771-791) */
+#define CILQR_COST_FIELDS 5  /* total,target,dynamic,corridor,lane_boundary     (h:14-27)    */
+#define CILQR_LANE_FIELDS 7  /* a,b,c,start_x,start_y,end_x,end_y               (corridor.h:24-25) */
+#define CILQR_MAX_DISCS 16
+#define CILQR_MAX_LANE_SEGMENTS 256
+
+/* error codes */
+#define CILQR_OK 0
+#define CILQR_ERR_NULL (-1)         /* null output / handle            (cc:64-66)  */
+#define CILQR_ERR_CONSTRAINTS (-2)  /* empty corridor or lane list     (cc:68-73)  */
+#define CILQR_ERR_KNOTS (-3)        /* n_knots != floor(horizon/dt+1)  (cc:75-78)  */
+#define CILQR_ERR_CAPACITY (-4)     /* batch / cmax / lane segments above what create() sized */
+#define CILQR_ERR_DEVICE (-5)       /* HIP runtime error or no gfx950 device */
+#define CILQR_ERR_ARG (-6)          /* invalid argument value */
+#define CILQR_ERR_STATE (-7)        /* stage called before the stage it depends on */
+
+/* per-problem termination status (exits of Optimize(), cc:154-320) */
+#define CILQR_ST_RUNNING 0
+#define CILQR_ST_CONVERGED_ABS 1 /* dcost < abs_cost_tol                  cc:281,287 */
+#define CILQR_ST_CONVERGED_REL 2 /* dcost / cost_old < rel_cost_tol      cc:282     */
+#define CILQR_ST_GNORM 3         /* gnorm < 1e-6 && lambda < 1e-5        cc:236     */
+#define CILQR_ST_UNSOLVED 4      /* lambda > 1e11                        cc:302     */
+#define CILQR_ST_MAX_ITER 5      /* iter == max_iter_num                 cc:312     */
+
+#define CILQR_MEM_HOST 0
+#define CILQR_MEM_DEVICE 1
+
+/* Live configuration fields only (dead ones -- IlqrConfig::t/t_rate/alpha/gamma/rho,
+ * planner_config.h:60-61,68-70 -- are not carried). */
+typedef struct cilqr_config {
+  int32_t n_steps;       /* N; knots K = N+1 = floor(horizon/dt + 1)  (cc:22) */
+  int32_t num_of_disc;   /* planner_config.h:58 */
+  int32_t max_iter;      /* :63 */
+  int32_t reserved0;
+  double dt;             /* delta_t, :94 */
+  double safe_margin;    /* :59 */
+  double w_jerk, w_delta_rate, w_x, w_y, w_theta, w_v, w_a, w_delta; /* Weights :45-55 */
+  double abs_cost_tol, rel_cost_tol;                                  /* :65-66 */
+  double front_hang, wheel_base, rear_hang, width;                    /* vehicle_param.h:26-41 */
+  double max_velocity, min_acceleration, max_acceleration;            /* :46-52 */
+  double jerk_min, jerk_max, delta_min, delta_max, delta_rate_min, delta_rate_max; /* :57-64 */
+  double barrier_t, barrier_eps;                                      /* barrier_function.h:144-145 */
+} cilqr_config;
+
+typedef struct cilqr_solver* cilqr_handle;
+
+/* Inputs of IlqrOptimizer::Plan (ilqr_optimizer.h:41-48) for B problems. */
+typedef struct cilqr_problem_batch {
+  int32_t batch;                 /* B */
+  int32_t n_knots;               /* K; must equal n_steps + 1 */
+  int32_t cmax;                  /* planes stored per knot in `corridor` (<= create() cmax) */
+  int32_t memory;                /* CILQR_MEM_* of start/coarse/corridor/corridor_count */
+  const double* start;           /* [B][4]  x, y, theta, velocity  (cc:151) */
+  const double* coarse;          /* [B][K][6]  x, y, theta, velocity, a, delta  (cc:148) */
+  const double* corridor;        /* [B][K][cmax][3]  a, b, c with "a x + b y < c"  (corridor.h:19-21) */
+  const int32_t* corridor_count; /* [B][K]  live planes per knot */
+  int32_t n_left, n_right;       /* lane segments, shared by the whole batch */
+  const double* left_lane;       /* [n_left][7]  HOST memory */
+  const double* right_lane;      /* [n_right][7] HOST memory */
+} cilqr_problem_batch;
+
+/* Outputs of Plan + cost().  iter_trajs is optional (NULL to skip). */
+typedef struct cilqr_solution_batch {
+  int32_t memory;                /* CILQR_MEM_* of every pointer below */
+  int32_t max_iter_trajs;        /* capacity per problem of iter_trajs */
+  double* traj;                  /* [B][K][10] */
+  double* cost_hist;             /* [B][max_iter+1][5]; rows >= n_cost[b] are left untouched */
+  int32_t* n_cost;               /* [B] */
+  int32_t* status;               /* [B] CILQR_ST_* */
+  int32_t* n_iter;               /* [B] iterations started */
+  double* iter_trajs;            /* [B][max_iter_trajs][K][10]: init guess + accepted non-final iterates (cc:170,294) */
+  int32_t* n_iter_trajs;         /* [B] number that would have been produced (may exceed the capacity) */
+} cilqr_solution_batch;
+
+/* Per-solve kernel timing, filled when profiling is on (cilqr_set_profiling). */
+typedef struct cilqr_profile {
+  int32_t iterations;            /* lockstep outer iterations of the last solve */
+  int32_t backward_launches;
+  double backward_ms;            /* sum of HIP-event durations of the backward kernel */
+  double quadratize_ms;
+  double linesearch_ms;          /* forward + cost + reduce kernels */
+  double other_ms;               /* load, init guess, update, export */
+  double total_ms;               /* first kernel start -> last kernel end */
+  int64_t backward_problem_steps;/* sum over launches of (active problems x N) */
+} cilqr_profile;
+
+int cilqr_abi_version(void);
+int cilqr_default_config(cilqr_config* cfg, int32_t n_steps);
+
+/* device: HIP ordinal.  batch_capacity/cmax/max_lane_segments size the HBM arena once. */
+int cilqr_create(const cilqr_config* cfg, int32_t device, int32_t batch_capacity, int32_t cmax,
+                 int32_t max_lane_segments, cilqr_handle* out);
+int cilqr_destroy(cilqr_handle h);
+/* hipStream_t to launch on (NULL = the handle's own stream). */
+int cilqr_set_stream(cilqr_handle h, void* hip_stream);
+int cilqr_set_profiling(cilqr_handle h, int32_t enable);
+int cilqr_get_profile(cilqr_handle h, cilqr_profile* out);
+/* bytes of device memory held by the handle */
+int64_t cilqr_device_bytes(cilqr_handle h);
+
+int cilqr_solve_batch(cilqr_handle h, const cilqr_problem_batch* in, cilqr_solution_batch* out);
+
+/* ---- stage entry points (operate on the handle's device state, whole batch) ---- */
+int cilqr_stage_load(cilqr_handle h, const cilqr_problem_batch* in);
+int cilqr_stage_init_guess(cilqr_handle h);
+/* overwrite the current iterate: X [B][K][6], U [B][N][2] */
+int cilqr_stage_set_trajectory(cilqr_handle h, const double* X, const double* U, int32_t memory);
+/* cost of the current iterate: cost5 [B][5] */
+int cilqr_stage_total_cost(cilqr_handle h, double* cost5, int32_t memory);
+int cilqr_stage_quadratize(cilqr_handle h);
+/* lambda: [B] regularisation per problem, or NULL to use the solver state */
+int cilqr_stage_backward(cilqr_handle h, const double* lambda, int32_t memory);
+/* roll out with step alpha into the candidate buffers */
+int cilqr_stage_forward(cilqr_handle h, double alpha);
+
+/* tensors readable with cilqr_stage_read, all returned problem-major fp64 */
+#define CILQR_T_GOALS 0      /* [B][K][6] */
+#define CILQR_T_CORRIDOR 1   /* [B][K][cmax][3] shrunk + normalised (create() cmax) */
+#define CILQR_T_LANES 2      /* [n_left+n_right][3] shrunk + normalised a,b,c (left rows first) */
+#define CILQR_T_X 3          /* [B][K][6] current iterate */
+#define CILQR_T_U 4          /* [B][N][2] */
+#define CILQR_T_XCAND 5      /* [B][K][6] candidate of the last forward */
+#define CILQR_T_UCAND 6      /* [B][N][2] */
+#define CILQR_T_A 7          /* [B][N][6][6] */
+#define CILQR_T_B 8          /* [B][N][6][2] */
+#define CILQR_T_LX 9         /* [B][K][6] */
+#define CILQR_T_LU 10        /* [B][N][2] */
+#define CILQR_T_LXX 11       /* [B][K][6][6] */
+#define CILQR_T_LUU 12       /* [B][N][2][2] */
+#define CILQR_T_KFB 13       /* [B][N][2][6] feedback gains K */
+#define CILQR_T_KFF 14       /* [B][N][2] feedforward k */
+#define CILQR_T_DV 15        /* [B][2] delta_V_ */
+#define CILQR_T_GNORM 16     /* [B] */
+int cilqr_stage_read(cilqr_handle h, int32_t tensor, double* dst, int32_t memory);
+
+/* X[b][0] = x0[b]; X[b][i+1] = Dynamics(X[b][i], U[b][i]).  x0 [B][6], U [B][N][2], X [B][K][6] */
+int cilqr_open_loop_rollout(cilqr_handle h, int32_t batch, const double* x0, const double* U,
+                            double* X, int32_t memory);
+
+const char* cilqr_error_string(int code);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CILQR_H_ */

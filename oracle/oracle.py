@@ -1,0 +1,238 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product (cilqr_amd/, include/) never imports this.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+_CFG_FIELDS = [
+    ("n_steps", C.c_int), ("dt", C.c_double), ("num_of_disc", C.c_int), ("safe_margin", C.c_double),
+    ("w_jerk", C.c_double), ("w_delta_rate", C.c_double), ("w_x", C.c_double), ("w_y", C.c_double),
+    ("w_theta", C.c_double), ("w_v", C.c_double), ("w_a", C.c_double), ("w_delta", C.c_double),
+    ("max_iter", C.c_int), ("abs_cost_tol", C.c_double), ("rel_cost_tol", C.c_double),
+    ("front_hang", C.c_double), ("wheel_base", C.c_double), ("rear_hang", C.c_double),
+    ("width", C.c_double), ("max_velocity", C.c_double), ("min_acceleration", C.c_double),
+    ("max_acceleration", C.c_double), ("jerk_min", C.c_double), ("jerk_max", C.c_double),
+    ("delta_min", C.c_double), ("delta_max", C.c_double), ("delta_rate_min", C.c_double),
+    ("delta_rate_max", C.c_double), ("barrier_t", C.c_double), ("barrier_eps", C.c_double),
+]
+
+
+class OracleConfig(C.Structure):
+    _fields_ = _CFG_FIELDS
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "cilqr_oracle.cc")
+    if force or not os.path.exists(so) or (
+            os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        L.oracle_create.restype = C.c_void_p
+        L.oracle_create.argtypes = [C.POINTER(OracleConfig)]
+        L.oracle_destroy.argtypes = [C.c_void_p]
+        L.oracle_total_cost.restype = C.c_double
+        L.oracle_grad_norm.restype = C.c_double
+        L.oracle_normalize_angle.restype = C.c_double
+        L.oracle_normalize_angle.argtypes = [C.c_double]
+        L.oracle_segment_distance.restype = C.c_double
+        L.oracle_barrier_value.restype = C.c_double
+        _LIB = L
+    return _LIB
+
+
+def default_config(n_steps: int = 50, **over) -> OracleConfig:
+    c = OracleConfig()
+    lib().oracle_default_config(C.byref(c), C.c_int(n_steps))
+    for k, v in over.items():
+        setattr(c, k, v)
+    return c
+
+
+def _p(a, t=C.c_double):
+    return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Oracle:
+    """One problem at a time; mirrors IlqrOptimizer (ilqr_optimizer.h:29-52) + its stages."""
+
+    def __init__(self, cfg: OracleConfig | None = None, n_steps: int = 50):
+        self.cfg = cfg or default_config(n_steps)
+        self.N = self.cfg.n_steps
+        self.K = self.N + 1
+        self.L = lib()
+        self.h = C.c_void_p(self.L.oracle_create(C.byref(self.cfg)))
+        self.cmax = 0
+        self.nl = self.nr = 0
+
+    def __del__(self):
+        try:
+            self.L.oracle_destroy(self.h)
+        except Exception:
+            pass
+
+    def set_problem(self, start, coarse, corridor, ccount, left, right) -> int:
+        start, coarse, corridor = _f64(start), _f64(coarse), _f64(corridor)
+        ccount = np.ascontiguousarray(ccount, dtype=np.int32)
+        left, right = _f64(left), _f64(right)
+        self.cmax = corridor.shape[1] if corridor.ndim == 3 else 0
+        self.nl, self.nr = left.shape[0], right.shape[0]
+        return self.L.oracle_set_problem(self.h, _p(start), _p(coarse), C.c_int(coarse.shape[0]),
+                                         _p(corridor) if corridor.size else None,
+                                         _p(ccount, C.c_int) if ccount.size else None,
+                                         C.c_int(self.cmax), _p(left), C.c_int(self.nl), _p(right),
+                                         C.c_int(self.nr))
+
+    def plan(self, max_iter_trajs: int = 0, want_trace: bool = False):
+        K, M = self.K, self.cfg.max_iter
+        traj = np.zeros((K, 10))
+        hist = np.zeros((M + 1, 5))
+        n_cost, status, n_iter, n_it = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        it = np.zeros((max_iter_trajs, K, 10)) if max_iter_trajs else None
+        trace = np.zeros((M, 8)) if want_trace else None
+        margin = C.c_double()
+        rc = self.L.oracle_plan(self.h, _p(traj), _p(hist), C.byref(n_cost), C.byref(status),
+                                C.byref(n_iter), _p(it), C.c_int(max_iter_trajs), C.byref(n_it),
+                                _p(trace), C.byref(margin))
+        return dict(rc=rc, traj=traj, cost_hist=hist, n_cost=n_cost.value, status=status.value,
+                    n_iter=n_iter.value, iter_trajs=it, n_iter_trajs=n_it.value,
+                    trace=trace[:n_iter.value] if trace is not None else None,
+                    min_margin=margin.value)
+
+    # ---- stages ----
+    def constraints(self):
+        goals = np.zeros((self.K, 6))
+        cor = np.zeros((self.K, self.cmax, 3))
+        l = np.zeros((self.nl, 3))
+        r = np.zeros((self.nr, 3))
+        rad = C.c_double()
+        self.L.oracle_get_constraints(self.h, _p(goals), _p(cor), _p(l), _p(r), C.byref(rad))
+        return goals, cor, l, r, rad.value
+
+    def init_guess(self):
+        X, U = np.zeros((self.K, 6)), np.zeros((self.N, 2))
+        self.L.oracle_init_guess(self.h, _p(X), _p(U))
+        return X, U
+
+    def open_loop_rollout(self, x0, U):
+        x0, U = _f64(x0), _f64(U)
+        X = np.zeros((self.K, 6))
+        self.L.oracle_open_loop_rollout(self.h, _p(x0), _p(U), _p(X))
+        return X
+
+    def total_cost(self, X, U):
+        X, U = _f64(X), _f64(U)
+        c5 = np.zeros(5)
+        self.L.oracle_total_cost(self.h, _p(X), _p(U), _p(c5))
+        return c5
+
+    def quadratize(self, X, U):
+        X, U = _f64(X), _f64(U)
+        N, K = self.N, self.K
+        out = dict(A=np.zeros((N, 6, 6)), B=np.zeros((N, 6, 2)), lx=np.zeros((K, 6)),
+                   lu=np.zeros((N, 2)), lxx=np.zeros((K, 6, 6)), luu=np.zeros((N, 2, 2)))
+        self.L.oracle_quadratize(self.h, _p(X), _p(U), _p(out["A"]), _p(out["B"]), _p(out["lx"]),
+                                 _p(out["lu"]), _p(out["lxx"]), _p(out["luu"]))
+        return out
+
+    def backward(self, lam, q):
+        N = self.N
+        Kfb, kff, dV = np.zeros((N, 2, 6)), np.zeros((N, 2)), np.zeros(2)
+        a = {k: _f64(v) for k, v in q.items()}
+        self.L.oracle_backward(self.h, C.c_double(lam), _p(a["A"]), _p(a["B"]), _p(a["lx"]),
+                               _p(a["lu"]), _p(a["lxx"]), _p(a["luu"]), _p(Kfb), _p(kff), _p(dV))
+        return Kfb, kff, dV
+
+    def grad_norm(self, kff, U):
+        kff, U = _f64(kff), _f64(U)
+        return self.L.oracle_grad_norm(self.h, _p(kff), _p(U))
+
+    def forward(self, alpha, X, U, Kfb, kff):
+        X, U, Kfb, kff = _f64(X), _f64(U), _f64(Kfb), _f64(kff)
+        Xn, Un = np.zeros_like(X), np.zeros_like(U)
+        self.L.oracle_forward(self.h, C.c_double(alpha), _p(X), _p(U), _p(Kfb), _p(kff), _p(Xn), _p(Un))
+        return Xn, Un
+
+    def dynamics(self, x, u):
+        x, u = _f64(x), _f64(u)
+        xn = np.zeros(6)
+        self.L.oracle_dynamics(self.h, _p(x), _p(u), _p(xn))
+        return xn
+
+    def dynamics_jacobian(self, x, u):
+        x, u = _f64(x), _f64(u)
+        A, B = np.zeros((6, 6)), np.zeros((6, 2))
+        self.L.oracle_dynamics_jacobian(self.h, _p(x), _p(u), _p(A), _p(B))
+        return A, B
+
+    def barrier_value(self, g):
+        return self.L.oracle_barrier_value(self.h, C.c_double(g))
+
+    def barrier_jacobian(self, g, dg):
+        dg = _f64(dg)
+        out = np.zeros_like(dg)
+        self.L.oracle_barrier_jacobian(self.h, C.c_double(g), _p(dg), C.c_int(dg.size), _p(out))
+        return out
+
+    def barrier_hessian(self, g, dg, ddg=None):
+        dg = _f64(dg)
+        n = dg.size
+        ddg = _f64(ddg) if ddg is not None else None
+        out = np.zeros((n, n))
+        self.L.oracle_barrier_hessian(self.h, C.c_double(g), _p(dg), _p(ddg), C.c_int(n), _p(out))
+        return out
+
+
+def normalize_angle(a: float) -> float:
+    return lib().oracle_normalize_angle(C.c_double(a))
+
+
+def segment_distance(seg4, px, py) -> float:
+    seg4 = _f64(seg4)
+    return lib().oracle_segment_distance(_p(seg4), C.c_double(px), C.c_double(py))
+
+
+def solve_batch(scene: dict, cfg: OracleConfig | None = None, want_margin: bool = True):
+    """Loop of independent Plan() calls over a problem-major scene dict (scenario.generate)."""
+    start, coarse = _f64(scene["start"]), _f64(scene["coarse"])
+    corridor = _f64(scene["corridor"])
+    ccount = np.ascontiguousarray(scene["ccount"], dtype=np.int32)
+    left, right = _f64(scene["left"]), _f64(scene["right"])
+    B, K = coarse.shape[0], coarse.shape[1]
+    cfg = cfg or default_config(K - 1)
+    assert cfg.n_steps == K - 1
+    M = cfg.max_iter
+    traj = np.zeros((B, K, 10))
+    hist = np.zeros((B, M + 1, 5))
+    n_cost = np.zeros(B, np.int32)
+    status = np.zeros(B, np.int32)
+    n_iter = np.zeros(B, np.int32)
+    margin = np.zeros(B) if want_margin else None
+    sec = C.c_double()
+    rc = lib().oracle_solve_batch(C.byref(cfg), C.c_int(B), _p(start), _p(coarse), _p(corridor),
+                                  _p(ccount, C.c_int), C.c_int(corridor.shape[2]), _p(left),
+                                  C.c_int(left.shape[0]), _p(right), C.c_int(right.shape[0]), _p(traj),
+                                  _p(hist), _p(n_cost, C.c_int), _p(status, C.c_int),
+                                  _p(n_iter, C.c_int), _p(margin), C.byref(sec))
+    return dict(rc=rc, traj=traj, cost_hist=hist, n_cost=n_cost, status=status, n_iter=n_iter,
+                min_margin=margin, seconds=sec.value)
