@@ -1,0 +1,201 @@
+#!/usr/bin/env python
+"""bench.py -- CILQR solves/sec on MI355X (BASELINE.json metric).
+
+One "step" = one cilqr_solve_batch over the whole per-GPU batch (inputs already resident in HBM):
+load/prepare -> init guess -> lockstep iLQR iterations until every problem terminated -> export.
+Workload (config.workload): BASELINE.json configs[2] -- batch 65536 per GPU, 50-step horizon,
+6 pedestrians + 3 moving + 2 static vehicles ("mix11" scenes of cilqr_amd.scenario).  With
+--gpus N every rank solves its own 65536 scenes (weak scaling, configs[3] at N=8) and the
+results are gathered to rank 0 with one RCCL gather per output tensor inside the timed region.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     backward-pass kernel: algorithmic bytes ((N*110+44)*8 B per problem
+               per launch) / HIP-event time of the launches, against the 8 TB/s HBM peak
+  cpu_baseline the CPU oracle (single thread) on a bounded sample of the same scenes
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=65536, help="problems per GPU")
+    ap.add_argument("--scene", default="mix11")
+    ap.add_argument("--seed", type=int, default=2)
+    ap.add_argument("--cpu-sample", type=int, default=1024, help="problems timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
+    ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "backward_traffic.json"))
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU path exists)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from cilqr_amd import api, scenario
+    from cilqr_amd.distributed import gather_results
+
+    spec = scenario.SPECS[args.scene]
+    B, N, K, cmax = args.batch, spec.n_steps, spec.n_steps + 1, spec.cmax
+    t0 = time.time()
+    workers = max(1, min(32, (os.cpu_count() or 8) // max(1, world)))
+    sc = scenario.generate(spec, B, seed=args.seed, first_problem=rank * B, workers=workers)
+    t_gen = time.time() - t0
+
+    cfg = api.default_config(N)
+    M = cfg.max_iter
+    opt = api.BatchIlqrOptimizer(cfg, device=local_rank, batch_capacity=B, cmax=cmax,
+                                 max_lane_segments=max(sc["left"].shape[0], sc["right"].shape[0]))
+    opt.set_stream(torch.cuda.current_stream().cuda_stream)
+    opt.set_profiling(not args.no_profile)
+
+    d_start = torch.from_numpy(sc["start"]).to(dev)
+    d_coarse = torch.from_numpy(sc["coarse"]).to(dev)
+    d_cor = torch.from_numpy(sc["corridor"]).to(dev)
+    d_cnt = torch.from_numpy(sc["ccount"]).to(dev)
+    left = np.ascontiguousarray(sc["left"])
+    right = np.ascontiguousarray(sc["right"])
+    prob = opt.make_problem(B, d_start.data_ptr(), d_coarse.data_ptr(), d_cor.data_ptr(), d_cnt.data_ptr(),
+                            cmax, left.ctypes.data, right.ctypes.data, left.shape[0], right.shape[0],
+                            api.MEM_DEVICE)
+    o_traj = torch.zeros((B, K, 10), dtype=torch.float64, device=dev)
+    o_hist = torch.zeros((B, M + 1, 5), dtype=torch.float64, device=dev)
+    o_nc = torch.zeros(B, dtype=torch.int32, device=dev)
+    o_st = torch.zeros(B, dtype=torch.int32, device=dev)
+    o_ni = torch.zeros(B, dtype=torch.int32, device=dev)
+    sol = api.SolutionBatch(api.MEM_DEVICE, 0, o_traj.data_ptr(), o_hist.data_ptr(), o_nc.data_ptr(),
+                            o_st.data_ptr(), o_ni.data_ptr(), None, None)
+
+    def step():
+        rc = opt.solve_raw(prob, sol)
+        if rc != api.OK:
+            raise api.CilqrError(rc, "in bench step")
+        if world > 1:
+            return gather_results(o_traj, o_hist, o_nc, o_st, dst=0)
+        return None
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    prof_acc = dict(bwd_ms=0.0, bwd_launches=0, bwd_steps=0, quad_ms=0.0, ls_ms=0.0, other_ms=0.0,
+                    total_ms=0.0, iters=0)
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        p = opt.profile()
+        prof_acc["bwd_ms"] += p.backward_ms
+        prof_acc["bwd_launches"] += p.backward_launches
+        prof_acc["bwd_steps"] += p.backward_problem_steps
+        prof_acc["quad_ms"] += p.quadratize_ms
+        prof_acc["ls_ms"] += p.linesearch_ms
+        prof_acc["other_ms"] += p.other_ms
+        prof_acc["total_ms"] += p.total_ms
+        prof_acc["iters"] += p.iterations
+    fence()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # sanity: every problem must have terminated with a valid status
+    st = o_st.cpu().numpy()
+    nc = o_nc.cpu().numpy()
+    assert ((st >= 1) & (st <= 5)).all() and (nc >= 1).all(), "unterminated problems in the batch"
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = world * B * args.steps / elapsed
+        roof = None
+        if not args.no_profile and prof_acc["bwd_ms"] > 0:
+            # algorithmic bytes: per launch n_act*(N*110+44)*8; backward_problem_steps = sum n_act*N
+            n_act_sum = prof_acc["bwd_steps"] / N
+            alg_bytes = n_act_sum * (N * api.DENSE_DOUBLES_PER_STEP + api.DENSE_DOUBLES_TERMINAL) * 8.0
+            achieved = alg_bytes / (prof_acc["bwd_ms"] * 1e-3) / 1e9
+            traffic = None
+            if os.path.exists(args.traffic_file):
+                try:
+                    with open(args.traffic_file) as f:
+                        tf = json.load(f)
+                    # measured HBM bytes per problem-step (rocprofv3 PMC, corrected per the guide)
+                    traffic = tf["hbm_bytes_per_problem_step"] * prof_acc["bwd_steps"] / prof_acc["bwd_launches"]
+                except Exception:
+                    traffic = None
+            roof = {
+                "bound": "hbm", "kernel": "cilqr::k_backward",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": traffic,
+                "algorithmic_bytes_per_launch": alg_bytes / prof_acc["bwd_launches"],
+                "avg_launch_ms": prof_acc["bwd_ms"] / prof_acc["bwd_launches"],
+                "launches": prof_acc["bwd_launches"],
+            }
+        cpu = None
+        if args.cpu_sample > 0:
+            from oracle import oracle as orc
+            ns = min(args.cpu_sample, B)
+            sub = {k: (v[:ns] if isinstance(v, np.ndarray) and v.shape[:1] == (B,) else v) for k, v in sc.items()}
+            ocfg = orc.OracleConfig()
+            for name, _ in orc.OracleConfig._fields_:
+                setattr(ocfg, name, getattr(cfg, name))
+            r = orc.solve_batch(sub, ocfg, want_margin=False)
+            cpu = {"value": round(ns / r["seconds"], 2), "unit": "solves/s", "cores": 1, "kind": "port",
+                   "sample": f"first {ns} scenes of rank 0's batch, single thread, g++ -O2 restatement "
+                             f"(oracle/cilqr_oracle.cc), {r['seconds']:.1f} s"}
+        out = {
+            "metric": "CILQR solves/sec (50-step horizon, batch=65536 per GPU)",
+            "value": round(value, 1), "unit": "solves/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[2]: batch={B}/GPU x {world} GPU, {N}-step horizon, "
+                                   f"scene family {args.scene} (6 pedestrians + 3 moving + 2 static vehicles), "
+                                   f"reference road, seed {args.seed}",
+                       "batch_per_gpu": B, "n_steps": N, "cmax": cmax, "results_gather": "rccl" if world > 1 else "none"},
+            "roofline": roof,
+            "cpu_baseline": cpu,
+            "breakdown_ms_per_step": {k: round(prof_acc[k] / args.steps, 3)
+                                      for k in ("quad_ms", "bwd_ms", "ls_ms", "other_ms", "total_ms")},
+            "lockstep_iterations_per_step": prof_acc["iters"] / args.steps,
+            "mean_cost_rows": float(nc.mean()),
+            "status_histogram": np.bincount(st, minlength=6).tolist(),
+            "scene_generation_s": round(t_gen, 1),
+            "device_bytes": opt.device_bytes(),
+        }
+        print(json.dumps(out), flush=True)
+    opt.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -174,10 +174,16 @@ def _rect_nearest(ox, oy, cx, cy, cth, hl, hw):
     return wx, wy, inside
 
 
+def _chunk_job(args):
+    spec, n, seed, first, road = args
+    return _generate_chunk(spec, n, seed, first, road)
+
+
 def generate(spec: SceneSpec | str, batch: int, seed: int = 0, first_problem: int = 0,
-             road: Road | None = None, chunk: int = 2048):
+             road: Road | None = None, chunk: int = 1024, workers: int = 0):
     """Generate `batch` scenes; problem p uses RNG stream (seed, first_problem + p).
 
+    workers > 1 spreads the chunks over a thread pool (results are identical).
     Returns dict(start[B,4], coarse[B,K,6], corridor[B,K,cmax,3], ccount[B,K] int32,
                  left[S,7], right[S,7], n_steps, dt, cmax).
     """
@@ -185,10 +191,16 @@ def generate(spec: SceneSpec | str, batch: int, seed: int = 0, first_problem: in
         spec = SPECS[spec]
     road = road or build_road()
     left, right = lane_constraints(road)
-    outs = []
-    for c0 in range(0, batch, chunk):
-        n = min(chunk, batch - c0)
-        outs.append(_generate_chunk(spec, n, seed, first_problem + c0, road))
+    jobs = [(spec, min(chunk, batch - c0), seed, first_problem + c0, road)
+            for c0 in range(0, batch, chunk)]
+    if workers > 1 and len(jobs) > 1:
+        # threads, not processes: numpy releases the GIL inside its loops, and forking a process
+        # that has HIP/rocprofv3 loaded is not safe
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(min(workers, len(jobs))) as pool:
+            outs = list(pool.map(_chunk_job, jobs))
+    else:
+        outs = [_chunk_job(j) for j in jobs]
     out = {k: np.concatenate([o[k] for o in outs], axis=0) for k in outs[0]}
     out.update(left=left, right=right, n_steps=spec.n_steps, dt=spec.dt, cmax=spec.cmax)
     return out
@@ -203,6 +215,8 @@ def _uniforms(seed, first, n, m):
 
 
 def _generate_chunk(spec: SceneSpec, B: int, seed: int, first: int, road: Road):
+    # Array convention inside: obstacle / candidate axes first, (problem, knot) last, so numpy's
+    # inner loops run over B*K contiguous elements.
     N, dt = spec.n_steps, spec.dt
     K = N + 1
     T = N * dt
@@ -218,45 +232,45 @@ def _generate_chunk(spec: SceneSpec, B: int, seed: int, first: int, road: Road):
     l0 = -3.5 + R[:, 2] * 4.0                       # start lateral in [-3.5, 0.5]
     dv = (R[:, 3] - 0.5) * 2.0                      # end-of-horizon speed change
     th_noise = (R[:, 4] - 0.5) * 0.1
-    v_t = v0[:, None] + dv[:, None] * (t[None, :] / T)            # [B,K]
-    v_t = np.clip(v_t, 2.0, 18.0)
+    v_t = np.clip(v0[:, None] + dv[:, None] * (t[None, :] / T), 2.0, 18.0)     # [B,K]
     s_t = s0[:, None] + np.concatenate(
         [np.zeros((B, 1)), np.cumsum(0.5 * (v_t[:, 1:] + v_t[:, :-1]) * dt, axis=1)], axis=1)
     s_t = np.minimum(s_t, road.length - 1.0)
 
-    # ---- obstacles: per obstacle (kind, station, lateral path, speed, timing) ----
-    ro = R[:, 8:8 + 6 * O].reshape(B, O, 6)
+    # ---- obstacles [O,B,(K)]: kind, station, lateral path, speed, timing ----
+    ro = np.ascontiguousarray(R[:, 8:8 + 6 * O].reshape(B, O, 6).transpose(1, 2, 0))   # [O,6,B]
     kind = np.concatenate([np.zeros(spec.n_pedestrians, int), np.ones(spec.n_dynamic, int),
                            2 * np.ones(spec.n_static, int)])  # 0 ped, 1 moving vehicle, 2 static
-    span = (s_t[:, -1] - s0)[:, None]
-    st_o = s0[:, None] + 8.0 + ro[:, :, 0] * (span + 6.0)          # station at t = t_on
-    hl = np.where(kind == 0, 0.5, 2.0)[None, :].repeat(B, 0)
-    hw = np.where(kind == 0, 0.5, 1.0)[None, :].repeat(B, 0)
+    is_ped = (kind == 0)[:, None, None]
+    is_dyn = (kind == 1)[:, None, None]
+    span = (s_t[:, -1] - s0)[None, :]
+    st_o = s0[None, :] + 8.0 + ro[:, 0] * (span + 6.0)             # [O,B] station at t = 0
+    hl = np.where(kind == 0, 0.5, 2.0)[:, None, None]
+    hw = np.where(kind == 0, 0.5, 1.0)[:, None, None]
     # pedestrians: lateral sweeps road_ub -> road_lb (or back) at 0.4..1.4 m/s from t_on = ds/20
     road_lb, road_ub = -RIGHT_BOUND - 1.0, LEFT_BOUND + 1.0
-    ped_v = 0.4 + ro[:, :, 1]
-    ped_dir = np.where(ro[:, :, 2] > 0.5, -1.0, 1.0)               # -1: ub -> lb
-    ped_t_on = (st_o - s0[:, None]) / 20.0
+    ped_v = 0.4 + ro[:, 1]
+    ped_dir = np.where(ro[:, 2] > 0.5, -1.0, 1.0)                  # -1: ub -> lb
+    ped_t_on = (st_o - s0[None, :]) / 20.0
     ped_dur = (road_ub - road_lb) / ped_v
     # vehicles: lateral 0 / -4 moving at 4..6 m/s; static: lateral {1, 0, -4}
-    veh_l = np.where(ro[:, :, 2] > 0.5, 0.0, -4.0)
-    sta_l = np.choose((ro[:, :, 2] * 3).astype(int).clip(0, 2), [1.0, 0.0, -4.0])
-    veh_v = 4.0 + 2.0 * ro[:, :, 1]
+    veh_l = np.where(ro[:, 2] > 0.5, 0.0, -4.0)
+    sta_l = np.choose((ro[:, 2] * 3).astype(int).clip(0, 2), [1.0, 0.0, -4.0])
+    veh_v = 4.0 + 2.0 * ro[:, 1]
 
-    tt = t[None, None, :]                                          # [1,1,K]
-    k3 = kind[None, :, None]
-    tau = np.clip(tt - ped_t_on[:, :, None], 0.0, ped_dur[:, :, None])
+    tt = np.broadcast_to(t[None, None, :], (O, B, K))
+    tau = np.minimum(np.maximum(tt - ped_t_on[:, :, None], 0.0), ped_dur[:, :, None])
     ped_l = np.where(ped_dir[:, :, None] < 0, road_ub - ped_v[:, :, None] * tau,
                      road_lb + ped_v[:, :, None] * tau)
     ped_live = (tt >= ped_t_on[:, :, None] - 1e-10) & (tt <= (ped_t_on + ped_dur)[:, :, None] + 1e-10)
-    o_s = np.where(k3 == 1, st_o[:, :, None] + veh_v[:, :, None] * tt, st_o[:, :, None] + 0.0 * tt)
+    o_s = np.where(is_dyn, st_o[:, :, None] + veh_v[:, :, None] * tt, st_o[:, :, None] + 0.0 * tt)
     o_s = np.minimum(o_s, road.length - 1.0)
-    o_l = np.where(k3 == 0, ped_l, np.where(k3 == 1, veh_l[:, :, None], sta_l[:, :, None]) + 0.0 * tt)
-    o_live = np.where(k3 == 0, ped_live, np.ones_like(ped_live))
+    o_l = np.where(is_ped, ped_l, np.where(is_dyn, veh_l[:, :, None], sta_l[:, :, None]) + 0.0 * tt)
+    o_live = np.where(is_ped, ped_live, np.ones_like(ped_live))
     ox_c, oy_c, oth_c, _ = road.eval(o_s)
     o_x = ox_c - o_l * np.sin(oth_c)
     o_y = oy_c + o_l * np.cos(oth_c)
-    o_th = np.where(k3 == 0, 0.0, oth_c)                           # pedestrians axis-aligned (publisher: theta=0)
+    o_th = np.where(is_ped, 0.0, oth_c)                            # pedestrians axis-aligned (publisher: theta=0)
 
     # ---- candidate lateral profiles: NT layer targets, piecewise linear in time ----
     rc = R[:, 8 + 6 * O:].reshape(B, C, NT)
@@ -269,38 +283,39 @@ def _generate_chunk(spec: SceneSpec, B: int, seed: int, first: int, road: Road):
         lay[:, :, j + 1] = np.clip(lay[:, :, j] + step, -RIGHT_BOUND + 1.6, LEFT_BOUND - 1.6)
     lay[:, 0, 1:] = np.clip(l0[:, None], -RIGHT_BOUND + 1.6, LEFT_BOUND - 1.6)
     tl = np.linspace(0.0, T, NT + 1)
-    # l(t) for every candidate: [B,C,K]
     seg = np.clip(np.searchsorted(tl, t, side="right") - 1, 0, NT - 1)
     w = (t - tl[seg]) / (tl[seg + 1] - tl[seg])
-    l_c = lay[:, :, seg] * (1.0 - w)[None, None, :] + lay[:, :, seg + 1] * w[None, None, :]
     ex_c, ey_c, eth_c, ekap_c = road.eval(s_t)                     # [B,K]
-    px = ex_c[:, None, :] - l_c * np.sin(eth_c)[:, None, :]        # [B,C,K]
-    py = ey_c[:, None, :] + l_c * np.cos(eth_c)[:, None, :]
-    # clearance of the ego centre path to every live obstacle rectangle
-    qx, qy, inside = _rect_nearest(px[:, :, None, :], py[:, :, None, :], o_x[:, None], o_y[:, None],
-                                   o_th[:, None] + 0.0 * o_x[:, None], hl[:, None, :, None],
-                                   hw[:, None, :, None])
-    dist = np.hypot(qx - px[:, :, None, :], qy - py[:, :, None, :])
-    dist = np.where(inside, 0.0, dist)
-    dist = np.where(o_live[:, None], dist, 1e3)
-    clear = dist.min(axis=(2, 3))                                  # [B,C]
-    effort = np.abs(np.diff(lay, axis=2)).sum(axis=2)
+    sin_e, cos_e = np.sin(eth_c), np.cos(eth_c)
+    clear = np.empty((C, B))
+    o_clear_c = np.empty((C, O, B))
+    l_c = np.empty((C, B, K))
+    for c in range(C):
+        l_c[c] = lay[:, c, seg] * (1.0 - w)[None, :] + lay[:, c, seg + 1] * w[None, :]
+        px = ex_c - l_c[c] * sin_e
+        py = ey_c + l_c[c] * cos_e
+        qx, qy, inside = _rect_nearest(px[None], py[None], o_x, o_y, o_th, hl, hw)
+        dist = np.hypot(qx - px[None], qy - py[None])
+        dist = np.where(inside, 0.0, dist)
+        dist = np.where(o_live, dist, 1e3)
+        o_clear_c[c] = dist.min(axis=2)
+        clear[c] = o_clear_c[c].min(axis=0)
+    effort = np.abs(np.diff(lay, axis=2)).sum(axis=2).T            # [C,B]
     score = np.minimum(clear, 3.5) - 0.05 * effort
-    best = score.argmax(axis=1)
+    best = score.argmax(axis=0)                                    # [B]
     bi = np.arange(B)
     # the DP planner only returns collision-free coarse paths (dp_planner.cpp:88-133): an obstacle
     # the chosen path cannot clear by MIN_CLEARANCE is dropped from the scene
-    o_clear = dist[bi, best].min(axis=2)                           # [B,O]
+    o_clear = o_clear_c[best, :, bi].T                             # [O,B]
     o_live = o_live & (o_clear >= MIN_CLEARANCE)[:, :, None]
-    l_t = l_c[bi, best]                                            # [B,K]
-    x_t = px[bi, best]
-    y_t = py[bi, best]
+    l_t = l_c[best, bi]                                            # [B,K]
+    x_t = ex_c - l_t * sin_e
+    y_t = ey_c + l_t * cos_e
 
     # ---- heading / speed / accel / curvature profile (finite differences) ----
     dl = np.gradient(l_t, axis=1)
     ds = np.maximum(np.gradient(s_t, axis=1), 1e-10)
     theta = eth_c + np.arctan((dl / ds) / (1.0 - ekap_c * l_t))
-    theta[:, 0] += th_noise * 0.0                                  # coarse heading itself stays smooth
     dxy = np.hypot(np.diff(x_t, axis=1), np.diff(y_t, axis=1))
     acc_s = np.concatenate([np.zeros((B, 1)), np.cumsum(dxy, axis=1)], axis=1)
     vel = np.gradient(acc_s, dt, axis=1)
@@ -312,36 +327,35 @@ def _generate_chunk(spec: SceneSpec, B: int, seed: int, first: int, road: Road):
     coarse = np.stack([x_t, y_t, theta, vel, acc, delta], axis=2)  # [B,K,6]
     start = np.stack([x_t[:, 0], y_t[:, 0], theta[:, 0] + th_noise, vel[:, 0]], axis=1)
 
-    # ---- corridor: box (4 planes) + one separating plane per live obstacle ----
+    # ---- corridor: box (4 planes) + one separating plane per live obstacle, [P,B,K] ----
     Cm = spec.cmax
-    planes = np.zeros((B, K, 4 + O, 3))
-    valid = np.zeros((B, K, 4 + O), bool)
+    P = 4 + O
+    pa = np.zeros((P, B, K))
+    pb = np.zeros((P, B, K))
+    pc = np.zeros((P, B, K))
+    valid = np.zeros((P, B, K), bool)
     ch, sh = np.cos(theta), np.sin(theta)
     half = 10.0
-    box_n = [(ch, sh), (-ch, -sh), (-sh, ch), (sh, -ch)]
-    for j, (nx, ny) in enumerate(box_n):
+    for j, (nx, ny) in enumerate([(ch, sh), (-ch, -sh), (-sh, ch), (sh, -ch)]):
         scale = 2.0 * half                                         # edge length of the 20 m box
-        planes[:, :, j, 0] = nx * scale
-        planes[:, :, j, 1] = ny * scale
-        planes[:, :, j, 2] = (nx * x_t + ny * y_t + half) * scale
-        valid[:, :, j] = True
-    ox_k = np.moveaxis(o_x, 1, 2)                                  # [B,K,O]
-    oy_k = np.moveaxis(o_y, 1, 2)
-    oth_k = np.moveaxis(o_th + 0.0 * o_x, 1, 2)
-    live_k = np.moveaxis(np.broadcast_to(o_live, o_x.shape), 1, 2)
-    qx, qy, inside = _rect_nearest(x_t[:, :, None], y_t[:, :, None], ox_k, oy_k, oth_k,
-                                   hl[:, None, :], hw[:, None, :])
-    ddx, ddy = qx - x_t[:, :, None], qy - y_t[:, :, None]
+        pa[j] = nx * scale
+        pb[j] = ny * scale
+        pc[j] = (nx * x_t + ny * y_t + half) * scale
+        valid[j] = True
+    qx, qy, inside = _rect_nearest(x_t[None], y_t[None], o_x, o_y, o_th, hl, hw)
+    ddx, ddy = qx - x_t[None], qy - y_t[None]
     d = np.hypot(ddx, ddy)
-    ok = live_k & ~inside & (d > 1e-6) & (np.abs(ddx) <= 25.0) & (np.abs(ddy) <= 25.0)
+    ok = o_live & ~inside & (d > 1e-6) & (np.abs(ddx) <= 25.0) & (np.abs(ddy) <= 25.0)
     dn = np.where(ok, d, 1.0)
     nx, ny = ddx / dn, ddy / dn
-    scale = 1.0 + 4.0 * (np.abs(np.sin(3.0 * ox_k + oy_k)))       # arbitrary |n| like a hull edge length
-    planes[:, :, 4:, 0] = nx * scale
-    planes[:, :, 4:, 1] = ny * scale
-    planes[:, :, 4:, 2] = (nx * qx + ny * qy) * scale
-    valid[:, :, 4:] = ok
-    # keep the cmax nearest planes (box first), packed to the front
+    scale = 1.0 + 4.0 * (np.abs(np.sin(3.0 * o_x + o_y)))          # arbitrary |n| like a hull edge length
+    pa[4:] = nx * scale
+    pb[4:] = ny * scale
+    pc[4:] = (nx * qx + ny * qy) * scale
+    valid[4:] = ok
+    planes = np.stack([pa, pb, pc], axis=-1).transpose(1, 2, 0, 3)  # [B,K,P,3]
+    valid = valid.transpose(1, 2, 0)                                # [B,K,P]
+    # live planes packed to the front (box first), at most cmax kept
     order = np.argsort(~valid, axis=2, kind="stable")
     planes = np.take_along_axis(planes, order[..., None], axis=2)
     valid = np.take_along_axis(valid, order, axis=2)

@@ -63,3 +63,50 @@ def compare_solutions(gpu: dict, ref: dict, tol=REL_TOL, margin_tol=1e-7):
         else:
             fails.append((b, why))
     return n_pass, n_exc, fails
+
+
+def oracle_reference(scene: dict, cfg=None, n_perturb: int = 2, eps: float = 4e-16, stable_tol: float = 1e-5):
+    """Oracle solve + a per-problem conditioning mask.
+
+    The reference algorithm is chaotic on a few percent of scenes: re-running the ORACLE ITSELF on
+    inputs perturbed by ~2 ulp (coarse trajectory scaled by 1 + eps*N(0,1)) changes cost histories
+    by far more than 1e-4 or even the iteration count (long line-search chains amplify rounding
+    noise).  No implementation with a different libm / summation order can match the oracle on
+    those scenes, so parity is asserted on the problems whose oracle result is stable under such
+    perturbations (`stable`), and the unstable fraction is reported and bounded separately.
+    """
+    r0 = orc.solve_batch(scene, cfg)
+    B = scene["coarse"].shape[0]
+    stable = np.ones(B, bool)
+    rng = np.random.default_rng(12345)
+    for _ in range(n_perturb):
+        sc2 = dict(scene)
+        sc2["coarse"] = scene["coarse"] * (1.0 + eps * rng.standard_normal(scene["coarse"].shape))
+        r1 = orc.solve_batch(sc2, cfg, want_margin=False)
+        for b in range(B):
+            if not stable[b]:
+                continue
+            nc = int(r0["n_cost"][b])
+            if int(r1["n_cost"][b]) != nc or int(r1["status"][b]) != int(r0["status"][b]):
+                stable[b] = False
+            elif rel_err(r1["cost_hist"][b, :nc], r0["cost_hist"][b, :nc]) > stable_tol or \
+                    rel_err(r1["traj"][b], r0["traj"][b]) > stable_tol:
+                stable[b] = False
+    r0["stable"] = stable
+    return r0
+
+
+def assert_parity(gpu: dict, ref: dict, tol=REL_TOL, max_unstable_frac=0.15, what=""):
+    """Every oracle-stable problem must match within tol; unstable ones are counted, not compared."""
+    stable = ref.get("stable")
+    B = ref["traj"].shape[0]
+    if stable is None:
+        stable = np.ones(B, bool)
+    n_pass, n_exc, fails = compare_solutions(gpu, ref, tol=tol, margin_tol=0.0)
+    bad = [(b, why) for b, why in fails if stable[b]]
+    n_unstable = int((~stable).sum())
+    assert n_unstable <= max(1, int(max_unstable_frac * B)), \
+        f"{what}: {n_unstable}/{B} scenes are ill-conditioned in the oracle itself"
+    assert not bad, f"{what}: {len(bad)} oracle-stable problems differ: {bad[:5]}"
+    return dict(n=B, n_stable=int(stable.sum()), n_match=n_pass, n_unstable=n_unstable,
+                n_unstable_matching=int(sum(1 for b in range(B) if not stable[b]) - sum(1 for b, _ in fails if not stable[b])))

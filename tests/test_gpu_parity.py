@@ -1,0 +1,263 @@
+"""GPU parity tests: every test calls the HIP path through the C-ABI (include/cilqr.h) and checks
+it against the CPU oracle or the committed golden fixtures.
+
+Tolerance: north_star asks for per-iteration costs and final trajectories within 1e-4 relative
+(REL_TOL); stage outputs are checked much tighter (1e-9 relative, the GPU differs from the oracle
+only through libm rounding and summation order)."""
+import ctypes as C
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from parity_util import REL_TOL, assert_parity, oracle_cfg_from, oracle_reference, rel_err
+from cilqr_amd import api, scenario
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+STAGE_TOL = 1e-9
+
+
+def _opt(sc, B=None, **cfg_over):
+    cfg = api.default_config(sc["n_steps"], **cfg_over)
+    return api.BatchIlqrOptimizer(cfg, batch_capacity=B or sc["coarse"].shape[0], cmax=sc["cmax"])
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _build(built):
+    return built
+
+
+# ---------------------------------------------------------------------------------------------
+# stages
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("family,B,seed", [("mix11", 24, 31), ("dyn20", 6, 32)])
+def test_stage_parity(family, B, seed):
+    sc = scenario.generate(family, B, seed=seed)
+    opt = _opt(sc)
+    ocfg = oracle_cfg_from(opt.cfg)
+    opt.stage_load(sc)
+    goals, cor, lanes = opt.read(api.T_GOALS), opt.read(api.T_CORRIDOR), opt.read(api.T_LANES)
+    opt.stage_init_guess()
+    X, U = opt.read(api.T_X), opt.read(api.T_U)
+    cost = opt.stage_total_cost()
+    opt.stage_quadratize()
+    q = {k: opt.read(t) for k, t in dict(A=api.T_A, B=api.T_B, lx=api.T_LX, lu=api.T_LU, lxx=api.T_LXX,
+                                         luu=api.T_LUU).items()}
+    lam = np.linspace(0.5, 3.0, B)
+    opt.stage_backward(lam)
+    Kfb, kff, dV, gn = opt.read(api.T_KFB), opt.read(api.T_KFF), opt.read(api.T_DV), opt.read(api.T_GNORM)
+    opt.stage_forward(0.2512)
+    Xc, Uc = opt.read(api.T_XCAND), opt.read(api.T_UCAND)
+    for b in range(B):
+        o = orc.Oracle(ocfg)
+        assert o.set_problem(sc["start"][b], sc["coarse"][b], sc["corridor"][b], sc["ccount"][b],
+                             sc["left"], sc["right"]) == 0
+        og, oc, ol, orr, _ = o.constraints()
+        assert np.array_equal(goals[b], og)
+        m = np.arange(sc["cmax"])[None, :] < sc["ccount"][b][:, None]
+        assert rel_err(cor[b][m], oc[m], 1e-3) < 1e-12
+        assert rel_err(lanes, np.concatenate([ol, orr]), 1e-3) < 1e-12
+        oX, oU = o.init_guess()
+        assert rel_err(X[b], oX) < STAGE_TOL and rel_err(U[b], oU, 1e-3) < STAGE_TOL
+        # from here on feed the oracle the GPU's own iterate: each stage is checked in isolation
+        assert rel_err(cost[b], o.total_cost(X[b], U[b])) < STAGE_TOL
+        oq = o.quadratize(X[b], U[b])
+        for k in q:
+            scale = max(1.0, float(np.abs(oq[k]).max()))
+            assert np.max(np.abs(q[k][b] - oq[k])) / scale < STAGE_TOL, k
+        oK, ok_, odV = o.backward(float(lam[b]), {k: q[k][b] for k in q})
+        assert rel_err(Kfb[b], oK, 1e-6) < STAGE_TOL and rel_err(kff[b], ok_, 1e-6) < STAGE_TOL
+        assert rel_err(dV[b], odV, 1e-6) < STAGE_TOL
+        assert gn[b] == pytest.approx(o.grad_norm(kff[b], U[b]), rel=1e-12)
+        oXn, oUn = o.forward(0.2512, X[b], U[b], Kfb[b], kff[b])
+        assert rel_err(Xc[b], oXn) < STAGE_TOL and rel_err(Uc[b], oUn, 1e-3) < STAGE_TOL
+    opt.close()
+
+
+def test_open_loop_rollout():
+    rng = np.random.default_rng(5)
+    B, N = 70, 50
+    x0 = np.stack([rng.normal(size=B) * 30, rng.normal(size=B) * 30, rng.uniform(-3.1, 3.1, B),
+                   rng.uniform(0, 15, B), rng.uniform(-3, 3, B), rng.uniform(-0.6, 0.6, B)], axis=1)
+    U = np.stack([rng.uniform(-10, 10, (B, N)), rng.uniform(-0.23, 0.23, (B, N))], axis=2)
+    opt = api.BatchIlqrOptimizer(n_steps=N, batch_capacity=B)
+    X = opt.open_loop_rollout(x0, U)
+    o = orc.Oracle(n_steps=N)
+    for b in range(B):
+        assert rel_err(X[b], o.open_loop_rollout(x0[b], U[b])) < 1e-11
+    opt.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# full solves
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("family,B,seed", [("ped6", 200, 41), ("mix11", 333, 42), ("dyn20", 96, 43)])
+def test_full_solve_parity(family, B, seed):
+    """Per-iteration Cost history, final trajectory, status and iteration counts vs the oracle."""
+    sc = scenario.generate(family, B, seed=seed)
+    opt = _opt(sc)
+    g = opt.plan(sc)
+    ref = oracle_reference(sc, oracle_cfg_from(opt.cfg), n_perturb=3, eps=1e-13)
+    rep = assert_parity(g, ref, what=f"{family} B={B}")
+    st = ref["stable"]
+    assert np.array_equal(g["n_iter"][st], ref["n_iter"][st])
+    assert rep["n_stable"] >= 0.85 * B
+    print(f"\n[{family}] {rep}")
+    opt.close()
+
+
+def test_golden_fixtures_through_the_c_abi():
+    for path in sorted(glob.glob(os.path.join(HERE, "golden", "*.npz"))):
+        g = np.load(path)
+        sc = {k: g[k] for k in ("start", "coarse", "corridor", "ccount", "left", "right")}
+        sc.update(n_steps=int(g["n_steps"]), cmax=int(g["cmax"]))
+        opt = _opt(sc)
+        r = opt.plan(sc, max_iter_trajs=8)
+        assert np.array_equal(r["n_cost"], g["ref_n_cost"]) and np.array_equal(r["status"], g["ref_status"])
+        assert np.array_equal(r["n_iter"], g["ref_n_iter"])
+        for b in range(sc["start"].shape[0]):
+            nc = int(g["ref_n_cost"][b])
+            assert rel_err(r["cost_hist"][b, :nc], g["ref_cost_hist"][b, :nc]) < REL_TOL
+            assert rel_err(r["traj"][b], g["ref_traj"][b]) < REL_TOL
+        # iter_trajs of the first scene: init guess + accepted non-final iterates (cc:170,294)
+        n_it = int(g["st_n_iter_trajs"])
+        assert r["n_iter_trajs"][0] == n_it
+        k = min(n_it, 8)
+        assert rel_err(r["iter_trajs"][0, :k], g["st_iter_trajs"][:k]) < REL_TOL
+        opt.close()
+
+
+@pytest.mark.parametrize("over,expect", [
+    (dict(max_iter=3), api.ST_MAX_ITER),
+    (dict(rel_cost_tol=0.0, abs_cost_tol=5.0), api.ST_CONVERGED_ABS),
+    (dict(rel_cost_tol=0.0, abs_cost_tol=0.0, max_iter=60), None),
+])
+def test_exit_paths(over, expect):
+    """Every exit of Optimize() (max-iter, abs tol, lambda > 1e11 / gnorm) agrees with the oracle."""
+    sc = scenario.generate("ped6", 48, seed=51)
+    opt = _opt(sc, **over)
+    g = opt.plan(sc)
+    ref = oracle_reference(sc, oracle_cfg_from(opt.cfg), n_perturb=2, eps=1e-13)
+    assert_parity(g, ref, max_unstable_frac=0.5, what=str(over))
+    if expect is not None:
+        assert (g["status"] == expect).sum() >= 1
+    else:
+        assert set(np.unique(g["status"])) <= {api.ST_GNORM, api.ST_UNSOLVED, api.ST_MAX_ITER}
+        assert (g["status"] == api.ST_UNSOLVED).sum() >= 1
+    opt.close()
+
+
+def test_ragged_counts_single_problem_and_odd_batches():
+    sc = scenario.generate("mix11", 130, seed=61)
+    # ragged corridor: drop to the 4 box planes on some knots, keep everything on others
+    sc["ccount"][::3, ::2] = 4
+    full = _opt(sc)
+    g = full.plan(sc)
+    ref = oracle_reference(sc, oracle_cfg_from(full.cfg), n_perturb=2, eps=1e-13)
+    assert_parity(g, ref, what="ragged")
+    # problems are independent: any sub-batch (1, 63, 65) gives bit-identical results
+    for lo, hi in [(7, 8), (0, 63), (65, 130)]:
+        sub = {k: (v[lo:hi] if isinstance(v, np.ndarray) and v.shape[:1] == (130,) else v) for k, v in sc.items()}
+        r = full.plan(sub)
+        assert np.array_equal(r["traj"], g["traj"][lo:hi]) and np.array_equal(r["cost_hist"], g["cost_hist"][lo:hi])
+        assert np.array_equal(r["status"], g["status"][lo:hi])
+    # idempotence: same handle, same input, same bits
+    g2 = full.plan(sc)
+    assert np.array_equal(g2["traj"], g["traj"]) and np.array_equal(g2["cost_hist"], g["cost_hist"])
+    full.close()
+
+
+def test_argument_errors_mirror_plan():
+    sc = scenario.generate("ped6", 4, seed=71)
+    opt = _opt(sc)
+    L, h = opt.L, opt.h
+    prob, keep = opt._host_problem(sc)
+    K, M = opt.K, opt.cfg.max_iter
+    traj, hist = np.zeros((4, K, 10)), np.zeros((4, M + 1, 5))
+    nc, st = np.zeros(4, np.int32), np.zeros(4, np.int32)
+
+    def sol(**kw):
+        d = dict(memory=api.MEM_HOST, max_iter_trajs=0, traj=traj.ctypes.data, cost_hist=hist.ctypes.data,
+                 n_cost=nc.ctypes.data, status=st.ctypes.data, n_iter=None, iter_trajs=None, n_iter_trajs=None)
+        d.update(kw)
+        return api.SolutionBatch(**d)
+
+    assert L.cilqr_solve_batch(h, C.byref(prob), C.byref(sol())) == api.OK
+    assert L.cilqr_solve_batch(h, C.byref(prob), C.byref(sol(traj=None))) == api.ERR_NULL      # cc:64
+    assert L.cilqr_solve_batch(h, C.byref(prob), None) == api.ERR_NULL
+    p2 = api.ProblemBatch.from_buffer_copy(prob); p2.n_left = 0
+    assert L.cilqr_solve_batch(h, C.byref(p2), C.byref(sol())) == api.ERR_CONSTRAINTS           # cc:68-73
+    p3 = api.ProblemBatch.from_buffer_copy(prob); p3.corridor = None
+    assert L.cilqr_solve_batch(h, C.byref(p3), C.byref(sol())) == api.ERR_CONSTRAINTS
+    p4 = api.ProblemBatch.from_buffer_copy(prob); p4.n_knots = K - 1
+    assert L.cilqr_solve_batch(h, C.byref(p4), C.byref(sol())) == api.ERR_KNOTS                 # cc:75-78
+    p5 = api.ProblemBatch.from_buffer_copy(prob); p5.batch = 5
+    assert L.cilqr_solve_batch(h, C.byref(p5), C.byref(sol())) == api.ERR_CAPACITY
+    fresh = _opt(sc)
+    assert fresh.L.cilqr_stage_quadratize(fresh.h) == api.ERR_STATE
+    assert fresh.L.cilqr_stage_init_guess(fresh.h) == api.ERR_STATE
+    fresh.close()
+    del keep
+    opt.close()
+
+
+def test_device_memory_interface_and_stream():
+    torch = pytest.importorskip("torch")
+    sc = scenario.generate("mix11", 100, seed=81)
+    B, K = 100, sc["n_steps"] + 1
+    opt = _opt(sc)
+    host = opt.plan(sc)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream()
+    opt.set_stream(stream.cuda_stream)
+    t = {k: torch.from_numpy(np.ascontiguousarray(sc[k])).to(dev) for k in ("start", "coarse", "corridor", "ccount")}
+    M = opt.cfg.max_iter
+    o_traj = torch.zeros((B, K, 10), dtype=torch.float64, device=dev)
+    o_hist = torch.zeros((B, M + 1, 5), dtype=torch.float64, device=dev)
+    o_nc = torch.zeros(B, dtype=torch.int32, device=dev)
+    o_st = torch.zeros(B, dtype=torch.int32, device=dev)
+    left, right = np.ascontiguousarray(sc["left"]), np.ascontiguousarray(sc["right"])
+    torch.cuda.synchronize()
+    prob = opt.make_problem(B, t["start"].data_ptr(), t["coarse"].data_ptr(), t["corridor"].data_ptr(),
+                            t["ccount"].data_ptr(), sc["cmax"], left.ctypes.data, right.ctypes.data,
+                            left.shape[0], right.shape[0], api.MEM_DEVICE)
+    sol = api.SolutionBatch(api.MEM_DEVICE, 0, o_traj.data_ptr(), o_hist.data_ptr(), o_nc.data_ptr(),
+                            o_st.data_ptr(), None, None, None)
+    assert opt.solve_raw(prob, sol) == api.OK
+    torch.cuda.synchronize()
+    assert np.array_equal(o_traj.cpu().numpy(), host["traj"])
+    assert np.array_equal(o_nc.cpu().numpy(), host["n_cost"]) and np.array_equal(o_st.cpu().numpy(), host["status"])
+    hist = o_hist.cpu().numpy()
+    for b in range(B):
+        assert np.array_equal(hist[b, :host["n_cost"][b]], host["cost_hist"][b, :host["n_cost"][b]])
+    opt.close()
+
+
+def test_full_size_batch_properties():
+    """BASELINE configs[2] size (B = 65536, N = 50): 256 distinct scenes tiled 256x.  Size-independent
+    properties: every copy of a scene gives bit-identical output wherever it sits in the batch, all
+    problems terminate, accepted costs decrease monotonically, and the 256 distinct scenes match
+    the oracle."""
+    base = scenario.generate("mix11", 256, seed=91)
+    rep = 256
+    sc = {k: (np.tile(v, (rep,) + (1,) * (v.ndim - 1)) if isinstance(v, np.ndarray) and v.shape[:1] == (256,) else v)
+          for k, v in base.items()}
+    B = 256 * rep
+    opt = _opt(sc)
+    g = opt.plan(sc)
+    assert ((g["status"] >= 1) & (g["status"] <= 5)).all()
+    tr = g["traj"].reshape(rep, 256, *g["traj"].shape[1:])
+    assert np.array_equal(tr, np.broadcast_to(tr[:1], tr.shape))
+    nc = g["n_cost"].reshape(rep, 256)
+    assert np.array_equal(nc, np.broadcast_to(nc[:1], nc.shape))
+    tot = g["cost_hist"][:256, :, 0]
+    for b in range(256):
+        assert np.all(np.diff(tot[b, :g["n_cost"][b]]) < 0)
+    first = {k: v[:256] for k, v in g.items() if isinstance(v, np.ndarray)}
+    ref = oracle_reference(base, oracle_cfg_from(opt.cfg), n_perturb=3, eps=1e-13)
+    assert_parity(first, ref, what="full-size batch")
+    assert B == 65536
+    opt.close()

@@ -1,0 +1,159 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every declared symbol, config
+defaults, argument errors that need no GPU, the scene generator, sharding + gather (gloo, world 2)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+from cilqr_amd import api, scenario
+from cilqr_amd.distributed import shard_range, shard_scene
+from oracle import oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(built):
+    hdr = open(api.HEADER_PATH).read()
+    declared = sorted(set(re.findall(r"\b(cilqr_[a-z_0-9]+)\s*\(", hdr)))
+    assert set(declared) == set(api.EXPORTS), (declared, api.EXPORTS)
+    L = api.lib()
+    for s in declared:
+        assert hasattr(L, s), f"{s} declared in include/cilqr.h but not exported"
+    assert L.cilqr_abi_version() == int(re.search(r"CILQR_ABI_VERSION (\d+)", hdr).group(1))
+    out = subprocess.run(["nm", "-D", "--defined-only", api.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (cilqr_[a-z_0-9]+)", out))
+    assert exported == set(declared)     # nothing else leaks through the C-ABI prefix
+
+
+def test_product_does_not_reference_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "cilqr_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cc", "Makefile")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "liboracle" not in txt and "cilqr_oracle" not in txt and "from oracle" not in txt, f
+    assert "oracle" not in open(api.HEADER_PATH).read().lower()
+
+
+def test_default_config_matches_reference_defaults(built):
+    c = api.default_config(50)
+    o = orc.default_config(50)
+    for name, _ in orc.OracleConfig._fields_:
+        assert getattr(c, name) == getattr(o, name), name
+    assert (c.n_steps, c.num_of_disc, c.max_iter) == (50, 5, 200)          # planner_config.h:58,63
+    assert (c.w_x, c.w_y, c.w_theta, c.w_jerk, c.w_delta_rate) == (0.5, 0.5, 1e-3, 1.0, 1.0)
+    assert c.delta_max == 40.0 / 180 * np.pi and c.delta_rate_max == c.delta_max / 3.0
+    assert (c.barrier_t, c.barrier_eps, c.safe_margin) == (5.0, 0.01, 0.2)
+    assert C.sizeof(api.Config) == 4 * 4 + 27 * 8
+
+
+def test_errors_without_gpu(built):
+    L = api.lib()
+    assert L.cilqr_default_config(None, 50) == api.ERR_NULL
+    assert L.cilqr_destroy(None) == api.ERR_NULL
+    assert L.cilqr_solve_batch(None, None, None) == api.ERR_NULL
+    assert L.cilqr_stage_init_guess(None) == api.ERR_NULL
+    h = C.c_void_p()
+    cfg = api.default_config(50)
+    assert L.cilqr_create(C.byref(cfg), 0, 0, 16, 64, C.byref(h)) == api.ERR_ARG      # zero capacity
+    bad = api.default_config(50, num_of_disc=99)
+    assert L.cilqr_create(C.byref(bad), 0, 8, 16, 64, C.byref(h)) == api.ERR_ARG
+    assert L.cilqr_create(C.byref(cfg), 0, 8, 16, 64, None) == api.ERR_NULL
+    assert b"coarse_traj" in L.cilqr_error_string(api.ERR_KNOTS)
+    assert b"constraints" in L.cilqr_error_string(api.ERR_CONSTRAINTS)
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if not has_gpu:
+        # the product path must fail loudly without a GPU: no CPU fallback
+        with pytest.raises(api.CilqrError) as e:
+            api.BatchIlqrOptimizer(n_steps=50, batch_capacity=4)
+        assert e.value.code == api.ERR_DEVICE
+
+
+def test_scene_generator_is_deterministic_and_well_formed():
+    a = scenario.generate("mix11", 12, seed=5, chunk=5)
+    b = scenario.generate("mix11", 4, seed=5, first_problem=8)
+    for k in ("start", "coarse", "corridor", "ccount"):
+        assert np.array_equal(a[k][8:12], b[k])
+    K = a["n_steps"] + 1
+    assert a["coarse"].shape == (12, K, 6) and a["corridor"].shape == (12, K, a["cmax"], 3)
+    assert a["ccount"].min() >= 4 and a["ccount"].max() <= a["cmax"]       # the 4 box planes are always live
+    assert a["left"].shape[1] == 7 and a["right"].shape[1] == 7
+    # every coarse knot lies strictly inside its own (unshrunk) corridor and between the lanes
+    for p in range(12):
+        for i in range(K):
+            n = a["ccount"][p, i]
+            pl = a["corridor"][p, i, :n]
+            x, y = a["coarse"][p, i, :2]
+            assert np.all(pl[:, 0] * x + pl[:, 1] * y < pl[:, 2])
+    # lane rows: (a,b) is the segment direction rotated by -90 degrees, c = a*sx + b*sy (corridor.cc:322-331)
+    for tab in (a["left"], a["right"]):
+        d = tab[:, 5:7] - tab[:, 3:5]
+        assert np.allclose(tab[:, 0], d[:, 1]) and np.allclose(tab[:, 1], -d[:, 0])
+        assert np.allclose(tab[:, 2], tab[:, 0] * tab[:, 3] + tab[:, 1] * tab[:, 4])
+        assert np.all(np.hypot(d[:, 0], d[:, 1]) >= 5.0 - 1e-9)
+    # consecutive segments share their end points exactly (ties in the nearest-segment scan)
+    assert np.array_equal(a["right"][:-1, 5:7], a["right"][1:, 3:5])
+    assert np.array_equal(a["left"][1:, 5:7], a["left"][:-1, 3:5])
+    road = scenario.build_road()
+    assert road.length == pytest.approx(30 + 10 * np.pi / 2 + 10 + 5 * np.pi + 36 + 12 * np.pi + 50, abs=0.11)
+
+
+def test_shard_range_partitions():
+    for total, world in [(65536, 8), (10, 3), (7, 8), (1, 1)]:
+        got = [shard_range(total, r, world) for r in range(world)]
+        assert got[0][0] == 0 and got[-1][1] == total
+        assert all(got[i][1] == got[i + 1][0] for i in range(world - 1))
+    sc = scenario.generate("ped6", 6, seed=1)
+    s1 = shard_scene(sc, 1, 2)
+    assert np.array_equal(s1["coarse"], sc["coarse"][3:]) and s1["left"] is sc["left"]
+
+
+_WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+    import numpy as np, torch, torch.distributed as dist
+    from cilqr_amd import scenario
+    from cilqr_amd.distributed import shard_scene, gather_results
+    from oracle import oracle as orc
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sc = scenario.generate("ped6", 8, seed=21)
+    mine = shard_scene(sc, rank, world)
+    # stand-in for the per-rank GPU solve: the CPU oracle (tests only)
+    r = orc.solve_batch(mine, want_margin=False)
+    out = gather_results(torch.from_numpy(r["traj"]), torch.from_numpy(r["cost_hist"]),
+                         torch.from_numpy(r["n_cost"]), torch.from_numpy(r["status"]), dst=0)
+    if rank == 0:
+        full = orc.solve_batch(sc, want_margin=False)
+        H = int(full["n_cost"].max())
+        assert np.array_equal(out["traj"].numpy(), full["traj"])            # rank order == problem order
+        assert np.array_equal(out["cost_hist"].numpy(), full["cost_hist"][:, :H])
+        assert np.array_equal(out["n_cost"].numpy(), full["n_cost"])
+        assert np.array_equal(out["status"].numpy(), full["status"])
+        print("GATHER_OK")
+    else:
+        assert out is None
+    dist.destroy_process_group()
+""")
+
+
+def test_sharded_solve_and_gather_gloo_world2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29517")
+    procs = []
+    for rank in range(2):
+        e = dict(env, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=e, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "GATHER_OK" in outs[0]
