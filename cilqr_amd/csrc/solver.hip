@@ -31,7 +31,7 @@ static thread_local char g_last_hip_error[256] = "";
 struct cilqr_solver {
   cilqr_config cfg;
   int device = 0;
-  int Bcap = 0, cmax = 0, smax = 0;
+  int Bcap = 0, capacity = 0, cmax = 0, smax = 0;
   DeviceState ds;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
@@ -112,7 +112,7 @@ int check_problem(const cilqr_solver* h, const cilqr_problem_batch* in) {
     return CILQR_ERR_CONSTRAINTS;                                 // cc:68-73
   if (in->start == nullptr || in->coarse == nullptr) return CILQR_ERR_NULL;
   if (in->n_knots != h->cfg.n_steps + 1) return CILQR_ERR_KNOTS;  // cc:75-78
-  if (in->batch > h->Bcap || in->cmax > h->cmax || in->n_left > h->smax || in->n_right > h->smax)
+  if (in->batch > h->capacity || in->cmax > h->cmax || in->n_left > h->smax || in->n_right > h->smax)
     return CILQR_ERR_CAPACITY;
   if (in->memory != CILQR_MEM_HOST && in->memory != CILQR_MEM_DEVICE) return CILQR_ERR_ARG;
   return CILQR_OK;
@@ -262,6 +262,7 @@ int cilqr_create(const cilqr_config* cfg, int32_t device, int32_t batch_capacity
   // slots are padded to a multiple of 64 so that every row of every tensor starts 512 B aligned
   const int Bc = ((batch_capacity + 63) / 64) * 64;
   h->Bcap = Bc;
+  h->capacity = batch_capacity;
   h->cmax = cmax;
   h->smax = max_lane_segments;
   std::memset(&h->ds, 0, sizeof(h->ds));

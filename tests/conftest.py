@@ -9,6 +9,14 @@ for p in (ROOT, os.path.dirname(os.path.abspath(__file__))):
         sys.path.insert(0, p)
 
 
+# One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64, so when a test uses both
+# torch and libcilqr_hip.so, torch has to be loaded first (as bench.py does).
+try:  # pragma: no cover - depends on the box
+    import torch  # noqa: F401
+except Exception:
+    torch = None
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs an MI355X (run with -m gpu on the GPU box)")
 
