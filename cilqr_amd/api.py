@@ -18,6 +18,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "cilqr.h")
 OK = 0
 ERR_NULL, ERR_CONSTRAINTS, ERR_KNOTS, ERR_CAPACITY, ERR_DEVICE, ERR_ARG, ERR_STATE = -1, -2, -3, -4, -5, -6, -7
 MEM_HOST, MEM_DEVICE = 0, 1
+OPT_SPEC_THRESHOLD = 1
 ST_RUNNING, ST_CONVERGED_ABS, ST_CONVERGED_REL, ST_GNORM, ST_UNSOLVED, ST_MAX_ITER = range(6)
 
 T_GOALS, T_CORRIDOR, T_LANES, T_X, T_U, T_XCAND, T_UCAND, T_A, T_B, T_LX, T_LU, T_LXX, T_LUU, \
@@ -70,10 +71,10 @@ class Profile(C.Structure):
 
 EXPORTS = [
     "cilqr_abi_version", "cilqr_default_config", "cilqr_create", "cilqr_destroy", "cilqr_set_stream",
-    "cilqr_set_profiling", "cilqr_get_profile", "cilqr_device_bytes", "cilqr_solve_batch",
+    "cilqr_set_option", "cilqr_set_profiling", "cilqr_get_profile", "cilqr_device_bytes", "cilqr_solve_batch",
     "cilqr_stage_load", "cilqr_stage_init_guess", "cilqr_stage_set_trajectory",
     "cilqr_stage_total_cost", "cilqr_stage_quadratize", "cilqr_stage_backward", "cilqr_stage_forward",
-    "cilqr_stage_read", "cilqr_open_loop_rollout", "cilqr_error_string",
+    "cilqr_stage_read", "cilqr_stage_nearest_lane", "cilqr_open_loop_rollout", "cilqr_error_string",
 ]
 
 _LIB = None
@@ -102,6 +103,7 @@ def lib():
         L.cilqr_destroy.argtypes = [C.c_void_p]
         L.cilqr_set_stream.argtypes = [C.c_void_p, C.c_void_p]
         L.cilqr_set_profiling.argtypes = [C.c_void_p, C.c_int32]
+        L.cilqr_set_option.argtypes = [C.c_void_p, C.c_int32, C.c_int64]
         L.cilqr_get_profile.argtypes = [C.c_void_p, C.POINTER(Profile)]
         L.cilqr_solve_batch.argtypes = [C.c_void_p, C.POINTER(ProblemBatch), C.POINTER(SolutionBatch)]
         L.cilqr_stage_load.argtypes = [C.c_void_p, C.POINTER(ProblemBatch)]
@@ -112,6 +114,8 @@ def lib():
         L.cilqr_stage_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         L.cilqr_stage_forward.argtypes = [C.c_void_p, C.c_double]
         L.cilqr_stage_read.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
+        L.cilqr_stage_nearest_lane.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_int32, C.c_int32]
         L.cilqr_open_loop_rollout.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.c_int32]
         _LIB = L
@@ -177,6 +181,11 @@ class BatchIlqrOptimizer:
         rc = self.L.cilqr_set_stream(self.h, C.c_void_p(stream_ptr))
         if rc != OK:
             raise CilqrError(rc)
+
+    def set_option(self, option: int, value: int):
+        rc = self.L.cilqr_set_option(self.h, option, value)
+        if rc != OK:
+            raise CilqrError(rc, "in cilqr_set_option")
 
     def set_profiling(self, on: bool):
         self.L.cilqr_set_profiling(self.h, 1 if on else 0)
@@ -281,6 +290,14 @@ class BatchIlqrOptimizer:
         out = np.zeros(shape)
         self._chk(self.L.cilqr_stage_read(self.h, tensor, _ptr(out), MEM_HOST), f"read({tensor})")
         return out
+
+    def nearest_lane(self, xy, use_grid: bool = True):
+        xy = _f64(xy)
+        n = xy.shape[0]
+        left, right = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        self._chk(self.L.cilqr_stage_nearest_lane(self.h, n, _ptr(xy), _ptr(left), _ptr(right),
+                                                  1 if use_grid else 0, MEM_HOST), "nearest_lane")
+        return left, right
 
     def open_loop_rollout(self, x0, U):
         x0, U = _f64(x0), _f64(U)

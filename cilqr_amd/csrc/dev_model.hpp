@@ -49,20 +49,36 @@ CILQR_DEV double bar_value(const Params& p, double g) {
   const double q = (-g - 2.0 * p.bar_eps) / p.bar_eps;
   return 0.5 * p.bar_r * (q * q - 1) - p.bar_rlogeps;
 }
-// coefficient multiplying the constraint gradient in Jacbian()
-CILQR_DEV double bar_jcoef(const Params& p, double g) {
-  if (g < -p.bar_eps) return -p.bar_r / g;
-  return p.bar_r * (g + 2.0 * p.bar_eps) / p.bar_eps / p.bar_eps;
-}
-// Hessian() = (c1 dg_i) dg_j - c2 ddg_ij; the relaxed branch reuses the gradient coefficient
-// and drops ddg (reference quirk, kept).
-CILQR_DEV void bar_hcoef(const Params& p, double g, double& c1, double& c2, bool& log_branch) {
+// Sum of barrier values with one log per group instead of one per constraint:
+//   sum_c -r log(-g_c) = -r log(prod_c -g_c)   over the constraints on the log branch.
+// `prod` collects the product (start at 1), `quad` the relaxed-branch values (start at 0);
+// bar_group_value() closes the group.  A group holds at most a few dozen factors of magnitude
+// 1e-3..1e2, far from fp64 over/underflow.  This only re-associates the reference's sum.
+CILQR_DEV void bar_accumulate(const Params& p, double g, double& prod, double& quad) {
   if (g < -p.bar_eps) {
-    c1 = p.bar_r / g / g;
+    prod *= -g;
+  } else {
+    const double q = (-g - 2.0 * p.bar_eps) / p.bar_eps;
+    quad += 0.5 * p.bar_r * (q * q - 1) - p.bar_rlogeps;
+  }
+}
+CILQR_DEV double bar_group_value(const Params& p, double prod, double quad) {
+  return quad - p.bar_r * log(prod);
+}
+// Gradient and Hessian coefficients of one constraint:
+//   Jacbian() = jc * dg;  Hessian() = (c1 dg_i) dg_j - c2 ddg_ij (c2 term only on the log branch;
+//   the relaxed branch reuses the gradient coefficient and drops ddg -- reference quirk, kept).
+// Log branch: jc = -r/g = -(r/g), c2 = r/g, c1 = r/g/g = c2/g: two divisions give all three,
+// bit-identical to evaluating each expression separately.
+CILQR_DEV void bar_coefs(const Params& p, double g, double& jc, double& c1, double& c2, bool& log_branch) {
+  if (g < -p.bar_eps) {
     c2 = p.bar_r / g;
+    c1 = c2 / g;
+    jc = -c2;
     log_branch = true;
   } else {
-    c1 = p.bar_r * (g + 2.0 * p.bar_eps) / p.bar_eps / p.bar_eps;
+    jc = p.bar_r * (g + 2.0 * p.bar_eps) / p.bar_eps / p.bar_eps;
+    c1 = jc;
     c2 = 0.0;
     log_branch = false;
   }
@@ -140,34 +156,62 @@ CILQR_DEV void dynamics_jacobian(const Params& p, const double* s, const double*
 }
 
 // ---- nearest lane segment (first minimum wins), cc:605-618 + line_segment2d.cpp:61-75 ----
-// `tab` rows: a b c | sx sy | ux uy | len | ex ey.  The table pointer and loop index are
-// wave-uniform, so the rows come in through scalar loads.  Squared distances are compared
-// (sqrt is monotone; exact ties -- the shared end point of two segments -- stay ties).
-CILQR_DEV int nearest_segment(const double* __restrict__ tab, int n, double px, double py) {
+// `tab` rows: a b c | sx sy | ux uy | len | ex ey.  Squared distances are compared (sqrt is
+// monotone; exact ties -- the shared end point of two consecutive segments -- stay ties, so the
+// strict '<' keeps the reference's "first index wins").
+CILQR_DEV double segment_dist2(const double* __restrict__ r, double px, double py) {
+  const double sx = r[3], sy = r[4], ux = r[5], uy = r[6], len = r[7];
+  const double x0 = px - sx, y0 = py - sy;
+  const double d_start = x0 * x0 + y0 * y0;
+  const double proj = x0 * ux + y0 * uy;
+  const double x1 = px - r[8], y1 = py - r[9];
+  const double d_end = x1 * x1 + y1 * y1;
+  const double c = x0 * uy - y0 * ux;
+  const double d_perp = c * c;
+  // same case order as DistanceTo: degenerate, before the start, past the end, foot inside
+  return (len <= kMathEps || proj <= 0.0) ? d_start : (proj >= len ? d_end : d_perp);
+}
+
+CILQR_DEV int nearest_segment_scan(const double* __restrict__ tab, int n, double px, double py) {
   double best = DBL_MAX;
   int bi = 0;
   for (int s = 0; s < n; ++s) {
-    const double* __restrict__ r = tab + s * kLaneFields;
-    const double sx = r[3], sy = r[4], ux = r[5], uy = r[6], len = r[7];
-    const double x0 = px - sx, y0 = py - sy;
-    double d2;
-    if (len <= kMathEps) {
-      d2 = x0 * x0 + y0 * y0;
-    } else {
-      const double proj = x0 * ux + y0 * uy;
-      if (proj <= 0.0) {
-        d2 = x0 * x0 + y0 * y0;
-      } else if (proj >= len) {
-        const double x1 = px - r[8], y1 = py - r[9];
-        d2 = x1 * x1 + y1 * y1;
-      } else {
-        const double c = x0 * uy - y0 * ux;
-        d2 = c * c;
-      }
-    }
+    const double d2 = segment_dist2(tab + s * kLaneFields, px, py);
     if (d2 < best) {
       best = d2;
       bi = s;
+    }
+  }
+  return bi;
+}
+
+// Grid-accelerated version: only the candidate segments of the point's cell are tested, in
+// ascending index order.  The candidate sets are conservative (triangle inequality, see
+// k_build_lane_grid), so the result is the one of the full scan.
+// `lanes`: the lane table (left rows then right rows), in global memory or staged in LDS.
+CILQR_DEV int nearest_segment(const DeviceState& s, const double* __restrict__ lanes, int side, double px,
+                              double py) {
+  const double* __restrict__ tab = lanes + (side ? s.nl * kLaneFields : 0);
+  const int n = side ? s.nr : s.nl;
+  const double fx = (px - s.gx0) * s.ginv_h, fy = (py - s.gy0) * s.ginv_h;
+  if (!(fx >= 0.0 && fy >= 0.0 && fx < (double)s.gnx && fy < (double)s.gny))
+    return nearest_segment_scan(tab, n, px, py);
+  const int cell = (int)fy * s.gnx + (int)fx;
+  const uint4 raw = *reinterpret_cast<const uint4*>(
+      s.lgrid + ((size_t)side * s.gnx * s.gny + cell) * kGridCellBytes);
+  const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+  const int cnt = (int)(w[0] & 0xffu);
+  if (cnt == kGridFullScan) return nearest_segment_scan(tab, n, px, py);
+  double best = DBL_MAX;
+  int bi = 0;
+#pragma unroll
+  for (int k = 1; k < kGridCellBytes; ++k) {
+    if (k > cnt) break;
+    const int seg = (int)((w[k >> 2] >> ((k & 3) * 8)) & 0xffu);
+    const double d2 = segment_dist2(tab + seg * kLaneFields, px, py);
+    if (d2 < best) {
+      best = d2;
+      bi = seg;
     }
   }
   return bi;

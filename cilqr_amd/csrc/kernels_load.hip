@@ -99,6 +99,62 @@ __global__ void k_load_lanes(DeviceState s, const double* __restrict__ raw) {
   o[8] = ex; o[9] = ey;
 }
 
+// Candidate sets of the lane grid.  For a cell with centre q and half-diagonal r, any point p of
+// the cell has d(q, s*) <= d(p, s*) + r <= d(p, s) + r <= d(q, s) + 2r for its nearest segment s*
+// and every s, so {s : d(q, s) <= min_s d(q, s) + 2r (+ slack)} contains every possible answer
+// (ties included).  Indices are stored ascending so the scan order of the reference is kept.
+__global__ __launch_bounds__(256) void k_build_lane_grid(DeviceState s) {
+  const int ncell = s.gnx * s.gny;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 2 * ncell) return;
+  const int side = t / ncell, cell = t - side * ncell;
+  const int iy = cell / s.gnx, ix = cell - iy * s.gnx;
+  const double h = 1.0 / s.ginv_h;
+  const double qx = s.gx0 + (ix + 0.5) * h, qy = s.gy0 + (iy + 0.5) * h;
+  const double* tab = s.lanes + (side ? s.nl * kLaneFields : 0);
+  const int n = side ? s.nr : s.nl;
+  double dmin = DBL_MAX;
+  for (int k = 0; k < n; ++k) dmin = fmin(dmin, sqrt(segment_dist2(tab + k * kLaneFields, qx, qy)));
+  const double thr = dmin + 1.4142135623730951 * h + 1e-6 * (1.0 + dmin);
+  unsigned char out[kGridCellBytes];
+  for (int k = 0; k < kGridCellBytes; ++k) out[k] = 0;
+  int cnt = 0;
+  for (int k = 0; k < n; ++k) {
+    if (sqrt(segment_dist2(tab + k * kLaneFields, qx, qy)) <= thr) {
+      if (cnt < kGridCellBytes - 1) out[1 + cnt] = (unsigned char)k;
+      ++cnt;
+    }
+  }
+  out[0] = (cnt <= kGridCellBytes - 1) ? (unsigned char)cnt : (unsigned char)kGridFullScan;
+  unsigned w[4] = {0, 0, 0, 0};
+  for (int k = 0; k < kGridCellBytes; ++k) w[k >> 2] |= (unsigned)out[k] << ((k & 3) * 8);
+  *reinterpret_cast<uint4*>(s.lgrid + ((size_t)side * ncell + cell) * kGridCellBytes) =
+      make_uint4(w[0], w[1], w[2], w[3]);
+}
+void launch_build_lane_grid(const DeviceState& s, hipStream_t st) {
+  const int n = 2 * s.gnx * s.gny;
+  hipLaunchKernelGGL(k_build_lane_grid, dim3((n + 255) / 256), dim3(256), 0, st, s);
+}
+
+// test hook: nearest left/right segment of arbitrary points, through the grid or the full scan
+__global__ void k_nearest_lane(DeviceState s, int n, const double* __restrict__ xy, int* __restrict__ left,
+                               int* __restrict__ right, int use_grid) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const double px = xy[2 * t], py = xy[2 * t + 1];
+  if (use_grid) {
+    left[t] = nearest_segment(s, s.lanes, 0, px, py);
+    right[t] = nearest_segment(s, s.lanes, 1, px, py);
+  } else {
+    left[t] = nearest_segment_scan(s.lanes, s.nl, px, py);
+    right[t] = nearest_segment_scan(s.lanes + s.nl * kLaneFields, s.nr, px, py);
+  }
+}
+void launch_nearest_lane(const DeviceState& s, int n, const double* xy, int* left, int* right, int use_grid,
+                         hipStream_t st) {
+  hipLaunchKernelGGL(k_nearest_lane, dim3((n + 255) / 256), dim3(256), 0, st, s, n, xy, left, right, use_grid);
+}
+
 void launch_load(const DeviceState& s, int B, const ProblemView& in, const double* lanes_raw,
                  hipStream_t st) {
   const int ld = in.cmax_in * 3 + 1;
@@ -107,6 +163,7 @@ void launch_load(const DeviceState& s, int B, const ProblemView& in, const doubl
   const int n = B * s.p.K;
   hipLaunchKernelGGL(k_load_goals, dim3((n + 255) / 256), dim3(256), 0, st, s, B, in);
   hipLaunchKernelGGL(k_load_lanes, dim3(1), dim3(512), 0, st, s, lanes_raw);
+  launch_build_lane_grid(s, st);
 }
 
 // ---------------------------------------------------------------------------------------------

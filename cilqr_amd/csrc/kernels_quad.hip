@@ -5,82 +5,235 @@
 //   LaneBoundaryCost cc:583;  CostJacbian cc:620-636 (+cc:657-671, 690-706, 729-746);
 //   CostHessian cc:638-655 (+cc:673-688, 708-727, 748-769); DynamicsJacbian vehicle_model.cc:21-86.
 //
-// Work decomposition: grid = (ceil(n/256), K); blockIdx.y is the knot, threads walk a list of
-// slots, so a wave reads 64 consecutive slots of one knot (coalesced) and the lane tables through
-// scalar loads.  Per-knot cost partials go to `part`; a per-problem pass sums them over knots in
-// index order (kernels_search.hip).
+// Work decomposition: grid = (ceil(n/256), K[, alpha]); blockIdx.y is the knot, threads walk a
+// list of slots, so a wave reads 64 consecutive slots of one knot (coalesced).  Inside a thread:
+//   * the corridor planes of the knot are read ONCE, four at a time (12 loads in flight), and
+//     every chunk is applied to all discs from registers -- the reference loops disc-major and
+//     would re-read each plane per disc;
+//   * the lane tables (a few KiB, shared by the batch) are staged in LDS per block; the nearest
+//     segment comes from the uniform-grid candidate lists (dev_model.hpp);
+//   * barrier values are grouped so that one log() serves all constraints of a disc.
+// Per-knot cost partials go to `part`; a per-problem pass sums them over knots in index order.
+// Sums over (disc, plane) are therefore re-associated with respect to the reference's running
+// sums; every individual term is computed with the reference's expression.
 #include "dev_model.hpp"
 
 namespace cilqr {
 
+constexpr int kPlaneChunk = 4;
+
+// lane tables -> LDS (call from every thread of the block, before any early exit)
+CILQR_DEV const double* stage_lanes(const DeviceState& s, double* lds) {
+  const int n = (s.nl + s.nr) * kLaneFields;
+  for (int e = threadIdx.x; e < n; e += blockDim.x) lds[e] = s.lanes[e];
+  __syncthreads();
+  return lds;
+}
+static inline size_t lane_lds_bytes(const DeviceState& s) {
+  return (size_t)(s.nl + s.nr) * kLaneFields * sizeof(double);
+}
+
+// one chunk of up to four corridor planes; missing planes are (0, 0, 1): g = -1, which multiplies
+// the barrier product by exactly 1 and adds exact zeros to every gradient / Hessian entry
+struct PlaneChunk {
+  double a[kPlaneChunk], b[kPlaneChunk], c[kPlaneChunk];
+};
+CILQR_DEV void load_chunk(const double* __restrict__ cor, int Bc, int c0, int cnt, PlaneChunk& pc) {
+#pragma unroll
+  for (int k = 0; k < kPlaneChunk; ++k) {
+    const bool live = (c0 + k) < cnt;
+    const double* q = cor + (size_t)(live ? (c0 + k) : 0) * 3 * Bc;
+    const double a = q[0], b = q[(size_t)Bc], c = q[(size_t)2 * Bc];
+    pc.a[k] = live ? a : 0.0;
+    pc.b[k] = live ? b : 0.0;
+    pc.c[k] = live ? c : 1.0;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
-// cost partials of knot i of buffer `buf`
+// cost partials of one knot.  x, u: the knot's state / control; out[0], out[stride], out[2*stride]
 // ---------------------------------------------------------------------------------------------
-CILQR_DEV void knot_cost(const DeviceState& s, int buf, int i, int slot) {
+template <int D>
+CILQR_DEV void knot_cost_core(const DeviceState& s, const double* __restrict__ lanes, int i, int slot,
+                              const double* x, const double* u, double2* __restrict__ out, size_t stride) {
   const Params& p = s.p;
   const int Bc = s.Bcap;
-  double x[6];
-  load_x(s, buf, i, slot, x);
   const double2* gp = s.goals + (size_t)i * 3 * Bc + slot;
   const double2 g0 = gp[0];
   const double gth = gp[(size_t)Bc].x;
+  const int cnt = s.ccnt[(size_t)i * Bc + slot];
+  const double* __restrict__ cor = s.cor + (size_t)i * s.cmax * 3 * Bc + slot;
+  PlaneChunk pc;
+  load_chunk(cor, Bc, 0, cnt, pc);
   // JCost cc:501-513
+  const double ex = x[0] - g0.x, ey = x[1] - g0.y, eth = x[2] - gth;
+  const double jx = p.w_x * (ex * ex) + p.w_y * (ey * ey) + p.w_theta * (eth * eth);
+  // DynamicsCost cc:518-551: the bound barriers of this knot, one log per group
+  double ju = 0.0, du = 0.0;
+  if (i < p.N) {
+    ju = p.w_jerk * (u[0] * u[0]) + p.w_delta_rate * (u[1] * u[1]);
+    double pr = 1.0, qd = 0.0;
+    bar_accumulate(p, u[0] - p.jerk_max, pr, qd);          // cc:543-546
+    bar_accumulate(p, p.jerk_min - u[0], pr, qd);
+    bar_accumulate(p, u[1] - p.delta_rate_max, pr, qd);
+    bar_accumulate(p, p.delta_rate_min - u[1], pr, qd);
+    du = bar_group_value(p, pr, qd);
+  }
+  double dx;
+  {
+    double pr = 1.0, qd = 0.0;                            // cc:523-528
+    bar_accumulate(p, -x[3], pr, qd);
+    bar_accumulate(p, x[3] - p.max_velocity, pr, qd);
+    bar_accumulate(p, x[4] - p.max_acc, pr, qd);
+    bar_accumulate(p, p.min_acc - x[4], pr, qd);
+    bar_accumulate(p, x[5] - p.delta_max, pr, qd);
+    bar_accumulate(p, p.delta_min - x[5], pr, qd);
+    dx = bar_group_value(p, pr, qd);
+  }
+  double sn, cs;
+  sincos(x[2], &sn, &cs);
+  double px[D], py[D], pr[D], qd[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    px[j] = x[0] + p.disc_off[j] * cs;                     // cc:564-565
+    py[j] = x[1] + p.disc_off[j] * sn;
+    pr[j] = 1.0;
+    qd[j] = 0.0;
+  }
+  // CorridorCost cc:553-581
+  for (int c0 = 0; c0 < cnt; c0 += kPlaneChunk) {
+    PlaneChunk nx;
+    if (c0 + kPlaneChunk < cnt) load_chunk(cor, Bc, c0 + kPlaneChunk, cnt, nx);
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+#pragma unroll
+      for (int k = 0; k < kPlaneChunk; ++k)
+        bar_accumulate(p, pc.a[k] * px[j] + pc.b[k] * py[j] - pc.c[k], pr[j], qd[j]);
+    pc = nx;
+  }
+  double ccost = 0.0, lcost = 0.0;
+#pragma unroll
+  for (int j = 0; j < D; ++j) ccost += bar_group_value(p, pr[j], qd[j]);
+  // LaneBoundaryCost cc:583-603
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    double pl = 1.0, ql = 0.0;
+    const double* L = lanes + nearest_segment(s, lanes, 0, px[j], py[j]) * kLaneFields;
+    bar_accumulate(p, L[0] * px[j] + L[1] * py[j] - L[2], pl, ql);
+    const double* Rr = lanes + (s.nl + nearest_segment(s, lanes, 1, px[j], py[j])) * kLaneFields;
+    bar_accumulate(p, Rr[0] * px[j] + Rr[1] * py[j] - Rr[2], pl, ql);
+    lcost += bar_group_value(p, pl, ql);
+  }
+  out[0] = make_double2(jx, ju);
+  out[stride] = make_double2(dx, du);
+  out[2 * stride] = make_double2(ccost, lcost);
+}
+
+// discs as a run-time count (any num_of_disc != 5): same arithmetic, disc-major loops
+CILQR_DEV void knot_cost_generic(const DeviceState& s, const double* __restrict__ lanes, int i, int slot,
+                                 const double* x, const double* u, double2* __restrict__ out, size_t stride) {
+  const Params& p = s.p;
+  const int Bc = s.Bcap;
+  const double2* gp = s.goals + (size_t)i * 3 * Bc + slot;
+  const double2 g0 = gp[0];
+  const double gth = gp[(size_t)Bc].x;
   const double ex = x[0] - g0.x, ey = x[1] - g0.y, eth = x[2] - gth;
   const double jx = p.w_x * (ex * ex) + p.w_y * (ey * ey) + p.w_theta * (eth * eth);
   double ju = 0.0, du = 0.0;
   if (i < p.N) {
-    double u[2];
-    load_u(s, buf, i, slot, u);
     ju = p.w_jerk * (u[0] * u[0]) + p.w_delta_rate * (u[1] * u[1]);
-    du += bar_value(p, u[0] - p.jerk_max);          // cc:543-546
-    du += bar_value(p, p.jerk_min - u[0]);
-    du += bar_value(p, u[1] - p.delta_rate_max);
-    du += bar_value(p, p.delta_rate_min - u[1]);
+    double pr = 1.0, qd = 0.0;
+    bar_accumulate(p, u[0] - p.jerk_max, pr, qd);
+    bar_accumulate(p, p.jerk_min - u[0], pr, qd);
+    bar_accumulate(p, u[1] - p.delta_rate_max, pr, qd);
+    bar_accumulate(p, p.delta_rate_min - u[1], pr, qd);
+    du = bar_group_value(p, pr, qd);
   }
-  double dx = 0.0;                                  // cc:523-528
-  dx += bar_value(p, -x[3]);
-  dx += bar_value(p, x[3] - p.max_velocity);
-  dx += bar_value(p, x[4] - p.max_acc);
-  dx += bar_value(p, p.min_acc - x[4]);
-  dx += bar_value(p, x[5] - p.delta_max);
-  dx += bar_value(p, p.delta_min - x[5]);
+  double dx;
+  {
+    double pr = 1.0, qd = 0.0;
+    bar_accumulate(p, -x[3], pr, qd);
+    bar_accumulate(p, x[3] - p.max_velocity, pr, qd);
+    bar_accumulate(p, x[4] - p.max_acc, pr, qd);
+    bar_accumulate(p, p.min_acc - x[4], pr, qd);
+    bar_accumulate(p, x[5] - p.delta_max, pr, qd);
+    bar_accumulate(p, p.delta_min - x[5], pr, qd);
+    dx = bar_group_value(p, pr, qd);
+  }
   double sn, cs;
   sincos(x[2], &sn, &cs);
   const int cnt = s.ccnt[(size_t)i * Bc + slot];
   const double* __restrict__ cor = s.cor + (size_t)i * s.cmax * 3 * Bc + slot;
   double ccost = 0.0, lcost = 0.0;
   for (int j = 0; j < p.num_of_disc; ++j) {
-    const double px = x[0] + p.disc_off[j] * cs;
-    const double py = x[1] + p.disc_off[j] * sn;
-    for (int c = 0; c < cnt; ++c) {                 // cc:566-574
+    const double px = x[0] + p.disc_off[j] * cs, py = x[1] + p.disc_off[j] * sn;
+    double pr = 1.0, qd = 0.0;
+    for (int c = 0; c < cnt; ++c) {
       const double* q = cor + (size_t)c * 3 * Bc;
-      const double a = q[0], b = q[(size_t)Bc], cc = q[(size_t)2 * Bc];
-      ccost += bar_value(p, a * px + b * py - cc);
+      bar_accumulate(p, q[0] * px + q[(size_t)Bc] * py - q[(size_t)2 * Bc], pr, qd);
     }
-    {                                               // cc:594-598
-      const double* L = s.lanes + nearest_segment(s.lanes, s.nl, px, py) * kLaneFields;
-      lcost += bar_value(p, L[0] * px + L[1] * py - L[2]);
-      const double* Rr = s.lanes + (s.nl + nearest_segment(s.lanes + s.nl * kLaneFields, s.nr, px, py)) * kLaneFields;
-      lcost += bar_value(p, Rr[0] * px + Rr[1] * py - Rr[2]);
-    }
+    ccost += bar_group_value(p, pr, qd);
+    double pl = 1.0, ql = 0.0;
+    const double* L = lanes + nearest_segment(s, lanes, 0, px, py) * kLaneFields;
+    bar_accumulate(p, L[0] * px + L[1] * py - L[2], pl, ql);
+    const double* Rr = lanes + (s.nl + nearest_segment(s, lanes, 1, px, py)) * kLaneFields;
+    bar_accumulate(p, Rr[0] * px + Rr[1] * py - Rr[2], pl, ql);
+    lcost += bar_group_value(p, pl, ql);
   }
-  double2* o = s.part + (size_t)i * kPartPairs * Bc + slot;
-  o[0] = make_double2(jx, ju);
-  o[(size_t)Bc] = make_double2(dx, du);
-  o[(size_t)2 * Bc] = make_double2(ccost, lcost);
+  out[0] = make_double2(jx, ju);
+  out[stride] = make_double2(dx, du);
+  out[2 * stride] = make_double2(ccost, lcost);
+}
+
+CILQR_DEV void knot_cost_any(const DeviceState& s, const double* __restrict__ lanes, int i, int slot,
+                             const double* x, const double* u, double2* __restrict__ out, size_t stride) {
+  if (s.p.num_of_disc == 5) knot_cost_core<5>(s, lanes, i, slot, x, u, out, stride);
+  else knot_cost_generic(s, lanes, i, slot, x, u, out, stride);
 }
 
 // list == nullptr: slots 0..n-1.  skip_done: ignore slots that already left the iteration.
 __global__ __launch_bounds__(256) void k_cost_knots(DeviceState s, const int* __restrict__ list,
                                                     const int* __restrict__ n_ptr, int n_max, int cand,
                                                     int skip_done) {
+  extern __shared__ double lds[];
   const int n = n_ptr ? min(*n_ptr, n_max) : n_max;
+  if ((int)(blockIdx.x * blockDim.x) >= n) return;   // whole block idle: skip the LDS staging too
+  const double* lanes = stage_lanes(s, lds);
   const int i = blockIdx.y;
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
     const int slot = list ? list[j] : j;
     if (skip_done && s.acc_idx[slot] != -1) continue;
-    knot_cost(s, s.cur[slot] ^ cand, i, slot);
+    const int buf = s.cur[slot] ^ cand;
+    double x[6], u[2] = {0.0, 0.0};
+    load_x(s, buf, i, slot, x);
+    if (i < s.p.N) load_u(s, buf, i, slot, u);
+    knot_cost_any(s, lanes, i, slot, x, u, s.part + (size_t)i * kPartPairs * s.Bcap + slot, (size_t)s.Bcap);
   }
+}
+
+// speculative line search: knot i of candidate alpha_r of list entry j
+__global__ __launch_bounds__(256) void k_spec_cost(DeviceState s, int n) {
+  extern __shared__ double lds[];
+  const double* lanes = stage_lanes(s, lds);
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int i = blockIdx.y, r = blockIdx.z;
+  const int slot = s.act[j];
+  if (s.acc_idx[slot] != -1) return;   // left at the gradient-norm exit
+  const size_t cap = (size_t)s.spec_cap;
+  const double2* xb = s.Xs + ((size_t)r * s.p.K + i) * 3 * cap + j;
+  const double2 p0 = xb[0], p1 = xb[cap], p2 = xb[2 * cap];
+  const double x[6] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y};
+  double u[2] = {0.0, 0.0};
+  if (i < s.p.N) {
+    const double2 q = s.Us[((size_t)r * s.p.N + i) * cap + j];
+    u[0] = q.x; u[1] = q.y;
+  }
+  knot_cost_any(s, lanes, i, slot, x, u, s.parts + ((size_t)r * s.p.K + i) * kPartPairs * cap + j, cap);
+}
+void launch_spec_cost(const DeviceState& s, int n, hipStream_t st) {
+  dim3 g((n + 255) / 256, s.p.K, kNumAlpha);
+  hipLaunchKernelGGL(k_spec_cost, g, dim3(256), lane_lds_bytes(s), st, s, n);
 }
 
 // sum of the knot partials in index order -> trial[5] (total, J, dynamics, corridor, lane)
@@ -120,13 +273,12 @@ void launch_cost_knots(const DeviceState& s, const int* list, const int* n_ptr, 
                        int cand, int skip_done, hipStream_t st) {
   if (n_grid <= 0) return;
   dim3 g((n_grid + 255) / 256, s.p.K);
-  hipLaunchKernelGGL(k_cost_knots, g, dim3(256), 0, st, s, list, n_ptr, n_max, cand, skip_done);
+  hipLaunchKernelGGL(k_cost_knots, g, dim3(256), lane_lds_bytes(s), st, s, list, n_ptr, n_max, cand, skip_done);
 }
 
 void launch_cost_only(const DeviceState& s, const int* list, int n, int cand, hipStream_t st) {
   if (n == 0) return;
-  dim3 g((n + 255) / 256, s.p.K);
-  hipLaunchKernelGGL(k_cost_knots, g, dim3(256), 0, st, s, list, (const int*)nullptr, n, cand, 0);
+  launch_cost_knots(s, list, nullptr, n, n, cand, 0, st);
   hipLaunchKernelGGL(k_reduce_only, dim3((n + 63) / 64), dim3(64), 0, st, s, list, n);
 }
 
@@ -156,16 +308,16 @@ struct Quad {
   double huu[2];   // luu(0,0), (1,1)
 };
 
+// one constraint g = a x + b y - c at disc point (px, py) = (x, y) + (lc, ls)   (cc:703, 723-724)
 CILQR_DEV void add_plane(const Params& p, Quad& q, double a, double b, double c, double px, double py,
                          double lc, double ls) {
   const double g = a * px + b * py - c;
   const double d[3] = {a, b, -a * ls + b * lc};
-  const double jc = bar_jcoef(p, g);
+  double jc, c1, c2;
+  bool lg;
+  bar_coefs(p, g, jc, c1, c2, lg);
 #pragma unroll
   for (int e = 0; e < 3; ++e) q.lx[e] += jc * d[e];
-  double c1, c2;
-  bool lg;
-  bar_hcoef(p, g, c1, c2, lg);
   const double dd22 = -a * lc - b * ls;            // cc:723
 #pragma unroll
   for (int e = 0; e < 3; ++e) {
@@ -179,16 +331,22 @@ CILQR_DEV void add_plane(const Params& p, Quad& q, double a, double b, double c,
   }
 }
 
-CILQR_DEV void knot_quadratize(const DeviceState& s, int buf, int i, int slot) {
+template <int D>
+CILQR_DEV void knot_quadratize(const DeviceState& s, const double* __restrict__ lanes, int buf, int i, int slot) {
   const Params& p = s.p;
   const int Bc = s.Bcap;
   const bool term = (i == p.N);
+  const int nd = (D > 0) ? D : p.num_of_disc;
   double x[6], u[2] = {0.0, 0.0};
   load_x(s, buf, i, slot, x);
   if (!term) load_u(s, buf, i, slot, u);
   const double2* gp = s.goals + (size_t)i * 3 * Bc + slot;
   const double2 g0 = gp[0];
   const double gth = gp[(size_t)Bc].x;
+  const int cnt = s.ccnt[(size_t)i * Bc + slot];
+  const double* __restrict__ cor = s.cor + (size_t)i * s.cmax * 3 * Bc + slot;
+  PlaneChunk pc;
+  load_chunk(cor, Bc, 0, cnt, pc);
   Quad q;
   q.lx[0] = 2.0 * p.w_x * (x[0] - g0.x);           // cc:623-628
   q.lx[1] = 2.0 * p.w_y * (x[1] - g0.y);
@@ -207,45 +365,47 @@ CILQR_DEV void knot_quadratize(const DeviceState& s, int buf, int i, int slot) {
     const double gh[3] = {x[3] - p.max_velocity, x[4] - p.max_acc, x[5] - p.delta_max};
 #pragma unroll
     for (int e = 0; e < 3; ++e) {
-      q.lx[3 + e] += bar_jcoef(p, gl[e]) * -1.0 + bar_jcoef(p, gh[e]) * 1.0;
-      double c1l, c1h, c2;
+      double jl, jh, c1l, c1h, c2;
       bool lg;
-      bar_hcoef(p, gl[e], c1l, c2, lg);
-      bar_hcoef(p, gh[e], c1h, c2, lg);
+      bar_coefs(p, gl[e], jl, c1l, c2, lg);
+      bar_coefs(p, gh[e], jh, c1h, c2, lg);
+      q.lx[3 + e] += jl * -1.0 + jh * 1.0;
       q.hd[e] += c1l + c1h;
     }
     const double ul[2] = {p.jerk_min - u[0], p.delta_rate_min - u[1]};
     const double uh[2] = {u[0] - p.jerk_max, u[1] - p.delta_rate_max};
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-      q.lu[e] += bar_jcoef(p, ul[e]) * -1.0 + bar_jcoef(p, uh[e]) * 1.0;
-      double c1l, c1h, c2;
+      double jl, jh, c1l, c1h, c2;
       bool lg;
-      bar_hcoef(p, ul[e], c1l, c2, lg);
-      bar_hcoef(p, uh[e], c1h, c2, lg);
+      bar_coefs(p, ul[e], jl, c1l, c2, lg);
+      bar_coefs(p, uh[e], jh, c1h, c2, lg);
+      q.lu[e] += jl * -1.0 + jh * 1.0;
       q.huu[e] += c1l + c1h;
     }
   }
   double sn, cs;
   sincos(x[2], &sn, &cs);
-  const int cnt = s.ccnt[(size_t)i * Bc + slot];
-  const double* __restrict__ cor = s.cor + (size_t)i * s.cmax * 3 * Bc + slot;
-  // corridor planes, all discs (cc:690-727)
-  for (int j = 0; j < p.num_of_disc; ++j) {
-    const double lc = p.disc_off[j] * cs, ls = p.disc_off[j] * sn;
-    const double px = x[0] + lc, py = x[1] + ls;
-    for (int c = 0; c < cnt; ++c) {
-      const double* r = cor + (size_t)c * 3 * Bc;
-      add_plane(p, q, r[0], r[(size_t)Bc], r[(size_t)2 * Bc], px, py, lc, ls);
+  // corridor planes x discs (cc:690-727); planes outer (each read once), discs inner
+  for (int c0 = 0; c0 < cnt; c0 += kPlaneChunk) {
+    PlaneChunk nx;
+    if (c0 + kPlaneChunk < cnt) load_chunk(cor, Bc, c0 + kPlaneChunk, cnt, nx);
+#pragma unroll 1
+    for (int j = 0; j < nd; ++j) {
+      const double lc = p.disc_off[j] * cs, ls = p.disc_off[j] * sn;
+#pragma unroll
+      for (int k = 0; k < kPlaneChunk; ++k)
+        add_plane(p, q, pc.a[k], pc.b[k], pc.c[k], x[0] + lc, x[1] + ls, lc, ls);
     }
+    pc = nx;
   }
   // nearest left / right lane plane, all discs (cc:729-769)
-  for (int j = 0; j < p.num_of_disc; ++j) {
+  for (int j = 0; j < nd; ++j) {
     const double lc = p.disc_off[j] * cs, ls = p.disc_off[j] * sn;
     const double px = x[0] + lc, py = x[1] + ls;
-    const double* L = s.lanes + nearest_segment(s.lanes, s.nl, px, py) * kLaneFields;
+    const double* L = lanes + nearest_segment(s, lanes, 0, px, py) * kLaneFields;
     add_plane(p, q, L[0], L[1], L[2], px, py, lc, ls);
-    const double* Rr = s.lanes + (s.nl + nearest_segment(s.lanes + s.nl * kLaneFields, s.nr, px, py)) * kLaneFields;
+    const double* Rr = lanes + (s.nl + nearest_segment(s, lanes, 1, px, py)) * kLaneFields;
     add_plane(p, q, Rr[0], Rr[1], Rr[2], px, py, lc, ls);
   }
   if (term) {
@@ -285,17 +445,20 @@ CILQR_DEV void knot_quadratize(const DeviceState& s, int buf, int i, int slot) {
 
 __global__ __launch_bounds__(256) void k_quadratize(DeviceState s, const int* __restrict__ list, int n,
                                                     int only_upd) {
+  extern __shared__ double lds[];
+  const double* lanes = stage_lanes(s, lds);
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   const int slot = list ? list[j] : j;
   if (only_upd && !s.upd[slot]) return;
-  knot_quadratize(s, s.cur[slot], blockIdx.y, slot);
+  if (s.p.num_of_disc == 5) knot_quadratize<5>(s, lanes, s.cur[slot], blockIdx.y, slot);
+  else knot_quadratize<0>(s, lanes, s.cur[slot], blockIdx.y, slot);
 }
 
 void launch_quadratize(const DeviceState& s, const int* list, int n, int only_upd, hipStream_t st) {
   if (n == 0) return;
   dim3 g((n + 255) / 256, s.p.K);
-  hipLaunchKernelGGL(k_quadratize, g, dim3(256), 0, st, s, list, n, only_upd);
+  hipLaunchKernelGGL(k_quadratize, g, dim3(256), lane_lds_bytes(s), st, s, list, n, only_upd);
 }
 
 }  // namespace cilqr

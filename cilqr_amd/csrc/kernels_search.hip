@@ -19,18 +19,41 @@ __device__ const double kAlpha[kNumAlpha] = {1.0000, 0.5012, 0.2512, 0.1259, 0.0
                                              0.0158, 0.0079, 0.0040, 0.0020, 0.0010};
 
 
-// roll the closed-loop policy out from goals_[0] into the candidate buffers (cc:392-415)
-CILQR_DEV void forward_problem(const DeviceState& s, int slot, double alpha) {
+// where a rollout is written: the slot's candidate buffer, or the speculative arena
+struct OutSlot {
+  const DeviceState& s;
+  int nb, slot;
+  CILQR_DEV void x(int i, const double* v) const { store_x(s, nb, i, slot, v); }
+  CILQR_DEV void u(int i, const double* v) const { store_u(s, nb, i, slot, v); }
+};
+struct OutSpec {
+  const DeviceState& s;
+  int r, j;
+  CILQR_DEV void x(int i, const double* v) const {
+    const size_t cap = (size_t)s.spec_cap;
+    double2* b = s.Xs + ((size_t)r * s.p.K + i) * 3 * cap + j;
+    b[0] = make_double2(v[0], v[1]);
+    b[cap] = make_double2(v[2], v[3]);
+    b[2 * cap] = make_double2(v[4], v[5]);
+  }
+  CILQR_DEV void u(int i, const double* v) const {
+    s.Us[((size_t)r * s.p.N + i) * (size_t)s.spec_cap + j] = make_double2(v[0], v[1]);
+  }
+};
+
+// roll the closed-loop policy out from goals_[0] (cc:392-415)
+template <class Out>
+CILQR_DEV void forward_core(const DeviceState& s, int slot, double alpha, const Out& out) {
   const Params& p = s.p;
   const int Bc = s.Bcap, N = p.N;
-  const int buf = s.cur[slot], nb = buf ^ 1;
+  const int buf = s.cur[slot];
   double x[6];
   {
     const double2* gp = s.goals + slot;
     const double2 g0 = gp[0], g1 = gp[(size_t)Bc], g2 = gp[(size_t)2 * Bc];
     x[0] = g0.x; x[1] = g0.y; x[2] = g1.x; x[3] = g1.y; x[4] = g2.x; x[5] = g2.y;
   }
-  store_x(s, nb, 0, slot, x);
+  out.x(0, x);
   for (int i = 0; i < N; ++i) {
     double xs[6], us[2];
     load_x(s, buf, i, slot, xs);
@@ -55,10 +78,13 @@ CILQR_DEV void forward_problem(const DeviceState& s, int slot, double alpha) {
       u[r] = (us[r] + acc) + alpha * kff;                           // cc:407
     }
     u[1] = normalize_angle(u[1]);                                     // cc:408
-    store_u(s, nb, i, slot, u);
+    out.u(i, u);
     dynamics(p, x, u, x);
-    store_x(s, nb, i + 1, slot, x);
+    out.x(i + 1, x);
   }
+}
+CILQR_DEV void forward_problem(const DeviceState& s, int slot, double alpha) {
+  forward_core(s, slot, alpha, OutSlot{s, s.cur[slot] ^ 1, slot});
 }
 
 // stage API: plain rollout of the listed slots with one alpha
@@ -139,8 +165,89 @@ __global__ __launch_bounds__(64) void k_search_round(DeviceState s, int r, int n
   }
 }
 
-void launch_linesearch(const DeviceState& s, int n_act, hipStream_t st) {
+// ---- speculative mode: all 11 step sizes of every listed problem at once (small active sets) ----
+__global__ __launch_bounds__(64) void k_spec_forward(DeviceState s, int n) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int r = blockIdx.y;
+  const int slot = s.act[j];
+  if (s.gnorm[slot] < 1e-6 && s.lambda[slot] < 1e-5) {   // cc:235-241
+    if (r == 0) {
+      s.status[slot] = 3;
+      s.acc_idx[slot] = -2;
+    }
+    return;
+  }
+  if (r == 0) s.acc_idx[slot] = -1;
+  forward_core(s, slot, kAlpha[r], OutSpec{s, r, j});
+}
+
+// first passing alpha wins (cc:246-261); its candidate is copied into the slot's other buffer
+__global__ __launch_bounds__(64) void k_spec_select(DeviceState s, int n) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int slot = s.act[j];
+  if (s.acc_idx[slot] != -1) return;
+  const size_t cap = (size_t)s.spec_cap;
+  const int K = s.p.K, N = s.p.N, Bc = s.Bcap;
+  const double cost_old = s.cost_old[slot], dV0 = s.dV[slot], dV1 = s.dV[(size_t)Bc + slot];
+  double c5[5] = {0, 0, 0, 0, 0};
+  int acc = -1;
+  double dcost = 0.0;
+  for (int r = 0; r < kNumAlpha; ++r) {
+    double jj = 0.0, dx = 0.0, du = 0.0, cc = 0.0, lc = 0.0;
+    const double2* pb = s.parts + (size_t)r * K * kPartPairs * cap + j;
+    for (int i = 0; i < K; ++i) {
+      const double2* o = pb + (size_t)i * kPartPairs * cap;
+      const double2 a = o[0], b = o[cap], c = o[2 * cap];
+      jj += a.x;
+      dx += b.x;
+      cc += c.x;
+      lc += c.y;
+    }
+    for (int i = 0; i < N; ++i) {
+      const double2* o = pb + (size_t)i * kPartPairs * cap;
+      jj += o[0].y;
+      du += o[cap].y;
+    }
+    const double dyn = dx + du;
+    c5[0] = jj + dyn + cc + lc;
+    c5[1] = jj; c5[2] = dyn; c5[3] = cc; c5[4] = lc;
+    const double alpha = kAlpha[r];
+    dcost = cost_old - c5[0];
+    const double expected = -alpha * (dV0 + alpha * dV1);
+    const double z = dcost / expected;
+    if ((z > 1e-4 && z < 10.0) && dcost > 0.0) {
+      acc = r;
+      break;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 5; ++c) s.trial[(size_t)c * Bc + slot] = c5[c];
+  if (acc < 0) return;
+  const int nb = s.cur[slot] ^ 1;
+  for (int i = 0; i < K; ++i) {
+    const double2* xb = s.Xs + ((size_t)acc * K + i) * 3 * cap + j;
+    double2* o = s.X + ((size_t)nb * K + i) * 3 * Bc + slot;
+    o[0] = xb[0];
+    o[(size_t)Bc] = xb[cap];
+    o[(size_t)2 * Bc] = xb[2 * cap];
+  }
+  for (int i = 0; i < N; ++i)
+    s.U[((size_t)nb * N + i) * Bc + slot] = s.Us[((size_t)acc * N + i) * cap + j];
+  s.acc_idx[slot] = acc;
+  s.dcost[slot] = dcost;
+  s.cur[slot] = nb;
+}
+
+void launch_linesearch(const DeviceState& s, int n_act, int spec_threshold, hipStream_t st) {
   if (n_act == 0) return;
+  if (n_act <= spec_threshold && n_act <= s.spec_cap) {
+    hipLaunchKernelGGL(k_spec_forward, dim3((n_act + 63) / 64, kNumAlpha), dim3(64), 0, st, s, n_act);
+    launch_spec_cost(s, n_act, st);
+    hipLaunchKernelGGL(k_spec_select, dim3((n_act + 63) / 64), dim3(64), 0, st, s, n_act);
+    return;
+  }
   hipLaunchKernelGGL(k_search_open, dim3((n_act + 63) / 64), dim3(64), 0, st, s, n_act);
   for (int r = 0; r < kNumAlpha; ++r) {
     // later rounds carry a small fraction of the batch: shrink their grids, stride inside

@@ -47,6 +47,7 @@ struct cilqr_solver {
   int* h_count = nullptr;  // pinned
   int B = 0;               // problems loaded
   int stage = 0;           // bit0 loaded, bit1 iterate, bit2 quadratized, bit3 gains
+  int spec_threshold = 8192;  // active sets up to this size evaluate all 11 step sizes at once
   // profiling
   bool profiling = false;
   std::vector<hipEvent_t> ev;
@@ -151,6 +152,30 @@ int do_load(cilqr_solver* h, const cilqr_problem_batch* in) {
                          (size_t)in->n_right * 7 * 8, hipMemcpyHostToDevice, h->stream));
   h->ds.nl = in->n_left;
   h->ds.nr = in->n_right;
+  {  // lane grid geometry: bounding box of the segment end points + 60 m, cells >= 1 m
+    double lo[2] = {1e300, 1e300}, hi[2] = {-1e300, -1e300};
+    for (int side = 0; side < 2; ++side) {
+      const double* tab = side ? in->right_lane : in->left_lane;
+      const int n = side ? in->n_right : in->n_left;
+      for (int k = 0; k < n; ++k)
+        for (int e = 0; e < 2; ++e)
+          for (int c = 0; c < 2; ++c) {
+            const double v = tab[k * 7 + 3 + 2 * e + c];
+            if (v < lo[c]) lo[c] = v;
+            if (v > hi[c]) hi[c] = v;
+          }
+    }
+    const double margin = 60.0;  // rejected line-search candidates overshoot far off the road
+    double w = (hi[0] - lo[0]) + 2 * margin, hgt = (hi[1] - lo[1]) + 2 * margin;
+    if (!(w > 0.0) || !(hgt > 0.0) || !std::isfinite(w) || !std::isfinite(hgt)) return CILQR_ERR_ARG;
+    double cell = 1.0;
+    while (std::ceil(w / cell) * std::ceil(hgt / cell) > (double)kGridMaxCells) cell *= 1.25;
+    h->ds.gx0 = lo[0] - margin;
+    h->ds.gy0 = lo[1] - margin;
+    h->ds.ginv_h = 1.0 / cell;
+    h->ds.gnx = (int)std::ceil(w / cell);
+    h->ds.gny = (int)std::ceil(hgt / cell);
+  }
   launch_load(h->ds, B, pv, h->lanes_raw, h->stream);
   HIP_TRY(hipGetLastError());
   h->B = B;
@@ -181,7 +206,7 @@ struct Timer {  // event pairs, resolved after the final sync
     if (!h->profiling) return;
     for (size_t i = 0; i < kind.size(); ++i) {
       float ms = 0.f;
-      hipEventElapsedTime(&ms, h->ev[2 * i], h->ev[2 * i + 1]);
+      (void)hipEventElapsedTime(&ms, h->ev[2 * i], h->ev[2 * i + 1]);
       switch (kind[i]) {
         case 0: p->quadratize_ms += ms; break;
         case 1: p->backward_ms += ms; break;
@@ -191,7 +216,7 @@ struct Timer {  // event pairs, resolved after the final sync
     }
     if (!kind.empty()) {
       float ms = 0.f;
-      hipEventElapsedTime(&ms, h->ev[0], h->ev[next - 1]);
+      (void)hipEventElapsedTime(&ms, h->ev[0], h->ev[next - 1]);
       p->total_ms = ms;
     }
   }
@@ -282,6 +307,7 @@ int cilqr_create(const cilqr_config* cfg, int32_t device, int32_t batch_capacity
   ALLOC(cor, K * cmax * 3 * B);
   ALLOC(ccnt, K * B);
   ALLOC(lanes, (size_t)2 * max_lane_segments * kLaneFields);
+  ALLOC(lgrid, (size_t)2 * kGridMaxCells * kGridCellBytes);
   ALLOC(lin, N * kLinPairs * B);
   ALLOC(term, (size_t)kTermPairs * B);
   ALLOC(gains, N * kGainPairs * B);
@@ -293,6 +319,10 @@ int cilqr_create(const cilqr_config* cfg, int32_t device, int32_t batch_capacity
   ALLOC(lambda, B); ALLOC(dlambda, B); ALLOC(cost_old, B); ALLOC(dcost, B);
   ALLOC(iter, B); ALLOC(status, B); ALLOC(n_cost, B); ALLOC(upd, B); ALLOC(acc_idx, B);
   ALLOC(n_iter_trajs, B); ALLOC(emit, B);
+  d.spec_cap = (int)(B < 8192 ? B : 8192);
+  ALLOC(Xs, (size_t)kNumAlpha * K * 3 * d.spec_cap);
+  ALLOC(Us, (size_t)kNumAlpha * N * d.spec_cap);
+  ALLOC(parts, (size_t)kNumAlpha * K * kPartPairs * d.spec_cap);
   ALLOC(act, B); ALLOC(act_next, B);
   ALLOC(pend, (size_t)(kNumAlpha + 1) * B);
   ALLOC(counters, 64);
@@ -332,6 +362,18 @@ int cilqr_set_stream(cilqr_handle h, void* hip_stream) {
   if (h == nullptr) return CILQR_ERR_NULL;
   h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
   return CILQR_OK;
+}
+
+int cilqr_set_option(cilqr_handle h, int32_t option, int64_t value) {
+  if (h == nullptr) return CILQR_ERR_NULL;
+  switch (option) {
+    case CILQR_OPT_SPEC_THRESHOLD:
+      if (value < 0) return CILQR_ERR_ARG;
+      h->spec_threshold = (int)(value > h->ds.spec_cap ? h->ds.spec_cap : value);
+      return CILQR_OK;
+    default:
+      return CILQR_ERR_ARG;
+  }
 }
 
 int cilqr_set_profiling(cilqr_handle h, int32_t enable) {
@@ -401,7 +443,7 @@ int cilqr_solve_batch(cilqr_handle h, const cilqr_problem_batch* in, cilqr_solut
     if (tm.end() || tm.begin(2)) return CILQR_ERR_DEVICE;
     h->prof.backward_launches += 1;
     h->prof.backward_problem_steps += (int64_t)n_act * h->cfg.n_steps;
-    launch_linesearch(d, n_act, st);                   // cc:235-270
+    launch_linesearch(d, n_act, h->spec_threshold, st);  // cc:235-270
     launch_update(d, n_act, st);                       // cc:272-308
     if (o_it) launch_export_iter_traj(d, d.act, n_act, o_it, out->max_iter_trajs, st);
     if (tm.end()) return CILQR_ERR_DEVICE;
@@ -610,6 +652,34 @@ int cilqr_stage_read(cilqr_handle h, int32_t tensor, double* dst, int32_t memory
     default: launch_expand(d, B, tensor, dev, st); break;
   }
   return finish_from_device(h, dst, count, memory, tmp);
+}
+
+int cilqr_stage_nearest_lane(cilqr_handle h, int32_t n, const double* xy, int32_t* left, int32_t* right,
+                             int32_t use_grid, int32_t memory) {
+  if (h == nullptr || xy == nullptr || left == nullptr || right == nullptr) return CILQR_ERR_NULL;
+  if (n <= 0) return CILQR_ERR_ARG;
+  if (!(h->stage & 1)) return CILQR_ERR_STATE;
+  HIP_TRY(hipSetDevice(h->device));
+  void *t0 = nullptr, *tl = nullptr;
+  const void* dxy = nullptr;
+  int rc = to_device(h, xy, (size_t)n * 2 * 8, memory, &t0, &dxy);
+  int* dl = left; int* dr = right;
+  if (rc == CILQR_OK && memory == CILQR_MEM_HOST) {
+    if (hipMalloc(&tl, (size_t)n * 2 * sizeof(int)) != hipSuccess) rc = CILQR_ERR_DEVICE;
+    dl = static_cast<int*>(tl); dr = dl + n;
+  }
+  if (rc == CILQR_OK) {
+    launch_nearest_lane(h->ds, n, static_cast<const double*>(dxy), dl, dr, use_grid, h->stream);
+    if (memory == CILQR_MEM_HOST) {
+      if (hipMemcpyAsync(left, dl, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+          hipMemcpyAsync(right, dr, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream) != hipSuccess)
+        rc = CILQR_ERR_DEVICE;
+    }
+    if (hipStreamSynchronize(h->stream) != hipSuccess) rc = CILQR_ERR_DEVICE;
+  }
+  if (t0) (void)hipFree(t0);
+  if (tl) (void)hipFree(tl);
+  return rc;
 }
 
 int cilqr_open_loop_rollout(cilqr_handle h, int32_t batch, const double* x0, const double* U, double* X,

@@ -37,6 +37,9 @@ constexpr int kPartPairs = 3;
 constexpr int kNumAlpha = 11;
 constexpr int kMaxDiscs = 16;
 constexpr int kLaneFields = 10;  // a b c | sx sy | ux uy | len | ex ey
+constexpr int kGridCellBytes = 16;
+constexpr int kGridMaxCells = 1 << 16;  // per side
+constexpr int kGridFullScan = 255;      // cell marker: too many candidates, scan every segment
 
 // pair rows of a step inside `lin`
 //  0 (a02,a03) 1 (a04,a05) 2 (a12,a13) 3 (a14,a15) 4 (a23,a24) 5 (a25,b21)
@@ -79,6 +82,12 @@ struct DeviceState {
   double* cor;     // [K][cmax][3][Bcap]
   int* ccnt;       // [K][Bcap]
   double* lanes;   // [nl+nr][kLaneFields]
+  // uniform grid over the lane polylines: per cell the (conservative) set of segments that can be
+  // the nearest one for a point of that cell, in ascending index order -> same result as the
+  // reference's linear scan with ~2 distance tests instead of nl / nr
+  unsigned char* lgrid;  // [2 sides][gnx*gny][kGridCellBytes]: count | up to 15 segment indices
+  double gx0, gy0, ginv_h;
+  int gnx, gny;
   double2* lin;    // [N][17][Bcap]
   double2* term;   // [9][Bcap]
   double2* gains;  // [N][7][Bcap]
@@ -101,6 +110,13 @@ struct DeviceState {
   int* n_iter_trajs;
   int* emit;         // iterate to append to iter_trajs this iteration
 
+  // speculative line search (all 11 step sizes at once) for small active sets: candidates and
+  // cost partials indexed by [alpha][...][list position], capacity spec_cap list entries
+  int spec_cap;
+  double2* Xs;       // [11][K][3][spec_cap]
+  double2* Us;       // [11][N][spec_cap]
+  double2* parts;    // [11][K][3][spec_cap]
+
   // work lists
   int* act;          // active slots
   int* act_next;
@@ -119,12 +135,16 @@ struct ProblemView {  // device pointers to the problem-major inputs
 
 void launch_load(const DeviceState& s, int B, const ProblemView& in, const double* lanes_raw,
                  hipStream_t st);
+void launch_build_lane_grid(const DeviceState& s, hipStream_t st);
+void launch_nearest_lane(const DeviceState& s, int n, const double* xy, int* left, int* right, int use_grid,
+                         hipStream_t st);
 void launch_init_guess(const DeviceState& s, int B, hipStream_t st);
 void launch_set_trajectory(const DeviceState& s, int B, const double* X, const double* U, hipStream_t st);
 // cost of buffer (cur ^ cand) for the n listed slots -> trial[], no accept logic
 void launch_cost_only(const DeviceState& s, const int* list, int n, int cand, hipStream_t st);
 void launch_cost_knots(const DeviceState& s, const int* list, const int* n_ptr, int n_max, int n_grid,
                        int cand, int skip_done, hipStream_t st);
+void launch_spec_cost(const DeviceState& s, int n, hipStream_t st);
 void launch_init_cost_commit(const DeviceState& s, int n, hipStream_t st);
 void launch_quadratize(const DeviceState& s, const int* list, int n, int only_upd, hipStream_t st);
 void launch_backward(const DeviceState& s, const int* list, int n, const double* lambda_override,
@@ -132,7 +152,7 @@ void launch_backward(const DeviceState& s, const int* list, int n, const double*
 void launch_forward(const DeviceState& s, const int* list, int n, double alpha, int skip_done,
                     hipStream_t st);
 // the 11-round line search of one lockstep iteration (forward/cost/accept with compaction)
-void launch_linesearch(const DeviceState& s, int n_act, hipStream_t st);
+void launch_linesearch(const DeviceState& s, int n_act, int spec_threshold, hipStream_t st);
 void launch_update(const DeviceState& s, int n_act, hipStream_t st);
 void launch_export_traj(const DeviceState& s, int B, double* traj, hipStream_t st);
 void launch_export_iter_traj(const DeviceState& s, const int* list, int n, double* iter_trajs,

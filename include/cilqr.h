@@ -20,6 +20,7 @@
  *       quadratize      DynamicsJacbian vehicle_model.cc:21 + CostJacbian cc:620 + CostHessian cc:638
  *       backward        Backward cc:334-390 (+ CalGradientNorm cc:322)
  *       forward         Forward cc:392-415
+ *       nearest_lane    FindNeastLaneSegment cc:605-618 + LineSegment2d::DistanceTo (algorithm/math/line_segment2d.cpp:61-75)
  *   cilqr_open_loop_rollout ilqr::iLQR::OpenLoopRollout (algorithm/slover/ilqr.h:363-370) on
  *                           VehicleModel::Dynamics (vehicle_model.cc:88-121)
  *
@@ -134,6 +135,11 @@ int cilqr_create(const cilqr_config* cfg, int32_t device, int32_t batch_capacity
 int cilqr_destroy(cilqr_handle h);
 /* hipStream_t to launch on (NULL = the handle's own stream). */
 int cilqr_set_stream(cilqr_handle h, void* hip_stream);
+/* Tuning knobs that never change results.  CILQR_OPT_SPEC_THRESHOLD: lockstep iterations with at
+ * most this many active problems evaluate all 11 line-search step sizes concurrently instead of
+ * round by round (0 disables; capped at 8192). */
+#define CILQR_OPT_SPEC_THRESHOLD 1
+int cilqr_set_option(cilqr_handle h, int32_t option, int64_t value);
 int cilqr_set_profiling(cilqr_handle h, int32_t enable);
 int cilqr_get_profile(cilqr_handle h, cilqr_profile* out);
 /* bytes of device memory held by the handle */
@@ -173,6 +179,12 @@ int cilqr_stage_forward(cilqr_handle h, double alpha);
 #define CILQR_T_DV 15        /* [B][2] delta_V_ */
 #define CILQR_T_GNORM 16     /* [B] */
 int cilqr_stage_read(cilqr_handle h, int32_t tensor, double* dst, int32_t memory);
+
+/* FindNeastLaneSegment (cc:605-618) for n arbitrary points xy[n][2]: index of the nearest left /
+ * right lane segment.  use_grid = 1: the accelerated lookup the solver uses; 0: the reference's
+ * linear scan.  Both must agree everywhere (test hook). */
+int cilqr_stage_nearest_lane(cilqr_handle h, int32_t n, const double* xy, int32_t* left, int32_t* right,
+                             int32_t use_grid, int32_t memory);
 
 /* X[b][0] = x0[b]; X[b][i+1] = Dynamics(X[b][i], U[b][i]).  x0 [B][6], U [B][N][2], X [B][K][6] */
 int cilqr_open_loop_rollout(cilqr_handle h, int32_t batch, const double* x0, const double* U,

@@ -270,3 +270,78 @@ def test_full_size_batch_properties():
     assert_parity(first, ref, what="full-size batch")
     assert B == 65536
     opt.close()
+
+
+def _dist_matrix(tab, pts):
+    """LineSegment2d::DistanceTo (line_segment2d.cpp:61-75) of every point to every segment."""
+    s, e = tab[:, 3:5], tab[:, 5:7]
+    d = e - s
+    ln = np.hypot(d[:, 0], d[:, 1])
+    u = d / ln[:, None]
+    x0 = pts[:, None, 0] - s[None, :, 0]
+    y0 = pts[:, None, 1] - s[None, :, 1]
+    proj = x0 * u[None, :, 0] + y0 * u[None, :, 1]
+    d_start = np.hypot(x0, y0)
+    d_end = np.hypot(pts[:, None, 0] - e[None, :, 0], pts[:, None, 1] - e[None, :, 1])
+    d_perp = np.abs(x0 * u[None, :, 1] - y0 * u[None, :, 0])
+    return np.where(proj <= 0.0, d_start, np.where(proj >= ln[None, :], d_end, d_perp))
+
+
+def _nearest_numpy(tab, pts):
+    dist = _dist_matrix(tab, pts)
+    return np.argmin(dist, axis=1), np.sort(dist, axis=1)
+
+
+def test_nearest_lane_grid_equals_linear_scan():
+    """The accelerated lookup must return the reference's linear-scan answer everywhere: on the road,
+    far outside the grid, and in the wedge regions where two segments tie exactly."""
+    sc = scenario.generate("ped6", 4, seed=3)
+    opt = _opt(sc)
+    opt.stage_load(sc)
+    rng = np.random.default_rng(7)
+    road = scenario.build_road()
+    s = rng.uniform(0, road.length, 200000)
+    lat = rng.uniform(-14.0, 10.0, s.size)
+    x, y = road.cartesian(s, lat)
+    pts = [np.stack([x, y], axis=1),
+           rng.uniform(-400, 400, (20000, 2)),                       # mostly outside the grid
+           np.concatenate([sc["left"][:, 3:5], sc["right"][:, 5:7]])]  # exact segment end points (ties)
+    # points pushed outwards from every joint: both neighbours are "past the end" -> exact tie
+    for tab in (sc["left"], sc["right"]):
+        d = tab[:, 5:7] - tab[:, 3:5]
+        nrm = np.stack([tab[:, 0], tab[:, 1]], axis=1) / np.hypot(tab[:, 0], tab[:, 1])[:, None]
+        for r in (0.3, 2.0, 6.0):
+            pts.append(tab[:, 5:7] + r * nrm + 1e-3 * d)
+            pts.append(tab[:, 3:5] + r * nrm - 1e-3 * d)
+    n_random = sum(len(q) for q in pts[:2])
+    pts = np.concatenate(pts)
+    gl, gr = opt.nearest_lane(pts, use_grid=True)
+    sl, sr = opt.nearest_lane(pts, use_grid=False)
+    assert np.array_equal(gl, sl) and np.array_equal(gr, sr)
+    # and the linear scan itself follows the reference's DistanceTo semantics (hypot-based) except
+    # where the two best distances agree to rounding
+    for tab, got in ((sc["left"], sl), (sc["right"], sr)):
+        ref, srt = _nearest_numpy(tab, pts)
+        clear = (srt[:, 1] - srt[:, 0]) > 1e-9 * (1.0 + srt[:, 0])
+        assert np.array_equal(got[clear], ref[clear])
+        assert clear.mean() > 0.8
+        # wherever the answers differ the two candidates are equidistant to rounding
+        d_got = np.take_along_axis(_dist_matrix(tab, pts), got[:, None].astype(np.int64), axis=1)[:, 0]
+        assert np.all(d_got - srt[:, 0] <= 1e-9 * (1.0 + srt[:, 0]))
+    opt.close()
+
+
+def test_speculative_line_search_is_bit_identical_to_round_by_round():
+    """Small active sets evaluate all 11 step sizes at once; the first passing index must win exactly
+    as in the sequential loop (ilqr_optimizer.cc:246-265), so both modes give the same bits."""
+    sc = scenario.generate("mix11", 300, seed=95)
+    opt = _opt(sc)
+    a = opt.plan(sc, max_iter_trajs=3)
+    opt.set_option(api.OPT_SPEC_THRESHOLD, 0)
+    b = opt.plan(sc, max_iter_trajs=3)
+    opt.set_option(api.OPT_SPEC_THRESHOLD, 64)       # switch modes in the middle of the solve
+    c = opt.plan(sc, max_iter_trajs=3)
+    for k in ("traj", "cost_hist", "n_cost", "status", "n_iter", "iter_trajs", "n_iter_trajs"):
+        assert np.array_equal(a[k], b[k]), k
+        assert np.array_equal(a[k], c[k]), k
+    opt.close()

@@ -1,0 +1,86 @@
+#!/usr/bin/env python
+"""Summarise a rocprofv3 --kernel-trace capture (rocpd .db or *_kernel_trace.csv): per-kernel
+count / total / avg / min / max, and optionally the kernel timeline of chosen lockstep iterations.
+
+    python tools/prof_summary.py <dir-or-file> [--iters 1,2,5,20] [--solve 1]
+"""
+import argparse
+import csv
+import glob
+import os
+import sqlite3
+import sys
+
+
+def load(path):
+    if os.path.isdir(path):
+        dbs = glob.glob(os.path.join(path, "**", "*.db"), recursive=True)
+        csvs = glob.glob(os.path.join(path, "**", "*kernel_trace.csv"), recursive=True)
+        path = (dbs or csvs or [None])[0]
+        if path is None:
+            sys.exit("no .db / kernel_trace.csv found")
+    rows = []
+    if path.endswith(".db"):
+        c = sqlite3.connect(path)
+        for name, start, end, gx, gy, gz in c.execute(
+                "select name, start, end, grid_x, grid_y, grid_z from kernels order by start"):
+            rows.append((name, int(start), int(end), gx, gy, gz))
+    else:
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                rows.append((r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"]),
+                             int(r.get("Grid_Size_X", 0)), int(r.get("Grid_Size_Y", 0)), int(r.get("Grid_Size_Z", 0))))
+        rows.sort(key=lambda r: r[1])
+    return rows
+
+
+def short(name):
+    return name.split("(")[0].replace("cilqr::", "")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("path")
+    ap.add_argument("--iters", default="")
+    ap.add_argument("--solve", type=int, default=1, help="which solve (0-based) to print the timeline of")
+    a = ap.parse_args()
+    rows = load(a.path)
+    stats = {}
+    for name, s, e, *_ in rows:
+        st = stats.setdefault(short(name), [0, 0, 1 << 62, 0])
+        d = e - s
+        st[0] += 1; st[1] += d; st[2] = min(st[2], d); st[3] = max(st[3], d)
+    tot = sum(v[1] for v in stats.values())
+    print(f"{'kernel':44s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>9s} {'min_us':>9s} {'max_us':>9s} {'pct':>6s}")
+    for k, v in sorted(stats.items(), key=lambda kv: -kv[1][1])[:30]:
+        print(f"{k[:44]:44s} {v[0]:7d} {v[1] / 1e6:10.3f} {v[1] / v[0] / 1e3:9.1f} {v[2] / 1e3:9.1f} {v[3] / 1e3:9.1f} {100 * v[1] / tot:6.2f}")
+    print(f"{'TOTAL':44s} {sum(v[0] for v in stats.values()):7d} {tot / 1e6:10.3f}")
+    if not a.iters:
+        return
+    want = [int(x) for x in a.iters.split(",")]
+    names = [short(r[0]) for r in rows]
+    starts = [i for i, n in enumerate(names) if n == "k_load_corridor"]
+    if a.solve >= len(starts):
+        return
+    lo = starts[a.solve]
+    hi = starts[a.solve + 1] if a.solve + 1 < len(starts) else len(rows)
+    its, cur = [], []
+    for r, n in zip(rows[lo:hi], names[lo:hi]):
+        if n == "k_quadratize":
+            if cur:
+                its.append(cur)
+            cur = []
+        cur.append((n, r))
+    its.append(cur)
+    print(f"\nsolve {a.solve}: {len(its) - 1} lockstep iterations")
+    for k in want:
+        if k >= len(its):
+            break
+        it = its[k]
+        wall = (it[-1][1][2] - it[0][1][1]) / 1e3
+        print(f"iter {k}: wall {wall:.0f} us, quadratize grid {it[0][1][3]}")
+        print("   " + " ".join(f"{n[2:8]}:{(r[2] - r[1]) / 1e3:.0f}" for n, r in it))
+
+
+if __name__ == "__main__":
+    main()
