@@ -345,3 +345,38 @@ def test_speculative_line_search_is_bit_identical_to_round_by_round():
         assert np.array_equal(a[k], b[k]), k
         assert np.array_equal(a[k], c[k]), k
     opt.close()
+
+
+def test_cpp_adapter_plan_matches_oracle(tmp_path):
+    """planning::IlqrOptimizer-shaped C++ adapter (B = 1, host containers) end to end."""
+    import subprocess
+    from test_host import build_adapter_test
+    exe = build_adapter_test(tmp_path)
+    g = np.load(os.path.join(HERE, "golden", "mix11_n50.npz"))
+    b = 1
+    K, cmax = g["coarse"].shape[1], int(g["cmax"])
+    scene = tmp_path / "scene.bin"
+    with open(scene, "wb") as f:
+        np.array([K, cmax, g["left"].shape[0], g["right"].shape[0]], np.int32).tofile(f)
+        for a in (g["start"][b], g["coarse"][b]):
+            np.ascontiguousarray(a, np.float64).tofile(f)
+        np.ascontiguousarray(g["ccount"][b], np.int32).tofile(f)
+        for a in (g["corridor"][b], g["left"], g["right"]):
+            np.ascontiguousarray(a, np.float64).tofile(f)
+    out = tmp_path / "out.bin"
+    r = subprocess.run([str(exe), str(scene), str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    raw = np.fromfile(out, np.uint8)
+    n_cost, n_it, flags = np.frombuffer(raw[:12].tobytes(), np.int32)
+    assert flags == 3                               # Plan ok + every error path returned false
+    body = np.frombuffer(raw[12:].tobytes(), np.float64)
+    traj = body[:K * 10].reshape(K, 10)
+    cost = body[K * 10:K * 10 + n_cost * 5].reshape(n_cost, 5)
+    it0 = body[K * 10 + n_cost * 5:].reshape(K, 10)
+    assert n_cost == g["ref_n_cost"][b] and n_it == n_cost - 1
+    assert rel_err(cost, g["ref_cost_hist"][b, :n_cost]) < REL_TOL
+    assert rel_err(traj, g["ref_traj"][b]) < REL_TOL
+    o = orc.Oracle(n_steps=K - 1)
+    o.set_problem(g["start"][b], g["coarse"][b], g["corridor"][b], g["ccount"][b], g["left"], g["right"])
+    X, U = o.init_guess()
+    assert rel_err(it0[:, 1:7], X) < 1e-9           # iter_trajs[0] is the init guess (cc:170)

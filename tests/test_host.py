@@ -157,3 +157,23 @@ def test_sharded_solve_and_gather_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=300)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "GATHER_OK" in outs[0]
+
+
+def build_adapter_test(tmp_path):
+    exe = tmp_path / "adapter_test"
+    cmd = ["g++", "-std=c++14", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "cpp", "adapter_test.cc"), "-o", str(exe),
+           "-L" + os.path.dirname(api.LIB_PATH), "-lcilqr_hip", "-Wl,-rpath," + os.path.dirname(api.LIB_PATH),
+           "-Wl,-rpath-link,/opt/rocm/lib"]
+    subprocess.check_call(cmd)
+    return exe
+
+
+def test_cpp_adapter_compiles_as_cxx14_against_the_c_abi(built, tmp_path):
+    """The drop-in header (include/cilqr/ilqr_optimizer.hpp) must build with the reference's own
+    toolchain settings (C++14, g++, no HIP headers) and link against the C-ABI library only."""
+    exe = build_adapter_test(tmp_path)
+    assert exe.exists()
+    hdr = open(os.path.join(ROOT, "include", "cilqr.h")).read()
+    includes = re.findall(r"#include\s+[<\"]([^>\"]+)", hdr)
+    assert includes == ["stdint.h"]             # plain C: no HIP, C++ or torch headers at the boundary
