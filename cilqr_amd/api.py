@@ -19,6 +19,7 @@ OK = 0
 ERR_NULL, ERR_CONSTRAINTS, ERR_KNOTS, ERR_CAPACITY, ERR_DEVICE, ERR_ARG, ERR_STATE = -1, -2, -3, -4, -5, -6, -7
 MEM_HOST, MEM_DEVICE = 0, 1
 OPT_SPEC_THRESHOLD = 1
+OPT_COMPACTION = 2
 ST_RUNNING, ST_CONVERGED_ABS, ST_CONVERGED_REL, ST_GNORM, ST_UNSOLVED, ST_MAX_ITER = range(6)
 
 T_GOALS, T_CORRIDOR, T_LANES, T_X, T_U, T_XCAND, T_UCAND, T_A, T_B, T_LX, T_LU, T_LXX, T_LUU, \

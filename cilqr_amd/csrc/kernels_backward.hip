@@ -103,12 +103,24 @@ CILQR_DEV void backward_problem(const DeviceState& s, int slot, double lambda) {
   }
   const int buf = s.cur[slot];
   double dV0 = 0.0, dV1 = 0.0, gsum = 0.0;
-  for (int i = N - 1; i >= 0; --i) {
-    const double2* q = s.lin + (size_t)i * kLinPairs * Bc + slot;
-    double2 w[kLinPairs];
+  // software pipeline: the operands of step i-1 are requested before step i is computed, so a
+  // wave (one per SIMD at B = 65536) always has 18 KiB of loads in flight behind its arithmetic
+  double2 w[kLinPairs], wn[kLinPairs];
+  double2 uu, uun;
+  {
+    const double2* q = s.lin + (size_t)(N - 1) * kLinPairs * Bc + slot;
 #pragma unroll
     for (int r = 0; r < kLinPairs; ++r) w[r] = q[(size_t)r * Bc];
-    const double2 uu = s.U[((size_t)buf * N + i) * Bc + slot];
+    uu = s.U[((size_t)buf * N + (N - 1)) * Bc + slot];
+  }
+  for (int i = N - 1; i >= 0; --i) {
+    {
+      const int ip = (i > 0) ? i - 1 : 0;
+      const double2* q = s.lin + (size_t)ip * kLinPairs * Bc + slot;
+#pragma unroll
+      for (int r = 0; r < kLinPairs; ++r) wn[r] = q[(size_t)r * Bc];
+      uun = s.U[((size_t)buf * N + ip) * Bc + slot];
+    }
     // A and B as dense register arrays; entries of kind 0/1 are never read
     double A[36], B[12];
     A[2] = w[0].x; A[3] = w[0].y; A[4] = w[1].x; A[5] = w[1].y;
@@ -204,6 +216,9 @@ CILQR_DEV void backward_problem(const DeviceState& s, int slot, double lambda) {
     const double hk0 = 0.5 * kc[0], hk1 = 0.5 * kc[1];
     const double r0 = hk0 * q00 + hk1 * q10, r1 = hk0 * q01 + hk1 * q11;
     dV1 += r0 * kc[0] + r1 * kc[1];
+#pragma unroll
+    for (int r = 0; r < kLinPairs; ++r) w[r] = wn[r];
+    uu = uun;
   }
   s.dV[slot] = dV0;
   s.dV[(size_t)Bc + slot] = dV1;

@@ -66,6 +66,8 @@ __global__ __launch_bounds__(256) void k_load_goals(DeviceState s, int B, Proble
     s.cur[slot] = 0;
     s.n_iter_trajs[slot] = 0;
     s.emit[slot] = 0;
+    s.pid[slot] = slot;
+    s.done_now[slot] = 0;
     s.act[slot] = slot;
   } else {
     const double* c = in.coarse + ((size_t)slot * K + i) * 6;
@@ -402,11 +404,76 @@ __global__ void k_export_traj(DeviceState s, int B, double* __restrict__ traj) {
   const int K = s.p.K;
   if (t >= B * K) return;
   const int i = t / B, slot = t - i * B;  // slot fastest: coalesced reads
-  write_traj_point(s, s.cur[slot], i, slot, traj + ((size_t)slot * K + i) * 10);
+  write_traj_point(s, s.cur[slot], i, slot, traj + ((size_t)s.pid[slot] * K + i) * 10);
 }
 void launch_export_traj(const DeviceState& s, int B, double* traj, hipStream_t st) {
   const int n = B * s.p.K;
   hipLaunchKernelGGL(k_export_traj, dim3((n + 255) / 256), dim3(256), 0, st, s, B, traj);
+}
+
+// final trajectory (cc:238,285,303,319) of every slot that terminated in the last k_update
+__global__ void k_export_done(DeviceState s, int n, double* __restrict__ traj) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int K = s.p.K;
+  if (t >= n * K) return;
+  const int i = t / n, j = t - i * n;
+  const int slot = s.act[j];
+  if (!s.done_now[slot]) return;
+  write_traj_point(s, s.cur[slot], i, slot, traj + ((size_t)s.pid[slot] * K + i) * 10);
+}
+void launch_export_done(const DeviceState& s, int n_act, double* traj, hipStream_t st) {
+  const int n = n_act * s.p.K;
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_export_done, dim3((n + 255) / 256), dim3(256), 0, st, s, n_act, traj);
+}
+
+// Re-pack the surviving problems: entry j of src's NEXT active list moves to slot j of dst.
+// Moved: the current iterate (into buffer 0), goals, corridor planes + counts, the scalar state.
+// Not moved: the linearisation / gains (recomputed: upd is forced to 1, which reproduces the
+// same values because they depend only on the iterate), and everything indexed by problem.
+__global__ __launch_bounds__(256) void k_compact(DeviceState a, DeviceState b, int n) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int i = blockIdx.y;   // knot
+  const int K = a.p.K, N = a.p.N;
+  const int src = a.act_next[j];
+  const int buf = a.cur[src];
+  {
+    const double2* x = a.X + ((size_t)buf * K + i) * 3 * a.Bcap + src;
+    double2* o = b.X + ((size_t)i) * 3 * b.Bcap + j;
+    o[0] = x[0];
+    o[(size_t)b.Bcap] = x[(size_t)a.Bcap];
+    o[(size_t)2 * b.Bcap] = x[(size_t)2 * a.Bcap];
+    if (i < N) b.U[(size_t)i * b.Bcap + j] = a.U[((size_t)buf * N + i) * a.Bcap + src];
+    const double2* g = a.goals + (size_t)i * 3 * a.Bcap + src;
+    double2* go = b.goals + (size_t)i * 3 * b.Bcap + j;
+    go[0] = g[0];
+    go[(size_t)b.Bcap] = g[(size_t)a.Bcap];
+    go[(size_t)2 * b.Bcap] = g[(size_t)2 * a.Bcap];
+    const int cnt = a.ccnt[(size_t)i * a.Bcap + src];
+    b.ccnt[(size_t)i * b.Bcap + j] = cnt;
+    const double* c = a.cor + (size_t)i * a.cmax * 3 * a.Bcap + src;
+    double* co = b.cor + (size_t)i * b.cmax * 3 * b.Bcap + j;
+    for (int e = 0; e < cnt * 3; ++e) co[(size_t)e * b.Bcap] = c[(size_t)e * a.Bcap];
+  }
+  if (i == 0) {
+    b.cur[j] = 0;
+    b.pid[j] = a.pid[src];
+    b.lambda[j] = a.lambda[src];
+    b.dlambda[j] = a.dlambda[src];
+    b.cost_old[j] = a.cost_old[src];
+    b.dcost[j] = a.dcost[src];
+    b.upd[j] = 1;
+    b.acc_idx[j] = -1;
+    b.emit[j] = 0;
+    b.done_now[j] = 0;
+    b.act[j] = j;
+  }
+}
+void launch_compact(const DeviceState& src, const DeviceState& dst, int n, hipStream_t st) {
+  if (n == 0) return;
+  dim3 g((n + 255) / 256, src.p.K);
+  hipLaunchKernelGGL(k_compact, g, dim3(256), 0, st, src, dst, n);
 }
 
 // iter_trajs: append the current iterate of every listed slot whose emit flag is set
@@ -418,9 +485,10 @@ __global__ void k_export_iter_traj(DeviceState s, const int* __restrict__ list, 
   const int i = t / n, j = t - i * n;
   const int slot = list ? list[j] : j;
   if (!s.emit[slot]) return;
-  const int idx = s.n_iter_trajs[slot] - 1;  // already counted by the kernel that set emit
+  const int pb = s.pid[slot];
+  const int idx = s.n_iter_trajs[pb] - 1;  // already counted by the kernel that set emit
   if (idx >= cap) return;
-  write_traj_point(s, s.cur[slot], i, slot, out + (((size_t)slot * cap + idx) * K + i) * 10);
+  write_traj_point(s, s.cur[slot], i, slot, out + (((size_t)pb * cap + idx) * K + i) * 10);
 }
 void launch_export_iter_traj(const DeviceState& s, const int* list, int n, double* iter_trajs,
                              int max_iter_trajs, hipStream_t st) {

@@ -286,11 +286,12 @@ void launch_cost_only(const DeviceState& s, const int* list, int n, int cand, hi
 __global__ void k_init_cost_commit(DeviceState s, int n) {
   const int slot = blockIdx.x * blockDim.x + threadIdx.x;
   if (slot >= n) return;
+  const int pb = s.pid[slot];
 #pragma unroll
-  for (int c = 0; c < 5; ++c) s.hist[(size_t)c * s.Bcap + slot] = s.trial[(size_t)c * s.Bcap + slot];
+  for (int c = 0; c < 5; ++c) s.hist[(size_t)c * s.Bcap + pb] = s.trial[(size_t)c * s.Bcap + slot];
   s.cost_old[slot] = s.trial[slot];
-  s.n_cost[slot] = 1;
-  s.n_iter_trajs[slot] = 1;
+  s.n_cost[pb] = 1;
+  s.n_iter_trajs[pb] = 1;
   s.emit[slot] = 1;
 }
 void launch_init_cost_commit(const DeviceState& s, int n, hipStream_t st) {

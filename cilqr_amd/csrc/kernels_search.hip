@@ -54,14 +54,29 @@ CILQR_DEV void forward_core(const DeviceState& s, int slot, double alpha, const 
     x[0] = g0.x; x[1] = g0.y; x[2] = g1.x; x[3] = g1.y; x[4] = g2.x; x[5] = g2.y;
   }
   out.x(0, x);
-  for (int i = 0; i < N; ++i) {
-    double xs[6], us[2];
-    load_x(s, buf, i, slot, xs);
-    load_u(s, buf, i, slot, us);
-    const double2* g = s.gains + (size_t)i * kGainPairs * Bc + slot;
-    double2 kk[kGainPairs];
+  // the nominal (xs, us) and the gains of step i+1 do not depend on the rollout: prefetch them
+  double2 nx0, nx1, nx2, nu, kk[kGainPairs], nkk[kGainPairs];
+  {
+    const double2* b = s.X + ((size_t)buf * p.K) * 3 * Bc + slot;
+    nx0 = b[0]; nx1 = b[(size_t)Bc]; nx2 = b[(size_t)2 * Bc];
+    nu = s.U[((size_t)buf * N) * Bc + slot];
+    const double2* g = s.gains + slot;
 #pragma unroll
-    for (int r = 0; r < kGainPairs; ++r) kk[r] = g[(size_t)r * Bc];
+    for (int r = 0; r < kGainPairs; ++r) nkk[r] = g[(size_t)r * Bc];
+  }
+  for (int i = 0; i < N; ++i) {
+    const double xs[6] = {nx0.x, nx0.y, nx1.x, nx1.y, nx2.x, nx2.y};
+    const double us[2] = {nu.x, nu.y};
+#pragma unroll
+    for (int r = 0; r < kGainPairs; ++r) kk[r] = nkk[r];
+    if (i + 1 < N) {
+      const double2* b = s.X + ((size_t)buf * p.K + (i + 1)) * 3 * Bc + slot;
+      nx0 = b[0]; nx1 = b[(size_t)Bc]; nx2 = b[(size_t)2 * Bc];
+      nu = s.U[((size_t)buf * N + (i + 1)) * Bc + slot];
+      const double2* g = s.gains + (size_t)(i + 1) * kGainPairs * Bc + slot;
+#pragma unroll
+      for (int r = 0; r < kGainPairs; ++r) nkk[r] = g[(size_t)r * Bc];
+    }
     double dx[6];
 #pragma unroll
     for (int e = 0; e < 6; ++e) dx[e] = x[e] - xs[e];
@@ -108,7 +123,7 @@ __global__ __launch_bounds__(64) void k_search_open(DeviceState s, int n) {
   if (j >= n) return;
   const int slot = s.act[j];
   if (s.gnorm[slot] < 1e-6 && s.lambda[slot] < 1e-5) {
-    s.status[slot] = 3;   // CILQR_ST_GNORM
+    s.status[s.pid[slot]] = 3;   // CILQR_ST_GNORM
     s.acc_idx[slot] = -2;
     return;
   }
@@ -173,7 +188,7 @@ __global__ __launch_bounds__(64) void k_spec_forward(DeviceState s, int n) {
   const int slot = s.act[j];
   if (s.gnorm[slot] < 1e-6 && s.lambda[slot] < 1e-5) {   // cc:235-241
     if (r == 0) {
-      s.status[slot] = 3;
+      s.status[s.pid[slot]] = 3;
       s.acc_idx[slot] = -2;
     }
     return;
@@ -182,62 +197,84 @@ __global__ __launch_bounds__(64) void k_spec_forward(DeviceState s, int n) {
   forward_core(s, slot, kAlpha[r], OutSpec{s, r, j});
 }
 
-// first passing alpha wins (cc:246-261); its candidate is copied into the slot's other buffer
-__global__ __launch_bounds__(64) void k_spec_select(DeviceState s, int n) {
+// total cost of candidate alpha_r of list entry j: knot partials summed in index order
+__global__ __launch_bounds__(64) void k_spec_reduce(DeviceState s, int n) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int r = blockIdx.y;
+  const int slot = s.act[j];
+  if (s.acc_idx[slot] != -1) return;
+  const size_t cap = (size_t)s.spec_cap;
+  const int K = s.p.K, N = s.p.N;
+  double jj = 0.0, dx = 0.0, du = 0.0, cc = 0.0, lc = 0.0;
+  const double2* pb = s.parts + (size_t)r * K * kPartPairs * cap + j;
+  for (int i = 0; i < K; ++i) {
+    const double2* o = pb + (size_t)i * kPartPairs * cap;
+    const double2 a = o[0], b = o[cap], c = o[2 * cap];
+    jj += a.x;
+    dx += b.x;
+    cc += c.x;
+    lc += c.y;
+  }
+  for (int i = 0; i < N; ++i) {
+    const double2* o = pb + (size_t)i * kPartPairs * cap;
+    jj += o[0].y;
+    du += o[cap].y;
+  }
+  const double dyn = dx + du;
+  double* t = s.spec_tot + (size_t)r * 5 * cap + j;
+  t[0] = jj + dyn + cc + lc;
+  t[cap] = jj; t[2 * cap] = dyn; t[3 * cap] = cc; t[4 * cap] = lc;
+}
+
+// first passing alpha wins (cc:246-261)
+__global__ __launch_bounds__(64) void k_spec_pick(DeviceState s, int n) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   const int slot = s.act[j];
   if (s.acc_idx[slot] != -1) return;
   const size_t cap = (size_t)s.spec_cap;
-  const int K = s.p.K, N = s.p.N, Bc = s.Bcap;
+  const int Bc = s.Bcap;
   const double cost_old = s.cost_old[slot], dV0 = s.dV[slot], dV1 = s.dV[(size_t)Bc + slot];
-  double c5[5] = {0, 0, 0, 0, 0};
-  int acc = -1;
+  int acc = -1, last = kNumAlpha - 1;
   double dcost = 0.0;
   for (int r = 0; r < kNumAlpha; ++r) {
-    double jj = 0.0, dx = 0.0, du = 0.0, cc = 0.0, lc = 0.0;
-    const double2* pb = s.parts + (size_t)r * K * kPartPairs * cap + j;
-    for (int i = 0; i < K; ++i) {
-      const double2* o = pb + (size_t)i * kPartPairs * cap;
-      const double2 a = o[0], b = o[cap], c = o[2 * cap];
-      jj += a.x;
-      dx += b.x;
-      cc += c.x;
-      lc += c.y;
-    }
-    for (int i = 0; i < N; ++i) {
-      const double2* o = pb + (size_t)i * kPartPairs * cap;
-      jj += o[0].y;
-      du += o[cap].y;
-    }
-    const double dyn = dx + du;
-    c5[0] = jj + dyn + cc + lc;
-    c5[1] = jj; c5[2] = dyn; c5[3] = cc; c5[4] = lc;
     const double alpha = kAlpha[r];
-    dcost = cost_old - c5[0];
+    dcost = cost_old - s.spec_tot[(size_t)r * 5 * cap + j];
     const double expected = -alpha * (dV0 + alpha * dV1);
     const double z = dcost / expected;
     if ((z > 1e-4 && z < 10.0) && dcost > 0.0) {
       acc = r;
+      last = r;
       break;
     }
   }
 #pragma unroll
-  for (int c = 0; c < 5; ++c) s.trial[(size_t)c * Bc + slot] = c5[c];
+  for (int c = 0; c < 5; ++c)
+    s.trial[(size_t)c * Bc + slot] = s.spec_tot[((size_t)last * 5 + c) * cap + j];
   if (acc < 0) return;
-  const int nb = s.cur[slot] ^ 1;
-  for (int i = 0; i < K; ++i) {
-    const double2* xb = s.Xs + ((size_t)acc * K + i) * 3 * cap + j;
-    double2* o = s.X + ((size_t)nb * K + i) * 3 * Bc + slot;
-    o[0] = xb[0];
-    o[(size_t)Bc] = xb[cap];
-    o[(size_t)2 * Bc] = xb[2 * cap];
-  }
-  for (int i = 0; i < N; ++i)
-    s.U[((size_t)nb * N + i) * Bc + slot] = s.Us[((size_t)acc * N + i) * cap + j];
   s.acc_idx[slot] = acc;
   s.dcost[slot] = dcost;
-  s.cur[slot] = nb;
+  s.cur[slot] ^= 1;   // k_spec_copy fills the new current buffer
+}
+
+// the accepted candidate becomes the iterate: one thread per (list entry, knot)
+__global__ __launch_bounds__(256) void k_spec_copy(DeviceState s, int n) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int i = blockIdx.y;
+  const int slot = s.act[j];
+  const int acc = s.acc_idx[slot];
+  if (acc < 0) return;
+  const size_t cap = (size_t)s.spec_cap;
+  const int K = s.p.K, N = s.p.N, Bc = s.Bcap;
+  const int nb = s.cur[slot];
+  const double2* xb = s.Xs + ((size_t)acc * K + i) * 3 * cap + j;
+  double2* o = s.X + ((size_t)nb * K + i) * 3 * Bc + slot;
+  o[0] = xb[0];
+  o[(size_t)Bc] = xb[cap];
+  o[(size_t)2 * Bc] = xb[2 * cap];
+  if (i < N) s.U[((size_t)nb * N + i) * Bc + slot] = s.Us[((size_t)acc * N + i) * cap + j];
 }
 
 void launch_linesearch(const DeviceState& s, int n_act, int spec_threshold, hipStream_t st) {
@@ -245,7 +282,9 @@ void launch_linesearch(const DeviceState& s, int n_act, int spec_threshold, hipS
   if (n_act <= spec_threshold && n_act <= s.spec_cap) {
     hipLaunchKernelGGL(k_spec_forward, dim3((n_act + 63) / 64, kNumAlpha), dim3(64), 0, st, s, n_act);
     launch_spec_cost(s, n_act, st);
-    hipLaunchKernelGGL(k_spec_select, dim3((n_act + 63) / 64), dim3(64), 0, st, s, n_act);
+    hipLaunchKernelGGL(k_spec_reduce, dim3((n_act + 63) / 64, kNumAlpha), dim3(64), 0, st, s, n_act);
+    hipLaunchKernelGGL(k_spec_pick, dim3((n_act + 63) / 64), dim3(64), 0, st, s, n_act);
+    hipLaunchKernelGGL(k_spec_copy, dim3((n_act + 255) / 256, s.p.K), dim3(256), 0, st, s, n_act);
     return;
   }
   hipLaunchKernelGGL(k_search_open, dim3((n_act + 63) / 64), dim3(64), 0, st, s, n_act);
@@ -264,9 +303,10 @@ __global__ __launch_bounds__(256) void k_update(DeviceState s, int n) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   const int slot = s.act[j];
+  const int pb = s.pid[slot];
   const Params& p = s.p;
   bool done = false;
-  int st = s.status[slot];
+  int st = s.status[pb];
   s.emit[slot] = 0;
   if (st == 3) {
     done = true;
@@ -279,16 +319,16 @@ __global__ __launch_bounds__(256) void k_update(DeviceState s, int n) {
       s.lambda[slot] = lam * ndl * ((lam > 1e-8) ? 1.0 : 0.0);                     // cc:275
       s.upd[slot] = 1;
       const double dc = s.dcost[slot], co = s.cost_old[slot];
-      const int nc = s.n_cost[slot];
+      const int nc = s.n_cost[pb];
 #pragma unroll
       for (int c = 0; c < 5; ++c)
-        s.hist[((size_t)nc * 5 + c) * s.Bcap + slot] = s.trial[(size_t)c * s.Bcap + slot];
-      s.n_cost[slot] = nc + 1;
+        s.hist[((size_t)nc * 5 + c) * s.Bcap + pb] = s.trial[(size_t)c * s.Bcap + slot];
+      s.n_cost[pb] = nc + 1;
       if (dc < p.abs_tol || dc / co < p.rel_tol) {                                 // cc:281-293
         st = (dc < p.abs_tol) ? 1 : 2;
         done = true;
       } else {
-        s.n_iter_trajs[slot] += 1;                                                 // cc:294
+        s.n_iter_trajs[pb] += 1;                                                   // cc:294
         s.emit[slot] = 1;
         s.cost_old[slot] = s.trial[slot];                                          // cc:295
       }
@@ -304,14 +344,15 @@ __global__ __launch_bounds__(256) void k_update(DeviceState s, int n) {
       }
     }
   }
-  const int it = s.iter[slot] + 1;
-  s.iter[slot] = it;
+  const int it = s.iter[pb] + 1;
+  s.iter[pb] = it;
   if (!done && it >= p.max_iter) {                                                 // cc:312
     st = 5;
     done = true;
   }
-  s.status[slot] = st;
+  s.status[pb] = st;
   s.acc_idx[slot] = -1;
+  s.done_now[slot] = done ? 1 : 0;
   if (!done) {
     const int pos = atomicAdd(&s.counters[0], 1);
     s.act_next[pos] = slot;

@@ -32,7 +32,9 @@ struct cilqr_solver {
   cilqr_config cfg;
   int device = 0;
   int Bcap = 0, capacity = 0, cmax = 0, smax = 0;
-  DeviceState ds;
+  DeviceState ds;      // arena A (also what the stage API works on)
+  DeviceState twin;    // arena B: only the fields k_compact moves are its own, the rest alias ds
+  bool compaction = true;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   std::vector<void*> allocs;
@@ -318,15 +320,31 @@ int cilqr_create(const cilqr_config* cfg, int32_t device, int32_t batch_capacity
   ALLOC(hist, (size_t)(cfg->max_iter + 1) * 5 * B);
   ALLOC(lambda, B); ALLOC(dlambda, B); ALLOC(cost_old, B); ALLOC(dcost, B);
   ALLOC(iter, B); ALLOC(status, B); ALLOC(n_cost, B); ALLOC(upd, B); ALLOC(acc_idx, B);
-  ALLOC(n_iter_trajs, B); ALLOC(emit, B);
+  ALLOC(n_iter_trajs, B); ALLOC(emit, B); ALLOC(pid, B); ALLOC(done_now, B);
   d.spec_cap = (int)(B < 8192 ? B : 8192);
   ALLOC(Xs, (size_t)kNumAlpha * K * 3 * d.spec_cap);
   ALLOC(Us, (size_t)kNumAlpha * N * d.spec_cap);
   ALLOC(parts, (size_t)kNumAlpha * K * kPartPairs * d.spec_cap);
+  ALLOC(spec_tot, (size_t)kNumAlpha * 5 * d.spec_cap);
   ALLOC(act, B); ALLOC(act_next, B);
   ALLOC(pend, (size_t)(kNumAlpha + 1) * B);
   ALLOC(counters, 64);
 #undef ALLOC
+  // twin arena for re-packing the survivors (k_compact)
+  DeviceState& t = h->twin;
+  t = d;
+#define ALLOC2(field, count) \
+  if (rc == CILQR_OK) rc = dev_alloc(h, &t.field, (size_t)(count))
+  ALLOC2(X, 2 * K * 3 * B);
+  ALLOC2(U, 2 * N * B);
+  ALLOC2(cur, B);
+  ALLOC2(goals, K * 3 * B);
+  ALLOC2(cor, K * cmax * 3 * B);
+  ALLOC2(ccnt, K * B);
+  ALLOC2(lambda, B); ALLOC2(dlambda, B); ALLOC2(cost_old, B); ALLOC2(dcost, B);
+  ALLOC2(upd, B); ALLOC2(acc_idx, B); ALLOC2(emit, B); ALLOC2(pid, B); ALLOC2(done_now, B);
+  ALLOC2(act, B); ALLOC2(act_next, B);
+#undef ALLOC2
   if (rc == CILQR_OK) rc = dev_alloc(h, &h->lanes_raw, (size_t)2 * max_lane_segments * 7);
   if (rc == CILQR_OK) rc = dev_alloc(h, &h->lambda_stage, B);
   if (rc == CILQR_OK && hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess)
@@ -367,6 +385,9 @@ int cilqr_set_stream(cilqr_handle h, void* hip_stream) {
 int cilqr_set_option(cilqr_handle h, int32_t option, int64_t value) {
   if (h == nullptr) return CILQR_ERR_NULL;
   switch (option) {
+    case CILQR_OPT_COMPACTION:
+      h->compaction = value != 0;
+      return CILQR_OK;
     case CILQR_OPT_SPEC_THRESHOLD:
       if (value < 0) return CILQR_ERR_ARG;
       h->spec_threshold = (int)(value > h->ds.spec_cap ? h->ds.spec_cap : value);
@@ -406,7 +427,17 @@ int cilqr_solve_batch(cilqr_handle h, const cilqr_problem_batch* in, cilqr_solut
   int rc = do_load(h, in);
   if (rc != CILQR_OK) return rc;
   const int B = in->batch, K = in->n_knots, M = h->cfg.max_iter;
-  DeviceState& d = h->ds;
+  // two views of the device state: `d` is the arena the active problems live in, `o` the other one
+  DeviceState d = h->ds;
+  DeviceState o = h->twin;
+  {  // the twin aliases everything k_compact does not move; refresh the per-solve fields
+    DeviceState t = h->ds;
+    t.X = o.X; t.U = o.U; t.cur = o.cur; t.goals = o.goals; t.cor = o.cor; t.ccnt = o.ccnt;
+    t.lambda = o.lambda; t.dlambda = o.dlambda; t.cost_old = o.cost_old; t.dcost = o.dcost;
+    t.upd = o.upd; t.acc_idx = o.acc_idx; t.emit = o.emit; t.pid = o.pid; t.done_now = o.done_now;
+    t.act = o.act; t.act_next = o.act_next;
+    o = t;
+  }
   hipStream_t st = h->stream;
 
   // output staging when the caller's buffers live in host memory
@@ -433,6 +464,7 @@ int cilqr_solve_batch(cilqr_handle h, const cilqr_problem_batch* in, cilqr_solut
   if (tm.end()) return CILQR_ERR_DEVICE;
 
   int n_act = B;
+  int span = B;   // slots occupied in the current arena
   int it = 0;
   for (; it < M && n_act > 0; ++it) {                  // cc:201
     HIP_TRY(hipMemsetAsync(d.counters, 0, 64 * sizeof(int), st));
@@ -445,17 +477,26 @@ int cilqr_solve_batch(cilqr_handle h, const cilqr_problem_batch* in, cilqr_solut
     h->prof.backward_problem_steps += (int64_t)n_act * h->cfg.n_steps;
     launch_linesearch(d, n_act, h->spec_threshold, st);  // cc:235-270
     launch_update(d, n_act, st);                       // cc:272-308
+    launch_export_done(d, n_act, o_traj, st);          // cc:238,285,303,319
     if (o_it) launch_export_iter_traj(d, d.act, n_act, o_it, out->max_iter_trajs, st);
     if (tm.end()) return CILQR_ERR_DEVICE;
     HIP_TRY(hipMemcpyAsync(h->h_count, d.counters, sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     n_act = h->h_count[0];
-    int* t = d.act; d.act = d.act_next; d.act_next = t;
+    if (h->compaction && n_act > 0 && 2 * n_act <= span) {
+      // the survivors fill less than half of the occupied slots: re-pack them densely
+      if (tm.begin(3)) return CILQR_ERR_DEVICE;
+      launch_compact(d, o, n_act, st);
+      if (tm.end()) return CILQR_ERR_DEVICE;
+      DeviceState t = d; d = o; o = t;
+      span = n_act;
+    } else {
+      int* t = d.act; d.act = d.act_next; d.act_next = t;
+    }
   }
   h->prof.iterations = it;
   if (tm.begin(3)) return CILQR_ERR_DEVICE;
-  launch_export_traj(d, B, o_traj, st);                // cc:319
-  launch_export_hist(d, B, o_hist, o_nc, o_st, o_ni, o_nit, st);
+  launch_export_hist(h->ds, B, o_hist, o_nc, o_st, o_ni, o_nit, st);
   if (tm.end()) return CILQR_ERR_DEVICE;
   HIP_TRY(hipGetLastError());
   if (out->memory == CILQR_MEM_HOST) {

@@ -97,6 +97,15 @@ struct DeviceState {
   double* trial;   // [5][Bcap] cost components of the last evaluated trajectory
   double* hist;    // [max_iter+1][5][Bcap]
 
+  // Slots vs problems.  A slot is where a problem's working set currently lives; once the active
+  // set has halved, the survivors are re-packed into the first slots of the twin arena
+  // (k_compact) so that every kernel keeps reading dense, coalesced rows.  pid[slot] is the
+  // caller's problem index.  Bookkeeping that is touched once per iteration (hist, status, n_cost,
+  // iter, n_iter_trajs) is indexed by PROBLEM and never moves; finished problems are exported the
+  // moment they finish (k_export_done).
+  int* pid;          // [Bcap] slot -> problem
+  int* done_now;     // [Bcap] slot finished in this iteration's update
+
   // per-problem solver state (ilqr_optimizer.cc:180-199)
   double* lambda;
   double* dlambda;
@@ -116,6 +125,7 @@ struct DeviceState {
   double2* Xs;       // [11][K][3][spec_cap]
   double2* Us;       // [11][N][spec_cap]
   double2* parts;    // [11][K][3][spec_cap]
+  double* spec_tot;  // [11][5][spec_cap] total cost of every candidate
 
   // work lists
   int* act;          // active slots
@@ -154,6 +164,10 @@ void launch_forward(const DeviceState& s, const int* list, int n, double alpha, 
 // the 11-round line search of one lockstep iteration (forward/cost/accept with compaction)
 void launch_linesearch(const DeviceState& s, int n_act, int spec_threshold, hipStream_t st);
 void launch_update(const DeviceState& s, int n_act, hipStream_t st);
+// trajectories of the slots that finished in the last update -> traj[pid]
+void launch_export_done(const DeviceState& s, int n_act, double* traj, hipStream_t st);
+// survivors (next active list of `src`, n of them) -> slots 0..n-1 of `dst`
+void launch_compact(const DeviceState& src, const DeviceState& dst, int n, hipStream_t st);
 void launch_export_traj(const DeviceState& s, int B, double* traj, hipStream_t st);
 void launch_export_iter_traj(const DeviceState& s, const int* list, int n, double* iter_trajs,
                              int max_iter_trajs, hipStream_t st);

@@ -139,6 +139,9 @@ int cilqr_set_stream(cilqr_handle h, void* hip_stream);
  * most this many active problems evaluate all 11 line-search step sizes concurrently instead of
  * round by round (0 disables; capped at 8192). */
 #define CILQR_OPT_SPEC_THRESHOLD 1
+/* CILQR_OPT_COMPACTION (default 1): re-pack the surviving problems into dense slots whenever the
+ * active set has halved, so later iterations keep reading coalesced rows. */
+#define CILQR_OPT_COMPACTION 2
 int cilqr_set_option(cilqr_handle h, int32_t option, int64_t value);
 int cilqr_set_profiling(cilqr_handle h, int32_t enable);
 int cilqr_get_profile(cilqr_handle h, cilqr_profile* out);

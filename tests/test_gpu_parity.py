@@ -341,9 +341,14 @@ def test_speculative_line_search_is_bit_identical_to_round_by_round():
     b = opt.plan(sc, max_iter_trajs=3)
     opt.set_option(api.OPT_SPEC_THRESHOLD, 64)       # switch modes in the middle of the solve
     c = opt.plan(sc, max_iter_trajs=3)
+    # re-packing the survivors into dense slots (default on) must not change a bit either
+    opt.set_option(api.OPT_COMPACTION, 0)
+    d = opt.plan(sc, max_iter_trajs=3)
+    opt.set_option(api.OPT_SPEC_THRESHOLD, 8192)
+    e = opt.plan(sc, max_iter_trajs=3)
     for k in ("traj", "cost_hist", "n_cost", "status", "n_iter", "iter_trajs", "n_iter_trajs"):
-        assert np.array_equal(a[k], b[k]), k
-        assert np.array_equal(a[k], c[k]), k
+        for other in (b, c, d, e):
+            assert np.array_equal(a[k], other[k]), k
     opt.close()
 
 
