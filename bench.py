@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--cpu-sample", type=int, default=1024, help="problems timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
+    ap.add_argument("--compact-percent", type=int, default=-1, help="CILQR_OPT_COMPACTION value (tuning experiments)")
+    ap.add_argument("--spec-threshold", type=int, default=-1, help="CILQR_OPT_SPEC_THRESHOLD value (tuning experiments)")
     ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "backward_traffic.json"))
     args = ap.parse_args()
 
@@ -72,6 +74,10 @@ def main():
                                  max_lane_segments=max(sc["left"].shape[0], sc["right"].shape[0]))
     opt.set_stream(torch.cuda.current_stream().cuda_stream)
     opt.set_profiling(not args.no_profile)
+    if args.compact_percent >= 0:
+        opt.set_option(api.OPT_COMPACTION, args.compact_percent)
+    if args.spec_threshold >= 0:
+        opt.set_option(api.OPT_SPEC_THRESHOLD, args.spec_threshold)
 
     d_start = torch.from_numpy(sc["start"]).to(dev)
     d_coarse = torch.from_numpy(sc["coarse"]).to(dev)
@@ -107,7 +113,7 @@ def main():
         step()
     fence()
     prof_acc = dict(bwd_ms=0.0, bwd_launches=0, bwd_steps=0, quad_ms=0.0, ls_ms=0.0, other_ms=0.0,
-                    total_ms=0.0, iters=0)
+                    total_ms=0.0, iters=0, full_ms=0.0, full_launches=0)
     t_start = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -120,6 +126,8 @@ def main():
         prof_acc["other_ms"] += p.other_ms
         prof_acc["total_ms"] += p.total_ms
         prof_acc["iters"] += p.iterations
+        prof_acc["full_ms"] += p.backward_full_ms
+        prof_acc["full_launches"] += p.backward_full_launches
     fence()
     elapsed = time.perf_counter() - t_start
     if world > 1:
@@ -137,17 +145,24 @@ def main():
         value = world * B * args.steps / elapsed
         roof = None
         if not args.no_profile and prof_acc["bwd_ms"] > 0:
-            # algorithmic bytes: per launch n_act*(N*110+44)*8; backward_problem_steps = sum n_act*N
+            # ALGORITHMIC bytes: a launch over n problems moves n*(N*110+44)*8 B dense.
+            # One solve launches k_backward once per lockstep iteration, over 65536 problems at first
+            # and over a few stragglers at the end; `achieved` aggregates ALL launches of the timed
+            # region (sum of bytes / sum of HIP-event durations = bytes per launch / avg duration, the
+            # figure `rocprofv3 --stats` reproduces); `full_batch` is the same ratio over the launches
+            # that covered the whole batch (the metric's "batch=65536" case).
+            per_problem = (N * api.DENSE_DOUBLES_PER_STEP + api.DENSE_DOUBLES_TERMINAL) * 8.0
             n_act_sum = prof_acc["bwd_steps"] / N
-            alg_bytes = n_act_sum * (N * api.DENSE_DOUBLES_PER_STEP + api.DENSE_DOUBLES_TERMINAL) * 8.0
+            alg_bytes = n_act_sum * per_problem
             achieved = alg_bytes / (prof_acc["bwd_ms"] * 1e-3) / 1e9
             traffic = None
             if os.path.exists(args.traffic_file):
                 try:
                     with open(args.traffic_file) as f:
                         tf = json.load(f)
-                    # measured HBM bytes per problem-step (rocprofv3 PMC, corrected per the guide)
-                    traffic = tf["hbm_bytes_per_problem_step"] * prof_acc["bwd_steps"] / prof_acc["bwd_launches"]
+                    # PMC-measured HBM bytes per problem-step of the same workload (rocprofv3
+                    # FETCH_SIZE x2 + WRITE_SIZE, separate passes), scaled to this run's launches
+                    traffic = tf["hbm_bytes_per_problem_step_all_launches"] * prof_acc["bwd_steps"] / prof_acc["bwd_launches"]
                 except Exception:
                     traffic = None
             roof = {
@@ -158,7 +173,16 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes / prof_acc["bwd_launches"],
                 "avg_launch_ms": prof_acc["bwd_ms"] / prof_acc["bwd_launches"],
                 "launches": prof_acc["bwd_launches"],
+                "mean_problems_per_launch": n_act_sum / prof_acc["bwd_launches"],
             }
+            if prof_acc["full_launches"] > 0:
+                fb = B * per_problem * prof_acc["full_launches"] / (prof_acc["full_ms"] * 1e-3) / 1e9
+                roof["full_batch"] = {
+                    "problems": B, "launches": prof_acc["full_launches"],
+                    "algorithmic_bytes_per_launch": B * per_problem,
+                    "launch_ms": prof_acc["full_ms"] / prof_acc["full_launches"],
+                    "achieved": round(fb, 1), "frac": round(fb / HBM_PEAK_GBS, 4),
+                }
         cpu = None
         if args.cpu_sample > 0:
             from oracle import oracle as orc

@@ -67,6 +67,7 @@ class Profile(C.Structure):
         ("iterations", C.c_int32), ("backward_launches", C.c_int32), ("backward_ms", C.c_double),
         ("quadratize_ms", C.c_double), ("linesearch_ms", C.c_double), ("other_ms", C.c_double),
         ("total_ms", C.c_double), ("backward_problem_steps", C.c_int64),
+        ("backward_full_launches", C.c_int32), ("reserved1", C.c_int32), ("backward_full_ms", C.c_double),
     ]
 
 

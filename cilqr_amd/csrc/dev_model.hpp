@@ -55,11 +55,15 @@ CILQR_DEV double bar_value(const Params& p, double g) {
 // bar_group_value() closes the group.  A group holds at most a few dozen factors of magnitude
 // 1e-3..1e2, far from fp64 over/underflow.  This only re-associates the reference's sum.
 CILQR_DEV void bar_accumulate(const Params& p, double g, double& prod, double& quad) {
-  if (g < -p.bar_eps) {
-    prod *= -g;
-  } else {
-    const double q = (-g - 2.0 * p.bar_eps) / p.bar_eps;
-    quad += 0.5 * p.bar_r * (q * q - 1) - p.bar_rlogeps;
+  // log branch without control flow (the common case); the relaxed branch, which needs a division,
+  // sits behind a wave-uniform test so the straight-line code of a whole chunk can be scheduled
+  const bool lg = g < -p.bar_eps;
+  prod *= lg ? -g : 1.0;
+  if (__builtin_amdgcn_ballot_w64(!lg) != 0) {
+    if (!lg) {
+      const double q = (-g - 2.0 * p.bar_eps) / p.bar_eps;
+      quad += 0.5 * p.bar_r * (q * q - 1) - p.bar_rlogeps;
+    }
   }
 }
 CILQR_DEV double bar_group_value(const Params& p, double prod, double quad) {

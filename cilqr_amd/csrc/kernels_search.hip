@@ -294,7 +294,8 @@ void launch_linesearch(const DeviceState& s, int n_act, int spec_threshold, hipS
     const int n_grid = (n_act + shrink - 1) / shrink;
     launch_cost_knots(s, (r == 0) ? (const int*)s.act : (const int*)(s.pend + (size_t)r * s.Bcap),
                       (r == 0) ? (const int*)nullptr : (const int*)(s.counters + r), n_act, n_grid, 1, 1, st);
-    hipLaunchKernelGGL(k_search_round, dim3((n_grid + 63) / 64), dim3(64), 0, st, s, r, n_act);
+    // one lane per pending problem (never strided: a lane's work is a whole 50-step rollout)
+    hipLaunchKernelGGL(k_search_round, dim3((n_act + 63) / 64), dim3(64), 0, st, s, r, n_act);
   }
 }
 

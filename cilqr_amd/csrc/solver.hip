@@ -35,6 +35,7 @@ struct cilqr_solver {
   DeviceState ds;      // arena A (also what the stage API works on)
   DeviceState twin;    // arena B: only the fields k_compact moves are its own, the rest alias ds
   bool compaction = true;
+  int compact_percent = 75;  // re-pack when the survivors fill at most this share of the occupied slots
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   std::vector<void*> allocs;
@@ -188,7 +189,7 @@ int do_load(cilqr_solver* h, const cilqr_problem_batch* in) {
 struct Timer {  // event pairs, resolved after the final sync
   cilqr_solver* h;
   size_t next = 0;
-  std::vector<int> kind;  // 0 quad, 1 backward, 2 linesearch, 3 other
+  std::vector<int> kind;  // 0 quad, 1 backward, 2 linesearch, 3 other, 4 backward over the whole batch
   int begin(int k) {
     if (!h->profiling) return 0;
     if (next + 2 > h->ev.size()) {
@@ -212,6 +213,7 @@ struct Timer {  // event pairs, resolved after the final sync
       switch (kind[i]) {
         case 0: p->quadratize_ms += ms; break;
         case 1: p->backward_ms += ms; break;
+        case 4: p->backward_ms += ms; p->backward_full_ms += ms; p->backward_full_launches += 1; break;
         case 2: p->linesearch_ms += ms; break;
         default: p->other_ms += ms; break;
       }
@@ -385,8 +387,10 @@ int cilqr_set_stream(cilqr_handle h, void* hip_stream) {
 int cilqr_set_option(cilqr_handle h, int32_t option, int64_t value) {
   if (h == nullptr) return CILQR_ERR_NULL;
   switch (option) {
-    case CILQR_OPT_COMPACTION:
+    case CILQR_OPT_COMPACTION:   // 0 = off, 1 = default, 2..100 = re-pack at that occupancy percentage
+      if (value < 0 || value > 100) return CILQR_ERR_ARG;
       h->compaction = value != 0;
+      if (value >= 2) h->compact_percent = (int)value;
       return CILQR_OK;
     case CILQR_OPT_SPEC_THRESHOLD:
       if (value < 0) return CILQR_ERR_ARG;
@@ -470,7 +474,7 @@ int cilqr_solve_batch(cilqr_handle h, const cilqr_problem_batch* in, cilqr_solut
     HIP_TRY(hipMemsetAsync(d.counters, 0, 64 * sizeof(int), st));
     if (tm.begin(0)) return CILQR_ERR_DEVICE;
     launch_quadratize(d, d.act, n_act, 1, st);         // cc:203-214
-    if (tm.end() || tm.begin(1)) return CILQR_ERR_DEVICE;
+    if (tm.end() || tm.begin(n_act == B ? 4 : 1)) return CILQR_ERR_DEVICE;
     launch_backward(d, d.act, n_act, nullptr, st);     // cc:218
     if (tm.end() || tm.begin(2)) return CILQR_ERR_DEVICE;
     h->prof.backward_launches += 1;
@@ -483,8 +487,8 @@ int cilqr_solve_batch(cilqr_handle h, const cilqr_problem_batch* in, cilqr_solut
     HIP_TRY(hipMemcpyAsync(h->h_count, d.counters, sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     n_act = h->h_count[0];
-    if (h->compaction && n_act > 0 && 2 * n_act <= span) {
-      // the survivors fill less than half of the occupied slots: re-pack them densely
+    if (h->compaction && n_act > 0 && (int64_t)100 * n_act <= (int64_t)h->compact_percent * span) {
+      // the survivors have thinned out: re-pack them densely
       if (tm.begin(3)) return CILQR_ERR_DEVICE;
       launch_compact(d, o, n_act, st);
       if (tm.end()) return CILQR_ERR_DEVICE;

@@ -124,6 +124,9 @@ typedef struct cilqr_profile {
   double other_ms;               /* load, init guess, update, export */
   double total_ms;               /* first kernel start -> last kernel end */
   int64_t backward_problem_steps;/* sum over launches of (active problems x N) */
+  int32_t backward_full_launches;/* launches whose active set was the whole batch */
+  int32_t reserved1;
+  double backward_full_ms;       /* their summed duration */
 } cilqr_profile;
 
 int cilqr_abi_version(void);
@@ -139,8 +142,9 @@ int cilqr_set_stream(cilqr_handle h, void* hip_stream);
  * most this many active problems evaluate all 11 line-search step sizes concurrently instead of
  * round by round (0 disables; capped at 8192). */
 #define CILQR_OPT_SPEC_THRESHOLD 1
-/* CILQR_OPT_COMPACTION (default 1): re-pack the surviving problems into dense slots whenever the
- * active set has halved, so later iterations keep reading coalesced rows. */
+/* CILQR_OPT_COMPACTION (default 1): re-pack the surviving problems into dense slots whenever they
+ * fill at most 75 % of the occupied slots, so later iterations keep reading coalesced rows.
+ * 0 = never, 2..100 = re-pack at that occupancy percentage. */
 #define CILQR_OPT_COMPACTION 2
 int cilqr_set_option(cilqr_handle h, int32_t option, int64_t value);
 int cilqr_set_profiling(cilqr_handle h, int32_t enable);
