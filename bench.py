@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
     ap.add_argument("--compact-percent", type=int, default=-1, help="CILQR_OPT_COMPACTION value (tuning experiments)")
     ap.add_argument("--spec-threshold", type=int, default=-1, help="CILQR_OPT_SPEC_THRESHOLD value (tuning experiments)")
+    ap.add_argument("--seq-rounds", type=int, default=-1, help="CILQR_OPT_SEQ_ROUNDS value (tuning experiments)")
     ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "backward_traffic.json"))
     args = ap.parse_args()
 
@@ -76,6 +77,8 @@ def main():
     opt.set_profiling(not args.no_profile)
     if args.compact_percent >= 0:
         opt.set_option(api.OPT_COMPACTION, args.compact_percent)
+    if args.seq_rounds >= 1:
+        opt.set_option(api.OPT_SEQ_ROUNDS, args.seq_rounds)
     if args.spec_threshold >= 0:
         opt.set_option(api.OPT_SPEC_THRESHOLD, args.spec_threshold)
 

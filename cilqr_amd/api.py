@@ -20,6 +20,7 @@ ERR_NULL, ERR_CONSTRAINTS, ERR_KNOTS, ERR_CAPACITY, ERR_DEVICE, ERR_ARG, ERR_STA
 MEM_HOST, MEM_DEVICE = 0, 1
 OPT_SPEC_THRESHOLD = 1
 OPT_COMPACTION = 2
+OPT_SEQ_ROUNDS = 3
 ST_RUNNING, ST_CONVERGED_ABS, ST_CONVERGED_REL, ST_GNORM, ST_UNSOLVED, ST_MAX_ITER = range(6)
 
 T_GOALS, T_CORRIDOR, T_LANES, T_X, T_U, T_XCAND, T_UCAND, T_A, T_B, T_LX, T_LU, T_LXX, T_LUU, \

@@ -211,29 +211,33 @@ __global__ __launch_bounds__(256) void k_cost_knots(DeviceState s, const int* __
   }
 }
 
-// speculative line search: knot i of candidate alpha_r of list entry j
-__global__ __launch_bounds__(256) void k_spec_cost(DeviceState s, int n) {
+// speculative line search: knot i of candidate alpha_{r0 + blockIdx.z} of list entry j
+__global__ __launch_bounds__(256) void k_spec_cost(DeviceState s, const int* __restrict__ list,
+                                                   const int* __restrict__ n_ptr, int n_max, int r0) {
   extern __shared__ double lds[];
+  const int n = n_ptr ? min(*n_ptr, n_max) : n_max;
+  if ((int)(blockIdx.x * blockDim.x) >= n) return;
   const double* lanes = stage_lanes(s, lds);
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
-  const int i = blockIdx.y, r = blockIdx.z;
-  const int slot = s.act[j];
-  if (s.acc_idx[slot] != -1) return;   // left at the gradient-norm exit
+  const int i = blockIdx.y, r = r0 + blockIdx.z;
   const size_t cap = (size_t)s.spec_cap;
-  const double2* xb = s.Xs + ((size_t)r * s.p.K + i) * 3 * cap + j;
-  const double2 p0 = xb[0], p1 = xb[cap], p2 = xb[2 * cap];
-  const double x[6] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y};
-  double u[2] = {0.0, 0.0};
-  if (i < s.p.N) {
-    const double2 q = s.Us[((size_t)r * s.p.N + i) * cap + j];
-    u[0] = q.x; u[1] = q.y;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+    const int slot = list[j];
+    if (s.acc_idx[slot] != -1) continue;   // left at the gradient-norm exit
+    const double2* xb = s.Xs + ((size_t)r * s.p.K + i) * 3 * cap + j;
+    const double2 p0 = xb[0], p1 = xb[cap], p2 = xb[2 * cap];
+    const double x[6] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y};
+    double u[2] = {0.0, 0.0};
+    if (i < s.p.N) {
+      const double2 q = s.Us[((size_t)r * s.p.N + i) * cap + j];
+      u[0] = q.x; u[1] = q.y;
+    }
+    knot_cost_any(s, lanes, i, slot, x, u, s.parts + ((size_t)r * s.p.K + i) * kPartPairs * cap + j, cap);
   }
-  knot_cost_any(s, lanes, i, slot, x, u, s.parts + ((size_t)r * s.p.K + i) * kPartPairs * cap + j, cap);
 }
-void launch_spec_cost(const DeviceState& s, int n, hipStream_t st) {
-  dim3 g((n + 255) / 256, s.p.K, kNumAlpha);
-  hipLaunchKernelGGL(k_spec_cost, g, dim3(256), lane_lds_bytes(s), st, s, n);
+void launch_spec_cost(const DeviceState& s, const int* list, const int* n_ptr, int n_max, int n_grid, int r0,
+                      hipStream_t st) {
+  dim3 g((n_grid + 255) / 256, s.p.K, kNumAlpha - r0);
+  hipLaunchKernelGGL(k_spec_cost, g, dim3(256), lane_lds_bytes(s), st, s, list, n_ptr, n_max, r0);
 }
 
 // sum of the knot partials in index order -> trial[5] (total, J, dynamics, corridor, lane)

@@ -154,7 +154,7 @@ CILQR_DEV void reduce_cost_ls(const DeviceState& s, int slot, double* c5) {
 
 // round r: total cost of the alpha_r candidate, acceptance test (cc:252-261); on rejection roll
 // out alpha_{r+1} and queue the slot for the next round.
-__global__ __launch_bounds__(64) void k_search_round(DeviceState s, int r, int n_max) {
+__global__ __launch_bounds__(64) void k_search_round(DeviceState s, int r, int n_max, int roll_next) {
   const int* __restrict__ list = (r == 0) ? s.act : s.pend + (size_t)r * s.Bcap;
   const int n = (r == 0) ? n_max : min(s.counters[r], n_max);
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
@@ -173,129 +173,158 @@ __global__ __launch_bounds__(64) void k_search_round(DeviceState s, int r, int n
       s.dcost[slot] = dcost;
       s.cur[slot] ^= 1;   // the candidate becomes the iterate
     } else if (r + 1 < kNumAlpha) {
-      forward_problem(s, slot, kAlpha[r + 1]);
+      if (roll_next) forward_problem(s, slot, kAlpha[r + 1]);
       const int pos = atomicAdd(&s.counters[r + 1], 1);
       s.pend[(size_t)(r + 1) * s.Bcap + pos] = slot;
     }
   }
 }
 
-// ---- speculative mode: all 11 step sizes of every listed problem at once (small active sets) ----
-__global__ __launch_bounds__(64) void k_spec_forward(DeviceState s, int n) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
-  const int r = blockIdx.y;
-  const int slot = s.act[j];
-  if (s.gnorm[slot] < 1e-6 && s.lambda[slot] < 1e-5) {   // cc:235-241
-    if (r == 0) {
-      s.status[s.pid[slot]] = 3;
-      s.acc_idx[slot] = -2;
+// ---- speculative mode: step sizes r0..10 of every listed problem at once ----
+// Used for the whole line search of small active sets (r0 = 0, list = active list, `open` = also
+// take the gradient-norm exit) and for the tail of the round-by-round search (r0 = number of
+// sequential rounds done, list = the problems that rejected all of them).
+__global__ __launch_bounds__(64) void k_spec_forward(DeviceState s, const int* __restrict__ list,
+                                                     const int* __restrict__ n_ptr, int n_max, int r0, int open) {
+  const int n = n_ptr ? min(*n_ptr, n_max) : n_max;
+  const int r = r0 + blockIdx.y;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+    const int slot = list[j];
+    if (open) {
+      if (s.gnorm[slot] < 1e-6 && s.lambda[slot] < 1e-5) {   // cc:235-241
+        if (r == 0) {
+          s.status[s.pid[slot]] = 3;
+          s.acc_idx[slot] = -2;
+        }
+        continue;
+      }
+      if (r == 0) s.acc_idx[slot] = -1;
     }
-    return;
+    forward_core(s, slot, kAlpha[r], OutSpec{s, r, j});
   }
-  if (r == 0) s.acc_idx[slot] = -1;
-  forward_core(s, slot, kAlpha[r], OutSpec{s, r, j});
 }
 
 // total cost of candidate alpha_r of list entry j: knot partials summed in index order
-__global__ __launch_bounds__(64) void k_spec_reduce(DeviceState s, int n) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
-  const int r = blockIdx.y;
-  const int slot = s.act[j];
-  if (s.acc_idx[slot] != -1) return;
+__global__ __launch_bounds__(64) void k_spec_reduce(DeviceState s, const int* __restrict__ list,
+                                                    const int* __restrict__ n_ptr, int n_max, int r0, int open) {
+  const int n = n_ptr ? min(*n_ptr, n_max) : n_max;
+  const int r = r0 + blockIdx.y;
   const size_t cap = (size_t)s.spec_cap;
   const int K = s.p.K, N = s.p.N;
-  double jj = 0.0, dx = 0.0, du = 0.0, cc = 0.0, lc = 0.0;
-  const double2* pb = s.parts + (size_t)r * K * kPartPairs * cap + j;
-  for (int i = 0; i < K; ++i) {
-    const double2* o = pb + (size_t)i * kPartPairs * cap;
-    const double2 a = o[0], b = o[cap], c = o[2 * cap];
-    jj += a.x;
-    dx += b.x;
-    cc += c.x;
-    lc += c.y;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+    const int slot = list[j];
+    if (open) {   // acc_idx is written by the r == 0 lanes of k_spec_forward, already complete here
+      if (s.acc_idx[slot] != -1) continue;
+    }
+    double jj = 0.0, dx = 0.0, du = 0.0, cc = 0.0, lc = 0.0;
+    const double2* pb = s.parts + (size_t)r * K * kPartPairs * cap + j;
+    for (int i = 0; i < K; ++i) {
+      const double2* o = pb + (size_t)i * kPartPairs * cap;
+      const double2 a = o[0], b = o[cap], c = o[2 * cap];
+      jj += a.x;
+      dx += b.x;
+      cc += c.x;
+      lc += c.y;
+    }
+    for (int i = 0; i < N; ++i) {
+      const double2* o = pb + (size_t)i * kPartPairs * cap;
+      jj += o[0].y;
+      du += o[cap].y;
+    }
+    const double dyn = dx + du;
+    double* t = s.spec_tot + (size_t)r * 5 * cap + j;
+    t[0] = jj + dyn + cc + lc;
+    t[cap] = jj; t[2 * cap] = dyn; t[3 * cap] = cc; t[4 * cap] = lc;
   }
-  for (int i = 0; i < N; ++i) {
-    const double2* o = pb + (size_t)i * kPartPairs * cap;
-    jj += o[0].y;
-    du += o[cap].y;
-  }
-  const double dyn = dx + du;
-  double* t = s.spec_tot + (size_t)r * 5 * cap + j;
-  t[0] = jj + dyn + cc + lc;
-  t[cap] = jj; t[2 * cap] = dyn; t[3 * cap] = cc; t[4 * cap] = lc;
 }
 
 // first passing alpha wins (cc:246-261)
-__global__ __launch_bounds__(64) void k_spec_pick(DeviceState s, int n) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
-  const int slot = s.act[j];
-  if (s.acc_idx[slot] != -1) return;
+__global__ __launch_bounds__(64) void k_spec_pick(DeviceState s, const int* __restrict__ list,
+                                                  const int* __restrict__ n_ptr, int n_max, int r0) {
+  const int n = n_ptr ? min(*n_ptr, n_max) : n_max;
   const size_t cap = (size_t)s.spec_cap;
   const int Bc = s.Bcap;
-  const double cost_old = s.cost_old[slot], dV0 = s.dV[slot], dV1 = s.dV[(size_t)Bc + slot];
-  int acc = -1, last = kNumAlpha - 1;
-  double dcost = 0.0;
-  for (int r = 0; r < kNumAlpha; ++r) {
-    const double alpha = kAlpha[r];
-    dcost = cost_old - s.spec_tot[(size_t)r * 5 * cap + j];
-    const double expected = -alpha * (dV0 + alpha * dV1);
-    const double z = dcost / expected;
-    if ((z > 1e-4 && z < 10.0) && dcost > 0.0) {
-      acc = r;
-      last = r;
-      break;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+    const int slot = list[j];
+    if (s.acc_idx[slot] != -1) continue;
+    const double cost_old = s.cost_old[slot], dV0 = s.dV[slot], dV1 = s.dV[(size_t)Bc + slot];
+    int acc = -1, last = kNumAlpha - 1;
+    double dcost = 0.0;
+    for (int r = r0; r < kNumAlpha; ++r) {
+      const double alpha = kAlpha[r];
+      dcost = cost_old - s.spec_tot[(size_t)r * 5 * cap + j];
+      const double expected = -alpha * (dV0 + alpha * dV1);
+      const double z = dcost / expected;
+      if ((z > 1e-4 && z < 10.0) && dcost > 0.0) {
+        acc = r;
+        last = r;
+        break;
+      }
     }
-  }
 #pragma unroll
-  for (int c = 0; c < 5; ++c)
-    s.trial[(size_t)c * Bc + slot] = s.spec_tot[((size_t)last * 5 + c) * cap + j];
-  if (acc < 0) return;
-  s.acc_idx[slot] = acc;
-  s.dcost[slot] = dcost;
-  s.cur[slot] ^= 1;   // k_spec_copy fills the new current buffer
+    for (int c = 0; c < 5; ++c)
+      s.trial[(size_t)c * Bc + slot] = s.spec_tot[((size_t)last * 5 + c) * cap + j];
+    if (acc < 0) continue;
+    s.acc_idx[slot] = acc;
+    s.dcost[slot] = dcost;
+    s.cur[slot] ^= 1;   // k_spec_copy fills the new current buffer
+  }
 }
 
 // the accepted candidate becomes the iterate: one thread per (list entry, knot)
-__global__ __launch_bounds__(256) void k_spec_copy(DeviceState s, int n) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
+__global__ __launch_bounds__(256) void k_spec_copy(DeviceState s, const int* __restrict__ list,
+                                                   const int* __restrict__ n_ptr, int n_max, int r0) {
+  const int n = n_ptr ? min(*n_ptr, n_max) : n_max;
   const int i = blockIdx.y;
-  const int slot = s.act[j];
-  const int acc = s.acc_idx[slot];
-  if (acc < 0) return;
   const size_t cap = (size_t)s.spec_cap;
   const int K = s.p.K, N = s.p.N, Bc = s.Bcap;
-  const int nb = s.cur[slot];
-  const double2* xb = s.Xs + ((size_t)acc * K + i) * 3 * cap + j;
-  double2* o = s.X + ((size_t)nb * K + i) * 3 * Bc + slot;
-  o[0] = xb[0];
-  o[(size_t)Bc] = xb[cap];
-  o[(size_t)2 * Bc] = xb[2 * cap];
-  if (i < N) s.U[((size_t)nb * N + i) * Bc + slot] = s.Us[((size_t)acc * N + i) * cap + j];
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+    const int slot = list[j];
+    const int acc = s.acc_idx[slot];
+    if (acc < r0) continue;   // not accepted (or accepted in an earlier sequential round)
+    const int nb = s.cur[slot];
+    const double2* xb = s.Xs + ((size_t)acc * K + i) * 3 * cap + j;
+    double2* o = s.X + ((size_t)nb * K + i) * 3 * Bc + slot;
+    o[0] = xb[0];
+    o[(size_t)Bc] = xb[cap];
+    o[(size_t)2 * Bc] = xb[2 * cap];
+    if (i < N) s.U[((size_t)nb * N + i) * Bc + slot] = s.Us[((size_t)acc * N + i) * cap + j];
+  }
 }
 
-void launch_linesearch(const DeviceState& s, int n_act, int spec_threshold, hipStream_t st) {
+static void launch_spec(const DeviceState& s, const int* list, const int* n_ptr, int n_max, int n_grid, int r0,
+                        int open, hipStream_t st) {
+  const int na = kNumAlpha - r0;
+  hipLaunchKernelGGL(k_spec_forward, dim3((n_grid + 63) / 64, na), dim3(64), 0, st, s, list, n_ptr, n_max, r0, open);
+  launch_spec_cost(s, list, n_ptr, n_max, n_grid, r0, st);
+  hipLaunchKernelGGL(k_spec_reduce, dim3((n_grid + 63) / 64, na), dim3(64), 0, st, s, list, n_ptr, n_max, r0, open);
+  hipLaunchKernelGGL(k_spec_pick, dim3((n_grid + 63) / 64), dim3(64), 0, st, s, list, n_ptr, n_max, r0);
+  hipLaunchKernelGGL(k_spec_copy, dim3((n_grid + 255) / 256, s.p.K), dim3(256), 0, st, s, list, n_ptr, n_max, r0);
+}
+
+// seq_rounds: how many step sizes are tried round by round before the rest is evaluated at once
+void launch_linesearch(const DeviceState& s, int n_act, int spec_threshold, int seq_rounds, hipStream_t st) {
   if (n_act == 0) return;
-  if (n_act <= spec_threshold && n_act <= s.spec_cap) {
-    hipLaunchKernelGGL(k_spec_forward, dim3((n_act + 63) / 64, kNumAlpha), dim3(64), 0, st, s, n_act);
-    launch_spec_cost(s, n_act, st);
-    hipLaunchKernelGGL(k_spec_reduce, dim3((n_act + 63) / 64, kNumAlpha), dim3(64), 0, st, s, n_act);
-    hipLaunchKernelGGL(k_spec_pick, dim3((n_act + 63) / 64), dim3(64), 0, st, s, n_act);
-    hipLaunchKernelGGL(k_spec_copy, dim3((n_act + 255) / 256, s.p.K), dim3(256), 0, st, s, n_act);
+  if (n_act <= spec_threshold) {
+    launch_spec(s, s.act, nullptr, n_act, n_act, 0, 1, st);
     return;
   }
+  const int R = seq_rounds < 1 ? 1 : (seq_rounds > kNumAlpha ? kNumAlpha : seq_rounds);
   hipLaunchKernelGGL(k_search_open, dim3((n_act + 63) / 64), dim3(64), 0, st, s, n_act);
-  for (int r = 0; r < kNumAlpha; ++r) {
-    // later rounds carry a small fraction of the batch: shrink their grids, stride inside
+  for (int r = 0; r < R; ++r) {
+    // later rounds carry a fraction of the batch: shrink the cost grid, stride inside
     const int shrink = (r == 0) ? 1 : (r == 1 ? 2 : 8);
     const int n_grid = (n_act + shrink - 1) / shrink;
     launch_cost_knots(s, (r == 0) ? (const int*)s.act : (const int*)(s.pend + (size_t)r * s.Bcap),
                       (r == 0) ? (const int*)nullptr : (const int*)(s.counters + r), n_act, n_grid, 1, 1, st);
     // one lane per pending problem (never strided: a lane's work is a whole 50-step rollout)
-    hipLaunchKernelGGL(k_search_round, dim3((n_act + 63) / 64), dim3(64), 0, st, s, r, n_act);
+    hipLaunchKernelGGL(k_search_round, dim3((n_act + 63) / 64), dim3(64), 0, st, s, r, n_act,
+                       (r + 1 < R || R == kNumAlpha) ? 1 : 0);
+  }
+  if (R < kNumAlpha) {
+    // the problems that rejected alpha_0..alpha_{R-1}: all remaining step sizes in one pass
+    const int n_grid = (n_act + 3) / 4;
+    launch_spec(s, s.pend + (size_t)R * s.Bcap, s.counters + R, n_act, n_grid, R, 0, st);
   }
 }
 

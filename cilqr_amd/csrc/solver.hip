@@ -51,6 +51,7 @@ struct cilqr_solver {
   int B = 0;               // problems loaded
   int stage = 0;           // bit0 loaded, bit1 iterate, bit2 quadratized, bit3 gains
   int spec_threshold = 8192;  // active sets up to this size evaluate all 11 step sizes at once
+  int seq_rounds = 4;         // larger sets: this many round-by-round trials, then the rest at once
   // profiling
   bool profiling = false;
   std::vector<hipEvent_t> ev;
@@ -323,7 +324,7 @@ int cilqr_create(const cilqr_config* cfg, int32_t device, int32_t batch_capacity
   ALLOC(lambda, B); ALLOC(dlambda, B); ALLOC(cost_old, B); ALLOC(dcost, B);
   ALLOC(iter, B); ALLOC(status, B); ALLOC(n_cost, B); ALLOC(upd, B); ALLOC(acc_idx, B);
   ALLOC(n_iter_trajs, B); ALLOC(emit, B); ALLOC(pid, B); ALLOC(done_now, B);
-  d.spec_cap = (int)(B < 8192 ? B : 8192);
+  d.spec_cap = (int)B;   // every active problem can have all 11 candidates in flight (4 GB at B = 65536)
   ALLOC(Xs, (size_t)kNumAlpha * K * 3 * d.spec_cap);
   ALLOC(Us, (size_t)kNumAlpha * N * d.spec_cap);
   ALLOC(parts, (size_t)kNumAlpha * K * kPartPairs * d.spec_cap);
@@ -395,6 +396,10 @@ int cilqr_set_option(cilqr_handle h, int32_t option, int64_t value) {
     case CILQR_OPT_SPEC_THRESHOLD:
       if (value < 0) return CILQR_ERR_ARG;
       h->spec_threshold = (int)(value > h->ds.spec_cap ? h->ds.spec_cap : value);
+      return CILQR_OK;
+    case CILQR_OPT_SEQ_ROUNDS:
+      if (value < 1 || value > kNumAlpha) return CILQR_ERR_ARG;
+      h->seq_rounds = (int)value;
       return CILQR_OK;
     default:
       return CILQR_ERR_ARG;
@@ -479,7 +484,7 @@ int cilqr_solve_batch(cilqr_handle h, const cilqr_problem_batch* in, cilqr_solut
     if (tm.end() || tm.begin(2)) return CILQR_ERR_DEVICE;
     h->prof.backward_launches += 1;
     h->prof.backward_problem_steps += (int64_t)n_act * h->cfg.n_steps;
-    launch_linesearch(d, n_act, h->spec_threshold, st);  // cc:235-270
+    launch_linesearch(d, n_act, h->spec_threshold, h->seq_rounds, st);  // cc:235-270
     launch_update(d, n_act, st);                       // cc:272-308
     launch_export_done(d, n_act, o_traj, st);          // cc:238,285,303,319
     if (o_it) launch_export_iter_traj(d, d.act, n_act, o_it, out->max_iter_trajs, st);

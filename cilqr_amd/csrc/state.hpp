@@ -154,7 +154,8 @@ void launch_set_trajectory(const DeviceState& s, int B, const double* X, const d
 void launch_cost_only(const DeviceState& s, const int* list, int n, int cand, hipStream_t st);
 void launch_cost_knots(const DeviceState& s, const int* list, const int* n_ptr, int n_max, int n_grid,
                        int cand, int skip_done, hipStream_t st);
-void launch_spec_cost(const DeviceState& s, int n, hipStream_t st);
+void launch_spec_cost(const DeviceState& s, const int* list, const int* n_ptr, int n_max, int n_grid, int r0,
+                      hipStream_t st);
 void launch_init_cost_commit(const DeviceState& s, int n, hipStream_t st);
 void launch_quadratize(const DeviceState& s, const int* list, int n, int only_upd, hipStream_t st);
 void launch_backward(const DeviceState& s, const int* list, int n, const double* lambda_override,
@@ -162,7 +163,7 @@ void launch_backward(const DeviceState& s, const int* list, int n, const double*
 void launch_forward(const DeviceState& s, const int* list, int n, double alpha, int skip_done,
                     hipStream_t st);
 // the 11-round line search of one lockstep iteration (forward/cost/accept with compaction)
-void launch_linesearch(const DeviceState& s, int n_act, int spec_threshold, hipStream_t st);
+void launch_linesearch(const DeviceState& s, int n_act, int spec_threshold, int seq_rounds, hipStream_t st);
 void launch_update(const DeviceState& s, int n_act, hipStream_t st);
 // trajectories of the slots that finished in the last update -> traj[pid]
 void launch_export_done(const DeviceState& s, int n_act, double* traj, hipStream_t st);

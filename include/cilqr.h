@@ -140,8 +140,12 @@ int cilqr_destroy(cilqr_handle h);
 int cilqr_set_stream(cilqr_handle h, void* hip_stream);
 /* Tuning knobs that never change results.  CILQR_OPT_SPEC_THRESHOLD: lockstep iterations with at
  * most this many active problems evaluate all 11 line-search step sizes concurrently instead of
- * round by round (0 disables; capped at 8192). */
+ * round by round (0 disables). */
 #define CILQR_OPT_SPEC_THRESHOLD 1
+/* CILQR_OPT_SEQ_ROUNDS (default 4, 1..11): with more active problems than the threshold above, this
+ * many step sizes are tried round by round; the problems that rejected all of them evaluate the
+ * remaining ones concurrently.  11 = fully sequential. */
+#define CILQR_OPT_SEQ_ROUNDS 3
 /* CILQR_OPT_COMPACTION (default 1): re-pack the surviving problems into dense slots whenever they
  * fill at most 75 % of the occupied slots, so later iterations keep reading coalesced rows.
  * 0 = never, 2..100 = re-pack at that occupancy percentage. */

@@ -338,6 +338,7 @@ def test_speculative_line_search_is_bit_identical_to_round_by_round():
     opt = _opt(sc)
     a = opt.plan(sc, max_iter_trajs=3)
     opt.set_option(api.OPT_SPEC_THRESHOLD, 0)
+    opt.set_option(api.OPT_SEQ_ROUNDS, 11)
     b = opt.plan(sc, max_iter_trajs=3)
     opt.set_option(api.OPT_SPEC_THRESHOLD, 64)       # switch modes in the middle of the solve
     c = opt.plan(sc, max_iter_trajs=3)
@@ -346,8 +347,14 @@ def test_speculative_line_search_is_bit_identical_to_round_by_round():
     d = opt.plan(sc, max_iter_trajs=3)
     opt.set_option(api.OPT_SPEC_THRESHOLD, 8192)
     e = opt.plan(sc, max_iter_trajs=3)
+    # hybrid schedules: R rounds one by one, the remaining step sizes at once (R = 11: all sequential)
+    outs = [b, c, d, e]
+    opt.set_option(api.OPT_SPEC_THRESHOLD, 0)
+    for rounds in (1, 2, 3, 5, 11):
+        opt.set_option(api.OPT_SEQ_ROUNDS, rounds)
+        outs.append(opt.plan(sc, max_iter_trajs=3))
     for k in ("traj", "cost_hist", "n_cost", "status", "n_iter", "iter_trajs", "n_iter_trajs"):
-        for other in (b, c, d, e):
+        for other in outs:
             assert np.array_equal(a[k], other[k]), k
     opt.close()
 
