@@ -26,6 +26,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+WORKLOADS = {("ped6", 4096): "configs[1]", ("mix11", 65536): "configs[2] (configs[3] when sharded over 8 GPUs)",
+             ("dyn20", 65536): "configs[4]"}
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -199,13 +201,14 @@ def main():
                    "sample": f"first {ns} scenes of rank 0's batch, single thread, g++ -O2 restatement "
                              f"(oracle/cilqr_oracle.cc), {r['seconds']:.1f} s"}
         out = {
-            "metric": "CILQR solves/sec (50-step horizon, batch=65536 per GPU)",
+            "metric": f"CILQR solves/sec ({N}-step horizon, batch={B} per GPU)",
             "value": round(value, 1), "unit": "solves/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[2]: batch={B}/GPU x {world} GPU, {N}-step horizon, "
-                                   f"scene family {args.scene} (6 pedestrians + 3 moving + 2 static vehicles), "
-                                   f"reference road, seed {args.seed}",
+            "config": {"workload": f"BASELINE {WORKLOADS.get((args.scene, B), 'custom')}: batch={B}/GPU x {world} GPU, "
+                                   f"{N}-step horizon, scene family {args.scene} ({spec.n_pedestrians} pedestrians + "
+                                   f"{spec.n_dynamic} moving + {spec.n_static} static vehicles), reference road, "
+                                   f"seed {args.seed}",
                        "batch_per_gpu": B, "n_steps": N, "cmax": cmax, "results_gather": "rccl" if world > 1 else "none"},
             "roofline": roof,
             "cpu_baseline": cpu,

@@ -179,6 +179,7 @@ CILQR_DEV double segment_dist2(const double* __restrict__ r, double px, double p
 CILQR_DEV int nearest_segment_scan(const double* __restrict__ tab, int n, double px, double py) {
   double best = DBL_MAX;
   int bi = 0;
+#pragma unroll 1
   for (int s = 0; s < n; ++s) {
     const double d2 = segment_dist2(tab + s * kLaneFields, px, py);
     if (d2 < best) {
@@ -208,10 +209,12 @@ CILQR_DEV int nearest_segment(const DeviceState& s, const double* __restrict__ l
   if (cnt == kGridFullScan) return nearest_segment_scan(tab, n, px, py);
   double best = DBL_MAX;
   int bi = 0;
-#pragma unroll
-  for (int k = 1; k < kGridCellBytes; ++k) {
-    if (k > cnt) break;
-    const int seg = (int)((w[k >> 2] >> ((k & 3) * 8)) & 0xffu);
+  // compact loop (not unrolled: this function is inlined at every disc of three kernels and an
+  // unrolled 15-way test made them instruction-cache bound)
+#pragma unroll 1
+  for (int k = 1; k <= cnt; ++k) {
+    const unsigned word = (k < 4) ? w[0] : (k < 8) ? w[1] : (k < 12) ? w[2] : w[3];
+    const int seg = (int)((word >> ((k & 3) * 8)) & 0xffu);
     const double d2 = segment_dist2(tab + seg * kLaneFields, px, py);
     if (d2 < best) {
       best = d2;

@@ -114,14 +114,15 @@ CILQR_DEV void knot_cost_core(const DeviceState& s, const double* __restrict__ l
   double ccost = 0.0, lcost = 0.0;
 #pragma unroll
   for (int j = 0; j < D; ++j) ccost += bar_group_value(p, pr[j], qd[j]);
-  // LaneBoundaryCost cc:583-603
-#pragma unroll
+  // LaneBoundaryCost cc:583-603 (rolled loop: one copy of the lookup code)
+#pragma unroll 1
   for (int j = 0; j < D; ++j) {
+    const double qx = x[0] + p.disc_off[j] * cs, qy = x[1] + p.disc_off[j] * sn;   // = px[j], py[j]
     double pl = 1.0, ql = 0.0;
-    const double* L = lanes + nearest_segment(s, lanes, 0, px[j], py[j]) * kLaneFields;
-    bar_accumulate(p, L[0] * px[j] + L[1] * py[j] - L[2], pl, ql);
-    const double* Rr = lanes + (s.nl + nearest_segment(s, lanes, 1, px[j], py[j])) * kLaneFields;
-    bar_accumulate(p, Rr[0] * px[j] + Rr[1] * py[j] - Rr[2], pl, ql);
+    const double* L = lanes + nearest_segment(s, lanes, 0, qx, qy) * kLaneFields;
+    bar_accumulate(p, L[0] * qx + L[1] * qy - L[2], pl, ql);
+    const double* Rr = lanes + (s.nl + nearest_segment(s, lanes, 1, qx, qy)) * kLaneFields;
+    bar_accumulate(p, Rr[0] * qx + Rr[1] * qy - Rr[2], pl, ql);
     lcost += bar_group_value(p, pl, ql);
   }
   out[0] = make_double2(jx, ju);
@@ -405,6 +406,7 @@ CILQR_DEV void knot_quadratize(const DeviceState& s, const double* __restrict__ 
     pc = nx;
   }
   // nearest left / right lane plane, all discs (cc:729-769)
+#pragma unroll 1
   for (int j = 0; j < nd; ++j) {
     const double lc = p.disc_off[j] * cs, ls = p.disc_off[j] * sn;
     const double px = x[0] + lc, py = x[1] + ls;
