@@ -224,6 +224,11 @@ CILQR_DEV int nearest_segment(const DeviceState& s, const double* __restrict__ l
   return bi;
 }
 
+// number of list entries a kernel of the solve loop has to process (see DeviceState::n_dev)
+CILQR_DEV int active_count(const DeviceState& s, int n_host) {
+  return s.n_dev ? min(*s.n_dev, n_host) : n_host;
+}
+
 // small helpers for the batch-fastest pair layout
 CILQR_DEV double2 ld2(const double2* __restrict__ base, int row, int Bcap, int slot) {
   return base[(size_t)row * Bcap + slot];

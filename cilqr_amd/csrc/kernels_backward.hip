@@ -228,7 +228,7 @@ CILQR_DEV void backward_problem(const DeviceState& s, int slot, double lambda) {
 __global__ __launch_bounds__(64, 1) void k_backward(DeviceState s, const int* __restrict__ list, int n,
                                                      const double* __restrict__ lambda_override) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
+  if (j >= active_count(s, n)) return;
   const int slot = list ? list[j] : j;
   const double lambda = lambda_override ? lambda_override[slot] : s.lambda[slot];
   backward_problem<true>(s, slot, lambda);

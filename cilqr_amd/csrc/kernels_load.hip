@@ -417,6 +417,7 @@ __global__ void k_export_done(DeviceState s, int n, double* __restrict__ traj) {
   const int K = s.p.K;
   if (t >= n * K) return;
   const int i = t / n, j = t - i * n;
+  if (j >= active_count(s, n)) return;
   const int slot = s.act[j];
   if (!s.done_now[slot]) return;
   write_traj_point(s, s.cur[slot], i, slot, traj + ((size_t)s.pid[slot] * K + i) * 10);
@@ -431,9 +432,9 @@ void launch_export_done(const DeviceState& s, int n_act, double* traj, hipStream
 // Moved: the current iterate (into buffer 0), goals, corridor planes + counts, the scalar state.
 // Not moved: the linearisation / gains (recomputed: upd is forced to 1, which reproduces the
 // same values because they depend only on the iterate), and everything indexed by problem.
-__global__ __launch_bounds__(256) void k_compact(DeviceState a, DeviceState b, int n) {
+__global__ __launch_bounds__(256) void k_compact(DeviceState a, DeviceState b, int n_max) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
+  if (j >= min(a.counters[0], n_max)) return;   // counters[0]: survivors counted by k_update
   const int i = blockIdx.y;   // knot
   const int K = a.p.K, N = a.p.N;
   const int src = a.act_next[j];
@@ -470,10 +471,10 @@ __global__ __launch_bounds__(256) void k_compact(DeviceState a, DeviceState b, i
     b.act[j] = j;
   }
 }
-void launch_compact(const DeviceState& src, const DeviceState& dst, int n, hipStream_t st) {
-  if (n == 0) return;
-  dim3 g((n + 255) / 256, src.p.K);
-  hipLaunchKernelGGL(k_compact, g, dim3(256), 0, st, src, dst, n);
+void launch_compact(const DeviceState& src, const DeviceState& dst, int n_max, hipStream_t st) {
+  if (n_max == 0) return;
+  dim3 g((n_max + 255) / 256, src.p.K);
+  hipLaunchKernelGGL(k_compact, g, dim3(256), 0, st, src, dst, n_max);
 }
 
 // iter_trajs: append the current iterate of every listed slot whose emit flag is set
@@ -483,6 +484,7 @@ __global__ void k_export_iter_traj(DeviceState s, const int* __restrict__ list, 
   const int K = s.p.K;
   if (t >= n * K) return;
   const int i = t / n, j = t - i * n;
+  if (list && j >= active_count(s, n)) return;
   const int slot = list ? list[j] : j;
   if (!s.emit[slot]) return;
   const int pb = s.pid[slot];

@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void k_cost_knots(DeviceState s, const int* __
                                                     const int* __restrict__ n_ptr, int n_max, int cand,
                                                     int skip_done) {
   extern __shared__ double lds[];
-  const int n = n_ptr ? min(*n_ptr, n_max) : n_max;
+  const int n = n_ptr ? min(*n_ptr, n_max) : active_count(s, n_max);
   if ((int)(blockIdx.x * blockDim.x) >= n) return;   // whole block idle: skip the LDS staging too
   const double* lanes = stage_lanes(s, lds);
   const int i = blockIdx.y;
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void k_cost_knots(DeviceState s, const int* __
 __global__ __launch_bounds__(256) void k_spec_cost(DeviceState s, const int* __restrict__ list,
                                                    const int* __restrict__ n_ptr, int n_max, int r0) {
   extern __shared__ double lds[];
-  const int n = n_ptr ? min(*n_ptr, n_max) : n_max;
+  const int n = n_ptr ? min(*n_ptr, n_max) : active_count(s, n_max);
   if ((int)(blockIdx.x * blockDim.x) >= n) return;
   const double* lanes = stage_lanes(s, lds);
   const int i = blockIdx.y, r = r0 + blockIdx.z;
@@ -453,6 +453,8 @@ CILQR_DEV void knot_quadratize(const DeviceState& s, const double* __restrict__ 
 __global__ __launch_bounds__(256) void k_quadratize(DeviceState s, const int* __restrict__ list, int n,
                                                     int only_upd) {
   extern __shared__ double lds[];
+  n = active_count(s, n);
+  if ((int)(blockIdx.x * blockDim.x) >= n) return;
   const double* lanes = stage_lanes(s, lds);
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;

@@ -120,7 +120,7 @@ void launch_forward(const DeviceState& s, const int* list, int n, double alpha, 
 // round 0 opener: gradient-norm exit (cc:235-241), else roll out alpha_0
 __global__ __launch_bounds__(64) void k_search_open(DeviceState s, int n) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
+  if (j >= active_count(s, n)) return;
   const int slot = s.act[j];
   if (s.gnorm[slot] < 1e-6 && s.lambda[slot] < 1e-5) {
     s.status[s.pid[slot]] = 3;   // CILQR_ST_GNORM
@@ -156,7 +156,7 @@ CILQR_DEV void reduce_cost_ls(const DeviceState& s, int slot, double* c5) {
 // out alpha_{r+1} and queue the slot for the next round.
 __global__ __launch_bounds__(64) void k_search_round(DeviceState s, int r, int n_max, int roll_next) {
   const int* __restrict__ list = (r == 0) ? s.act : s.pend + (size_t)r * s.Bcap;
-  const int n = (r == 0) ? n_max : min(s.counters[r], n_max);
+  const int n = (r == 0) ? active_count(s, n_max) : min(s.counters[r], n_max);
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
     const int slot = list[j];
     if (s.acc_idx[slot] != -1) continue;   // left at the gradient-norm exit
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(64) void k_search_round(DeviceState s, int r, int n
 // sequential rounds done, list = the problems that rejected all of them).
 __global__ __launch_bounds__(64) void k_spec_forward(DeviceState s, const int* __restrict__ list,
                                                      const int* __restrict__ n_ptr, int n_max, int r0, int open) {
-  const int n = n_ptr ? min(*n_ptr, n_max) : n_max;
+  const int n = n_ptr ? min(*n_ptr, n_max) : active_count(s, n_max);
   const int r = r0 + blockIdx.y;
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
     const int slot = list[j];
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(64) void k_spec_forward(DeviceState s, const int* _
 // total cost of candidate alpha_r of list entry j: knot partials summed in index order
 __global__ __launch_bounds__(64) void k_spec_reduce(DeviceState s, const int* __restrict__ list,
                                                     const int* __restrict__ n_ptr, int n_max, int r0, int open) {
-  const int n = n_ptr ? min(*n_ptr, n_max) : n_max;
+  const int n = n_ptr ? min(*n_ptr, n_max) : active_count(s, n_max);
   const int r = r0 + blockIdx.y;
   const size_t cap = (size_t)s.spec_cap;
   const int K = s.p.K, N = s.p.N;
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(64) void k_spec_reduce(DeviceState s, const int* __
 // first passing alpha wins (cc:246-261)
 __global__ __launch_bounds__(64) void k_spec_pick(DeviceState s, const int* __restrict__ list,
                                                   const int* __restrict__ n_ptr, int n_max, int r0) {
-  const int n = n_ptr ? min(*n_ptr, n_max) : n_max;
+  const int n = n_ptr ? min(*n_ptr, n_max) : active_count(s, n_max);
   const size_t cap = (size_t)s.spec_cap;
   const int Bc = s.Bcap;
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(64) void k_spec_pick(DeviceState s, const int* __re
 // the accepted candidate becomes the iterate: one thread per (list entry, knot)
 __global__ __launch_bounds__(256) void k_spec_copy(DeviceState s, const int* __restrict__ list,
                                                    const int* __restrict__ n_ptr, int n_max, int r0) {
-  const int n = n_ptr ? min(*n_ptr, n_max) : n_max;
+  const int n = n_ptr ? min(*n_ptr, n_max) : active_count(s, n_max);
   const int i = blockIdx.y;
   const size_t cap = (size_t)s.spec_cap;
   const int K = s.p.K, N = s.p.N, Bc = s.Bcap;
@@ -329,9 +329,20 @@ void launch_linesearch(const DeviceState& s, int n_act, int spec_threshold, int 
 }
 
 // per-problem bookkeeping after the line search (cc:272-308, 312-319) + next active list
+// start of a lockstep iteration: latch the active count the previous k_update produced (or the
+// batch size) where every kernel of this iteration can read it, and clear the list counters
+__global__ void k_begin_iteration(DeviceState s, int first_n) {
+  if (threadIdx.x == 0) s.counters[kCntActive] = (first_n >= 0) ? first_n : s.counters[0];
+  __syncthreads();
+  if (threadIdx.x < kCntActive) s.counters[threadIdx.x] = 0;
+}
+void launch_begin_iteration(const DeviceState& s, int first_n, hipStream_t st) {
+  hipLaunchKernelGGL(k_begin_iteration, dim3(1), dim3(64), 0, st, s, first_n);
+}
+
 __global__ __launch_bounds__(256) void k_update(DeviceState s, int n) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
+  if (j >= active_count(s, n)) return;
   const int slot = s.act[j];
   const int pb = s.pid[slot];
   const Params& p = s.p;

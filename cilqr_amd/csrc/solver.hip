@@ -55,6 +55,7 @@ struct cilqr_solver {
   // profiling
   bool profiling = false;
   std::vector<hipEvent_t> ev;
+  std::vector<hipEvent_t> iter_ev;  // one per lockstep iteration (count read-back)
   cilqr_profile prof;
 };
 
@@ -190,7 +191,8 @@ int do_load(cilqr_solver* h, const cilqr_problem_batch* in) {
 struct Timer {  // event pairs, resolved after the final sync
   cilqr_solver* h;
   size_t next = 0;
-  std::vector<int> kind;  // 0 quad, 1 backward, 2 linesearch, 3 other, 4 backward over the whole batch
+  std::vector<int> kind;  // 0 quad, 1 backward, 2 linesearch, 3 other
+  std::vector<char> full_flags, live_flags;  // per backward launch: covered the whole batch / had work
   int begin(int k) {
     if (!h->profiling) return 0;
     if (next + 2 > h->ev.size()) {
@@ -208,13 +210,18 @@ struct Timer {  // event pairs, resolved after the final sync
   }
   void resolve(cilqr_profile* p) {
     if (!h->profiling) return;
+    size_t nb = 0;
     for (size_t i = 0; i < kind.size(); ++i) {
       float ms = 0.f;
       (void)hipEventElapsedTime(&ms, h->ev[2 * i], h->ev[2 * i + 1]);
       switch (kind[i]) {
         case 0: p->quadratize_ms += ms; break;
-        case 1: p->backward_ms += ms; break;
-        case 4: p->backward_ms += ms; p->backward_full_ms += ms; p->backward_full_launches += 1; break;
+        case 1:
+          if (nb < live_flags.size() && !live_flags[nb]) { ++nb; p->other_ms += ms; break; }  // run-ahead no-op
+          p->backward_ms += ms;
+          if (nb < full_flags.size() && full_flags[nb]) { p->backward_full_ms += ms; p->backward_full_launches += 1; }
+          ++nb;
+          break;
         case 2: p->linesearch_ms += ms; break;
         default: p->other_ms += ms; break;
       }
@@ -352,7 +359,7 @@ int cilqr_create(const cilqr_config* cfg, int32_t device, int32_t batch_capacity
   if (rc == CILQR_OK) rc = dev_alloc(h, &h->lambda_stage, B);
   if (rc == CILQR_OK && hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess)
     rc = CILQR_ERR_DEVICE;
-  if (rc == CILQR_OK && hipHostMalloc(reinterpret_cast<void**>(&h->h_count), 64 * sizeof(int)) != hipSuccess)
+  if (rc == CILQR_OK && hipHostMalloc(reinterpret_cast<void**>(&h->h_count), (size_t)(cfg->max_iter + 64) * sizeof(int)) != hipSuccess)
     rc = CILQR_ERR_DEVICE;
   if (rc == CILQR_OK && hipMemset(d.cor, 0, K * cmax * 3 * B * sizeof(double)) != hipSuccess)
     rc = CILQR_ERR_DEVICE;
@@ -374,6 +381,7 @@ int cilqr_destroy(cilqr_handle h) {
   if (h->out_stage) (void)hipFree(h->out_stage);
   if (h->h_count) (void)hipHostFree(h->h_count);
   for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->iter_ev) (void)hipEventDestroy(e);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
   return CILQR_OK;
@@ -472,36 +480,74 @@ int cilqr_solve_batch(cilqr_handle h, const cilqr_problem_batch* in, cilqr_solut
   if (o_it) launch_export_iter_traj(d, nullptr, B, o_it, out->max_iter_trajs, st);
   if (tm.end()) return CILQR_ERR_DEVICE;
 
-  int n_act = B;
-  int span = B;   // slots occupied in the current arena
+  // The host runs kLead iterations ahead of the GPU: before enqueueing iteration `it` it waits only
+  // for the active count produced by iteration it - kLead (normally long finished), which bounds
+  // the grids of iteration `it`; the kernels clamp to the exact device-side count (n_dev).
+  constexpr int kLead = 2;
+  if ((int)h->iter_ev.size() < M) {
+    const size_t old = h->iter_ev.size();
+    h->iter_ev.resize(M);
+    for (size_t i = old; i < h->iter_ev.size(); ++i)
+      HIP_TRY(hipEventCreateWithFlags(&h->iter_ev[i], hipEventDisableTiming));
+  }
+  d.n_dev = d.counters + kCntActive;
+  o.n_dev = d.n_dev;
+  int n_hint = B;   // upper bound of the active count of the iteration being enqueued
+  int span = B;     // slots occupied in the current arena (upper bound)
   int it = 0;
-  for (; it < M && n_act > 0; ++it) {                  // cc:201
-    HIP_TRY(hipMemsetAsync(d.counters, 0, 64 * sizeof(int), st));
+  std::vector<int> bwd_iter;   // iteration index of every profiled backward launch
+  for (; it < M; ++it) {                               // cc:201
+    if (it >= kLead) {
+      HIP_TRY(hipEventSynchronize(h->iter_ev[it - kLead]));
+      n_hint = h->h_count[it - kLead];
+      if (n_hint == 0) break;                          // iterations it-kLead+1 .. it-1 were no-ops
+    }
+    launch_begin_iteration(d, it == 0 ? B : -1, st);
     if (tm.begin(0)) return CILQR_ERR_DEVICE;
-    launch_quadratize(d, d.act, n_act, 1, st);         // cc:203-214
-    if (tm.end() || tm.begin(n_act == B ? 4 : 1)) return CILQR_ERR_DEVICE;
-    launch_backward(d, d.act, n_act, nullptr, st);     // cc:218
+    launch_quadratize(d, d.act, n_hint, 1, st);        // cc:203-214
+    if (tm.end() || tm.begin(1)) return CILQR_ERR_DEVICE;
+    launch_backward(d, d.act, n_hint, nullptr, st);    // cc:218
     if (tm.end() || tm.begin(2)) return CILQR_ERR_DEVICE;
-    h->prof.backward_launches += 1;
-    h->prof.backward_problem_steps += (int64_t)n_act * h->cfg.n_steps;
-    launch_linesearch(d, n_act, h->spec_threshold, h->seq_rounds, st);  // cc:235-270
-    launch_update(d, n_act, st);                       // cc:272-308
-    launch_export_done(d, n_act, o_traj, st);          // cc:238,285,303,319
-    if (o_it) launch_export_iter_traj(d, d.act, n_act, o_it, out->max_iter_trajs, st);
+    bwd_iter.push_back(it);
+    launch_linesearch(d, n_hint, h->spec_threshold, h->seq_rounds, st);  // cc:235-270
+    launch_update(d, n_hint, st);                      // cc:272-308
+    launch_export_done(d, n_hint, o_traj, st);         // cc:238,285,303,319
+    if (o_it) launch_export_iter_traj(d, d.act, n_hint, o_it, out->max_iter_trajs, st);
     if (tm.end()) return CILQR_ERR_DEVICE;
-    HIP_TRY(hipMemcpyAsync(h->h_count, d.counters, sizeof(int), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    n_act = h->h_count[0];
-    if (h->compaction && n_act > 0 && (int64_t)100 * n_act <= (int64_t)h->compact_percent * span) {
-      // the survivors have thinned out: re-pack them densely
+    HIP_TRY(hipMemcpyAsync(h->h_count + it, d.counters, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipEventRecord(h->iter_ev[it], st));
+    if (h->compaction && (int64_t)100 * n_hint <= (int64_t)h->compact_percent * span) {
+      // the survivors have thinned out: re-pack them densely (k_compact reads the exact count)
       if (tm.begin(3)) return CILQR_ERR_DEVICE;
-      launch_compact(d, o, n_act, st);
+      launch_compact(d, o, n_hint, st);
       if (tm.end()) return CILQR_ERR_DEVICE;
       DeviceState t = d; d = o; o = t;
-      span = n_act;
+      span = n_hint;
     } else {
       int* t = d.act; d.act = d.act_next; d.act_next = t;
     }
+  }
+  HIP_TRY(hipStreamSynchronize(st));
+  {  // lockstep iterations that had work, and the problem-steps each backward launch covered
+    int used = 0;
+    for (int i = 0; i < it; ++i) {
+      const int n_in = (i == 0) ? B : h->h_count[i - 1];
+      if (n_in > 0) used = i + 1;
+    }
+    for (int i : bwd_iter) {
+      const int n_in = (i == 0) ? B : h->h_count[i - 1];
+      if (n_in <= 0) continue;
+      h->prof.backward_launches += 1;
+      h->prof.backward_problem_steps += (int64_t)n_in * h->cfg.n_steps;
+    }
+    tm.full_flags.assign(bwd_iter.size(), 0);
+    tm.live_flags.assign(bwd_iter.size(), 0);
+    for (size_t k = 0; k < bwd_iter.size(); ++k) {
+      const int n_in = (bwd_iter[k] == 0) ? B : h->h_count[bwd_iter[k] - 1];
+      tm.full_flags[k] = (n_in == B);
+      tm.live_flags[k] = (n_in > 0);
+    }
+    it = used;
   }
   h->prof.iterations = it;
   if (tm.begin(3)) return CILQR_ERR_DEVICE;

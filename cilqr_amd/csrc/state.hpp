@@ -131,8 +131,13 @@ struct DeviceState {
   int* act;          // active slots
   int* act_next;
   int* pend;         // [kNumAlpha+1][Bcap] line-search pending lists (round r uses list r)
-  int* counters;     // [0] = n_act_next, [1..kNumAlpha] = pending counts of rounds 1..10
+  int* counters;     // [0] = n_act_next, [1..kNumAlpha] = pending counts of rounds 1..10,
+                     // [kCntActive] = active count of the iteration in flight
+  // Non-null inside the solve loop: the host runs a couple of iterations ahead of the GPU and only
+  // knows an upper bound of the active count; kernels clamp to the device-side value.
+  const int* n_dev;
 };
+constexpr int kCntActive = 32;
 
 // ---- launchers (one per kernel family; all asynchronous on `st`) ----
 struct ProblemView {  // device pointers to the problem-major inputs
@@ -164,11 +169,12 @@ void launch_forward(const DeviceState& s, const int* list, int n, double alpha, 
                     hipStream_t st);
 // the 11-round line search of one lockstep iteration (forward/cost/accept with compaction)
 void launch_linesearch(const DeviceState& s, int n_act, int spec_threshold, int seq_rounds, hipStream_t st);
+void launch_begin_iteration(const DeviceState& s, int first_n, hipStream_t st);
 void launch_update(const DeviceState& s, int n_act, hipStream_t st);
 // trajectories of the slots that finished in the last update -> traj[pid]
 void launch_export_done(const DeviceState& s, int n_act, double* traj, hipStream_t st);
 // survivors (next active list of `src`, n of them) -> slots 0..n-1 of `dst`
-void launch_compact(const DeviceState& src, const DeviceState& dst, int n, hipStream_t st);
+void launch_compact(const DeviceState& src, const DeviceState& dst, int n_max, hipStream_t st);
 void launch_export_traj(const DeviceState& s, int B, double* traj, hipStream_t st);
 void launch_export_iter_traj(const DeviceState& s, const int* list, int n, double* iter_trajs,
                              int max_iter_trajs, hipStream_t st);

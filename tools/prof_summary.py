@@ -55,6 +55,21 @@ def main():
     for k, v in sorted(stats.items(), key=lambda kv: -kv[1][1])[:30]:
         print(f"{k[:44]:44s} {v[0]:7d} {v[1] / 1e6:10.3f} {v[1] / v[0] / 1e3:9.1f} {v[2] / 1e3:9.1f} {v[3] / 1e3:9.1f} {100 * v[1] / tot:6.2f}")
     print(f"{'TOTAL':44s} {sum(v[0] for v in stats.values()):7d} {tot / 1e6:10.3f}")
+    # the roofline kernel by launch size (grid x = problems rounded up to 64)
+    sizes = {}
+    for name, s_, e_, gx, *_ in rows:
+        if short(name) != "k_backward":
+            continue
+        b = ">=65536" if gx >= 65536 else (">=8192" if gx >= 8192 else (">=1024" if gx >= 1024 else "<1024"))
+        st = sizes.setdefault(b, [0, 0, 0])
+        st[0] += 1; st[1] += e_ - s_; st[2] += gx
+    if sizes:
+        print("\nk_backward by launch size (threads = problems, one lane each):")
+        for b in (">=65536", ">=8192", ">=1024", "<1024"):
+            if b in sizes:
+                n, t, g = sizes[b]
+                print(f"  {b:8s} launches {n:5d}  avg {t / n / 1e3:8.1f} us  avg problems {g / n:9.0f}  "
+                      f"algorithmic GB/s {(g / n) * (50 * 110 + 44) * 8 / (t / n):9.1f}")
     if not a.iters:
         return
     want = [int(x) for x in a.iters.split(",")]
