@@ -44,6 +44,9 @@ def main():
     ap.add_argument("--compact-percent", type=int, default=-1, help="CILQR_OPT_COMPACTION value (tuning experiments)")
     ap.add_argument("--spec-threshold", type=int, default=-1, help="CILQR_OPT_SPEC_THRESHOLD value (tuning experiments)")
     ap.add_argument("--seq-rounds", type=int, default=-1, help="CILQR_OPT_SEQ_ROUNDS value (tuning experiments)")
+    ap.add_argument("--pipeline", type=int, default=3,
+                    help="after the timed region, also measure throughput with this many batches in flight "
+                         "(one handle + stream + host thread each; 0/1 = skip; single-GPU runs only)")
     ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "backward_traffic.json"))
     args = ap.parse_args()
 
@@ -140,6 +143,58 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # Extra (never `value`): several batches in flight.  The tail of a solve (a few hundred straggler
+    # problems for ~60 iterations) leaves the GPU mostly idle; a second batch on its own stream fills it.
+    pipelined = None
+    if world == 1 and args.pipeline > 1:
+        import threading
+        P = args.pipeline
+        ctx = []
+        for i in range(P):
+            o_i = opt if i == 0 else api.BatchIlqrOptimizer(
+                cfg, device=local_rank, batch_capacity=B, cmax=cmax,
+                max_lane_segments=max(sc["left"].shape[0], sc["right"].shape[0]))
+            st_i = torch.cuda.Stream()
+            o_i.set_stream(st_i.cuda_stream)
+            o_i.set_profiling(False)
+            bufs = (torch.zeros((B, K, 10), dtype=torch.float64, device=dev),
+                    torch.zeros((B, M + 1, 5), dtype=torch.float64, device=dev),
+                    torch.zeros(B, dtype=torch.int32, device=dev), torch.zeros(B, dtype=torch.int32, device=dev))
+            sol_i = api.SolutionBatch(api.MEM_DEVICE, 0, bufs[0].data_ptr(), bufs[1].data_ptr(),
+                                      bufs[2].data_ptr(), bufs[3].data_ptr(), None, None, None)
+            ctx.append((o_i, st_i, bufs, sol_i))
+        torch.cuda.synchronize()
+        per_thread = max(2, args.steps)
+        errs = []
+
+        def work(c, n):
+            try:
+                for _ in range(n):
+                    rc_ = c[0].solve_raw(prob, c[3])
+                    if rc_ != api.OK:
+                        errs.append(rc_)
+            except Exception as e:  # pragma: no cover
+                errs.append(e)
+
+        for c in ctx:                      # warm-up (staging buffers, clocks)
+            work(c, 1)
+        torch.cuda.synchronize()
+        ths = [threading.Thread(target=work, args=(c, per_thread)) for c in ctx]
+        t1 = time.perf_counter()
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        if not errs:
+            same = all(bool(torch.equal(c[2][0], o_traj)) and bool(torch.equal(c[2][2], o_nc)) for c in ctx)
+            pipelined = {"batches_in_flight": P, "steps": P * per_thread, "value": round(P * per_thread * B / dt, 1),
+                         "unit": "solves/s", "results_identical_to_timed_region": same}
+        for c in ctx[1:]:
+            c[0].close()
+        opt.set_stream(torch.cuda.current_stream().cuda_stream)
+
     # sanity: every problem must have terminated with a valid status
     st = o_st.cpu().numpy()
     nc = o_nc.cpu().numpy()
@@ -212,6 +267,7 @@ def main():
                        "batch_per_gpu": B, "n_steps": N, "cmax": cmax, "results_gather": "rccl" if world > 1 else "none"},
             "roofline": roof,
             "cpu_baseline": cpu,
+            "pipelined": pipelined,
             "breakdown_ms_per_step": {k: round(prof_acc[k] / args.steps, 3)
                                       for k in ("quad_ms", "bwd_ms", "ls_ms", "other_ms", "total_ms")},
             "lockstep_iterations_per_step": prof_acc["iters"] / args.steps,
