@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void k_load_corridor(DeviceState s, int B, Pro
   const int pb = threadIdx.x & 63;
   if (pb >= nb) return;
   const int slot = b0 + pb;
-  const int cnt = min(in.ccount[(size_t)slot * s.p.K + i], s.cmax);
+  const int cnt = max(0, min(in.ccount[(size_t)slot * s.p.K + i], min(s.cmax, in.cmax_in)));
   if ((threadIdx.x >> 6) == 0) s.ccnt[(size_t)i * s.Bcap + slot] = cnt;
   for (int c = threadIdx.x >> 6; c < cnt; c += 4) {
     double a = tile[pb * ld + c * 3 + 0];

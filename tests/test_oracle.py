@@ -180,6 +180,32 @@ def test_cost_components_sum_and_shrink(o50):
     assert np.all(np.abs(U[:, 0]) <= 10.0) and np.all(np.abs(U[:, 1]) <= 40 / 180 * np.pi / 3 + 1e-15)
 
 
+def test_cost_gradient_matches_finite_differences_of_total_cost(o50):
+    """CostJacbian (cc:620-636) must be the gradient of TotalCost (cc:417-436): both are restated
+    independently, so this ties them together.  (The Hessian is NOT the second derivative on the
+    relaxed branch -- reference quirk -- and is not checked this way.)"""
+    sc = scenario.generate("mix11", 3, seed=17)
+    for b in range(3):
+        o50.set_problem(sc["start"][b], sc["coarse"][b], sc["corridor"][b], sc["ccount"][b], sc["left"], sc["right"])
+        X, U = o50.init_guess()
+        q = o50.quadratize(X, U)
+        h = 1e-6
+        for i in (0, 7, 23, 50):
+            for e in range(6):
+                Xp, Xm = X.copy(), X.copy()
+                Xp[i, e] += h
+                Xm[i, e] -= h
+                fd = (o50.total_cost(Xp, U)[0] - o50.total_cost(Xm, U)[0]) / (2 * h)
+                assert fd == pytest.approx(q["lx"][i, e], rel=2e-4, abs=2e-4), (b, i, e)
+        for i in (0, 11, 49):
+            for e in range(2):
+                Up, Um = U.copy(), U.copy()
+                Up[i, e] += h
+                Um[i, e] -= h
+                fd = (o50.total_cost(X, Up)[0] - o50.total_cost(X, Um)[0]) / (2 * h)
+                assert fd == pytest.approx(q["lu"][i, e], rel=2e-4, abs=2e-4), (b, i, e)
+
+
 def test_plan_error_paths(o50):
     sc = scenario.generate("ped6", 1, seed=4)
     args = (sc["start"][0], sc["coarse"][0], sc["corridor"][0], sc["ccount"][0], sc["left"], sc["right"])
