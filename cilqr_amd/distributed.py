@@ -30,38 +30,37 @@ def shard_scene(scene: dict, rank: int, world: int) -> dict:
     return out
 
 
-def _gather_equal(t, dst, dist):
-    """dist.gather of equally shaped tensors; returns the concatenation on dst, None elsewhere."""
-    world, rank = dist.get_world_size(), dist.get_rank()
-    if rank == dst:
-        parts = [t.new_empty(t.shape) for _ in range(world)]
-        dist.gather(t, parts, dst=dst)
-        return parts
-    dist.gather(t, None, dst=dst)
-    return None
-
-
 def gather_results(traj, cost_hist, n_cost, status, dst: int = 0):
-    """One collective per output tensor: rank `dst` receives every rank's block, in rank order.
+    """ONE gather: every rank packs its results into a single [B_rank, W] fp64 tensor
+    (trajectory | live cost-history rows | n_cost | status) and rank `dst` receives the blocks in
+    rank order.  The only other collective is a 4-byte all-reduce(MAX) that agrees on the number
+    of history rows to ship (rows >= n_cost are unspecified by the ABI, and shipping all
+    max_iter+1 rows would quadruple the payload).
 
     Every rank must hold the same per-rank batch size (weak scaling; pad the last shard
-    otherwise).  cost_hist is trimmed to the longest live history before it travels
-    (rows >= n_cost are unspecified by the ABI).  Returns a dict of concatenated tensors on
-    `dst`, None on the other ranks.
+    otherwise).  Returns a dict of concatenated tensors on `dst`, None on the other ranks.
     """
     import torch
     import torch.distributed as dist
 
+    world, rank = dist.get_world_size(), dist.get_rank()
+    B, K = traj.shape[0], traj.shape[1]
     h = n_cost.max().to(torch.int32).reshape(1)
     dist.all_reduce(h, op=dist.ReduceOp.MAX)
     H = int(h.item())
-    hist = cost_hist[:, :H].contiguous()
-    parts = {
-        "traj": _gather_equal(traj.contiguous(), dst, dist),
-        "cost_hist": _gather_equal(hist, dst, dist),
-        "n_cost": _gather_equal(n_cost.contiguous(), dst, dist),
-        "status": _gather_equal(status.contiguous(), dst, dist),
-    }
-    if dist.get_rank() != dst:
+    packed = torch.cat([traj.reshape(B, -1), cost_hist[:, :H].reshape(B, -1),
+                        n_cost.to(torch.float64).reshape(B, 1), status.to(torch.float64).reshape(B, 1)], dim=1)
+    if rank == dst:
+        parts = [torch.empty_like(packed) for _ in range(world)]
+        dist.gather(packed, parts, dst=dst)
+    else:
+        dist.gather(packed, None, dst=dst)
         return None
-    return {k: torch.cat(v, dim=0) for k, v in parts.items()}
+    full = torch.cat(parts, dim=0)
+    w_traj, w_hist = K * traj.shape[2], H * cost_hist.shape[2]
+    return {
+        "traj": full[:, :w_traj].reshape(world * B, K, traj.shape[2]),
+        "cost_hist": full[:, w_traj:w_traj + w_hist].reshape(world * B, H, cost_hist.shape[2]),
+        "n_cost": full[:, w_traj + w_hist].to(n_cost.dtype),
+        "status": full[:, w_traj + w_hist + 1].to(status.dtype),
+    }
