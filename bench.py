@@ -60,8 +60,12 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU path exists)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # CILQR_BENCH_FORCE_DIST=1 exercises the RCCL path (process group, all-reduce, gather) even
+    # with a single rank -- the only way to smoke-test it on a 1-GPU box
+    use_dist = world > 1 or os.environ.get("CILQR_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from cilqr_amd import api, scenario
@@ -108,12 +112,12 @@ def main():
         rc = opt.solve_raw(prob, sol)
         if rc != api.OK:
             raise api.CilqrError(rc, "in bench step")
-        if world > 1:
+        if use_dist:
             return gather_results(o_traj, o_hist, o_nc, o_st, dst=0)
         return None
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -138,7 +142,7 @@ def main():
         prof_acc["full_launches"] += p.backward_full_launches
     fence()
     elapsed = time.perf_counter() - t_start
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -277,7 +281,7 @@ def main():
                                    f"{N}-step horizon, scene family {args.scene} ({spec.n_pedestrians} pedestrians + "
                                    f"{spec.n_dynamic} moving + {spec.n_static} static vehicles), reference road, "
                                    f"seed {args.seed}",
-                       "batch_per_gpu": B, "n_steps": N, "cmax": cmax, "results_gather": "rccl" if world > 1 else "none"},
+                       "batch_per_gpu": B, "n_steps": N, "cmax": cmax, "results_gather": "rccl" if use_dist else "none"},
             "roofline": roof,
             "cpu_baseline": cpu,
             "pipelined": pipelined,
@@ -291,7 +295,7 @@ def main():
         }
         print(json.dumps(out), flush=True)
     opt.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
