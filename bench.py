@@ -50,6 +50,11 @@ def main():
     ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "backward_traffic.json"))
     args = ap.parse_args()
 
+    # stdout carries exactly one line (rank 0's JSON); everything else any library prints on fd 1
+    # (RCCL's version banner, for one) is sent to stderr
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -64,6 +69,8 @@ def main():
     # with a single rank -- the only way to smoke-test it on a 1-GPU box
     use_dist = world > 1 or os.environ.get("CILQR_BENCH_FORCE_DIST") == "1"
     if use_dist:
+        # keep RCCL's log lines off stdout (rank 0 prints exactly one JSON line there, last)
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -293,11 +300,18 @@ def main():
             "scene_generation_s": round(t_gen, 1),
             "device_bytes": opt.device_bytes(),
         }
-        print(json.dumps(out), flush=True)
     opt.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        try:  # flush what native libraries left in the C stdio buffer (to stderr), then the JSON line
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":
