@@ -31,36 +31,50 @@ def shard_scene(scene: dict, rank: int, world: int) -> dict:
 
 
 def gather_results(traj, cost_hist, n_cost, status, dst: int = 0):
-    """ONE gather: every rank packs its results into a single [B_rank, W] fp64 tensor
-    (trajectory | live cost-history rows | n_cost | status) and rank `dst` receives the blocks in
-    rank order.  The only other collective is a 4-byte all-reduce(MAX) that agrees on the number
-    of history rows to ship (rows >= n_cost are unspecified by the ABI, and shipping all
-    max_iter+1 rows would quadruple the payload).
+    """ONE gather: every rank packs its results into a single flat fp64 tensor
+    (trajectories | live cost-history rows, ragged | n_cost | status) and rank `dst` receives the
+    blocks in rank order.  Only the n_cost[b] live rows of each problem's history travel (9 of
+    the 201 rows on average; rows >= n_cost are unspecified by the ABI).  The only other
+    collective is a 4-byte all-reduce(MAX) that agrees on the padded length of the ragged part.
 
     Every rank must hold the same per-rank batch size (weak scaling; pad the last shard
-    otherwise).  Returns a dict of concatenated tensors on `dst`, None on the other ranks.
+    otherwise).  Returns a dict of concatenated tensors on `dst` (cost_hist dense again, with as
+    many rows as the longest history), None on the other ranks.
     """
     import torch
     import torch.distributed as dist
 
     world, rank = dist.get_world_size(), dist.get_rank()
-    B, K = traj.shape[0], traj.shape[1]
-    h = n_cost.max().to(torch.int32).reshape(1)
-    dist.all_reduce(h, op=dist.ReduceOp.MAX)
-    H = int(h.item())
-    packed = torch.cat([traj.reshape(B, -1), cost_hist[:, :H].reshape(B, -1),
-                        n_cost.to(torch.float64).reshape(B, 1), status.to(torch.float64).reshape(B, 1)], dim=1)
+    B, K, F = traj.shape
+    C = cost_hist.shape[2]
+    nc = n_cost.to(torch.int64)
+    h_loc = int(nc.max().item()) if B > 0 else 0
+    live = torch.arange(h_loc, device=nc.device)[None, :] < nc[:, None]          # [B, h_loc]
+    rows = cost_hist[:, :h_loc][live]                                             # [R_loc, C], problem-major
+    r_max = torch.tensor([rows.shape[0]], dtype=torch.int64, device=nc.device)
+    dist.all_reduce(r_max, op=dist.ReduceOp.MAX)
+    R = int(r_max.item())
+    pad = torch.zeros((R - rows.shape[0], C), dtype=cost_hist.dtype, device=cost_hist.device)
+    packed = torch.cat([traj.reshape(-1), rows.reshape(-1), pad.reshape(-1),
+                        n_cost.to(torch.float64), status.to(torch.float64)])
     if rank == dst:
         parts = [torch.empty_like(packed) for _ in range(world)]
         dist.gather(packed, parts, dst=dst)
     else:
         dist.gather(packed, None, dst=dst)
         return None
-    full = torch.cat(parts, dim=0)
-    w_traj, w_hist = K * traj.shape[2], H * cost_hist.shape[2]
-    return {
-        "traj": full[:, :w_traj].reshape(world * B, K, traj.shape[2]),
-        "cost_hist": full[:, w_traj:w_traj + w_hist].reshape(world * B, H, cost_hist.shape[2]),
-        "n_cost": full[:, w_traj + w_hist].to(n_cost.dtype),
-        "status": full[:, w_traj + w_hist + 1].to(status.dtype),
-    }
+    n_traj, n_rows = B * K * F, R * C
+    trajs, ncs, sts, hists = [], [], [], []
+    for p in parts:
+        trajs.append(p[:n_traj].reshape(B, K, F))
+        ncs.append(p[n_traj + n_rows:n_traj + n_rows + B].to(n_cost.dtype))
+        sts.append(p[n_traj + n_rows + B:].to(status.dtype))
+    H = int(max(int(c.max().item()) for c in ncs)) if B > 0 else 0
+    for p, c in zip(parts, ncs):
+        c64 = c.to(torch.int64)
+        dense = torch.zeros((B, H, C), dtype=cost_hist.dtype, device=cost_hist.device)
+        m = torch.arange(H, device=c64.device)[None, :] < c64[:, None]
+        dense[m] = p[n_traj:n_traj + int(c64.sum().item()) * C].reshape(-1, C)
+        hists.append(dense)
+    return {"traj": torch.cat(trajs), "cost_hist": torch.cat(hists), "n_cost": torch.cat(ncs),
+            "status": torch.cat(sts)}
