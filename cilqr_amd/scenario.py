@@ -154,6 +154,10 @@ SPECS = {
     "ped6": SceneSpec(n_steps=50, n_pedestrians=6, n_dynamic=0, n_static=0, cmax=16),
     # configs[2]/[3]: 6 pedestrians + 3 moving + 2 static vehicles
     "mix11": SceneSpec(n_steps=50, n_pedestrians=6, n_dynamic=3, n_static=2, cmax=16),
+    # the reference's demo: tf = 8 s (81 knots), ego starts at the road origin with v = 10
+    # (planning_node.cc:24-30, planner_config.h:94,99), 6 pedestrians + 3 moving + 2 static vehicles
+    "demo80": SceneSpec(n_steps=80, n_pedestrians=6, n_dynamic=3, n_static=2, cmax=16,
+                        v_range=(10.0, 10.0), s0_range=(0.5, 0.5)),
     # configs[4]: 100-step horizon, 20 dynamic obstacles
     "dyn20": SceneSpec(n_steps=100, n_pedestrians=12, n_dynamic=8, n_static=0, cmax=24,
                        v_range=(5.0, 9.0), s0_range=(2.0, 60.0)),

@@ -206,6 +206,30 @@ def test_cost_gradient_matches_finite_differences_of_total_cost(o50):
                 assert fd == pytest.approx(q["lu"][i, e], rel=2e-4, abs=2e-4), (b, i, e)
 
 
+def test_demo_like_scenes_look_like_the_readme_figures():
+    """The only recorded output of the reference is resources/cost.png (README.md:27-28): one 80-step
+    demo scene, ~19 cost rows, total ~1e5 at the init guess dominated by the corridor term (8.6e4)
+    with target ~1.4e4, lane ~3e2 and dynamic ~0, decreasing monotonically to O(1e2..1e3).  The
+    oracle on demo-like scenes (same horizon, start pose, obstacle mix) must show that picture."""
+    sc = scenario.generate("demo80", 48, seed=123)
+    r = orc.solve_batch(sc, orc.default_config(80))
+    n = r["n_cost"]
+    init = r["cost_hist"][:, 0]
+    fin = np.array([r["cost_hist"][b, n[b] - 1] for b in range(48)])
+    for b in range(48):
+        assert np.all(np.diff(r["cost_hist"][b, :n[b], 0]) < 0)
+    assert 3 <= np.median(n) <= 40 and n.max() <= 120
+    assert np.median(init[:, 3] / init[:, 0]) > 0.5            # corridor term dominates the init cost
+    assert 1e3 < np.median(init[:, 0]) < 5e6
+    assert np.all(init[:, 2] < 50.0)                            # dynamic (bound) barriers inactive at the start
+    assert np.median(fin[:, 0]) < 0.5 * np.median(init[:, 0])
+    assert np.median(fin[:, 0]) < 5e3
+    # typical controls sit well inside the bounds the barriers encode (resources/results.png); the
+    # relaxed barrier does let hard scenes (the 5 m U-turn at 10 m/s) exceed them
+    jerk, drate = r["traj"][:, :-1, 8], r["traj"][:, :-1, 9]
+    assert np.percentile(np.abs(jerk), 90) <= 10.0 and np.percentile(np.abs(drate), 75) <= 0.2327
+
+
 def test_plan_error_paths(o50):
     sc = scenario.generate("ped6", 1, seed=4)
     args = (sc["start"][0], sc["coarse"][0], sc["corridor"][0], sc["ccount"][0], sc["left"], sc["right"])
