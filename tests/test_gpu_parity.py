@@ -98,17 +98,19 @@ def test_open_loop_rollout():
 # ---------------------------------------------------------------------------------------------
 # full solves
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("family,B,seed", [("ped6", 200, 41), ("mix11", 333, 42), ("dyn20", 96, 43)])
+@pytest.mark.parametrize("family,B,seed", [("ped6", 200, 41), ("mix11", 333, 42), ("dyn20", 96, 43), ("demo80", 64, 44)])
 def test_full_solve_parity(family, B, seed):
     """Per-iteration Cost history, final trajectory, status and iteration counts vs the oracle."""
     sc = scenario.generate(family, B, seed=seed)
     opt = _opt(sc)
     g = opt.plan(sc)
     ref = oracle_reference(sc, oracle_cfg_from(opt.cfg), n_perturb=3, eps=1e-13)
-    rep = assert_parity(g, ref, what=f"{family} B={B}")
+    # the 80-step demo scenes are chaotic in the oracle itself more often than the 50-step families
+    frac = 0.3 if family == "demo80" else 0.15
+    rep = assert_parity(g, ref, what=f"{family} B={B}", max_unstable_frac=frac)
     st = ref["stable"]
     assert np.array_equal(g["n_iter"][st], ref["n_iter"][st])
-    assert rep["n_stable"] >= 0.85 * B
+    assert rep["n_stable"] >= (1.0 - frac) * B
     print(f"\n[{family}] {rep}")
     opt.close()
 
