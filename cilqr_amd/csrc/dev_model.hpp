@@ -44,11 +44,7 @@ CILQR_DEV double normalize_angle(double angle) {
 }
 
 // ---- relaxed log barrier, barrier_function.h:104-140 ----
-CILQR_DEV double bar_value(const Params& p, double g) {
-  if (g < -p.bar_eps) return -p.bar_r * log(-g);
-  const double q = (-g - 2.0 * p.bar_eps) / p.bar_eps;
-  return 0.5 * p.bar_r * (q * q - 1) - p.bar_rlogeps;
-}
+// value(g) = g < -eps ? -r log(-g) : r/2 (((-g - 2 eps)/eps)^2 - 1) - r log(eps)
 // Sum of barrier values with one log per group instead of one per constraint:
 //   sum_c -r log(-g_c) = -r log(prod_c -g_c)   over the constraints on the log branch.
 // `prod` collects the product (start at 1), `quad` the relaxed-branch values (start at 0);
@@ -256,5 +252,28 @@ CILQR_DEV void load_u(const DeviceState& s, int buf, int i, int slot, double* u)
 CILQR_DEV void store_u(const DeviceState& s, int buf, int i, int slot, const double* u) {
   s.U[((size_t)buf * s.p.N + i) * s.Bcap + slot] = make_double2(u[0], u[1]);
 }
+
+// sum of the knot partials in index order -> trial[5] (total, J, dynamics, corridor, lane)
+CILQR_DEV void reduce_cost(const DeviceState& s, int slot, double* c5) {
+  const int Bc = s.Bcap, K = s.p.K, N = s.p.N;
+  double j = 0.0, dx = 0.0, du = 0.0, cc = 0.0, lc = 0.0;
+  for (int i = 0; i < K; ++i) {
+    const double2* o = s.part + (size_t)i * kPartPairs * Bc + slot;
+    const double2 a = o[0], b = o[(size_t)Bc], c = o[(size_t)2 * Bc];
+    j += a.x;
+    dx += b.x;
+    cc += c.x;
+    lc += c.y;
+  }
+  for (int i = 0; i < N; ++i) {   // control terms follow the state terms (cc:510-513)
+    const double2* o = s.part + (size_t)i * kPartPairs * Bc + slot;
+    j += o[0].y;
+    du += o[(size_t)Bc].y;
+  }
+  const double dyn = dx + du;                      // cc:550
+  c5[0] = j + dyn + cc + lc;                       // cc:429
+  c5[1] = j; c5[2] = dyn; c5[3] = cc; c5[4] = lc;
+}
+
 
 }  // namespace cilqr

@@ -399,18 +399,6 @@ CILQR_DEV void write_traj_point(const DeviceState& s, int buf, int i, int slot, 
   o[7] = tan(x[5]) / s.p.wheel_base;
   o[8] = u[0]; o[9] = u[1];
 }
-__global__ void k_export_traj(DeviceState s, int B, double* __restrict__ traj) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int K = s.p.K;
-  if (t >= B * K) return;
-  const int i = t / B, slot = t - i * B;  // slot fastest: coalesced reads
-  write_traj_point(s, s.cur[slot], i, slot, traj + ((size_t)s.pid[slot] * K + i) * 10);
-}
-void launch_export_traj(const DeviceState& s, int B, double* traj, hipStream_t st) {
-  const int n = B * s.p.K;
-  hipLaunchKernelGGL(k_export_traj, dim3((n + 255) / 256), dim3(256), 0, st, s, B, traj);
-}
-
 // final trajectory (cc:238,285,303,319) of every slot that terminated in the last k_update
 __global__ void k_export_done(DeviceState s, int n, double* __restrict__ traj) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;

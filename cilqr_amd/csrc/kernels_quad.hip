@@ -241,28 +241,6 @@ void launch_spec_cost(const DeviceState& s, const int* list, const int* n_ptr, i
   hipLaunchKernelGGL(k_spec_cost, g, dim3(256), lane_lds_bytes(s), st, s, list, n_ptr, n_max, r0);
 }
 
-// sum of the knot partials in index order -> trial[5] (total, J, dynamics, corridor, lane)
-CILQR_DEV void reduce_cost(const DeviceState& s, int slot, double* c5) {
-  const int Bc = s.Bcap, K = s.p.K, N = s.p.N;
-  double j = 0.0, dx = 0.0, du = 0.0, cc = 0.0, lc = 0.0;
-  for (int i = 0; i < K; ++i) {
-    const double2* o = s.part + (size_t)i * kPartPairs * Bc + slot;
-    const double2 a = o[0], b = o[(size_t)Bc], c = o[(size_t)2 * Bc];
-    j += a.x;
-    dx += b.x;
-    cc += c.x;
-    lc += c.y;
-  }
-  for (int i = 0; i < N; ++i) {   // control terms follow the state terms (cc:510-513)
-    const double2* o = s.part + (size_t)i * kPartPairs * Bc + slot;
-    j += o[0].y;
-    du += o[(size_t)Bc].y;
-  }
-  const double dyn = dx + du;                      // cc:550
-  c5[0] = j + dyn + cc + lc;                       // cc:429
-  c5[1] = j; c5[2] = dyn; c5[3] = cc; c5[4] = lc;
-}
-
 __global__ __launch_bounds__(64) void k_reduce_only(DeviceState s, const int* __restrict__ list, int n) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;

@@ -131,27 +131,6 @@ __global__ __launch_bounds__(64) void k_search_open(DeviceState s, int n) {
   forward_problem(s, slot, kAlpha[0]);
 }
 
-CILQR_DEV void reduce_cost_ls(const DeviceState& s, int slot, double* c5) {
-  const int Bc = s.Bcap, K = s.p.K, N = s.p.N;
-  double j = 0.0, dx = 0.0, du = 0.0, cc = 0.0, lc = 0.0;
-  for (int i = 0; i < K; ++i) {
-    const double2* o = s.part + (size_t)i * kPartPairs * Bc + slot;
-    const double2 a = o[0], b = o[(size_t)Bc], c = o[(size_t)2 * Bc];
-    j += a.x;
-    dx += b.x;
-    cc += c.x;
-    lc += c.y;
-  }
-  for (int i = 0; i < N; ++i) {
-    const double2* o = s.part + (size_t)i * kPartPairs * Bc + slot;
-    j += o[0].y;
-    du += o[(size_t)Bc].y;
-  }
-  const double dyn = dx + du;
-  c5[0] = j + dyn + cc + lc;
-  c5[1] = j; c5[2] = dyn; c5[3] = cc; c5[4] = lc;
-}
-
 // round r: total cost of the alpha_r candidate, acceptance test (cc:252-261); on rejection roll
 // out alpha_{r+1} and queue the slot for the next round.
 __global__ __launch_bounds__(64) void k_search_round(DeviceState s, int r, int n_max, int roll_next) {
@@ -161,7 +140,7 @@ __global__ __launch_bounds__(64) void k_search_round(DeviceState s, int r, int n
     const int slot = list[j];
     if (s.acc_idx[slot] != -1) continue;   // left at the gradient-norm exit
     double c5[5];
-    reduce_cost_ls(s, slot, c5);
+    reduce_cost(s, slot, c5);
     const double alpha = kAlpha[r];
     const double dcost = s.cost_old[slot] - c5[0];                                  // cc:254
     const double expected = -alpha * (s.dV[slot] + alpha * s.dV[(size_t)s.Bcap + slot]);  // cc:255

@@ -175,7 +175,6 @@ void launch_update(const DeviceState& s, int n_act, hipStream_t st);
 void launch_export_done(const DeviceState& s, int n_act, double* traj, hipStream_t st);
 // survivors (next active list of `src`, n of them) -> slots 0..n-1 of `dst`
 void launch_compact(const DeviceState& src, const DeviceState& dst, int n_max, hipStream_t st);
-void launch_export_traj(const DeviceState& s, int B, double* traj, hipStream_t st);
 void launch_export_iter_traj(const DeviceState& s, const int* list, int n, double* iter_trajs,
                              int max_iter_trajs, hipStream_t st);
 void launch_export_hist(const DeviceState& s, int B, double* cost_hist, int* n_cost, int* status,
