@@ -189,17 +189,20 @@ CILQR_DEV int nearest_segment_scan(const double* __restrict__ tab, int n, double
 // Grid-accelerated version: only the candidate segments of the point's cell are tested, in
 // ascending index order.  The candidate sets are conservative (triangle inequality, see
 // k_build_lane_grid), so the result is the one of the full scan.
-// `lanes`: the lane table (left rows then right rows), in global memory or staged in LDS.
-CILQR_DEV int nearest_segment(const DeviceState& s, const double* __restrict__ lanes, int side, double px,
-                              double py) {
-  const double* __restrict__ tab = lanes + (side ? s.nl * kLaneFields : 0);
-  const int n = side ? s.nr : s.nl;
+// candidate list of the grid cell that contains (px, py); off-grid points get the "scan
+// everything" marker.  Split from the search so a kernel can issue the loads of all its discs
+// first and hide their latency behind each other.
+CILQR_DEV uint4 lane_cell_fetch(const DeviceState& s, int side, double px, double py) {
   const double fx = (px - s.gx0) * s.ginv_h, fy = (py - s.gy0) * s.ginv_h;
   if (!(fx >= 0.0 && fy >= 0.0 && fx < (double)s.gnx && fy < (double)s.gny))
-    return nearest_segment_scan(tab, n, px, py);
+    return make_uint4((unsigned)kGridFullScan, 0u, 0u, 0u);
   const int cell = (int)fy * s.gnx + (int)fx;
-  const uint4 raw = *reinterpret_cast<const uint4*>(
-      s.lgrid + ((size_t)side * s.gnx * s.gny + cell) * kGridCellBytes);
+  return *reinterpret_cast<const uint4*>(s.lgrid + ((size_t)side * s.gnx * s.gny + cell) * kGridCellBytes);
+}
+CILQR_DEV int nearest_from_cell(const DeviceState& s, const double* __restrict__ lanes, int side, uint4 raw,
+                                double px, double py) {
+  const double* __restrict__ tab = lanes + (side ? s.nl * kLaneFields : 0);
+  const int n = side ? s.nr : s.nl;
   const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
   const int cnt = (int)(w[0] & 0xffu);
   if (cnt == kGridFullScan) return nearest_segment_scan(tab, n, px, py);
@@ -218,6 +221,11 @@ CILQR_DEV int nearest_segment(const DeviceState& s, const double* __restrict__ l
     }
   }
   return bi;
+}
+// `lanes`: the lane table (left rows then right rows), in global memory or staged in LDS.
+CILQR_DEV int nearest_segment(const DeviceState& s, const double* __restrict__ lanes, int side, double px,
+                              double py) {
+  return nearest_from_cell(s, lanes, side, lane_cell_fetch(s, side, px, py), px, py);
 }
 
 // number of list entries a kernel of the solve loop has to process (see DeviceState::n_dev)

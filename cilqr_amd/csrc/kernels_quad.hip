@@ -114,15 +114,20 @@ CILQR_DEV void knot_cost_core(const DeviceState& s, const double* __restrict__ l
   double ccost = 0.0, lcost = 0.0;
 #pragma unroll
   for (int j = 0; j < D; ++j) ccost += bar_group_value(p, pr[j], qd[j]);
-  // LaneBoundaryCost cc:583-603 (rolled loop: one copy of the lookup code)
-#pragma unroll 1
+  // LaneBoundaryCost cc:583-603: the ten candidate-list loads go out together, then the searches
+  uint4 cl[D], cr[D];
+#pragma unroll
   for (int j = 0; j < D; ++j) {
-    const double qx = x[0] + p.disc_off[j] * cs, qy = x[1] + p.disc_off[j] * sn;   // = px[j], py[j]
+    cl[j] = lane_cell_fetch(s, 0, px[j], py[j]);
+    cr[j] = lane_cell_fetch(s, 1, px[j], py[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
     double pl = 1.0, ql = 0.0;
-    const double* L = lanes + nearest_segment(s, lanes, 0, qx, qy) * kLaneFields;
-    bar_accumulate(p, L[0] * qx + L[1] * qy - L[2], pl, ql);
-    const double* Rr = lanes + (s.nl + nearest_segment(s, lanes, 1, qx, qy)) * kLaneFields;
-    bar_accumulate(p, Rr[0] * qx + Rr[1] * qy - Rr[2], pl, ql);
+    const double* L = lanes + nearest_from_cell(s, lanes, 0, cl[j], px[j], py[j]) * kLaneFields;
+    bar_accumulate(p, L[0] * px[j] + L[1] * py[j] - L[2], pl, ql);
+    const double* Rr = lanes + (s.nl + nearest_from_cell(s, lanes, 1, cr[j], px[j], py[j])) * kLaneFields;
+    bar_accumulate(p, Rr[0] * px[j] + Rr[1] * py[j] - Rr[2], pl, ql);
     lcost += bar_group_value(p, pl, ql);
   }
   out[0] = make_double2(jx, ju);
