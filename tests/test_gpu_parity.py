@@ -394,3 +394,34 @@ def test_cpp_adapter_plan_matches_oracle(tmp_path):
     o.set_problem(g["start"][b], g["coarse"][b], g["corridor"][b], g["ccount"][b], g["left"], g["right"])
     X, U = o.init_guess()
     assert rel_err(it0[:, 1:7], X) < 1e-9           # iter_trajs[0] is the init guess (cc:170)
+
+
+@pytest.mark.parametrize("over", [
+    dict(num_of_disc=3),                                             # run-time disc count (generic kernels)
+    dict(num_of_disc=7, safe_margin=0.05),
+    dict(w_v=0.2, w_a=0.1, w_delta=0.3, w_theta=0.05, w_jerk=0.3),    # every weight live
+    dict(barrier_t=10.0, barrier_eps=0.05),
+    dict(dt=0.08, max_velocity=15.0, jerk_max=6.0, jerk_min=-6.0, width=1.6, wheel_base=1.4),
+])
+def test_nondefault_configuration_parity(over):
+    """Every live field of IlqrConfig / VehicleParam reaches the kernels (nothing is hard-wired to
+    the reference defaults)."""
+    sc = scenario.generate("mix11", 72, seed=97)
+    opt = _opt(sc, **over)
+    g = opt.plan(sc)
+    ref = oracle_reference(sc, oracle_cfg_from(opt.cfg), n_perturb=2, eps=1e-13)
+    rep = assert_parity(g, ref, max_unstable_frac=0.35, what=str(over))
+    assert rep["n_stable"] >= 40
+    # the stages too, on one problem
+    opt.stage_load(sc)
+    opt.stage_init_guess()
+    X, U = opt.read(api.T_X), opt.read(api.T_U)
+    opt.stage_quadratize()
+    o = orc.Oracle(oracle_cfg_from(opt.cfg))
+    o.set_problem(sc["start"][5], sc["coarse"][5], sc["corridor"][5], sc["ccount"][5], sc["left"], sc["right"])
+    oq = o.quadratize(X[5], U[5])
+    for k, t in dict(A=api.T_A, B=api.T_B, lx=api.T_LX, lu=api.T_LU, lxx=api.T_LXX, luu=api.T_LUU).items():
+        got = opt.read(t)[5]
+        assert np.max(np.abs(got - oq[k])) / max(1.0, float(np.abs(oq[k]).max())) < STAGE_TOL, k
+    assert rel_err(opt.stage_total_cost()[5], o.total_cost(X[5], U[5])) < STAGE_TOL
+    opt.close()
