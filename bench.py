@@ -115,12 +115,14 @@ def main():
     sol = api.SolutionBatch(api.MEM_DEVICE, 0, o_traj.data_ptr(), o_hist.data_ptr(), o_nc.data_ptr(),
                             o_st.data_ptr(), o_ni.data_ptr(), None, None)
 
+    torch.cuda.synchronize()   # inputs uploaded and outputs zero-filled before the solver's own stream starts
+
     def step():
         rc = opt.solve_raw(prob, sol)
         if rc != api.OK:
             raise api.CilqrError(rc, "in bench step")
         if use_dist:
-            return gather_results(o_traj, o_hist, o_nc, o_st, dst=0)
+            return gather_results(o_traj, o_hist, o_nc, o_st, dst=0, densify=False)
         return None
 
     def fence():

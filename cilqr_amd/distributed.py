@@ -30,7 +30,7 @@ def shard_scene(scene: dict, rank: int, world: int) -> dict:
     return out
 
 
-def gather_results(traj, cost_hist, n_cost, status, dst: int = 0):
+def gather_results(traj, cost_hist, n_cost, status, dst: int = 0, densify: bool = True):
     """ONE gather: every rank packs its results into a single flat fp64 tensor
     (trajectories | live cost-history rows, ragged | n_cost | status) and rank `dst` receives the
     blocks in rank order.  Only the n_cost[b] live rows of each problem's history travel (9 of
@@ -38,8 +38,10 @@ def gather_results(traj, cost_hist, n_cost, status, dst: int = 0):
     collective is a 4-byte all-reduce(MAX) that agrees on the padded length of the ragged part.
 
     Every rank must hold the same per-rank batch size (weak scaling; pad the last shard
-    otherwise).  Returns a dict of concatenated tensors on `dst` (cost_hist dense again, with as
-    many rows as the longest history), None on the other ranks.
+    otherwise).  Returns a dict of concatenated tensors on `dst`, None on the other ranks:
+    traj, n_cost, status, and the history either dense again (`cost_hist`, as many rows as the
+    longest history; densify=True) or ragged as it travelled (`hist_rows` [sum n_cost, 5] in problem
+    order, problem b's rows start at cumsum(n_cost)[b-1]; densify=False, no extra passes on rank 0).
     """
     import torch
     import torch.distributed as dist
@@ -69,6 +71,11 @@ def gather_results(traj, cost_hist, n_cost, status, dst: int = 0):
         trajs.append(p[:n_traj].reshape(B, K, F))
         ncs.append(p[n_traj + n_rows:n_traj + n_rows + B].to(n_cost.dtype))
         sts.append(p[n_traj + n_rows + B:].to(status.dtype))
+    out = {"traj": torch.cat(trajs), "n_cost": torch.cat(ncs), "status": torch.cat(sts)}
+    if not densify:
+        out["hist_rows"] = torch.cat([p[n_traj:n_traj + int(c.to(torch.int64).sum().item()) * C].reshape(-1, C)
+                                      for p, c in zip(parts, ncs)])
+        return out
     H = int(max(int(c.max().item()) for c in ncs)) if B > 0 else 0
     for p, c in zip(parts, ncs):
         c64 = c.to(torch.int64)
@@ -76,5 +83,5 @@ def gather_results(traj, cost_hist, n_cost, status, dst: int = 0):
         m = torch.arange(H, device=c64.device)[None, :] < c64[:, None]
         dense[m] = p[n_traj:n_traj + int(c64.sum().item()) * C].reshape(-1, C)
         hists.append(dense)
-    return {"traj": torch.cat(trajs), "cost_hist": torch.cat(hists), "n_cost": torch.cat(ncs),
-            "status": torch.cat(sts)}
+    out["cost_hist"] = torch.cat(hists)
+    return out

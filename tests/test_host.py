@@ -138,6 +138,12 @@ _WORKER = textwrap.dedent("""
         assert np.array_equal(out["cost_hist"].numpy(), full["cost_hist"][:, :H])
         assert np.array_equal(out["n_cost"].numpy(), full["n_cost"])
         assert np.array_equal(out["status"].numpy(), full["status"])
+        rag = None
+    rag = gather_results(torch.from_numpy(r["traj"]), torch.from_numpy(r["cost_hist"]),
+                         torch.from_numpy(r["n_cost"]), torch.from_numpy(r["status"]), dst=0, densify=False)
+    if rank == 0:
+        rows = np.concatenate([full["cost_hist"][b, :full["n_cost"][b]] for b in range(8)])
+        assert np.array_equal(rag["hist_rows"].numpy(), rows) and np.array_equal(rag["traj"].numpy(), full["traj"])
         print("GATHER_OK")
     else:
         assert out is None
