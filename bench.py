@@ -160,7 +160,6 @@ def main():
     # problems for ~60 iterations) leaves the GPU mostly idle; a second batch on its own stream fills it.
     pipelined = None
     if world == 1 and args.pipeline > 1:
-        import threading
         P = args.pipeline
         ctx = []
         for i in range(P):
@@ -177,29 +176,30 @@ def main():
                                       bufs[2].data_ptr(), bufs[3].data_ptr(), None, None, None)
             ctx.append((o_i, st_i, bufs, sol_i))
         torch.cuda.synchronize()
-        per_thread = max(2, args.steps)
+        per_handle = max(2, args.steps)
         errs = []
-
-        def work(c, n):
-            try:
-                for _ in range(n):
-                    rc_ = c[0].solve_raw(prob, c[3])
-                    if rc_ != api.OK:
-                        errs.append(rc_)
-            except Exception as e:  # pragma: no cover
-                errs.append(e)
-
         for c in ctx:                      # warm-up (staging buffers, clocks)
-            work(c, 1)
+            if c[0].solve_raw(prob, c[3]) != api.OK:
+                errs.append("warm-up")
         torch.cuda.synchronize()
-        ths = [threading.Thread(target=work, args=(c, per_thread)) for c in ctx]
         t1 = time.perf_counter()
-        for t in ths:
-            t.start()
-        for t in ths:
-            t.join()
+        inflight = [False] * P
+        for s_ in range(P * per_handle):   # round-robin over the handles, each keeps one batch in flight
+            i = s_ % P
+            if inflight[i]:
+                rc_ = ctx[i][0].wait()
+                if rc_ != api.OK:
+                    errs.append(rc_)
+            rc_ = ctx[i][0].submit_raw(prob, ctx[i][3])
+            if rc_ != api.OK:
+                errs.append(rc_)
+            inflight[i] = True
+        for i in range(P):
+            if inflight[i] and ctx[i][0].wait() != api.OK:
+                errs.append("wait")
         torch.cuda.synchronize()
         dt = time.perf_counter() - t1
+        per_thread = per_handle
         if not errs:
             same = all(bool(torch.equal(c[2][0], o_traj)) and bool(torch.equal(c[2][2], o_nc)) for c in ctx)
             pipelined = {"batches_in_flight": P, "steps": P * per_thread, "value": round(P * per_thread * B / dt, 1),

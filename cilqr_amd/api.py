@@ -75,7 +75,7 @@ class Profile(C.Structure):
 EXPORTS = [
     "cilqr_abi_version", "cilqr_default_config", "cilqr_create", "cilqr_destroy", "cilqr_set_stream",
     "cilqr_set_option", "cilqr_set_profiling", "cilqr_get_profile", "cilqr_device_bytes", "cilqr_solve_batch",
-    "cilqr_stage_load", "cilqr_stage_init_guess", "cilqr_stage_set_trajectory",
+    "cilqr_submit", "cilqr_wait", "cilqr_stage_load", "cilqr_stage_init_guess", "cilqr_stage_set_trajectory",
     "cilqr_stage_total_cost", "cilqr_stage_quadratize", "cilqr_stage_backward", "cilqr_stage_forward",
     "cilqr_stage_read", "cilqr_stage_nearest_lane", "cilqr_open_loop_rollout", "cilqr_error_string",
 ]
@@ -109,6 +109,8 @@ def lib():
         L.cilqr_set_option.argtypes = [C.c_void_p, C.c_int32, C.c_int64]
         L.cilqr_get_profile.argtypes = [C.c_void_p, C.POINTER(Profile)]
         L.cilqr_solve_batch.argtypes = [C.c_void_p, C.POINTER(ProblemBatch), C.POINTER(SolutionBatch)]
+        L.cilqr_submit.argtypes = [C.c_void_p, C.POINTER(ProblemBatch), C.POINTER(SolutionBatch)]
+        L.cilqr_wait.argtypes = [C.c_void_p]
         L.cilqr_stage_load.argtypes = [C.c_void_p, C.POINTER(ProblemBatch)]
         L.cilqr_stage_init_guess.argtypes = [C.c_void_p]
         L.cilqr_stage_set_trajectory.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
@@ -203,6 +205,13 @@ class BatchIlqrOptimizer:
 
     def solve_raw(self, prob: ProblemBatch, sol: SolutionBatch) -> int:
         return self.L.cilqr_solve_batch(self.h, C.byref(prob), C.byref(sol))
+
+    def submit_raw(self, prob: ProblemBatch, sol: SolutionBatch) -> int:
+        """Asynchronous solve_raw; collect the result code with wait()."""
+        return self.L.cilqr_submit(self.h, C.byref(prob), C.byref(sol))
+
+    def wait(self) -> int:
+        return self.L.cilqr_wait(self.h)
 
     # ---- numpy (host memory) interface ----
     def _host_problem(self, scene: dict):

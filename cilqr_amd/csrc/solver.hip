@@ -6,7 +6,10 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
+#include <mutex>
+#include <thread>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -52,6 +55,14 @@ struct cilqr_solver {
   int stage = 0;           // bit0 loaded, bit1 iterate, bit2 quadratized, bit3 gains
   int spec_threshold = 8192;  // active sets up to this size evaluate all 11 step sizes at once
   int seq_rounds = 4;         // larger sets: this many round-by-round trials, then the rest at once
+  // asynchronous submit / wait: one worker thread per handle, one job in flight
+  std::thread worker;
+  std::mutex mu;
+  std::condition_variable cv;
+  bool worker_started = false, job_pending = false, job_done = false, quit = false;
+  cilqr_problem_batch job_in;
+  cilqr_solution_batch job_out;
+  int job_rc = CILQR_OK;
   // profiling
   bool profiling = false;
   std::vector<hipEvent_t> ev;
@@ -374,6 +385,14 @@ int cilqr_create(const cilqr_config* cfg, int32_t device, int32_t batch_capacity
 
 int cilqr_destroy(cilqr_handle h) {
   if (h == nullptr) return CILQR_ERR_NULL;
+  if (h->worker_started) {
+    {
+      std::lock_guard<std::mutex> lk(h->mu);
+      h->quit = true;
+    }
+    h->cv.notify_all();
+    h->worker.join();
+  }
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (void* p : h->allocs) (void)hipFree(p);
@@ -570,6 +589,49 @@ int cilqr_solve_batch(cilqr_handle h, const cilqr_problem_batch* in, cilqr_solut
   tm.resolve(&h->prof);
   h->stage = 1 | 2 | 4 | 8;
   return CILQR_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// asynchronous solves: several handles (each with its own stream) keep several batches in flight,
+// so the latency-bound tail of one solve overlaps the throughput-bound start of the next
+// ------------------------------------------------------------------------------------------
+static void worker_main(cilqr_solver* h) {
+  std::unique_lock<std::mutex> lk(h->mu);
+  for (;;) {
+    h->cv.wait(lk, [h] { return h->quit || h->job_pending; });
+    if (h->quit) return;
+    lk.unlock();
+    const int rc = cilqr_solve_batch(h, &h->job_in, &h->job_out);
+    lk.lock();
+    h->job_rc = rc;
+    h->job_pending = false;
+    h->job_done = true;
+    h->cv.notify_all();
+  }
+}
+
+int cilqr_submit(cilqr_handle h, const cilqr_problem_batch* in, cilqr_solution_batch* out) {
+  if (h == nullptr || in == nullptr || out == nullptr) return CILQR_ERR_NULL;
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (h->job_pending || h->job_done) return CILQR_ERR_STATE;   // previous job not collected yet
+  if (!h->worker_started) {
+    h->worker = std::thread(worker_main, h);
+    h->worker_started = true;
+  }
+  h->job_in = *in;
+  h->job_out = *out;
+  h->job_pending = true;
+  h->cv.notify_all();
+  return CILQR_OK;
+}
+
+int cilqr_wait(cilqr_handle h) {
+  if (h == nullptr) return CILQR_ERR_NULL;
+  std::unique_lock<std::mutex> lk(h->mu);
+  if (!h->job_pending && !h->job_done) return CILQR_ERR_STATE;
+  h->cv.wait(lk, [h] { return h->job_done; });
+  h->job_done = false;
+  return h->job_rc;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -158,6 +158,14 @@ int64_t cilqr_device_bytes(cilqr_handle h);
 
 int cilqr_solve_batch(cilqr_handle h, const cilqr_problem_batch* in, cilqr_solution_batch* out);
 
+/* Asynchronous form of cilqr_solve_batch: submit returns at once (the structs are copied, the
+ * arrays they point to must stay valid), wait blocks for the result code.  One job in flight per
+ * handle; several handles on different streams keep several batches in flight, which lets the
+ * latency-bound tail of one solve overlap the start of the next.  A handle is not re-entrant:
+ * do not call anything else on it between submit and wait. */
+int cilqr_submit(cilqr_handle h, const cilqr_problem_batch* in, cilqr_solution_batch* out);
+int cilqr_wait(cilqr_handle h);
+
 /* ---- stage entry points (operate on the handle's device state, whole batch) ---- */
 int cilqr_stage_load(cilqr_handle h, const cilqr_problem_batch* in);
 int cilqr_stage_init_guess(cilqr_handle h);
