@@ -75,7 +75,7 @@ class Profile(C.Structure):
 EXPORTS = [
     "cilqr_abi_version", "cilqr_default_config", "cilqr_create", "cilqr_destroy", "cilqr_set_stream",
     "cilqr_set_option", "cilqr_set_profiling", "cilqr_get_profile", "cilqr_device_bytes", "cilqr_solve_batch",
-    "cilqr_submit", "cilqr_wait", "cilqr_stage_load", "cilqr_stage_init_guess", "cilqr_stage_set_trajectory",
+    "cilqr_submit", "cilqr_wait", "cilqr_device_math", "cilqr_stage_load", "cilqr_stage_init_guess", "cilqr_stage_set_trajectory",
     "cilqr_stage_total_cost", "cilqr_stage_quadratize", "cilqr_stage_backward", "cilqr_stage_forward",
     "cilqr_stage_read", "cilqr_stage_nearest_lane", "cilqr_open_loop_rollout", "cilqr_error_string",
 ]
@@ -111,6 +111,7 @@ def lib():
         L.cilqr_solve_batch.argtypes = [C.c_void_p, C.POINTER(ProblemBatch), C.POINTER(SolutionBatch)]
         L.cilqr_submit.argtypes = [C.c_void_p, C.POINTER(ProblemBatch), C.POINTER(SolutionBatch)]
         L.cilqr_wait.argtypes = [C.c_void_p]
+        L.cilqr_device_math.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
         L.cilqr_stage_load.argtypes = [C.c_void_p, C.POINTER(ProblemBatch)]
         L.cilqr_stage_init_guess.argtypes = [C.c_void_p]
         L.cilqr_stage_set_trajectory.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
@@ -212,6 +213,13 @@ class BatchIlqrOptimizer:
 
     def wait(self) -> int:
         return self.L.cilqr_wait(self.h)
+
+    def device_math(self, fn: int, x) -> np.ndarray:
+        """Test hook: the kernels' lean log (fn 0, 2) / reciprocal (fn 1) on a host array."""
+        x = _f64(x).ravel()
+        out = np.empty_like(x)
+        self._chk(self.L.cilqr_device_math(self.h, fn, x.size, _ptr(x), _ptr(out)), "device_math")
+        return out
 
     # ---- numpy (host memory) interface ----
     def _host_problem(self, scene: dict):

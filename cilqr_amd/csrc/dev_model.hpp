@@ -43,45 +43,108 @@ CILQR_DEV double normalize_angle(double angle) {
   return r - kPi;
 }
 
+// ---- lean fp64 math for the barrier terms ----
+// The barrier arguments are finite, normal and of moderate size (distances in metres), so the
+// special-case handling of the library routines (NaN / inf / denormal / sign tests, IEEE-exact
+// division) is dead weight in kernels that are bound by the fp64 pipe.  Both routines below are
+// accurate to about 1 ulp; the reference's results are reproduced to ~1e-15 relative, far inside
+// the 1e-4 parity tolerance (the grouped logs already re-associate at that level).
+
+// 1 / g for normal finite g != 0: hardware estimate + two Newton steps (6 instructions; the
+// IEEE-exact division sequence is 12)
+CILQR_DEV double fast_rcp(double g) {
+  double r = __builtin_amdgcn_rcp(g);
+  r = fma(fma(-g, r, 1.0), r, r);
+  r = fma(fma(-g, r, 1.0), r, r);
+  return r;
+}
+
+// log(x * 2^e2) for normal finite x > 0.  Classic argument reduction x = 2^k (1 + f),
+// sqrt(1/2) <= 1 + f < sqrt(2), s = f / (2 + f), log(1 + f) = f - f^2/2 + s (f^2/2 + R(s^2)) with
+// the degree-7 minimax polynomial R of Sun's fdlibm e_log.c (error < 1 ulp); ~40 instructions
+// against ~100 for the library log().  e2 lets a caller carry the exponent of a long product
+// separately (see bar_group_value).
+CILQR_DEV double log_pos(double x, int e2) {
+  constexpr double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+  constexpr double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
+                   Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
+                   Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                   Lg7 = 1.479819860511658591e-01;
+  double m = __builtin_amdgcn_frexp_mant(x);          // [0.5, 1)
+  int k = __builtin_amdgcn_frexp_exp(x) + e2;
+  const bool low = m < 0.70710678118654752440;
+  m = low ? 2.0 * m : m;                              // [sqrt(1/2), sqrt(2))
+  k -= low ? 1 : 0;
+  const double f = m - 1.0;
+  const double s = f * fast_rcp(2.0 + f);
+  const double z = s * s, w = z * z;
+  const double t1 = w * fma(w, fma(w, Lg6, Lg4), Lg2);
+  const double t2 = z * fma(w, fma(w, fma(w, Lg7, Lg5), Lg3), Lg1);
+  const double R = t2 + t1;
+  const double hfsq = 0.5 * f * f;
+  const double dk = (double)k;
+  return dk * ln2_hi - ((hfsq - fma(s, hfsq + R, dk * ln2_lo)) - f);
+}
+
 // ---- relaxed log barrier, barrier_function.h:104-140 ----
 // value(g) = g < -eps ? -r log(-g) : r/2 (((-g - 2 eps)/eps)^2 - 1) - r log(eps)
 // Sum of barrier values with one log per group instead of one per constraint:
 //   sum_c -r log(-g_c) = -r log(prod_c -g_c)   over the constraints on the log branch.
-// `prod` collects the product (start at 1), `quad` the relaxed-branch values (start at 0);
-// bar_group_value() closes the group.  A group holds at most a few dozen factors of magnitude
-// 1e-3..1e2, far from fp64 over/underflow.  This only re-associates the reference's sum.
-CILQR_DEV void bar_accumulate(const Params& p, double g, double& prod, double& quad) {
-  // log branch without control flow (the common case); the relaxed branch, which needs a division,
-  // sits behind a wave-uniform test so the straight-line code of a whole chunk can be scheduled
-  const bool lg = g < -p.bar_eps;
-  prod *= lg ? -g : 1.0;
-  if (__builtin_amdgcn_ballot_w64(!lg) != 0) {
-    if (!lg) {
-      const double q = (-g - 2.0 * p.bar_eps) / p.bar_eps;
-      quad += 0.5 * p.bar_r * (q * q - 1) - p.bar_rlogeps;
-    }
+// A BarGroup collects the product (mantissa and exponent apart, so any number of factors is
+// safe) and the relaxed-branch values.  This only re-associates the reference's sum.
+struct BarGroup {
+  double prod = 1.0;   // running product of the current run of factors
+  double quad = 0.0;   // relaxed-branch values
+  int e2 = 0;          // exponent carried over from closed runs
+};
+// value of one constraint on the relaxed (quadratic) branch; (x / eps) as x * (1 / eps)
+CILQR_DEV double bar_relaxed_value(const Params& p, double g) {
+  const double q = (-g - 2.0 * p.bar_eps) * p.bar_inv_eps;
+  return 0.5 * p.bar_r * (q * q - 1) - p.bar_rlogeps;
+}
+// N constraints at once: the log-branch part is straight-line code; the relaxed branch sits
+// behind ONE wave-uniform test for the N constraints (it is rare once the iterate is feasible)
+template <int N>
+CILQR_DEV void bar_accumulate(const Params& p, const double (&g)[N], BarGroup& grp) {
+  bool any = false;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const bool lg = g[k] < -p.bar_eps;
+    grp.prod *= lg ? -g[k] : 1.0;
+    any |= !lg;
+  }
+  if (__builtin_amdgcn_ballot_w64(any) != 0) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) grp.quad += (g[k] < -p.bar_eps) ? 0.0 : bar_relaxed_value(p, g[k]);
   }
 }
-CILQR_DEV double bar_group_value(const Params& p, double prod, double quad) {
-  return quad - p.bar_r * log(prod);
+// closes a run of factors: the product's exponent moves to e2, the mantissa stays.  Call at
+// least every ~100 factors (a factor is a distance in metres: 1e-2 .. 1e3).
+CILQR_DEV void bar_renormalize(BarGroup& grp) {
+  grp.e2 += __builtin_amdgcn_frexp_exp(grp.prod);
+  grp.prod = __builtin_amdgcn_frexp_mant(grp.prod);
+}
+CILQR_DEV void bar_merge(BarGroup& into, const BarGroup& g) {
+  into.prod *= g.prod;
+  into.quad += g.quad;
+  into.e2 += g.e2;
+}
+CILQR_DEV double bar_group_value(const Params& p, const BarGroup& grp) {
+  return grp.quad - p.bar_r * log_pos(grp.prod, grp.e2);
 }
 // Gradient and Hessian coefficients of one constraint:
 //   Jacbian() = jc * dg;  Hessian() = (c1 dg_i) dg_j - c2 ddg_ij (c2 term only on the log branch;
 //   the relaxed branch reuses the gradient coefficient and drops ddg -- reference quirk, kept).
-// Log branch: jc = -r/g = -(r/g), c2 = r/g, c1 = r/g/g = c2/g: two divisions give all three,
-// bit-identical to evaluating each expression separately.
+// Log branch: c2 = r/g, c1 = r/g/g, jc = -r/g from one reciprocal; relaxed branch:
+// r (g + 2 eps) / eps^2.  Branch-free: both sides are a handful of instructions.
 CILQR_DEV void bar_coefs(const Params& p, double g, double& jc, double& c1, double& c2, bool& log_branch) {
-  if (g < -p.bar_eps) {
-    c2 = p.bar_r / g;
-    c1 = c2 / g;
-    jc = -c2;
-    log_branch = true;
-  } else {
-    jc = p.bar_r * (g + 2.0 * p.bar_eps) / p.bar_eps / p.bar_eps;
-    c1 = jc;
-    c2 = 0.0;
-    log_branch = false;
-  }
+  log_branch = g < -p.bar_eps;
+  const double inv = fast_rcp(log_branch ? g : 1.0);
+  const double c2l = p.bar_r * inv;
+  const double jr = p.bar_r * (g + 2.0 * p.bar_eps) * p.bar_inv_eps * p.bar_inv_eps;
+  c2 = log_branch ? c2l : 0.0;
+  c1 = log_branch ? c2l * inv : jr;
+  jc = log_branch ? -c2l : jr;
 }
 
 // ---- continuous dynamics f(x,u), vehicle_model.cc:123-138 ----

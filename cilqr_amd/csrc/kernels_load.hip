@@ -157,6 +157,17 @@ void launch_nearest_lane(const DeviceState& s, int n, const double* xy, int* lef
   hipLaunchKernelGGL(k_nearest_lane, dim3((n + 255) / 256), dim3(256), 0, st, s, n, xy, left, right, use_grid);
 }
 
+// test hook: the lean fp64 routines of dev_model.hpp on arbitrary inputs
+__global__ void k_device_math(int fn, int n, const double* __restrict__ in, double* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const double x = in[t];
+  out[t] = (fn == 0) ? log_pos(x, 0) : (fn == 1) ? fast_rcp(x) : log_pos(__builtin_amdgcn_frexp_mant(x), __builtin_amdgcn_frexp_exp(x));
+}
+void launch_device_math(int fn, int n, const double* in, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(k_device_math, dim3((n + 255) / 256), dim3(256), 0, st, fn, n, in, out);
+}
+
 void launch_load(const DeviceState& s, int B, const ProblemView& in, const double* lanes_raw,
                  hipStream_t st) {
   const int ld = in.cmax_in * 3 + 1;

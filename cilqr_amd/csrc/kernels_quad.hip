@@ -53,6 +53,23 @@ CILQR_DEV void load_chunk(const double* __restrict__ cor, int Bc, int c0, int cn
 // ---------------------------------------------------------------------------------------------
 // cost partials of one knot.  x, u: the knot's state / control; out[0], out[stride], out[2*stride]
 // ---------------------------------------------------------------------------------------------
+// bound barriers of one knot (DynamicsCost cc:518-551); returns {state part, control part}
+CILQR_DEV double2 knot_bound_cost(const Params& p, int i, const double* x, const double* u) {
+  double du = 0.0;
+  if (i < p.N) {
+    BarGroup g;
+    const double gu[4] = {u[0] - p.jerk_max, p.jerk_min - u[0],                    // cc:543-546
+                          u[1] - p.delta_rate_max, p.delta_rate_min - u[1]};
+    bar_accumulate(p, gu, g);
+    du = bar_group_value(p, g);
+  }
+  BarGroup g;
+  const double gx[6] = {-x[3], x[3] - p.max_velocity, x[4] - p.max_acc,            // cc:523-528
+                        p.min_acc - x[4], x[5] - p.delta_max, p.delta_min - x[5]};
+  bar_accumulate(p, gx, g);
+  return make_double2(bar_group_value(p, g), du);
+}
+
 template <int D>
 CILQR_DEV void knot_cost_core(const DeviceState& s, const double* __restrict__ lanes, int i, int slot,
                               const double* x, const double* u, double2* __restrict__ out, size_t stride) {
@@ -68,52 +85,41 @@ CILQR_DEV void knot_cost_core(const DeviceState& s, const double* __restrict__ l
   // JCost cc:501-513
   const double ex = x[0] - g0.x, ey = x[1] - g0.y, eth = x[2] - gth;
   const double jx = p.w_x * (ex * ex) + p.w_y * (ey * ey) + p.w_theta * (eth * eth);
-  // DynamicsCost cc:518-551: the bound barriers of this knot, one log per group
-  double ju = 0.0, du = 0.0;
-  if (i < p.N) {
-    ju = p.w_jerk * (u[0] * u[0]) + p.w_delta_rate * (u[1] * u[1]);
-    double pr = 1.0, qd = 0.0;
-    bar_accumulate(p, u[0] - p.jerk_max, pr, qd);          // cc:543-546
-    bar_accumulate(p, p.jerk_min - u[0], pr, qd);
-    bar_accumulate(p, u[1] - p.delta_rate_max, pr, qd);
-    bar_accumulate(p, p.delta_rate_min - u[1], pr, qd);
-    du = bar_group_value(p, pr, qd);
-  }
-  double dx;
-  {
-    double pr = 1.0, qd = 0.0;                            // cc:523-528
-    bar_accumulate(p, -x[3], pr, qd);
-    bar_accumulate(p, x[3] - p.max_velocity, pr, qd);
-    bar_accumulate(p, x[4] - p.max_acc, pr, qd);
-    bar_accumulate(p, p.min_acc - x[4], pr, qd);
-    bar_accumulate(p, x[5] - p.delta_max, pr, qd);
-    bar_accumulate(p, p.delta_min - x[5], pr, qd);
-    dx = bar_group_value(p, pr, qd);
-  }
+  const double ju = (i < p.N) ? p.w_jerk * (u[0] * u[0]) + p.w_delta_rate * (u[1] * u[1]) : 0.0;
+  const double2 dyn = knot_bound_cost(p, i, x, u);
   double sn, cs;
   sincos(x[2], &sn, &cs);
-  double px[D], py[D], pr[D], qd[D];
+  double px[D], py[D];
+  BarGroup grp[D];
 #pragma unroll
   for (int j = 0; j < D; ++j) {
     px[j] = x[0] + p.disc_off[j] * cs;                     // cc:564-565
     py[j] = x[1] + p.disc_off[j] * sn;
-    pr[j] = 1.0;
-    qd[j] = 0.0;
   }
-  // CorridorCost cc:553-581
+  // CorridorCost cc:553-581: planes outer (each read once), discs inner; one log for the knot
   for (int c0 = 0; c0 < cnt; c0 += kPlaneChunk) {
     PlaneChunk nx;
     if (c0 + kPlaneChunk < cnt) load_chunk(cor, Bc, c0 + kPlaneChunk, cnt, nx);
 #pragma unroll
-    for (int j = 0; j < D; ++j)
+    for (int j = 0; j < D; ++j) {
+      double g[kPlaneChunk];
 #pragma unroll
-      for (int k = 0; k < kPlaneChunk; ++k)
-        bar_accumulate(p, pc.a[k] * px[j] + pc.b[k] * py[j] - pc.c[k], pr[j], qd[j]);
+      for (int k = 0; k < kPlaneChunk; ++k) g[k] = pc.a[k] * px[j] + pc.b[k] * py[j] - pc.c[k];
+      bar_accumulate(p, g, grp[j]);
+    }
+    if ((c0 & (16 * kPlaneChunk - 1)) == 15 * kPlaneChunk) {   // every 64 planes: keep the products in range
+#pragma unroll
+      for (int j = 0; j < D; ++j) bar_renormalize(grp[j]);
+    }
     pc = nx;
   }
-  double ccost = 0.0, lcost = 0.0;
+  BarGroup call;
 #pragma unroll
-  for (int j = 0; j < D; ++j) ccost += bar_group_value(p, pr[j], qd[j]);
+  for (int j = 0; j < D; ++j) {
+    bar_renormalize(grp[j]);
+    bar_merge(call, grp[j]);
+  }
+  const double ccost = bar_group_value(p, call);
   // LaneBoundaryCost cc:583-603: the ten candidate-list loads go out together, then the searches
   uint4 cl[D], cr[D];
 #pragma unroll
@@ -121,17 +127,17 @@ CILQR_DEV void knot_cost_core(const DeviceState& s, const double* __restrict__ l
     cl[j] = lane_cell_fetch(s, 0, px[j], py[j]);
     cr[j] = lane_cell_fetch(s, 1, px[j], py[j]);
   }
+  BarGroup lall;
 #pragma unroll
   for (int j = 0; j < D; ++j) {
-    double pl = 1.0, ql = 0.0;
     const double* L = lanes + nearest_from_cell(s, lanes, 0, cl[j], px[j], py[j]) * kLaneFields;
-    bar_accumulate(p, L[0] * px[j] + L[1] * py[j] - L[2], pl, ql);
     const double* Rr = lanes + (s.nl + nearest_from_cell(s, lanes, 1, cr[j], px[j], py[j])) * kLaneFields;
-    bar_accumulate(p, Rr[0] * px[j] + Rr[1] * py[j] - Rr[2], pl, ql);
-    lcost += bar_group_value(p, pl, ql);
+    const double g[2] = {L[0] * px[j] + L[1] * py[j] - L[2], Rr[0] * px[j] + Rr[1] * py[j] - Rr[2]};
+    bar_accumulate(p, g, lall);
   }
+  const double lcost = bar_group_value(p, lall);
   out[0] = make_double2(jx, ju);
-  out[stride] = make_double2(dx, du);
+  out[stride] = dyn;
   out[2 * stride] = make_double2(ccost, lcost);
 }
 
@@ -145,50 +151,31 @@ CILQR_DEV void knot_cost_generic(const DeviceState& s, const double* __restrict_
   const double gth = gp[(size_t)Bc].x;
   const double ex = x[0] - g0.x, ey = x[1] - g0.y, eth = x[2] - gth;
   const double jx = p.w_x * (ex * ex) + p.w_y * (ey * ey) + p.w_theta * (eth * eth);
-  double ju = 0.0, du = 0.0;
-  if (i < p.N) {
-    ju = p.w_jerk * (u[0] * u[0]) + p.w_delta_rate * (u[1] * u[1]);
-    double pr = 1.0, qd = 0.0;
-    bar_accumulate(p, u[0] - p.jerk_max, pr, qd);
-    bar_accumulate(p, p.jerk_min - u[0], pr, qd);
-    bar_accumulate(p, u[1] - p.delta_rate_max, pr, qd);
-    bar_accumulate(p, p.delta_rate_min - u[1], pr, qd);
-    du = bar_group_value(p, pr, qd);
-  }
-  double dx;
-  {
-    double pr = 1.0, qd = 0.0;
-    bar_accumulate(p, -x[3], pr, qd);
-    bar_accumulate(p, x[3] - p.max_velocity, pr, qd);
-    bar_accumulate(p, x[4] - p.max_acc, pr, qd);
-    bar_accumulate(p, p.min_acc - x[4], pr, qd);
-    bar_accumulate(p, x[5] - p.delta_max, pr, qd);
-    bar_accumulate(p, p.delta_min - x[5], pr, qd);
-    dx = bar_group_value(p, pr, qd);
-  }
+  const double ju = (i < p.N) ? p.w_jerk * (u[0] * u[0]) + p.w_delta_rate * (u[1] * u[1]) : 0.0;
+  const double2 dyn = knot_bound_cost(p, i, x, u);
   double sn, cs;
   sincos(x[2], &sn, &cs);
   const int cnt = s.ccnt[(size_t)i * Bc + slot];
   const double* __restrict__ cor = s.cor + (size_t)i * s.cmax * 3 * Bc + slot;
-  double ccost = 0.0, lcost = 0.0;
+  BarGroup call, lall;
   for (int j = 0; j < p.num_of_disc; ++j) {
     const double px = x[0] + p.disc_off[j] * cs, py = x[1] + p.disc_off[j] * sn;
-    double pr = 1.0, qd = 0.0;
     for (int c = 0; c < cnt; ++c) {
       const double* q = cor + (size_t)c * 3 * Bc;
-      bar_accumulate(p, q[0] * px + q[(size_t)Bc] * py - q[(size_t)2 * Bc], pr, qd);
+      const double g[1] = {q[0] * px + q[(size_t)Bc] * py - q[(size_t)2 * Bc]};
+      bar_accumulate(p, g, call);
+      if ((c & 63) == 63) bar_renormalize(call);
     }
-    ccost += bar_group_value(p, pr, qd);
-    double pl = 1.0, ql = 0.0;
+    bar_renormalize(call);
     const double* L = lanes + nearest_segment(s, lanes, 0, px, py) * kLaneFields;
-    bar_accumulate(p, L[0] * px + L[1] * py - L[2], pl, ql);
     const double* Rr = lanes + (s.nl + nearest_segment(s, lanes, 1, px, py)) * kLaneFields;
-    bar_accumulate(p, Rr[0] * px + Rr[1] * py - Rr[2], pl, ql);
-    lcost += bar_group_value(p, pl, ql);
+    const double g[2] = {L[0] * px + L[1] * py - L[2], Rr[0] * px + Rr[1] * py - Rr[2]};
+    bar_accumulate(p, g, lall);
+    bar_renormalize(lall);
   }
   out[0] = make_double2(jx, ju);
-  out[stride] = make_double2(dx, du);
-  out[2 * stride] = make_double2(ccost, lcost);
+  out[stride] = dyn;
+  out[2 * stride] = make_double2(bar_group_value(p, call), bar_group_value(p, lall));
 }
 
 CILQR_DEV void knot_cost_any(const DeviceState& s, const double* __restrict__ lanes, int i, int slot,

@@ -111,6 +111,7 @@ void fill_params(const cilqr_config& c, Params* p) {
   p->delta_rate_min = c.delta_rate_min; p->delta_rate_max = c.delta_rate_max;
   p->bar_r = 1.0 / c.barrier_t;                       // barrier_function.h:85
   p->bar_eps = c.barrier_eps;
+  p->bar_inv_eps = 1.0 / c.barrier_eps;
   p->bar_rlogeps = p->bar_r * std::log(c.barrier_eps);
   // CalculateDiscRadius cc:97-104 and the disc offsets of cc:556-565
   const double length = c.front_hang + c.wheel_base + c.rear_hang;
@@ -837,6 +838,24 @@ int cilqr_stage_nearest_lane(cilqr_handle h, int32_t n, const double* xy, int32_
   }
   if (t0) (void)hipFree(t0);
   if (tl) (void)hipFree(tl);
+  return rc;
+}
+
+int cilqr_device_math(cilqr_handle h, int32_t fn, int32_t n, const double* in, double* out) {
+  if (h == nullptr || in == nullptr || out == nullptr) return CILQR_ERR_NULL;
+  if (n <= 0 || fn < 0 || fn > 2) return CILQR_ERR_ARG;
+  HIP_TRY(hipSetDevice(h->device));
+  double* d = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&d), (size_t)n * 16) != hipSuccess) return CILQR_ERR_DEVICE;
+  int rc = CILQR_OK;
+  if (hipMemcpyAsync(d, in, (size_t)n * 8, hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = CILQR_ERR_DEVICE;
+  if (rc == CILQR_OK) {
+    launch_device_math(fn, n, d, d + n, h->stream);
+    if (hipMemcpyAsync(out, d + n, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        hipStreamSynchronize(h->stream) != hipSuccess)
+      rc = CILQR_ERR_DEVICE;
+  }
+  (void)hipFree(d);
   return rc;
 }
 

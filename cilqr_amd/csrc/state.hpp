@@ -63,6 +63,7 @@ struct Params {
   double delta_rate_min, delta_rate_max;
   double bar_r;        // 1 / t            (barrier_function.h:85)
   double bar_eps;      // epsilon
+  double bar_inv_eps;  // 1 / epsilon
   double bar_rlogeps;  // r * log(eps), evaluated once on the host in fp64
   double disc_off[kMaxDiscs];  // L*(j-0.5) - rf   (ilqr_optimizer.cc:564)
   double shrink_corridor;      // disc_radius + safe_margin   (cc:448)
@@ -179,6 +180,7 @@ void launch_export_iter_traj(const DeviceState& s, const int* list, int n, doubl
                              int max_iter_trajs, hipStream_t st);
 void launch_export_hist(const DeviceState& s, int B, double* cost_hist, int* n_cost, int* status,
                         int* n_iter, int* n_iter_trajs, hipStream_t st);
+void launch_device_math(int fn, int n, const double* in, double* out, hipStream_t st);
 void launch_rollout(const Params& p, int B, const double* x0, const double* U, double* X, hipStream_t st);
 // stage_read helpers: gather a batch-fastest tensor into problem-major order
 void launch_gather_pairs(const double2* src, int rows_pairs, int Bcap, int B, double* dst,

@@ -205,6 +205,11 @@ int cilqr_stage_read(cilqr_handle h, int32_t tensor, double* dst, int32_t memory
 int cilqr_stage_nearest_lane(cilqr_handle h, int32_t n, const double* xy, int32_t* left, int32_t* right,
                              int32_t use_grid, int32_t memory);
 
+/* Test hook for the kernels' own fp64 routines (host arrays of n doubles):
+ * fn 0: log(x) for normal finite x > 0;  fn 1: 1 / x for normal finite x != 0;
+ * fn 2: log(x) with mantissa and exponent handed over separately (the long-product path). */
+int cilqr_device_math(cilqr_handle h, int32_t fn, int32_t n, const double* in, double* out);
+
 /* X[b][0] = x0[b]; X[b][i+1] = Dynamics(X[b][i], U[b][i]).  x0 [B][6], U [B][N][2], X [B][K][6] */
 int cilqr_open_loop_rollout(cilqr_handle h, int32_t batch, const double* x0, const double* U,
                             double* X, int32_t memory);
