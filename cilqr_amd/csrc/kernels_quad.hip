@@ -284,27 +284,43 @@ struct Quad {
   double huu[2];   // luu(0,0), (1,1)
 };
 
-// one constraint g = a x + b y - c at disc point (px, py) = (x, y) + (lc, ls)   (cc:703, 723-724)
-CILQR_DEV void add_plane(const Params& p, Quad& q, double a, double b, double c, double px, double py,
-                         double lc, double ls) {
+// One half-plane g = a x + b y - c seen from the discs of a knot, disc point (px, py) =
+// (x, y) + (lc, ls).  dg = (a, b, d2) with d2 = -a ls + b lc (cc:703), ddg(2,2) = -a lc - b ls
+// (cc:723-724).  a and b are the same for every disc, so the sums over the discs of
+//   jc dg            = (a T0, b T0, T1)
+//   c1 dg dg^T       = [a a S0, a b S0, a S1; . , b b S0, b S1; . , . , S2]
+//   c2 ddg           = W   (entry (2,2) only; c2 = 0 on the relaxed branch)
+// need five running sums per plane instead of a 3-vector and a 3x3 update per (plane, disc).
+// This re-associates the reference's accumulation (and makes the 3x3 block exactly symmetric,
+// which the reference's is only to rounding).
+struct PlaneSums {
+  double T0 = 0.0, T1 = 0.0, S0 = 0.0, S1 = 0.0, S2 = 0.0, W = 0.0;
+};
+CILQR_DEV void plane_disc(const Params& p, double a, double b, double c, double px, double py, double lc,
+                          double ls, PlaneSums& m) {
   const double g = a * px + b * py - c;
-  const double d[3] = {a, b, -a * ls + b * lc};
+  const double d2 = -a * ls + b * lc;
+  const double dd22 = -a * lc - b * ls;
   double jc, c1, c2;
   bool lg;
   bar_coefs(p, g, jc, c1, c2, lg);
-#pragma unroll
-  for (int e = 0; e < 3; ++e) q.lx[e] += jc * d[e];
-  const double dd22 = -a * lc - b * ls;            // cc:723
-#pragma unroll
-  for (int e = 0; e < 3; ++e) {
-    const double ce = c1 * d[e];
-#pragma unroll
-    for (int f = 0; f < 3; ++f) {
-      double v = ce * d[f];
-      if (lg) v = v - c2 * ((e == 2 && f == 2) ? dd22 : 0.0);
-      q.h[e * 3 + f] += v;
-    }
-  }
+  m.T0 += jc;
+  m.T1 += jc * d2;
+  m.S0 += c1;
+  const double t = c1 * d2;
+  m.S1 += t;
+  m.S2 += t * d2;
+  m.W += c2 * dd22;
+}
+CILQR_DEV void plane_commit(Quad& q, double a, double b, const PlaneSums& m) {
+  q.lx[0] += a * m.T0;
+  q.lx[1] += b * m.T0;
+  q.lx[2] += m.T1;
+  const double aS = a * m.S0, bS = b * m.S0;
+  const double h01 = aS * b, h02 = a * m.S1, h12 = b * m.S1;
+  q.h[0] += aS * a; q.h[1] += h01; q.h[2] += h02;
+  q.h[3] += h01; q.h[4] += bS * b; q.h[5] += h12;
+  q.h[6] += h02; q.h[7] += h12; q.h[8] += m.S2 - m.W;
 }
 
 template <int D>
@@ -366,24 +382,38 @@ CILQR_DEV void knot_quadratize(const DeviceState& s, const double* __restrict__ 
   for (int c0 = 0; c0 < cnt; c0 += kPlaneChunk) {
     PlaneChunk nx;
     if (c0 + kPlaneChunk < cnt) load_chunk(cor, Bc, c0 + kPlaneChunk, cnt, nx);
-#pragma unroll 1
-    for (int j = 0; j < nd; ++j) {
-      const double lc = p.disc_off[j] * cs, ls = p.disc_off[j] * sn;
 #pragma unroll
-      for (int k = 0; k < kPlaneChunk; ++k)
-        add_plane(p, q, pc.a[k], pc.b[k], pc.c[k], x[0] + lc, x[1] + ls, lc, ls);
+    for (int k = 0; k < kPlaneChunk; ++k) {
+      PlaneSums m;
+      if constexpr (D > 0) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+          const double lc = p.disc_off[j] * cs, ls = p.disc_off[j] * sn;
+          plane_disc(p, pc.a[k], pc.b[k], pc.c[k], x[0] + lc, x[1] + ls, lc, ls, m);
+        }
+      } else {
+#pragma unroll 1
+        for (int j = 0; j < nd; ++j) {
+          const double lc = p.disc_off[j] * cs, ls = p.disc_off[j] * sn;
+          plane_disc(p, pc.a[k], pc.b[k], pc.c[k], x[0] + lc, x[1] + ls, lc, ls, m);
+        }
+      }
+      plane_commit(q, pc.a[k], pc.b[k], m);
     }
     pc = nx;
   }
   // nearest left / right lane plane, all discs (cc:729-769)
 #pragma unroll 1
   for (int j = 0; j < nd; ++j) {
-    const double lc = p.disc_off[j] * cs, ls = p.disc_off[j] * sn;
-    const double px = x[0] + lc, py = x[1] + ls;
+    const double lcj = p.disc_off[j] * cs, lsj = p.disc_off[j] * sn;
+    const double px = x[0] + lcj, py = x[1] + lsj;
     const double* L = lanes + nearest_segment(s, lanes, 0, px, py) * kLaneFields;
-    add_plane(p, q, L[0], L[1], L[2], px, py, lc, ls);
+    PlaneSums ml, mr;
+    plane_disc(p, L[0], L[1], L[2], px, py, lcj, lsj, ml);
+    plane_commit(q, L[0], L[1], ml);
     const double* Rr = lanes + (s.nl + nearest_segment(s, lanes, 1, px, py)) * kLaneFields;
-    add_plane(p, q, Rr[0], Rr[1], Rr[2], px, py, lc, ls);
+    plane_disc(p, Rr[0], Rr[1], Rr[2], px, py, lcj, lsj, mr);
+    plane_commit(q, Rr[0], Rr[1], mr);
   }
   if (term) {
     double2* o = s.term + slot;
