@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcilqr_hip.so")
+LIB_PATH = os.environ.get("CILQR_LIB") or os.path.join(_HERE, "lib", "libcilqr_hip.so")   # CILQR_LIB: development override
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "cilqr.h")
 
 OK = 0

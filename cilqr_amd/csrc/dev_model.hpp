@@ -91,32 +91,27 @@ CILQR_DEV double log_pos(double x, int e2) {
 // Sum of barrier values with one log per group instead of one per constraint:
 //   sum_c -r log(-g_c) = -r log(prod_c -g_c)   over the constraints on the log branch.
 // A BarGroup collects the product (mantissa and exponent apart, so any number of factors is
-// safe) and the relaxed-branch values.  This only re-associates the reference's sum.
+// safe) and the relaxed-branch part.  This only re-associates the reference's sum.
+// Branch-free form.  With w = max(g, -eps) + 2 eps the relaxed value is
+//   r/2 ((w/eps)^2 - 1) - r log(eps)  =  r/(2 eps^2) (w^2 - eps^2)  -  r log(max(-g, eps)),
+// and on the log branch the same expression gives exactly 0 - r log(-g) (w = eps there, bit for
+// bit).  So every constraint multiplies max(-g, eps) into the product and adds w^2 to a sum of
+// squares: two max, two multiplies and an fma per constraint, no test, no divergence.
 struct BarGroup {
-  double prod = 1.0;   // running product of the current run of factors
-  double quad = 0.0;   // relaxed-branch values
+  double prod = 1.0;   // running product of max(-g, eps) over the current run of factors
+  double sq = 0.0;     // sum of w^2
+  int n = 0;           // constraints so far
   int e2 = 0;          // exponent carried over from closed runs
 };
-// value of one constraint on the relaxed (quadratic) branch; (x / eps) as x * (1 / eps)
-CILQR_DEV double bar_relaxed_value(const Params& p, double g) {
-  const double q = (-g - 2.0 * p.bar_eps) * p.bar_inv_eps;
-  return 0.5 * p.bar_r * (q * q - 1) - p.bar_rlogeps;
-}
-// N constraints at once: the log-branch part is straight-line code; the relaxed branch sits
-// behind ONE wave-uniform test for the N constraints (it is rare once the iterate is feasible)
 template <int N>
 CILQR_DEV void bar_accumulate(const Params& p, const double (&g)[N], BarGroup& grp) {
-  bool any = false;
 #pragma unroll
   for (int k = 0; k < N; ++k) {
-    const bool lg = g[k] < -p.bar_eps;
-    grp.prod *= lg ? -g[k] : 1.0;
-    any |= !lg;
+    grp.prod *= fmax(-g[k], p.bar_eps);
+    const double w = fmax(g[k], -p.bar_eps) + 2.0 * p.bar_eps;
+    grp.sq = fma(w, w, grp.sq);
   }
-  if (__builtin_amdgcn_ballot_w64(any) != 0) {
-#pragma unroll
-    for (int k = 0; k < N; ++k) grp.quad += (g[k] < -p.bar_eps) ? 0.0 : bar_relaxed_value(p, g[k]);
-  }
+  grp.n += N;
 }
 // closes a run of factors: the product's exponent moves to e2, the mantissa stays.  Call at
 // least every ~100 factors (a factor is a distance in metres: 1e-2 .. 1e3).
@@ -126,11 +121,13 @@ CILQR_DEV void bar_renormalize(BarGroup& grp) {
 }
 CILQR_DEV void bar_merge(BarGroup& into, const BarGroup& g) {
   into.prod *= g.prod;
-  into.quad += g.quad;
+  into.sq += g.sq;
+  into.n += g.n;
   into.e2 += g.e2;
 }
 CILQR_DEV double bar_group_value(const Params& p, const BarGroup& grp) {
-  return grp.quad - p.bar_r * log_pos(grp.prod, grp.e2);
+  const double quad = p.bar_half_r_inv_eps2 * (grp.sq - (double)grp.n * (p.bar_eps * p.bar_eps));
+  return quad - p.bar_r * log_pos(grp.prod, grp.e2);
 }
 // Gradient and Hessian coefficients of one constraint:
 //   Jacbian() = jc * dg;  Hessian() = (c1 dg_i) dg_j - c2 ddg_ij (c2 term only on the log branch;

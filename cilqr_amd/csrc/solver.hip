@@ -112,6 +112,7 @@ void fill_params(const cilqr_config& c, Params* p) {
   p->bar_r = 1.0 / c.barrier_t;                       // barrier_function.h:85
   p->bar_eps = c.barrier_eps;
   p->bar_inv_eps = 1.0 / c.barrier_eps;
+  p->bar_half_r_inv_eps2 = 0.5 * p->bar_r / (c.barrier_eps * c.barrier_eps);
   p->bar_rlogeps = p->bar_r * std::log(c.barrier_eps);
   // CalculateDiscRadius cc:97-104 and the disc offsets of cc:556-565
   const double length = c.front_hang + c.wheel_base + c.rear_hang;

@@ -64,6 +64,7 @@ struct Params {
   double bar_r;        // 1 / t            (barrier_function.h:85)
   double bar_eps;      // epsilon
   double bar_inv_eps;  // 1 / epsilon
+  double bar_half_r_inv_eps2;  // r / (2 eps^2)
   double bar_rlogeps;  // r * log(eps), evaluated once on the host in fp64
   double disc_off[kMaxDiscs];  // L*(j-0.5) - rf   (ilqr_optimizer.cc:564)
   double shrink_corridor;      // disc_radius + safe_margin   (cc:448)
