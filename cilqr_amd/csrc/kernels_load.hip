@@ -101,10 +101,21 @@ __global__ void k_load_lanes(DeviceState s, const double* __restrict__ raw) {
   o[8] = ex; o[9] = ey;
 }
 
-// Candidate sets of the lane grid.  For a cell with centre q and half-diagonal r, any point p of
-// the cell has d(q, s*) <= d(p, s*) + r <= d(p, s) + r <= d(q, s) + 2r for its nearest segment s*
+// Candidate sets of the lane grid.  For a square with centre q and half-diagonal r, any point p of
+// the square has d(q, s*) <= d(p, s*) + r <= d(p, s) + r <= d(q, s) + 2r for its nearest segment s*
 // and every s, so {s : d(q, s) <= min_s d(q, s) + 2r (+ slack)} contains every possible answer
-// (ties included).  Indices are stored ascending so the scan order of the reference is kept.
+// (ties included).  Applied to the whole cell this bound keeps every segment within
+// sqrt(2 d 2r) of the true Voronoi boundary -- about 2.5 candidates per cell a few metres from a
+// lane.  So cells near the lanes are refined: the bound is applied to the four quarters of the
+// square, recursively, and the cell's set is the union of its leaves' sets.  A square is a leaf
+// when one candidate is left, when everything it could add is in the union already, or at
+// kGridRefineLevels (12.5 cm squares for 1 m cells: at most 85 squares per cell, and deeper levels
+// no longer shorten the longest list of a wave, which is what the kernels pay for).  Still
+// conservative; ~1.75 candidates per cell instead of ~2.5, longest list of a wave 2 instead of 3.2.
+// Indices are stored ascending so the scan order of the reference is kept.
+constexpr int kGridRefineLevels = 3;
+constexpr double kGridRefineRange = 15.0;   // cells farther than this from the lane keep the cell-level set
+
 __global__ __launch_bounds__(256) void k_build_lane_grid(DeviceState s) {
   const int ncell = s.gnx * s.gny;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -118,16 +129,52 @@ __global__ __launch_bounds__(256) void k_build_lane_grid(DeviceState s) {
   double dmin = DBL_MAX;
   for (int k = 0; k < n; ++k) dmin = fmin(dmin, sqrt(segment_dist2(tab + k * kLaneFields, qx, qy)));
   const double thr = dmin + 1.4142135623730951 * h + 1e-6 * (1.0 + dmin);
-  unsigned char out[kGridCellBytes];
-  for (int k = 0; k < kGridCellBytes; ++k) out[k] = 0;
+  constexpr int kMaxList = kGridCellBytes - 1;
+  unsigned char root[kMaxList];
   int cnt = 0;
   for (int k = 0; k < n; ++k) {
     if (sqrt(segment_dist2(tab + k * kLaneFields, qx, qy)) <= thr) {
-      if (cnt < kGridCellBytes - 1) out[1 + cnt] = (unsigned char)k;
+      if (cnt < kMaxList) root[cnt] = (unsigned char)k;
       ++cnt;
     }
   }
-  out[0] = (cnt <= kGridCellBytes - 1) ? (unsigned char)cnt : (unsigned char)kGridFullScan;
+  unsigned keep = (cnt <= kMaxList) ? ((1u << cnt) - 1u) : 0u;   // bit e: root[e] stays in the cell's list
+  if (cnt > 1 && cnt <= kMaxList && dmin <= kGridRefineRange) {
+    struct Node { double cx, cy; int level; unsigned mask; };
+    Node stack[3 * kGridRefineLevels + 4];
+    int sp = 0;
+    unsigned got = 0u;
+    stack[sp++] = Node{qx, qy, 0, keep};
+    while (sp > 0) {
+      const Node nd = stack[--sp];
+      if ((got & nd.mask) == nd.mask) continue;          // nothing new can come from this square
+      const double half = 0.5 * h / (double)(1 << nd.level);   // half side of this square
+      double dm = DBL_MAX;
+      for (int e = 0; e < cnt; ++e)
+        if (nd.mask >> e & 1u) dm = fmin(dm, sqrt(segment_dist2(tab + root[e] * kLaneFields, nd.cx, nd.cy)));
+      const double th = dm + 2.0 * 1.4142135623730951 * half + 1e-6 * (1.0 + dm);
+      unsigned m = 0u;
+      for (int e = 0; e < cnt; ++e)
+        if ((nd.mask >> e & 1u) && sqrt(segment_dist2(tab + root[e] * kLaneFields, nd.cx, nd.cy)) <= th) m |= 1u << e;
+      if ((m & (m - 1u)) == 0u || nd.level == kGridRefineLevels) {
+        got |= m;
+        continue;
+      }
+      const double q = 0.5 * half;
+      stack[sp++] = Node{nd.cx - q, nd.cy - q, nd.level + 1, m};
+      stack[sp++] = Node{nd.cx + q, nd.cy - q, nd.level + 1, m};
+      stack[sp++] = Node{nd.cx - q, nd.cy + q, nd.level + 1, m};
+      stack[sp++] = Node{nd.cx + q, nd.cy + q, nd.level + 1, m};
+    }
+    keep = got;
+  }
+  unsigned char out[kGridCellBytes];
+  for (int k = 0; k < kGridCellBytes; ++k) out[k] = 0;
+  int kept = 0;
+  if (cnt <= kMaxList)
+    for (int e = 0; e < cnt; ++e)
+      if (keep >> e & 1u) out[1 + kept++] = root[e];
+  out[0] = (cnt <= kMaxList) ? (unsigned char)kept : (unsigned char)kGridFullScan;
   unsigned w[4] = {0, 0, 0, 0};
   for (int k = 0; k < kGridCellBytes; ++k) w[k >> 2] |= (unsigned)out[k] << ((k & 3) * 8);
   *reinterpret_cast<uint4*>(s.lgrid + ((size_t)side * ncell + cell) * kGridCellBytes) =
