@@ -114,7 +114,7 @@ __global__ void k_load_lanes(DeviceState s, const double* __restrict__ raw) {
 // conservative; ~1.75 candidates per cell instead of ~2.5, longest list of a wave 2 instead of 3.2.
 // Indices are stored ascending so the scan order of the reference is kept.
 constexpr int kGridRefineLevels = 3;
-constexpr double kGridRefineRange = 15.0;   // cells farther than this from the lane keep the cell-level set
+constexpr double kGridRefineRange = 12.0;   // cells farther than this from the lane keep the cell-level set
 
 __global__ __launch_bounds__(256) void k_build_lane_grid(DeviceState s) {
   const int ncell = s.gnx * s.gny;
@@ -149,13 +149,15 @@ __global__ __launch_bounds__(256) void k_build_lane_grid(DeviceState s) {
       const Node nd = stack[--sp];
       if ((got & nd.mask) == nd.mask) continue;          // nothing new can come from this square
       const double half = 0.5 * h / (double)(1 << nd.level);   // half side of this square
-      double dm = DBL_MAX;
-      for (int e = 0; e < cnt; ++e)
-        if (nd.mask >> e & 1u) dm = fmin(dm, sqrt(segment_dist2(tab + root[e] * kLaneFields, nd.cx, nd.cy)));
+      double dm = DBL_MAX, dd[kMaxList];
+      for (int e = 0; e < cnt; ++e) {
+        dd[e] = (nd.mask >> e & 1u) ? sqrt(segment_dist2(tab + root[e] * kLaneFields, nd.cx, nd.cy)) : DBL_MAX;
+        dm = fmin(dm, dd[e]);
+      }
       const double th = dm + 2.0 * 1.4142135623730951 * half + 1e-6 * (1.0 + dm);
       unsigned m = 0u;
       for (int e = 0; e < cnt; ++e)
-        if ((nd.mask >> e & 1u) && sqrt(segment_dist2(tab + root[e] * kLaneFields, nd.cx, nd.cy)) <= th) m |= 1u << e;
+        if (dd[e] <= th) m |= 1u << e;
       if ((m & (m - 1u)) == 0u || nd.level == kGridRefineLevels) {
         got |= m;
         continue;
@@ -209,7 +211,11 @@ __global__ void k_device_math(int fn, int n, const double* __restrict__ in, doub
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
   const double x = in[t];
-  out[t] = (fn == 0) ? log_pos(x, 0) : (fn == 1) ? fast_rcp(x) : log_pos(__builtin_amdgcn_frexp_mant(x), __builtin_amdgcn_frexp_exp(x));
+  double sn, cs;
+  lean_sincos(x, &sn, &cs);
+  out[t] = (fn == 0) ? log_pos(x, 0) : (fn == 1) ? fast_rcp(x)
+         : (fn == 2) ? log_pos(__builtin_amdgcn_frexp_mant(x), __builtin_amdgcn_frexp_exp(x))
+         : (fn == 3) ? sn : (fn == 4) ? cs : lean_tan(x);
 }
 void launch_device_math(int fn, int n, const double* in, double* out, hipStream_t st) {
   hipLaunchKernelGGL(k_device_math, dim3((n + 255) / 256), dim3(256), 0, st, fn, n, in, out);

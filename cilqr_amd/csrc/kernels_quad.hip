@@ -88,7 +88,7 @@ CILQR_DEV void knot_cost_core(const DeviceState& s, const double* __restrict__ l
   const double ju = (i < p.N) ? p.w_jerk * (u[0] * u[0]) + p.w_delta_rate * (u[1] * u[1]) : 0.0;
   const double2 dyn = knot_bound_cost(p, i, x, u);
   double sn, cs;
-  sincos(x[2], &sn, &cs);
+  lean_sincos(x[2], &sn, &cs);
   double px[D], py[D];
   BarGroup grp[D];
 #pragma unroll
@@ -154,7 +154,7 @@ CILQR_DEV void knot_cost_generic(const DeviceState& s, const double* __restrict_
   const double ju = (i < p.N) ? p.w_jerk * (u[0] * u[0]) + p.w_delta_rate * (u[1] * u[1]) : 0.0;
   const double2 dyn = knot_bound_cost(p, i, x, u);
   double sn, cs;
-  sincos(x[2], &sn, &cs);
+  lean_sincos(x[2], &sn, &cs);
   const int cnt = s.ccnt[(size_t)i * Bc + slot];
   const double* __restrict__ cor = s.cor + (size_t)i * s.cmax * 3 * Bc + slot;
   BarGroup call, lall;
@@ -377,7 +377,7 @@ CILQR_DEV void knot_quadratize(const DeviceState& s, const double* __restrict__ 
     }
   }
   double sn, cs;
-  sincos(x[2], &sn, &cs);
+  lean_sincos(x[2], &sn, &cs);
   // corridor planes x discs (cc:690-727); planes outer (each read once), discs inner
   for (int c0 = 0; c0 < cnt; c0 += kPlaneChunk) {
     PlaneChunk nx;

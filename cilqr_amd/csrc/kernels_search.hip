@@ -41,6 +41,21 @@ struct OutSpec {
   }
 };
 
+// what step i of a rollout reads: nominal state / control and the gains K_i, k_i
+constexpr int kFwdAhead = 4;
+struct FwdStep {
+  double2 x0, x1, x2, u, kk[kGainPairs];
+};
+CILQR_DEV void load_fwd_step(const DeviceState& s, int buf, int i, int slot, FwdStep& f) {
+  const int Bc = s.Bcap;
+  const double2* b = s.X + ((size_t)buf * s.p.K + i) * 3 * Bc + slot;
+  f.x0 = b[0]; f.x1 = b[(size_t)Bc]; f.x2 = b[(size_t)2 * Bc];
+  f.u = s.U[((size_t)buf * s.p.N + i) * Bc + slot];
+  const double2* g = s.gains + (size_t)i * kGainPairs * Bc + slot;
+#pragma unroll
+  for (int r = 0; r < kGainPairs; ++r) f.kk[r] = g[(size_t)r * Bc];
+}
+
 // roll the closed-loop policy out from goals_[0] (cc:392-415)
 template <class Out>
 CILQR_DEV void forward_core(const DeviceState& s, int slot, double alpha, const Out& out) {
@@ -54,48 +69,43 @@ CILQR_DEV void forward_core(const DeviceState& s, int slot, double alpha, const 
     x[0] = g0.x; x[1] = g0.y; x[2] = g1.x; x[3] = g1.y; x[4] = g2.x; x[5] = g2.y;
   }
   out.x(0, x);
-  // the nominal (xs, us) and the gains of step i+1 do not depend on the rollout: prefetch them
-  double2 nx0, nx1, nx2, nu, kk[kGainPairs], nkk[kGainPairs];
-  {
-    const double2* b = s.X + ((size_t)buf * p.K) * 3 * Bc + slot;
-    nx0 = b[0]; nx1 = b[(size_t)Bc]; nx2 = b[(size_t)2 * Bc];
-    nu = s.U[((size_t)buf * N) * Bc + slot];
-    const double2* g = s.gains + slot;
+  // The nominal (xs, us) and the gains of a step do not depend on the rollout, and one lane's step
+  // is short (~0.5 us of arithmetic) against the latency of a load that misses L2 (the gains were
+  // just written by another kernel): keep the loads of the next kFwdAhead steps in flight.
+  FwdStep pf[kFwdAhead];
 #pragma unroll
-    for (int r = 0; r < kGainPairs; ++r) nkk[r] = g[(size_t)r * Bc];
-  }
-  for (int i = 0; i < N; ++i) {
-    const double xs[6] = {nx0.x, nx0.y, nx1.x, nx1.y, nx2.x, nx2.y};
-    const double us[2] = {nu.x, nu.y};
+  for (int d = 0; d < kFwdAhead; ++d)
+    if (d < N) load_fwd_step(s, buf, d, slot, pf[d]);
+  for (int i0 = 0; i0 < N; i0 += kFwdAhead) {
 #pragma unroll
-    for (int r = 0; r < kGainPairs; ++r) kk[r] = nkk[r];
-    if (i + 1 < N) {
-      const double2* b = s.X + ((size_t)buf * p.K + (i + 1)) * 3 * Bc + slot;
-      nx0 = b[0]; nx1 = b[(size_t)Bc]; nx2 = b[(size_t)2 * Bc];
-      nu = s.U[((size_t)buf * N + (i + 1)) * Bc + slot];
-      const double2* g = s.gains + (size_t)(i + 1) * kGainPairs * Bc + slot;
+    for (int d = 0; d < kFwdAhead; ++d) {
+      const int i = i0 + d;
+      if (i < N) {
+        const FwdStep c = pf[d];
+        if (i + kFwdAhead < N) load_fwd_step(s, buf, i + kFwdAhead, slot, pf[d]);
+        const double xs[6] = {c.x0.x, c.x0.y, c.x1.x, c.x1.y, c.x2.x, c.x2.y};
+        const double us[2] = {c.u.x, c.u.y};
+        double dx[6];
 #pragma unroll
-      for (int r = 0; r < kGainPairs; ++r) nkk[r] = g[(size_t)r * Bc];
+        for (int e = 0; e < 6; ++e) dx[e] = x[e] - xs[e];
+        double u[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          double acc = c.kk[r * 3].x * dx[0];
+          acc += c.kk[r * 3].y * dx[1];
+          acc += c.kk[r * 3 + 1].x * dx[2];
+          acc += c.kk[r * 3 + 1].y * dx[3];
+          acc += c.kk[r * 3 + 2].x * dx[4];
+          acc += c.kk[r * 3 + 2].y * dx[5];
+          const double kff = (r == 0) ? c.kk[6].x : c.kk[6].y;
+          u[r] = (us[r] + acc) + alpha * kff;                           // cc:407
+        }
+        u[1] = normalize_angle(u[1]);                                     // cc:408
+        out.u(i, u);
+        dynamics(p, x, u, x);
+        out.x(i + 1, x);
+      }
     }
-    double dx[6];
-#pragma unroll
-    for (int e = 0; e < 6; ++e) dx[e] = x[e] - xs[e];
-    double u[2];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      double acc = kk[r * 3].x * dx[0];
-      acc += kk[r * 3].y * dx[1];
-      acc += kk[r * 3 + 1].x * dx[2];
-      acc += kk[r * 3 + 1].y * dx[3];
-      acc += kk[r * 3 + 2].x * dx[4];
-      acc += kk[r * 3 + 2].y * dx[5];
-      const double kff = (r == 0) ? kk[6].x : kk[6].y;
-      u[r] = (us[r] + acc) + alpha * kff;                           // cc:407
-    }
-    u[1] = normalize_angle(u[1]);                                     // cc:408
-    out.u(i, u);
-    dynamics(p, x, u, x);
-    out.x(i + 1, x);
   }
 }
 CILQR_DEV void forward_problem(const DeviceState& s, int slot, double alpha) {

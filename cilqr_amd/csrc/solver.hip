@@ -101,6 +101,7 @@ void fill_params(const cilqr_config& c, Params* p) {
   p->max_iter = c.max_iter;
   p->dt = c.dt;
   p->wheel_base = c.wheel_base;
+  p->inv_wheel_base = 1.0 / c.wheel_base;
   p->w_jerk = c.w_jerk; p->w_delta_rate = c.w_delta_rate;
   p->w_x = c.w_x; p->w_y = c.w_y; p->w_theta = c.w_theta;
   p->w_v = c.w_v; p->w_a = c.w_a; p->w_delta = c.w_delta;
@@ -844,7 +845,7 @@ int cilqr_stage_nearest_lane(cilqr_handle h, int32_t n, const double* xy, int32_
 
 int cilqr_device_math(cilqr_handle h, int32_t fn, int32_t n, const double* in, double* out) {
   if (h == nullptr || in == nullptr || out == nullptr) return CILQR_ERR_NULL;
-  if (n <= 0 || fn < 0 || fn > 2) return CILQR_ERR_ARG;
+  if (n <= 0 || fn < 0 || fn > 5) return CILQR_ERR_ARG;
   HIP_TRY(hipSetDevice(h->device));
   double* d = nullptr;
   if (hipMalloc(reinterpret_cast<void**>(&d), (size_t)n * 16) != hipSuccess) return CILQR_ERR_DEVICE;

@@ -57,6 +57,7 @@ struct Params {
   int max_iter;
   double dt;
   double wheel_base;
+  double inv_wheel_base;
   double w_jerk, w_delta_rate, w_x, w_y, w_theta, w_v, w_a, w_delta;
   double abs_tol, rel_tol;
   double max_velocity, min_acc, max_acc, jerk_min, jerk_max, delta_min, delta_max;

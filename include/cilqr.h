@@ -207,7 +207,8 @@ int cilqr_stage_nearest_lane(cilqr_handle h, int32_t n, const double* xy, int32_
 
 /* Test hook for the kernels' own fp64 routines (host arrays of n doubles):
  * fn 0: log(x) for normal finite x > 0;  fn 1: 1 / x for normal finite x != 0;
- * fn 2: log(x) with mantissa and exponent handed over separately (the long-product path). */
+ * fn 2: log(x) with mantissa and exponent handed over separately (the long-product path);
+ * fn 3 / 4 / 5: sin / cos / tan(x) for |x| <= 1e5. */
 int cilqr_device_math(cilqr_handle h, int32_t fn, int32_t n, const double* in, double* out);
 
 /* X[b][0] = x0[b]; X[b][i+1] = Dynamics(X[b][i], U[b][i]).  x0 [B][6], U [B][N][2], X [B][K][6] */

@@ -328,6 +328,36 @@ def test_lean_log_and_reciprocal_are_accurate_to_an_ulp_or_two():
     opt.close()
 
 
+def test_lean_sin_cos_tan_are_accurate_to_a_few_ulp():
+    """dev_model.hpp lean_sincos / lean_tan (dynamics, Jacobian, disc positions) against numpy's
+    libm: sin / cos within 2 ulp of max(|value|, tiny) over the angle range the states live in
+    ([-pi, pi) after NormalizeAngle) and well beyond; tan within 4 ulp relative."""
+    sc = scenario.generate("ped6", 4, seed=3)
+    opt = _opt(sc)
+    rng = np.random.default_rng(6)
+    k = np.arange(-40, 41)
+    near = np.concatenate([k * (np.pi / 2) + d for d in (0.0, 1e-9, -1e-9, 1e-5, -1e-5, 1e-13)])
+    x = np.concatenate([rng.uniform(-np.pi, np.pi, 200000), rng.uniform(-0.8, 0.8, 100000),
+                        rng.uniform(-100.0, 100.0, 100000), rng.uniform(-1e5, 1e5, 50000),
+                        rng.uniform(-1e-6, 1e-6, 10000), near, np.array([0.0, np.pi, -np.pi, np.pi / 4, 1e-300])])
+    eps = np.finfo(np.float64).eps
+    for fn, ref in ((3, np.sin(x)), (4, np.cos(x))):
+        got = opt.device_math(fn, x)
+        small = np.abs(x) <= 100.0
+        err = np.abs(got - ref) / (eps * np.maximum(np.abs(ref), 1e-300))
+        # relative accuracy wherever the argument reduction has bits to spare (|x| <= 100) ...
+        assert err[small].max() <= 3.0, (fn, err[small].max(), x[small][err[small].argmax()])
+        # ... and absolute accuracy everywhere
+        assert (np.abs(got - ref) <= 2 * eps).all(), fn
+    got = opt.device_math(5, x)
+    ref = np.tan(x)
+    small = np.abs(x) <= 100.0
+    rel = np.abs(got - ref)[small] / np.maximum(np.abs(ref[small]), 1e-300)
+    assert rel.max() <= 5 * eps, (rel.max(), x[small][rel.argmax()])
+    assert opt.device_math(3, np.array([0.0]))[0] == 0.0 and opt.device_math(4, np.array([0.0]))[0] == 1.0
+    opt.close()
+
+
 def test_full_size_batch_properties():
     """BASELINE configs[2] size (B = 65536, N = 50): 256 distinct scenes tiled 256x.  Size-independent
     properties: every copy of a scene gives bit-identical output wherever it sits in the batch, all

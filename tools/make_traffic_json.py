@@ -18,7 +18,8 @@ wf, ws, _ = parse(write_txt)
 b = json.load(open(bench_json))
 N = b["config"]["n_steps"]
 B = b["config"]["batch_per_gpu"]
-n_act_sum = b["roofline"]["mean_problems_per_launch"] * b["roofline"]["launches"] / b["steps"]
+al = b["roofline"].get("all_launches", b["roofline"])
+n_act_sum = al["mean_problems_per_launch"] * al["launches"] / b["steps"]
 hbm = fs * 1024 * 2 + ws * 1024
 o = {
     "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) -- python bench.py --steps 1 --warmup 0 --cpu-sample 0 --no-profile",
