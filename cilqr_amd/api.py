@@ -63,6 +63,12 @@ class SolutionBatch(C.Structure):
     ]
 
 
+class CorridorConfig(C.Structure):
+    """CorridorConfig of the reference (algorithm/params/planner_config.h:75-86)."""
+    _fields_ = [("max_diff_x", C.c_double), ("max_diff_y", C.c_double), ("radius", C.c_double),
+                ("max_axis_x", C.c_double), ("max_axis_y", C.c_double), ("lane_segment_length", C.c_double)]
+
+
 class Profile(C.Structure):
     _fields_ = [
         ("iterations", C.c_int32), ("backward_launches", C.c_int32), ("backward_ms", C.c_double),
@@ -78,6 +84,7 @@ EXPORTS = [
     "cilqr_submit", "cilqr_wait", "cilqr_device_math", "cilqr_stage_load", "cilqr_stage_init_guess", "cilqr_stage_set_trajectory",
     "cilqr_stage_total_cost", "cilqr_stage_quadratize", "cilqr_stage_backward", "cilqr_stage_forward",
     "cilqr_stage_read", "cilqr_stage_nearest_lane", "cilqr_open_loop_rollout", "cilqr_error_string",
+    "cilqr_default_corridor_config", "cilqr_build_corridors", "cilqr_lane_constraints",
 ]
 
 _LIB = None
@@ -111,6 +118,12 @@ def lib():
         L.cilqr_solve_batch.argtypes = [C.c_void_p, C.POINTER(ProblemBatch), C.POINTER(SolutionBatch)]
         L.cilqr_submit.argtypes = [C.c_void_p, C.POINTER(ProblemBatch), C.POINTER(SolutionBatch)]
         L.cilqr_wait.argtypes = [C.c_void_p]
+        L.cilqr_default_corridor_config.argtypes = [C.POINTER(CorridorConfig)]
+        L.cilqr_default_corridor_config.restype = None
+        L.cilqr_build_corridors.argtypes = [C.c_void_p, C.POINTER(CorridorConfig), C.c_int32, C.c_int32, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
+                                            C.c_int32, C.POINTER(C.c_int32)]
+        L.cilqr_lane_constraints.argtypes = [C.c_void_p, C.c_int32, C.c_double, C.c_int32, C.c_void_p, C.c_int32]
         L.cilqr_device_math.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
         L.cilqr_stage_load.argtypes = [C.c_void_p, C.POINTER(ProblemBatch)]
         L.cilqr_stage_init_guess.argtypes = [C.c_void_p]
@@ -319,9 +332,53 @@ class BatchIlqrOptimizer:
                                                   1 if use_grid else 0, MEM_HOST), "nearest_lane")
         return left, right
 
+    def build_corridors(self, knots, points, point_count, cmax: int = 16, cfg: "CorridorConfig | None" = None):
+        """Corridor::BuildCorridorConstraints for a batch (corridor.cc:58-87): knots [B,K,3] = x, y, theta,
+        points [B,K,P,2] obstacle corner points per knot, point_count [B,K].  Returns (corridor [B,K,cmax,3],
+        corridor_count [B,K] int32 -- negative where a corridor could not be built --, n_failed)."""
+        knots = _f64(knots)
+        B, K = knots.shape[:2]
+        points = _f64(points).reshape(B, K, -1, 2)
+        P = points.shape[2]
+        cnt = np.ascontiguousarray(point_count, dtype=np.int32).reshape(B, K)
+        cfg = cfg or default_corridor_config()
+        cor = np.zeros((B, K, cmax, 3))
+        ccnt = np.zeros((B, K), dtype=np.int32)
+        nf = C.c_int32(0)
+        self._chk(self.L.cilqr_build_corridors(self.h, C.byref(cfg), B, K, _ptr(knots), _ptr(points) if P else None,
+                                               cnt.ctypes.data, P, _ptr(cor), ccnt.ctypes.data, cmax, MEM_HOST,
+                                               C.byref(nf)), "build_corridors")
+        return cor, ccnt, int(nf.value)
+
+    def build_corridors_raw(self, cfg, batch, n_knots, knots_ptr, points_ptr, count_ptr, max_points, corridor_ptr,
+                            ccount_ptr, cmax, memory):
+        """Pointer-level form (device or host memory); returns (rc, n_failed)."""
+        nf = C.c_int32(0)
+        rc = self.L.cilqr_build_corridors(self.h, C.byref(cfg), batch, n_knots, knots_ptr, points_ptr, count_ptr,
+                                          max_points, corridor_ptr, ccount_ptr, cmax, memory, C.byref(nf))
+        return rc, int(nf.value)
+
     def open_loop_rollout(self, x0, U):
         x0, U = _f64(x0), _f64(U)
         B = x0.shape[0]
         X = np.zeros((B, self.K, 6))
         self._chk(self.L.cilqr_open_loop_rollout(self.h, B, _ptr(x0), _ptr(U), _ptr(X), MEM_HOST), "rollout")
         return X
+
+
+def default_corridor_config() -> CorridorConfig:
+    c = CorridorConfig()
+    lib().cilqr_default_corridor_config(C.byref(c))
+    return c
+
+
+def lane_constraints(boundary, segment_length: float = 5.0, is_left: bool = True) -> np.ndarray:
+    """LaneBoundarySample + Cal{Left,Right}LaneConstraints (corridor.cc:265-321), host only:
+    boundary [n,2] -> rows [m,7] = a b c sx sy ex ey (the left_lane / right_lane layout)."""
+    b = _f64(np.asarray(boundary, dtype=np.float64).reshape(-1, 2))
+    rows = np.zeros((max(1, b.shape[0]), 7))
+    m = lib().cilqr_lane_constraints(b.ctypes.data, b.shape[0], float(segment_length), int(bool(is_left)),
+                                     rows.ctypes.data, rows.shape[0])
+    if m < 0:
+        raise CilqrError(m, "lane_constraints")
+    return rows[:m].copy()

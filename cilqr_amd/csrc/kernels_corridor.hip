@@ -1,0 +1,239 @@
+// Safe-corridor construction for a batch of (problem, knot) pairs: the producer of the per-knot
+// half-planes the CILQR cost consumes.  Behaviour follows (not copied from)
+//   Corridor::BuildCorridorConstraints  algorithm/ilqr/corridor.cc:58-87   (the loop over knots)
+//   Corridor::AddCorridorPoints         corridor.cc:89-120
+//   Corridor::BuildCorridor             corridor.cc:122-263
+// with cv::convexHull (OpenCV, not part of the reference tree) replaced by a monotone-chain hull
+// on float32 points that drops collinear points, as OpenCV's Sklansky scan does.  The reference's
+// mixed float32 / float64 arithmetic is kept statement by statement (the hulls run on
+// cv::Point2f), and so are its quirks: safe_radius = norm of the LAST point inside `radius`
+// (cc:169-171); (OriginIndex - 1) % size in unsigned 64-bit arithmetic (cc:203).
+//
+// Mapping: every knot of every problem is independent, so one lane builds one corridor.  The
+// working set of a lane (<= kCorMaxPts points, three small hulls) lives in its private segment;
+// the arrays are indexed dynamically, which the compiler keeps in scratch memory backed by L1/L2.
+// The kernel is a once-per-solve prologue (3.3 M corridors for 65536 x 51 knots).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "state.hpp"
+
+namespace cilqr {
+
+namespace {
+
+constexpr double kEps = 1e-10;  // algorithm/math/vec2d.h:33
+
+struct P2f {
+  float x, y;
+};
+
+// strictly convex hull of p[0..n): indices into p, counter-clockwise (y up) from the
+// lexicographically smallest point; `order` and `h` are caller-provided work arrays
+// (n and 2n + 2 entries).  Returns the number of hull vertices.
+__device__ int hull_indices(const P2f* p, int n, unsigned char* order, unsigned char* h) {
+  for (int i = 0; i < n; ++i) {  // stable insertion sort by (x, y)
+    const P2f q = p[i];
+    int j = i;
+    while (j > 0) {
+      const P2f r = p[order[j - 1]];
+      if (r.x < q.x || (r.x == q.x && r.y <= q.y)) break;
+      order[j] = order[j - 1];
+      --j;
+    }
+    order[j] = (unsigned char)i;
+  }
+  auto cross = [&](int o, int a, int b) {
+    const float ax = p[a].x - p[o].x, ay = p[a].y - p[o].y;
+    const float bx = p[b].x - p[o].x, by = p[b].y - p[o].y;
+    const float t1 = ax * by, t2 = ay * bx;
+    return t1 - t2;
+  };
+  int k = 0;
+  for (int i = 0; i < n; ++i) {
+    while (k >= 2 && cross(h[k - 2], h[k - 1], order[i]) <= 0.0f) --k;
+    h[k++] = order[i];
+  }
+  for (int i = n - 2, t = k + 1; i >= 0; --i) {
+    while (k >= t && cross(h[k - 2], h[k - 1], order[i]) <= 0.0f) --k;
+    h[k++] = order[i];
+  }
+  if (k > 1) --k;
+  if (k == 2 && p[h[0]].x == p[h[1]].x && p[h[0]].y == p[h[1]].y) k = 1;
+  return k;
+}
+__device__ void make_clockwise(unsigned char* h, int k) {
+  for (int a = 1, b = k - 1; a < b; ++a, --b) {
+    const unsigned char t = h[a];
+    h[a] = h[b];
+    h[b] = t;
+  }
+}
+
+}  // namespace
+
+// knots [n][3] = x, y, theta; points [n][pmax][2]; count [n]; out corridor [n][cmax][3], ccount [n]
+// (m >= 3 half-planes, or -1 no points, -2 fewer than 4 flipped points, -3 more than cmax
+// half-planes, -4 degenerate hull); *n_failed counts the knots with a negative code.
+__global__ __launch_bounds__(64) void k_build_corridors(int n, CorridorParams cp, const double* __restrict__ knots,
+                                                        const double* __restrict__ points,
+                                                        const int* __restrict__ count, int pmax,
+                                                        double* __restrict__ corridor, int* __restrict__ ccount,
+                                                        int cmax, int* __restrict__ n_failed) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const double ox = knots[3 * t], oy = knots[3 * t + 1], theta = knots[3 * t + 2];
+  double fx[kCorMaxPts], fy[kCorMaxPts];
+  P2f flip[kCorMaxPts + 1], vd[kCorMaxPts + 1], dual[kCorMaxPts + 1];
+  unsigned char order[kCorMaxPts + 1], hull[2 * kCorMaxPts + 4], v1[kCorMaxPts + 1], v2[kCorMaxPts + 1];
+  int code = 0;
+  int nf = 0;
+  double safe_radius = cp.radius;
+  {
+    const int np = min(max(count[t], 0), pmax);
+    const double* pp = points + (size_t)t * pmax * 2;
+    // box points of AddCorridorPoints (cc:89-120, is_multiple_sample = false: both ends of each edge)
+    const double ch = cos(theta), sh = sin(theta);
+    const double dx1 = ch * cp.max_axis_x, dy1 = sh * cp.max_axis_x;
+    const double dx2 = sh * cp.max_axis_y, dy2 = -ch * cp.max_axis_y;
+    const double cx[4] = {ox + dx1 + dx2, ox + dx1 - dx2, ox - dx1 - dx2, ox - dx1 + dx2};
+    const double cy[4] = {oy + dy1 + dy2, oy + dy1 - dy2, oy - dy1 - dy2, oy - dy1 + dy2};
+    for (int i = 0; i < np + 8; ++i) {
+      double x, y;
+      if (i < np) {
+        x = pp[2 * i];
+        y = pp[2 * i + 1];
+      } else {
+        const int e = (i - np) >> 1, second = (i - np) & 1;
+        const int nx = (e + 1) & 3;
+        const double ratio = second ? 1.0 : 0.0;
+        x = cx[e] * (1 - ratio) + cx[nx] * ratio;
+        y = cy[e] * (1 - ratio) + cy[nx] * ratio;
+      }
+      // filter cc:136-149 and sphere flip cc:154-177
+      const double dx = x - ox, dy = y - oy;
+      if (fabs(dx) > cp.max_diff_x || fabs(dy) > cp.max_diff_y) continue;
+      const double norm2 = sqrt(dx * dx + dy * dy);
+      if (fabs(norm2) < kEps) continue;
+      if (norm2 < cp.radius) safe_radius = norm2;
+      fx[nf] = x;
+      fy[nf] = y;
+      flip[nf].x = (float)(dx + 2 * (cp.radius - norm2) * dx / norm2);
+      flip[nf].y = (float)(dy + 2 * (cp.radius - norm2) * dy / norm2);
+      ++nf;
+    }
+  }
+  int m = 0;
+  if (nf < 4) {
+    code = -2;
+  } else {
+    flip[nf] = P2f{0.0f, 0.0f};
+    const int n1 = hull_indices(flip, nf + 1, order, hull);  // cc:184
+    if (n1 < 3) {
+      code = -4;
+    } else {
+      // star-shaped polygon through the visible points cc:186-198
+      int origin_index = -1;
+      for (int i = 0; i < n1; ++i) {
+        v1[i] = hull[i];
+        if (hull[i] == nf) {
+          origin_index = i;
+          vd[i] = P2f{(float)ox, (float)oy};
+        } else {
+          vd[i] = P2f{(float)fx[hull[i]], (float)fy[hull[i]]};
+        }
+      }
+      double ix = ox, iy = oy;  // cc:200-216
+      if (origin_index >= 0) {
+        const uint64_t sz = (uint64_t)n1;
+        const int last = (int)(((uint64_t)(int64_t)(origin_index - 1)) % sz);
+        const int next = (int)(((uint64_t)(int64_t)(origin_index + 1)) % sz);
+        const int vl = v1[last], vn = v1[next];
+        const double lx = (vl == nf) ? ox : fx[vl], ly = (vl == nf) ? oy : fy[vl];
+        const double nx = (vn == nf) ? ox : fx[vn], ny = (vn == nf) ? oy : fy[vn];
+        const double dx = (lx + ox + nx) / 3 - ox;
+        const double dy = (ly + oy + ny) / 3 - oy;
+        const double d = sqrt(dx * dx + dy * dy);
+        ix = 0.99 * safe_radius * dx / d + ox;
+        iy = 0.99 * safe_radius * dy / d + oy;
+      }
+      const int n2 = hull_indices(vd, n1, order, hull);  // cc:218
+      if (n2 < 3) {
+        code = -4;
+      } else {
+        for (int j = 0; j < n2; ++j) v2[j] = hull[j];
+        // one half-plane per star vertex, normal of the hull edge it hides behind  cc:220-239
+        int nt = 0;
+        for (int j = 0; j < n2; ++j) {
+          const int j1 = (j + 1 == n2) ? 0 : j + 1;
+          const float rx = vd[v2[j1]].x - vd[v2[j]].x, ry = vd[v2[j1]].y - vd[v2[j]].y;
+          float n0 = ry, nn1 = -rx;
+          const float z = n0 * n0 + nn1 * nn1;
+          if (z > 0.0f) {
+            const float s = sqrtf(z);
+            n0 = n0 / s;
+            nn1 = nn1 / s;
+          }
+          int idx = v2[j];
+          int guard = 0;
+          while (idx != v2[j1] && guard++ <= n1 && nt < kCorMaxPts + 1) {
+            const double c = (vd[idx].x - ix) * n0 + (vd[idx].y - iy) * nn1;
+            const float cf = (float)c;
+            dual[nt].x = n0 / cf;
+            dual[nt].y = nn1 / cf;
+            ++nt;
+            idx = (idx + 1 == n1) ? 0 : idx + 1;
+          }
+        }
+        const int n3 = hull_indices(dual, nt, order, hull);  // cc:241-242
+        if (n3 < 3) {
+          code = -4;
+        } else if (n3 > cmax) {
+          code = -3;
+        } else {
+          make_clockwise(hull, n3);
+          m = n3;
+          double* out = corridor + (size_t)t * cmax * 3;
+          double qx0 = 0.0, qy0 = 0.0, qxp = 0.0, qyp = 0.0;
+          for (int i = 0; i <= m; ++i) {  // polygon vertices cc:244-249, half-planes cc:251-261
+            double qx, qy;
+            if (i < m) {
+              const P2f a = dual[hull[i]], b = dual[hull[(i + 1 == m) ? 0 : i + 1]];
+              const float rx = b.x - a.x, ry = b.y - a.y;
+              const float t1 = ry * a.x, t2 = rx * a.y;
+              const double c = t1 - t2;
+              qx = ix + ry / c;
+              qy = iy - rx / c;
+            } else {
+              qx = qx0;
+              qy = qy0;
+            }
+            if (i == 0) {
+              qx0 = qx;
+              qy0 = qy;
+            } else {
+              const double rx = qx - qxp, ry = qy - qyp;
+              const double c = -ry * qxp + rx * qyp;
+              out[3 * (i - 1)] = -ry;
+              out[3 * (i - 1) + 1] = rx;
+              out[3 * (i - 1) + 2] = c;
+            }
+            qxp = qx;
+            qyp = qy;
+          }
+        }
+      }
+    }
+  }
+  ccount[t] = code < 0 ? code : m;
+  if (code < 0) atomicAdd(n_failed, 1);
+}
+
+void launch_build_corridors(int n, const CorridorParams& cp, const double* knots, const double* points,
+                            const int* count, int pmax, double* corridor, int* ccount, int cmax, int* n_failed,
+                            hipStream_t st) {
+  hipLaunchKernelGGL(k_build_corridors, dim3((n + 63) / 64), dim3(64), 0, st, n, cp, knots, points, count, pmax,
+                     corridor, ccount, cmax, n_failed);
+}
+
+}  // namespace cilqr

@@ -843,6 +843,107 @@ int cilqr_stage_nearest_lane(cilqr_handle h, int32_t n, const double* xy, int32_
   return rc;
 }
 
+// ------------------------------------------------------------------------------------------
+// corridor producer
+// ------------------------------------------------------------------------------------------
+void cilqr_default_corridor_config(cilqr_corridor_config* c) {
+  if (c == nullptr) return;
+  c->max_diff_x = 25.0; c->max_diff_y = 25.0; c->radius = 150.0;   // planner_config.h:77-79
+  c->max_axis_x = 10.0; c->max_axis_y = 10.0;                      // planner_config.h:81-82
+  c->lane_segment_length = 5.0;                                    // planner_config.h:85
+}
+
+int cilqr_build_corridors(cilqr_handle h, const cilqr_corridor_config* cfg, int32_t batch, int32_t n_knots,
+                          const double* knots, const double* points, const int32_t* point_count,
+                          int32_t max_points, double* corridor, int32_t* corridor_count, int32_t cmax,
+                          int32_t memory, int32_t* n_failed) {
+  if (h == nullptr || cfg == nullptr || knots == nullptr || point_count == nullptr || corridor == nullptr ||
+      corridor_count == nullptr)
+    return CILQR_ERR_NULL;                                          // corridor.cc:29-35
+  if (points == nullptr && max_points > 0) return CILQR_ERR_NULL;
+  if (batch <= 0 || n_knots <= 0 || cmax < 3 || max_points < 0) return CILQR_ERR_ARG;   // empty trajectory cc:24-27
+  if (max_points + 8 > kCorMaxPts) return CILQR_ERR_CAPACITY;
+  if (memory != CILQR_MEM_HOST && memory != CILQR_MEM_DEVICE) return CILQR_ERR_ARG;
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t n = (size_t)batch * n_knots;
+  const size_t b_knots = n * 3 * 8, b_pts = n * (size_t)max_points * 2 * 8, b_cnt = n * 4;
+  const size_t b_cor = n * (size_t)cmax * 3 * 8;
+  CorridorParams cp{cfg->max_diff_x, cfg->max_diff_y, cfg->radius, cfg->max_axis_x, cfg->max_axis_y};
+  void *t_in = nullptr, *t_out = nullptr, *t_fail = nullptr;
+  int rc = CILQR_OK;
+  const double *d_knots = knots, *d_pts = points;
+  const int* d_cnt = point_count;
+  double* d_cor = corridor;
+  int* d_ccnt = corridor_count;
+  if (hipMalloc(&t_fail, 256) != hipSuccess) return CILQR_ERR_DEVICE;
+  if (hipMemsetAsync(t_fail, 0, 4, h->stream) != hipSuccess) rc = CILQR_ERR_DEVICE;
+  if (rc == CILQR_OK && memory == CILQR_MEM_HOST) {
+    const size_t o_pts = (b_knots + 255) / 256 * 256, o_cnt = o_pts + (b_pts + 255) / 256 * 256;
+    if (hipMalloc(&t_in, o_cnt + b_cnt + 256) != hipSuccess || hipMalloc(&t_out, b_cor + 256 + b_cnt) != hipSuccess) {
+      rc = CILQR_ERR_DEVICE;
+    } else {
+      char* bi = static_cast<char*>(t_in);
+      char* bo = static_cast<char*>(t_out);
+      if (hipMemcpyAsync(bi, knots, b_knots, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+          (b_pts && hipMemcpyAsync(bi + o_pts, points, b_pts, hipMemcpyHostToDevice, h->stream) != hipSuccess) ||
+          hipMemcpyAsync(bi + o_cnt, point_count, b_cnt, hipMemcpyHostToDevice, h->stream) != hipSuccess)
+        rc = CILQR_ERR_DEVICE;
+      d_knots = reinterpret_cast<const double*>(bi);
+      d_pts = reinterpret_cast<const double*>(bi + o_pts);
+      d_cnt = reinterpret_cast<const int*>(bi + o_cnt);
+      d_cor = reinterpret_cast<double*>(bo);
+      d_ccnt = reinterpret_cast<int*>(bo + (b_cor + 255) / 256 * 256);
+    }
+  }
+  int failed = 0;
+  if (rc == CILQR_OK) {
+    launch_build_corridors((int)n, cp, d_knots, d_pts, d_cnt, max_points, d_cor, d_ccnt, cmax,
+                           static_cast<int*>(t_fail), h->stream);
+    if (hipGetLastError() != hipSuccess) rc = CILQR_ERR_DEVICE;
+    if (rc == CILQR_OK && memory == CILQR_MEM_HOST) {
+      if (hipMemcpyAsync(corridor, d_cor, b_cor, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+          hipMemcpyAsync(corridor_count, d_ccnt, b_cnt, hipMemcpyDeviceToHost, h->stream) != hipSuccess)
+        rc = CILQR_ERR_DEVICE;
+    }
+    if (rc == CILQR_OK &&
+        hipMemcpyAsync(&failed, t_fail, 4, hipMemcpyDeviceToHost, h->stream) != hipSuccess)
+      rc = CILQR_ERR_DEVICE;
+    if (hipStreamSynchronize(h->stream) != hipSuccess) rc = CILQR_ERR_DEVICE;
+  }
+  if (t_in) (void)hipFree(t_in);
+  if (t_out) (void)hipFree(t_out);
+  (void)hipFree(t_fail);
+  if (n_failed) *n_failed = failed;
+  return rc;
+}
+
+int cilqr_lane_constraints(const double* boundary, int32_t n, double segment_length, int32_t is_left,
+                           double* rows, int32_t max_rows) {
+  if (boundary == nullptr || rows == nullptr) return CILQR_ERR_NULL;
+  if (n < 1 || max_rows < 1) return CILQR_ERR_ARG;
+  // LaneBoundarySample corridor.cc:298-311: keep a point once it is a segment length from the last kept one
+  int m = 0;              // rows written
+  double lx = boundary[0], ly = boundary[1];
+  for (int i = 0; i < n; ++i) {
+    const double x = boundary[2 * i], y = boundary[2 * i + 1];
+    if (std::hypot(x - lx, y - ly) >= segment_length - 1e-10) {
+      if (m >= max_rows) return CILQR_ERR_CAPACITY;
+      // Cal{Left,Right}LaneConstraints cc:265-296: the left barrier runs from the new point back to
+      // the previous one, the right barrier forward; HalfPlaneConstraint cc:313-321
+      const double ax = is_left ? x : lx, ay = is_left ? y : ly;
+      const double bx = is_left ? lx : x, by = is_left ? ly : y;
+      const double a = by - ay, b = -(bx - ax);
+      double* r = rows + 7 * (size_t)m;
+      r[0] = a; r[1] = b; r[2] = a * ax + b * ay;
+      r[3] = ax; r[4] = ay; r[5] = bx; r[6] = by;
+      ++m;
+      lx = x; ly = y;
+    }
+  }
+  if (m < 1) return CILQR_ERR_CONSTRAINTS;   // fewer than two sampled points  cc:273-275
+  return m;
+}
+
 int cilqr_device_math(cilqr_handle h, int32_t fn, int32_t n, const double* in, double* out) {
   if (h == nullptr || in == nullptr || out == nullptr) return CILQR_ERR_NULL;
   if (n <= 0 || fn < 0 || fn > 5) return CILQR_ERR_ARG;

@@ -182,6 +182,14 @@ void launch_export_iter_traj(const DeviceState& s, const int* list, int n, doubl
                              int max_iter_trajs, hipStream_t st);
 void launch_export_hist(const DeviceState& s, int B, double* cost_hist, int* n_cost, int* status,
                         int* n_iter, int* n_iter_trajs, hipStream_t st);
+// corridor producer (kernels_corridor.hip)
+constexpr int kCorMaxPts = 96;   // obstacle points of one knot + the 8 box points
+struct CorridorParams {
+  double max_diff_x, max_diff_y, radius, max_axis_x, max_axis_y;   // planner_config.h:75-86
+};
+void launch_build_corridors(int n, const CorridorParams& cp, const double* knots, const double* points,
+                            const int* count, int pmax, double* corridor, int* ccount, int cmax, int* n_failed,
+                            hipStream_t st);
 void launch_device_math(int fn, int n, const double* in, double* out, hipStream_t st);
 void launch_rollout(const Params& p, int B, const double* x0, const double* U, double* X, hipStream_t st);
 // stage_read helpers: gather a batch-fastest tensor into problem-major order

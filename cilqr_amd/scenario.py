@@ -179,23 +179,27 @@ def _rect_nearest(ox, oy, cx, cy, cth, hl, hw):
 
 
 def _chunk_job(args):
-    spec, n, seed, first, road = args
-    return _generate_chunk(spec, n, seed, first, road)
+    spec, n, seed, first, road, want_points = args
+    return _generate_chunk(spec, n, seed, first, road, want_points)
 
 
 def generate(spec: SceneSpec | str, batch: int, seed: int = 0, first_problem: int = 0,
-             road: Road | None = None, chunk: int = 1024, workers: int = 0):
+             road: Road | None = None, chunk: int = 1024, workers: int = 0, obstacle_points: bool = False):
     """Generate `batch` scenes; problem p uses RNG stream (seed, first_problem + p).
 
     workers > 1 spreads the chunks over a thread pool (results are identical).
     Returns dict(start[B,4], coarse[B,K,6], corridor[B,K,cmax,3], ccount[B,K] int32,
                  left[S,7], right[S,7], n_steps, dt, cmax).
+    obstacle_points=True adds what the reference's Environment hands to Corridor::Plan
+    (Query{Static,Dynamic}ObstaclesPoints, environment.cpp:153-182): obstacle_points[B,K,4*O,2], the
+    corner points of the obstacles alive at each knot's time (packed to the front), and
+    obstacle_count[B,K] int32 -- the inputs of BatchIlqrOptimizer.build_corridors.
     """
     if isinstance(spec, str):
         spec = SPECS[spec]
     road = road or build_road()
     left, right = lane_constraints(road)
-    jobs = [(spec, min(chunk, batch - c0), seed, first_problem + c0, road)
+    jobs = [(spec, min(chunk, batch - c0), seed, first_problem + c0, road, obstacle_points)
             for c0 in range(0, batch, chunk)]
     if workers > 1 and len(jobs) > 1:
         # threads, not processes: numpy releases the GIL inside its loops, and forking a process
@@ -218,7 +222,7 @@ def _uniforms(seed, first, n, m):
     return out
 
 
-def _generate_chunk(spec: SceneSpec, B: int, seed: int, first: int, road: Road):
+def _generate_chunk(spec: SceneSpec, B: int, seed: int, first: int, road: Road, want_points: bool = False):
     # Array convention inside: obstacle / candidate axes first, (problem, knot) last, so numpy's
     # inner loops run over B*K contiguous elements.
     N, dt = spec.n_steps, spec.dt
@@ -370,5 +374,18 @@ def _generate_chunk(spec: SceneSpec, B: int, seed: int, first: int, road: Road):
     planes = planes[:, :, :Cm]
     mask = np.arange(Cm)[None, None, :] < ccount[:, :, None]
     planes = np.where(mask[..., None], planes, 0.0)
-    return dict(start=np.ascontiguousarray(start), coarse=np.ascontiguousarray(coarse),
-                corridor=np.ascontiguousarray(planes), ccount=np.ascontiguousarray(ccount))
+    out = dict(start=np.ascontiguousarray(start), coarse=np.ascontiguousarray(coarse),
+               corridor=np.ascontiguousarray(planes), ccount=np.ascontiguousarray(ccount))
+    if want_points:
+        # corners of every live obstacle at every knot time, [O,4,B,K] -> [B,K,4*O,2], live ones first
+        co, so = np.cos(o_th), np.sin(o_th)
+        cx = np.stack([o_x + sx * hl * co - sy * hw * so for sx, sy in ((1, 1), (1, -1), (-1, -1), (-1, 1))], axis=1)
+        cy = np.stack([o_y + sx * hl * so + sy * hw * co for sx, sy in ((1, 1), (1, -1), (-1, -1), (-1, 1))], axis=1)
+        pts = np.stack([cx, cy], axis=-1).reshape(O * 4, B, K, 2).transpose(1, 2, 0, 3)     # [B,K,4O,2]
+        live = np.repeat(o_live, 4, axis=0).transpose(1, 2, 0)                               # [B,K,4O]
+        order = np.argsort(~live, axis=2, kind="stable")
+        pts = np.take_along_axis(pts, order[..., None], axis=2)
+        cnt = live.sum(axis=2).astype(np.int32)
+        pts = np.where((np.arange(O * 4)[None, None, :] < cnt[:, :, None])[..., None], pts, 0.0)
+        out.update(obstacle_points=np.ascontiguousarray(pts), obstacle_count=np.ascontiguousarray(cnt))
+    return out

@@ -205,6 +205,41 @@ int cilqr_stage_read(cilqr_handle h, int32_t tensor, double* dst, int32_t memory
 int cilqr_stage_nearest_lane(cilqr_handle h, int32_t n, const double* xy, int32_t* left, int32_t* right,
                              int32_t use_grid, int32_t memory);
 
+/* ---- corridor producer: the inputs of cilqr_problem_batch from obstacle points ---- */
+
+/* CorridorConfig, algorithm/params/planner_config.h:75-86 (is_multiple_sample = false only) */
+typedef struct cilqr_corridor_config {
+  double max_diff_x, max_diff_y;   /* obstacle points farther than this from the knot are ignored */
+  double radius;                   /* sphere-flip radius */
+  double max_axis_x, max_axis_y;   /* half extents of the box added around every knot */
+  double lane_segment_length;      /* LaneBoundarySample spacing */
+} cilqr_corridor_config;
+void cilqr_default_corridor_config(cilqr_corridor_config* cfg);
+
+/* Corridor::BuildCorridorConstraints (algorithm/ilqr/corridor.cc:58-87) for `batch` trajectories of
+ * `n_knots` knots: per knot AddCorridorPoints (cc:89-120) + BuildCorridor (cc:122-263), with
+ * cv::convexHull replaced by an own float32 hull (see kernels_corridor.hip).
+ *   knots          [batch][n_knots][3]              x, y, theta of the coarse trajectory point
+ *   points         [batch][n_knots][max_points][2]  obstacle corner points valid at the knot's time
+ *                                                   (Environment::Query{Static,Dynamic}ObstaclesPoints)
+ *   point_count    [batch][n_knots]
+ *   corridor       [batch][n_knots][cmax][3]        out: a, b, c with a x + b y <= c -- the layout of
+ *   corridor_count [batch][n_knots]                 cilqr_problem_batch::corridor / corridor_count
+ * A knot whose corridor cannot be built gets a negative count (-2: fewer than 4 usable points,
+ * -3: more than cmax half-planes, -4: degenerate hull) and is counted in *n_failed; the reference
+ * fails the whole Plan in that case (cc:78-81).  max_points <= 88.  `memory` applies to all arrays. */
+int cilqr_build_corridors(cilqr_handle h, const cilqr_corridor_config* cfg, int32_t batch, int32_t n_knots,
+                          const double* knots, const double* points, const int32_t* point_count,
+                          int32_t max_points, double* corridor, int32_t* corridor_count, int32_t cmax,
+                          int32_t memory, int32_t* n_failed);
+
+/* LaneBoundarySample (corridor.cc:298-311) + CalLeftLaneConstraints / CalRightLaneConstraints
+ * (cc:265-296) + HalfPlaneConstraint (cc:313-321), host only: boundary [n][2] -> rows [.][7] in the
+ * layout of cilqr_problem_batch::left_lane / right_lane.  Returns the number of rows (>= 1) or a
+ * negative error code. */
+int cilqr_lane_constraints(const double* boundary, int32_t n, double segment_length, int32_t is_left,
+                           double* rows, int32_t max_rows);
+
 /* Test hook for the kernels' own fp64 routines (host arrays of n doubles):
  * fn 0: log(x) for normal finite x > 0;  fn 1: 1 / x for normal finite x != 0;
  * fn 2: log(x) with mantissa and exponent handed over separately (the long-product path);

@@ -33,9 +33,9 @@ class OracleConfig(C.Structure):
 
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "liboracle.so")
-    src = os.path.join(_HERE, "cilqr_oracle.cc")
-    if force or not os.path.exists(so) or (
-            os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)):
+    srcs = [os.path.join(_HERE, f) for f in ("cilqr_oracle.cc", "corridor_oracle.cc")]
+    if force or not os.path.exists(so) or any(
+            os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so) for src in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return so
 
@@ -53,6 +53,9 @@ def lib():
         L.oracle_normalize_angle.argtypes = [C.c_double]
         L.oracle_segment_distance.restype = C.c_double
         L.oracle_barrier_value.restype = C.c_double
+        L.oracle_build_corridor.argtypes = [C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_int, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_int]
+        L.oracle_lane_constraints.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_int]
         _LIB = L
     return _LIB
 
@@ -236,3 +239,31 @@ def solve_batch(scene: dict, cfg: OracleConfig | None = None, want_margin: bool 
                                   _p(n_iter, C.c_int), _p(margin), C.byref(sec))
     return dict(rc=rc, traj=traj, cost_hist=hist, n_cost=n_cost, status=status, n_iter=n_iter,
                 min_margin=margin, seconds=sec.value)
+
+
+CORRIDOR_CFG = (25.0, 25.0, 150.0, 10.0, 10.0)   # max_diff_x/y, radius, max_axis_x/y (planner_config.h:75-86)
+
+
+def build_corridor(ox, oy, theta, pts, cfg=CORRIDOR_CFG, max_out=64):
+    """Corridor::AddCorridorPoints + BuildCorridor for one knot.  Returns (cons [m,3], poly [m,2]);
+    raises ValueError with the oracle's code on failure."""
+    pts = _f64(np.asarray(pts, dtype=np.float64).reshape(-1, 2))
+    cfg = _f64(np.asarray(cfg, dtype=np.float64))
+    cons = np.zeros((max_out, 3))
+    poly = np.zeros((max_out, 2))
+    m = lib().oracle_build_corridor(float(ox), float(oy), float(theta), pts.ctypes.data, pts.shape[0],
+                                    cfg.ctypes.data, cons.ctypes.data, poly.ctypes.data, max_out)
+    if m < 0:
+        raise ValueError(m)
+    return cons[:m].copy(), poly[:m].copy()
+
+
+def lane_constraints(boundary, segment_length=5.0, is_left=True, max_rows=4096):
+    """LaneBoundarySample + Cal{Left,Right}LaneConstraints: rows [m,7] = a b c sx sy ex ey."""
+    b = _f64(np.asarray(boundary, dtype=np.float64).reshape(-1, 2))
+    rows = np.zeros((max_rows, 7))
+    m = lib().oracle_lane_constraints(b.ctypes.data, b.shape[0], float(segment_length), int(bool(is_left)),
+                                      rows.ctypes.data, max_rows)
+    if m < 0:
+        raise ValueError(m)
+    return rows[:m].copy()

@@ -1,0 +1,221 @@
+"""Corridor producer: Corridor::BuildCorridorConstraints / lane constraints.
+
+CPU tests pin the oracle's restatement (oracle/corridor_oracle.cc) through the geometric properties
+the construction guarantees -- the reference holds no vectors for this path and its hull lives in
+OpenCV, so parity with the reference is UNPINNED here (see the oracle's header).  GPU tests compare
+the HIP kernel (cilqr_build_corridors) with the oracle knot by knot and run the full
+obstacle points -> corridors -> CILQR solve chain on the device."""
+import numpy as np
+import pytest
+
+from parity_util import assert_parity, oracle_cfg_from, oracle_reference
+from cilqr_amd import api, scenario
+from oracle import oracle as orc
+
+
+def _check_corridor(cons, ox, oy, pts):
+    """Properties of one corridor: origin strictly inside, no obstacle point inside (1 mm: the hulls
+    run in float32)."""
+    nrm = np.hypot(cons[:, 0], cons[:, 1])
+    assert len(cons) >= 3 and (nrm > 0).all()
+    assert (cons[:, 0] * ox + cons[:, 1] * oy - cons[:, 2] < 0).all()
+    if len(pts):
+        g = (pts @ cons[:, :2].T - cons[:, 2]) / nrm
+        assert not (g < -1e-3).all(axis=1).any()
+
+
+def _random_knot(rng):
+    ox, oy = rng.uniform(-50, 50, 2)
+    th = rng.uniform(-3, 3)
+    pts = []
+    for _ in range(rng.integers(0, 12)):
+        c = np.array([ox, oy]) + rng.uniform(-30, 30, 2)
+        if np.hypot(*(c - [ox, oy])) < 2.5:
+            continue
+        w, h = ((1, 1), (4, 2))[rng.integers(0, 2)]
+        a = rng.uniform(-3, 3)
+        R = np.array([[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]])
+        pts += [c + R @ np.array([sx * w / 2, sy * h / 2]) for sx, sy in ((1, 1), (1, -1), (-1, -1), (-1, 1))]
+    return ox, oy, th, np.array(pts).reshape(-1, 2)
+
+
+def test_oracle_corridor_properties_on_random_knots():
+    rng = np.random.default_rng(11)
+    sizes = []
+    for _ in range(1500):
+        ox, oy, th, pts = _random_knot(rng)
+        cons, poly = orc.build_corridor(ox, oy, th, pts)
+        _check_corridor(cons, ox, oy, pts)
+        # the polygon's vertices lie on its own half-planes.  (The polygon may reach past the 20 m
+        # box: with is_multiple_sample = false the box is only its four corners, cc:89-120.)
+        g = (poly @ cons[:, :2].T - cons[:, 2]) / np.hypot(cons[:, 0], cons[:, 1])
+        assert g.max() < 1e-6
+        sizes.append(len(cons))
+    assert max(sizes) > 6 and min(sizes) >= 3
+
+
+def test_oracle_corridor_without_obstacles_is_the_box():
+    """Only the 8 box points of AddCorridorPoints (corridor.cc:89-120): the corridor is the 20 m box."""
+    for th in (0.0, 0.7, -2.1):
+        cons, poly = orc.build_corridor(3.0, -4.0, th, np.zeros((0, 2)))
+        assert len(cons) == 4
+        local = (poly - [3.0, -4.0]) @ np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+        assert np.allclose(np.abs(local), 10.0, atol=1e-3)
+
+
+def test_oracle_corridor_failure_codes():
+    cfg = list(orc.CORRIDOR_CFG)
+    cfg[3] = cfg[4] = 0.0          # box collapses onto the knot: every box point is filtered out (cc:145-147)
+    with pytest.raises(ValueError) as e:
+        orc.build_corridor(0.0, 0.0, 0.0, np.zeros((0, 2)), cfg=cfg)
+    assert e.value.args[0] == -2   # "Flip Points Size to Build Corridor is less than 4" (cc:179-182)
+    with pytest.raises(ValueError) as e:
+        orc.build_corridor(0.0, 0.0, 0.0, np.zeros((0, 2)), max_out=3)
+    assert e.value.args[0] == -3
+
+
+def test_lane_constraints_host_function_matches_oracle_and_generator(built):
+    road = scenario.build_road()
+    left, right = scenario.lane_constraints(road)
+    lb = np.stack(road.cartesian(road.s, scenario.LEFT_BOUND), 1)
+    rb = np.stack(road.cartesian(road.s, -scenario.RIGHT_BOUND), 1)
+    for boundary, is_left, table in ((lb, True, left), (rb, False, right)):
+        o = orc.lane_constraints(boundary, 5.0, is_left)
+        a = api.lane_constraints(boundary, 5.0, is_left)
+        assert np.array_equal(o, a)
+        assert o.shape == table.shape and np.allclose(o, table, rtol=1e-12, atol=1e-12)
+    with pytest.raises(api.CilqrError):
+        api.lane_constraints(lb[:3], 5.0, True)     # fewer than two sampled points (cc:273-275)
+
+
+def test_generator_obstacle_points_do_not_change_the_scene():
+    a = scenario.generate("mix11", 6, seed=5)
+    b = scenario.generate("mix11", 6, seed=5, obstacle_points=True)
+    assert all(np.array_equal(a[k], b[k]) for k in a if isinstance(a[k], np.ndarray))
+    assert b["obstacle_points"].shape == (6, 51, 44, 2) and b["obstacle_count"].max() <= 44
+    assert (b["obstacle_count"] % 4 == 0).all()
+
+
+# ---------------------------------------------------------------------------------------------
+# GPU
+# ---------------------------------------------------------------------------------------------
+def _opt(sc, **kw):
+    cfg = api.default_config(sc["n_steps"])
+    return api.BatchIlqrOptimizer(cfg, batch_capacity=sc["coarse"].shape[0], cmax=sc["cmax"], **kw)
+
+
+def _oracle_corridors(sc, cmax):
+    B, K = sc["coarse"].shape[:2]
+    cor = np.zeros((B, K, cmax, 3))
+    cnt = np.zeros((B, K), np.int32)
+    for b in range(B):
+        for k in range(K):
+            n = sc["obstacle_count"][b, k]
+            cons, _ = orc.build_corridor(*sc["coarse"][b, k, :3], sc["obstacle_points"][b, k, :n], max_out=cmax)
+            cnt[b, k] = len(cons)
+            cor[b, k, :len(cons)] = cons
+    return cor, cnt
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("family,B,seed", [("mix11", 48, 41), ("dyn20", 8, 42)])
+def test_build_corridors_matches_oracle(built, family, B, seed):
+    sc = scenario.generate(family, B, seed=seed, obstacle_points=True)
+    opt = _opt(sc)
+    cor, cnt, n_failed = opt.build_corridors(sc["coarse"][:, :, :3], sc["obstacle_points"], sc["obstacle_count"],
+                                             cmax=sc["cmax"])
+    assert n_failed == 0 and (cnt >= 3).all()
+    ocor, ocnt = _oracle_corridors(sc, sc["cmax"])
+    same_count = cnt == ocnt
+    # device cos/sin and libm's may differ in the last bit of a box corner, which can move a
+    # float32 hull decision: allow a handful of knots to differ in their plane count
+    assert same_count.mean() > 0.995
+    K = cnt.shape[1]
+    worst = 0.0
+    for b in range(B):
+        for k in range(K):
+            m = cnt[b, k]
+            ox, oy = sc["coarse"][b, k, :2]
+            _check_corridor(cor[b, k, :m], ox, oy, sc["obstacle_points"][b, k, :sc["obstacle_count"][b, k]])
+            assert (cor[b, k, m:] == 0).all()
+            if same_count[b, k]:
+                g, o = cor[b, k, :m], ocor[b, k, :m]
+                scale = np.abs(o).max(axis=1, keepdims=True)
+                worst = max(worst, float((np.abs(g - o) / scale).max()))
+    assert worst < 1e-5, worst   # float32 hulls: identical decisions, fp64 tails agree to rounding
+    opt.close()
+
+
+@pytest.mark.gpu
+def test_build_corridors_failure_codes_and_arguments(built):
+    sc = scenario.generate("ped6", 4, seed=43, obstacle_points=True)
+    opt = _opt(sc)
+    knots = sc["coarse"][:, :, :3]
+    cfg = api.default_corridor_config()
+    cfg.max_axis_x = cfg.max_axis_y = 0.0
+    none = np.zeros_like(sc["obstacle_count"])
+    cor, cnt, nf = opt.build_corridors(knots, sc["obstacle_points"], none, cfg=cfg)
+    assert nf == cnt.size and (cnt == -2).all()                 # cc:179-182
+    cor, cnt, nf = opt.build_corridors(knots, sc["obstacle_points"], sc["obstacle_count"], cmax=3)
+    full = opt.build_corridors(knots, sc["obstacle_points"], sc["obstacle_count"], cmax=16)[1]
+    assert ((cnt == -3) == (full > 3)).all() and nf == int((full > 3).sum())
+    # no obstacle points at all: the box
+    cor, cnt, nf = opt.build_corridors(knots, np.zeros((4, 51, 0, 2)), none)
+    assert nf == 0 and (cnt == 4).all()
+    # argument errors
+    c = api.default_corridor_config()
+    i32 = np.zeros((4, 51), np.int32)
+    out = np.zeros((4, 51, 16, 3))
+    k = np.ascontiguousarray(knots)
+    assert opt.build_corridors_raw(c, 4, 51, None, None, i32.ctypes.data, 0, out.ctypes.data, i32.ctypes.data, 16,
+                                   api.MEM_HOST)[0] == api.ERR_NULL
+    assert opt.build_corridors_raw(c, 0, 51, k.ctypes.data, None, i32.ctypes.data, 0, out.ctypes.data,
+                                   i32.ctypes.data, 16, api.MEM_HOST)[0] == api.ERR_ARG      # empty trajectory cc:24-27
+    assert opt.build_corridors_raw(c, 4, 51, k.ctypes.data, k.ctypes.data, i32.ctypes.data, 89, out.ctypes.data,
+                                   i32.ctypes.data, 16, api.MEM_HOST)[0] == api.ERR_CAPACITY
+    opt.close()
+
+
+@pytest.mark.gpu
+def test_obstacles_to_trajectories_on_the_device(built):
+    """The whole chain with device-resident data: obstacle points -> cilqr_build_corridors ->
+    cilqr_solve_batch, no host copy of the corridors in between; equal to the host-memory route bit
+    for bit, and the solve matches the oracle fed with the same corridors."""
+    torch = pytest.importorskip("torch")
+    sc = scenario.generate("mix11", 96, seed=44, obstacle_points=True)
+    B, K, cmax = 96, sc["n_steps"] + 1, sc["cmax"]
+    opt = _opt(sc)
+    knots = np.ascontiguousarray(sc["coarse"][:, :, :3])
+    cor_h, cnt_h, nf = opt.build_corridors(knots, sc["obstacle_points"], sc["obstacle_count"], cmax=cmax)
+    assert nf == 0
+    dev = torch.device("cuda", 0)
+    t = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in
+         dict(knots=knots, pts=sc["obstacle_points"], pcnt=sc["obstacle_count"], start=sc["start"],
+              coarse=sc["coarse"]).items()}
+    d_cor = torch.zeros((B, K, cmax, 3), dtype=torch.float64, device=dev)
+    d_cnt = torch.zeros((B, K), dtype=torch.int32, device=dev)
+    opt.set_stream(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    rc, nf = opt.build_corridors_raw(api.default_corridor_config(), B, K, t["knots"].data_ptr(), t["pts"].data_ptr(),
+                                     t["pcnt"].data_ptr(), sc["obstacle_points"].shape[2], d_cor.data_ptr(),
+                                     d_cnt.data_ptr(), cmax, api.MEM_DEVICE)
+    assert rc == api.OK and nf == 0
+    assert np.array_equal(d_cor.cpu().numpy(), cor_h) and np.array_equal(d_cnt.cpu().numpy(), cnt_h)
+    M = opt.cfg.max_iter
+    o_traj = torch.zeros((B, K, 10), dtype=torch.float64, device=dev)
+    o_hist = torch.zeros((B, M + 1, 5), dtype=torch.float64, device=dev)
+    o_nc = torch.zeros(B, dtype=torch.int32, device=dev)
+    o_st = torch.zeros(B, dtype=torch.int32, device=dev)
+    left, right = np.ascontiguousarray(sc["left"]), np.ascontiguousarray(sc["right"])
+    prob = opt.make_problem(B, t["start"].data_ptr(), t["coarse"].data_ptr(), d_cor.data_ptr(), d_cnt.data_ptr(),
+                            cmax, left.ctypes.data, right.ctypes.data, left.shape[0], right.shape[0], api.MEM_DEVICE)
+    sol = api.SolutionBatch(api.MEM_DEVICE, 0, o_traj.data_ptr(), o_hist.data_ptr(), o_nc.data_ptr(),
+                            o_st.data_ptr(), None, None, None)
+    assert opt.solve_raw(prob, sol) == api.OK
+    torch.cuda.synchronize()
+    sc2 = dict(sc, corridor=cor_h, ccount=cnt_h)
+    host = opt.plan(sc2)
+    assert np.array_equal(o_traj.cpu().numpy(), host["traj"]) and np.array_equal(o_st.cpu().numpy(), host["status"])
+    ref = oracle_reference(sc2, oracle_cfg_from(opt.cfg))
+    assert_parity(host, ref, max_unstable_frac=0.3)
+    opt.close()
