@@ -32,16 +32,17 @@ struct P2f {
 // lexicographically smallest point; `order` and `h` are caller-provided work arrays
 // (n and 2n + 2 entries).  Returns the number of hull vertices.
 __device__ int hull_indices(const P2f* p, int n, unsigned char* order, unsigned char* h) {
-  for (int i = 0; i < n; ++i) {  // stable insertion sort by (x, y)
+  // stable sort by (x, y) through ranks: rank(i) = number of points that sort before point i.
+  // n^2 comparisons, but the loads of the inner loop do not depend on each other (an insertion
+  // sort is a chain of dependent memory round trips, which is what a lane of this kernel waits on).
+  for (int i = 0; i < n; ++i) {
     const P2f q = p[i];
-    int j = i;
-    while (j > 0) {
-      const P2f r = p[order[j - 1]];
-      if (r.x < q.x || (r.x == q.x && r.y <= q.y)) break;
-      order[j] = order[j - 1];
-      --j;
+    int rank = 0;
+    for (int j = 0; j < n; ++j) {
+      const P2f r = p[j];
+      rank += (r.x < q.x || (r.x == q.x && (r.y < q.y || (r.y == q.y && j < i)))) ? 1 : 0;
     }
-    order[j] = (unsigned char)i;
+    order[rank] = (unsigned char)i;
   }
   auto cross = [&](int o, int a, int b) {
     const float ax = p[a].x - p[o].x, ay = p[a].y - p[o].y;
@@ -72,7 +73,8 @@ __device__ void make_clockwise(unsigned char* h, int k) {
 
 }  // namespace
 
-// knots [n][3] = x, y, theta; points [n][pmax][2]; count [n]; out corridor [n][cmax][3], ccount [n]
+// knots [n][3] = x, y, theta; points [n][pmax][2]; count [n]; out corridor [n][cmax][3] (rows past
+// the count zeroed), ccount [n]
 // (m >= 3 half-planes, or -1 no points, -2 fewer than 4 flipped points, -3 more than cmax
 // half-planes, -4 degenerate hull); *n_failed counts the knots with a negative code.
 __global__ __launch_bounds__(64) void k_build_corridors(int n, CorridorParams cp, const double* __restrict__ knots,
@@ -224,6 +226,10 @@ __global__ __launch_bounds__(64) void k_build_corridors(int n, CorridorParams cp
         }
       }
     }
+  }
+  {
+    double* out = corridor + (size_t)t * cmax * 3;
+    for (int i = 3 * m; i < 3 * cmax; ++i) out[i] = 0.0;   // rows past the count: zeros
   }
   ccount[t] = code < 0 ? code : m;
   if (code < 0) atomicAdd(n_failed, 1);
