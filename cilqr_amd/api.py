@@ -21,6 +21,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 OPT_SPEC_THRESHOLD = 1
 OPT_COMPACTION = 2
 OPT_SEQ_ROUNDS = 3
+OPT_TEAM_THRESHOLD = 4
 ST_RUNNING, ST_CONVERGED_ABS, ST_CONVERGED_REL, ST_GNORM, ST_UNSOLVED, ST_MAX_ITER = range(6)
 
 T_GOALS, T_CORRIDOR, T_LANES, T_X, T_U, T_XCAND, T_UCAND, T_A, T_B, T_LX, T_LU, T_LXX, T_LUU, \

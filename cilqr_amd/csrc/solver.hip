@@ -54,6 +54,7 @@ struct cilqr_solver {
   int B = 0;               // problems loaded
   int stage = 0;           // bit0 loaded, bit1 iterate, bit2 quadratized, bit3 gains
   int spec_threshold = 8192;  // active sets up to this size evaluate all 11 step sizes at once
+  int team_threshold = 4096;  // active sets up to this size run the backward pass with 8 lanes per problem
   int seq_rounds = 4;         // larger sets: this many round-by-round trials, then the rest at once
   // asynchronous submit / wait: one worker thread per handle, one job in flight
   std::thread worker;
@@ -431,6 +432,10 @@ int cilqr_set_option(cilqr_handle h, int32_t option, int64_t value) {
       if (value < 1 || value > kNumAlpha) return CILQR_ERR_ARG;
       h->seq_rounds = (int)value;
       return CILQR_OK;
+    case CILQR_OPT_TEAM_THRESHOLD:
+      if (value < 0) return CILQR_ERR_ARG;
+      h->team_threshold = (int)(value > 0x7fffffff ? 0x7fffffff : value);
+      return CILQR_OK;
     default:
       return CILQR_ERR_ARG;
   }
@@ -528,7 +533,7 @@ int cilqr_solve_batch(cilqr_handle h, const cilqr_problem_batch* in, cilqr_solut
     if (tm.begin(0)) return CILQR_ERR_DEVICE;
     launch_quadratize(d, d.act, n_hint, 1, st);        // cc:203-214
     if (tm.end() || tm.begin(1)) return CILQR_ERR_DEVICE;
-    launch_backward(d, d.act, n_hint, nullptr, st);    // cc:218
+    launch_backward(d, d.act, n_hint, nullptr, h->team_threshold, st);    // cc:218
     if (tm.end() || tm.begin(2)) return CILQR_ERR_DEVICE;
     bwd_iter.push_back(it);
     launch_linesearch(d, n_hint, h->spec_threshold, h->seq_rounds, st);  // cc:235-270
@@ -744,7 +749,7 @@ int cilqr_stage_backward(cilqr_handle h, const double* lambda, int32_t memory) {
       dl = lambda;
     }
   }
-  launch_backward(h->ds, nullptr, h->B, dl, h->stream);
+  launch_backward(h->ds, nullptr, h->B, dl, h->team_threshold, h->stream);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
   h->stage |= 8;

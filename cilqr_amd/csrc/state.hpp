@@ -167,6 +167,7 @@ void launch_spec_cost(const DeviceState& s, const int* list, const int* n_ptr, i
 void launch_init_cost_commit(const DeviceState& s, int n, hipStream_t st);
 void launch_quadratize(const DeviceState& s, const int* list, int n, int only_upd, hipStream_t st);
 void launch_backward(const DeviceState& s, const int* list, int n, const double* lambda_override,
+                     int team_threshold,
                      hipStream_t st);
 void launch_forward(const DeviceState& s, const int* list, int n, double alpha, int skip_done,
                     hipStream_t st);

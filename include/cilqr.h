@@ -150,6 +150,10 @@ int cilqr_set_stream(cilqr_handle h, void* hip_stream);
  * fill at most 75 % of the occupied slots, so later iterations keep reading coalesced rows.
  * 0 = never, 2..100 = re-pack at that occupancy percentage. */
 #define CILQR_OPT_COMPACTION 2
+/* CILQR_OPT_TEAM_THRESHOLD (default 4096): backward passes over at most this many problems spread each
+ * problem over eight lanes (column-wise) instead of one, which shortens the chain of dependent
+ * steps a small launch waits on; 0 = always one lane per problem.  Bit-identical results. */
+#define CILQR_OPT_TEAM_THRESHOLD 4
 int cilqr_set_option(cilqr_handle h, int32_t option, int64_t value);
 int cilqr_set_profiling(cilqr_handle h, int32_t enable);
 int cilqr_get_profile(cilqr_handle h, cilqr_profile* out);
