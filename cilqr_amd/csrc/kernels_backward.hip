@@ -295,18 +295,44 @@ __global__ __launch_bounds__(64) void k_backward_team(DeviceState s, const int* 
   const int buf = s.cur[slot];
   const double B30 = 0.5 * dt * dt, B40 = dt, B51 = dt;
   double dV0 = 0.0, dV1 = 0.0, gsum = 0.0;
-  double2 w[kLinPairs], wn[kLinPairs];
-  double2 uu, uun;
-  {
-    const double2* q = s.lin + (size_t)(N - 1) * kLinPairs * Bc + slot;
+  // What a lane needs from the linearisation of a step is a handful of scalars that depend on its
+  // column: rows 0..3 of A's column c, lx(c), column c of lxx -- plus the pairs every lane needs
+  // (B(2,1), lu, luu).  Each is fetched straight from its place in the [17 pairs][Bcap] record
+  // (offsets in doubles from the step's first pair, fixed per lane), instead of loading all 17
+  // pairs and selecting by column.  Structural zeros / ones never touch memory: `k` = kind.
+  const size_t row = (size_t)Bc * 2;                       // doubles per pair row
+  auto at = [&](int pair, int half) { return (size_t)pair * row + (size_t)half; };
+  // A(0,c): pairs 0,1 = (A02,A03),(A04,A05); A(1,c): pairs 2,3; A(2,c): pair 4 = (A23,A24), 5.x = A25
+  const size_t o_a0 = c >= 2 ? at((c - 2) >> 1, (c - 2) & 1) : 0;
+  const size_t o_a1 = c >= 2 ? at(2 + ((c - 2) >> 1), (c - 2) & 1) : 0;
+  const size_t o_a2 = c >= 3 ? at(4 + ((c - 3) >> 1), (c - 3) & 1) : 0;
+  const size_t o_lx = at(6 + (c >> 1), c & 1);
+  // lxx: pairs 10..15 = (H00,H01),(H02,H10),(H11,H12),(H20,H21),(H22,H33),(H44,H55)
+  //   column c < 3: rows 0..2 -> H(r,c) is scalar number 3 r + c of the first nine
+  //   column c >= 3: the diagonal entry, scalar number 6 + c
+  auto hs = [&](int sidx) { return at(10 + (sidx >> 1), sidx & 1); };
+  const size_t o_h0 = hs(c < 3 ? c : 6 + c), o_h1 = hs(c < 3 ? 3 + c : 6 + c), o_h2 = hs(c < 3 ? 6 + c : 6 + c);
+  const double ka0 = c0 ? 1.0 : 0.0, ka1 = c1 ? 1.0 : 0.0, ka2 = c2 ? 1.0 : 0.0;   // value when not loaded
+  struct StepIn {
+    double a0, a1, a2, lx, h0, h1, h2;
+    double2 wa[6], lu, luu, u;     // wa: the pairs that hold A (and B(2,1)): A^T x needs all of A
+  };
+  auto load_step = [&](int i, StepIn& o) {
+    const double* q = reinterpret_cast<const double*>(s.lin + (size_t)i * kLinPairs * Bc + slot);
+    o.a0 = q[o_a0]; o.a1 = q[o_a1]; o.a2 = q[o_a2]; o.lx = q[o_lx];
+    o.h0 = q[o_h0]; o.h1 = q[o_h1]; o.h2 = q[o_h2];
+    const double2* q2 = s.lin + (size_t)i * kLinPairs * Bc + slot;
 #pragma unroll
-    for (int r = 0; r < kLinPairs; ++r) w[r] = q[(size_t)r * Bc];
-    uu = s.U[((size_t)buf * N + (N - 1)) * Bc + slot];
-  }
+    for (int r = 0; r < 6; ++r) o.wa[r] = q2[(size_t)r * Bc];
+    o.lu = q2[(size_t)9 * Bc]; o.luu = q2[(size_t)16 * Bc];
+    o.u = s.U[((size_t)buf * N + i) * Bc + slot];
+  };
+  StepIn w, wn;
+  load_step(N - 1, w);
   // B^T Vxx and Vx of the terminal value function, for the first step
   if (owner) {
     T[oB0 + c] = B30 * V[3] + B40 * V[4];
-    T[oBn + c] = w[5].y * V[2] + B51 * V[5];
+    T[oBn + c] = w.wa[5].y * V[2] + B51 * V[5];
     T[oVx + c] = vx;
   }
   __syncthreads();
@@ -318,37 +344,29 @@ __global__ __launch_bounds__(64) void k_backward_team(DeviceState s, const int* 
     Vxa[k] = T[oVx + k];
   }
   for (int i = N - 1; i >= 0; --i) {
-    {
-      const int ip = (i > 0) ? i - 1 : 0;
-      const double2* q = s.lin + (size_t)ip * kLinPairs * Bc + slot;
-#pragma unroll
-      for (int r = 0; r < kLinPairs; ++r) wn[r] = q[(size_t)r * Bc];
-      uun = s.U[((size_t)buf * N + ip) * Bc + slot];
-    }
+    load_step((i > 0) ? i - 1 : 0, wn);
+    // A (the entries the column-independent product A^T x reads) and B
     double A[36], B[12];
-    A[2] = w[0].x; A[3] = w[0].y; A[4] = w[1].x; A[5] = w[1].y;
-    A[8] = w[2].x; A[9] = w[2].y; A[10] = w[3].x; A[11] = w[3].y;
-    A[15] = w[4].x; A[16] = w[4].y; A[17] = w[5].x;
+    A[2] = w.wa[0].x; A[3] = w.wa[0].y; A[4] = w.wa[1].x; A[5] = w.wa[1].y;
+    A[8] = w.wa[2].x; A[9] = w.wa[2].y; A[10] = w.wa[3].x; A[11] = w.wa[3].y;
+    A[15] = w.wa[4].x; A[16] = w.wa[4].y; A[17] = w.wa[5].x;
     A[22] = dt;
-    B[5] = w[5].y; B[6] = B30; B[8] = B40; B[11] = B51;
+    B[5] = w.wa[5].y; B[6] = B30; B[8] = B40; B[11] = B51;
     // rows 0..3 of A's column c, exact zeros and ones included; rows 4, 5 of a column hold only
     // its diagonal one
-    const double a0 = sel6(1.0, 0.0, A[2], A[3], A[4], A[5]);
-    const double a1 = sel6(0.0, 1.0, A[8], A[9], A[10], A[11]);
-    const double a2 = sel6(0.0, 0.0, 1.0, A[15], A[16], A[17]);
-    const double a3 = sel6(0.0, 0.0, 0.0, 1.0, A[22], 0.0);
+    const double a0 = c >= 2 ? w.a0 : ka0;
+    const double a1 = c >= 2 ? w.a1 : ka1;
+    const double a2 = c >= 3 ? w.a2 : ka2;
+    const double a3 = c3 ? 1.0 : c4 ? dt : 0.0;
     const bool late = c >= 4;   // diagonal entry below row 3: one more term, the own column
-    const double lxc = sel6(w[6].x, w[6].y, w[7].x, w[7].y, w[8].x, w[8].y);
-    const double lu[2] = {w[9].x, w[9].y};
+    const double lxc = w.lx;
+    const double lu[2] = {w.lu.x, w.lu.y};
     // column c of lxx (zeros where the reference's lxx has none)
-    const double h0 = sel6(w[10].x, w[10].y, w[11].x, 0.0, 0.0, 0.0);
-    const double h1 = sel6(w[11].y, w[12].x, w[12].y, 0.0, 0.0, 0.0);
-    const double h2 = sel6(w[13].x, w[13].y, w[14].x, 0.0, 0.0, 0.0);
-    const double h3 = sel6(0.0, 0.0, 0.0, w[14].y, 0.0, 0.0);
-    const double h4 = sel6(0.0, 0.0, 0.0, 0.0, w[15].x, 0.0);
-    const double h5 = sel6(0.0, 0.0, 0.0, 0.0, 0.0, w[15].y);
-    const double hc[6] = {h0, h1, h2, h3, h4, h5};
-    const double luu0 = w[16].x, luu1 = w[16].y;
+    const bool blk = c < 3;
+    const double hc[6] = {blk ? w.h0 : 0.0, blk ? w.h1 : 0.0, blk ? w.h2 : 0.0,
+                          c3 ? w.h0 : 0.0, c4 ? w.h0 : 0.0, (c == 5) ? w.h0 : 0.0};
+    const double luu0 = w.luu.x, luu1 = w.luu.y;
+    const double2 uu = w.u;
 
     // ---- quantities from the OLD Vx / Vxx ----
     // column c of Qux = (B^T Vxx) A                                               cc:353
@@ -461,7 +479,7 @@ __global__ __launch_bounds__(64) void k_backward_team(DeviceState s, const int* 
     if (owner) {
       T[oB0 + c] = B30 * V[3] + B40 * V[4];
       T[oB1 + c] = B[5] * V[2] + B51 * V[5];
-      T[oBn + c] = wn[5].y * V[2] + B51 * V[5];
+      T[oBn + c] = wn.wa[5].y * V[2] + B51 * V[5];
       T[oVx + c] = vx;
     }
     __syncthreads();
@@ -485,9 +503,7 @@ __global__ __launch_bounds__(64) void k_backward_team(DeviceState s, const int* 
       const double r0 = hk0 * q00 + hk1 * q10, r1 = hk0 * q01 + hk1 * q11;
       dV1 += r0 * kc[0] + r1 * kc[1];
     }
-#pragma unroll
-    for (int r = 0; r < kLinPairs; ++r) w[r] = wn[r];
-    uu = uun;
+    w = wn;
   }
   if (live && cl == 0) {
     s.dV[slot] = dV0;
