@@ -9,9 +9,12 @@
 // cv::Point2f), and so are its quirks: safe_radius = norm of the LAST point inside `radius`
 // (cc:169-171); (OriginIndex - 1) % size in unsigned 64-bit arithmetic (cc:203).
 //
-// Mapping: every knot of every problem is independent, so one lane builds one corridor.  The
-// working set of a lane (<= kCorMaxPts points, three small hulls) lives in its private segment;
-// the arrays are indexed dynamically, which the compiler keeps in scratch memory backed by L1/L2.
+// Mapping: every knot of every problem is independent, so one lane builds one corridor (64 corridors
+// share one instruction stream; spreading a corridor over a wave would cost ~10x the instructions,
+// the hull scans being sequential).  The working set of a lane (<= MAXP points, three small hulls)
+// lives in its private segment: the arrays are indexed with data-dependent indices, which means
+// scratch memory (built with -disable-promote-alloca-to-vector, see the Makefile).  That scratch
+// traffic is the kernel's cost, so the arrays are kept minimal and the occupancy is capped.
 // The kernel is a once-per-solve prologue (3.3 M corridors for 65536 x 51 knots).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -77,6 +80,7 @@ __device__ void make_clockwise(unsigned char* h, int k) {
 // the count zeroed), ccount [n]
 // (m >= 3 half-planes, or -1 no points, -2 fewer than 4 flipped points, -3 more than cmax
 // half-planes, -4 degenerate hull); *n_failed counts the knots with a negative code.
+template <int MAXP>
 __global__ __launch_bounds__(64) void k_build_corridors(int n, CorridorParams cp, const double* __restrict__ knots,
                                                         const double* __restrict__ points,
                                                         const int* __restrict__ count, int pmax,
@@ -85,41 +89,49 @@ __global__ __launch_bounds__(64) void k_build_corridors(int n, CorridorParams cp
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
   const double ox = knots[3 * t], oy = knots[3 * t + 1], theta = knots[3 * t + 2];
-  double fx[kCorMaxPts], fy[kCorMaxPts];
-  P2f flip[kCorMaxPts + 1], vd[kCorMaxPts + 1], dual[kCorMaxPts + 1];
-  unsigned char order[kCorMaxPts + 1], hull[2 * kCorMaxPts + 4], v1[kCorMaxPts + 1], v2[kCorMaxPts + 1];
+  // private working set (scratch), kept small: it is what the kernel's memory traffic consists of.
+  // `flip` is dead once the first hull is known and is reused for the dual points; the kept points
+  // are remembered by their index in the input list and re-read (or re-derived) when needed.
+  P2f flip[MAXP + 1], vd[MAXP + 1];
+  P2f* dual = flip;
+  unsigned char src[MAXP], order[MAXP + 1], hull[MAXP + 3], v2[MAXP + 1];
   int code = 0;
   int nf = 0;
   double safe_radius = cp.radius;
+  const int np = min(max(count[t], 0), pmax);
+  const double* pp = points + (size_t)t * pmax * 2;
+  // box points of AddCorridorPoints (cc:89-120, is_multiple_sample = false: both ends of each edge)
+  const double ch = cos(theta), sh = sin(theta);
+  const double dx1 = ch * cp.max_axis_x, dy1 = sh * cp.max_axis_x;
+  const double dx2 = sh * cp.max_axis_y, dy2 = -ch * cp.max_axis_y;
+  auto input_point = [&](int i, double& x, double& y) {   // obstacle points, then the 8 box points
+    if (i < np) {
+      x = pp[2 * i];
+      y = pp[2 * i + 1];
+    } else {
+      // corners: +dx1 +dx2, +dx1 -dx2, -dx1 -dx2, -dx1 +dx2; edge e runs from corner e to e + 1
+      const int e = (i - np) >> 1, second = (i - np) & 1;
+      const int k0 = e, k1 = (e + 1) & 3;
+      const double s1a = (k0 < 2) ? 1.0 : -1.0, s2a = (k0 == 0 || k0 == 3) ? 1.0 : -1.0;
+      const double s1b = (k1 < 2) ? 1.0 : -1.0, s2b = (k1 == 0 || k1 == 3) ? 1.0 : -1.0;
+      const double ax = ox + s1a * dx1 + s2a * dx2, ay = oy + s1a * dy1 + s2a * dy2;
+      const double bx = ox + s1b * dx1 + s2b * dx2, by = oy + s1b * dy1 + s2b * dy2;
+      const double ratio = second ? 1.0 : 0.0;
+      x = ax * (1 - ratio) + bx * ratio;
+      y = ay * (1 - ratio) + by * ratio;
+    }
+  };
   {
-    const int np = min(max(count[t], 0), pmax);
-    const double* pp = points + (size_t)t * pmax * 2;
-    // box points of AddCorridorPoints (cc:89-120, is_multiple_sample = false: both ends of each edge)
-    const double ch = cos(theta), sh = sin(theta);
-    const double dx1 = ch * cp.max_axis_x, dy1 = sh * cp.max_axis_x;
-    const double dx2 = sh * cp.max_axis_y, dy2 = -ch * cp.max_axis_y;
-    const double cx[4] = {ox + dx1 + dx2, ox + dx1 - dx2, ox - dx1 - dx2, ox - dx1 + dx2};
-    const double cy[4] = {oy + dy1 + dy2, oy + dy1 - dy2, oy - dy1 - dy2, oy - dy1 + dy2};
     for (int i = 0; i < np + 8; ++i) {
       double x, y;
-      if (i < np) {
-        x = pp[2 * i];
-        y = pp[2 * i + 1];
-      } else {
-        const int e = (i - np) >> 1, second = (i - np) & 1;
-        const int nx = (e + 1) & 3;
-        const double ratio = second ? 1.0 : 0.0;
-        x = cx[e] * (1 - ratio) + cx[nx] * ratio;
-        y = cy[e] * (1 - ratio) + cy[nx] * ratio;
-      }
+      input_point(i, x, y);
       // filter cc:136-149 and sphere flip cc:154-177
       const double dx = x - ox, dy = y - oy;
       if (fabs(dx) > cp.max_diff_x || fabs(dy) > cp.max_diff_y) continue;
       const double norm2 = sqrt(dx * dx + dy * dy);
       if (fabs(norm2) < kEps) continue;
       if (norm2 < cp.radius) safe_radius = norm2;
-      fx[nf] = x;
-      fy[nf] = y;
+      src[nf] = (unsigned char)i;
       flip[nf].x = (float)(dx + 2 * (cp.radius - norm2) * dx / norm2);
       flip[nf].y = (float)(dy + 2 * (cp.radius - norm2) * dy / norm2);
       ++nf;
@@ -137,12 +149,13 @@ __global__ __launch_bounds__(64) void k_build_corridors(int n, CorridorParams cp
       // star-shaped polygon through the visible points cc:186-198
       int origin_index = -1;
       for (int i = 0; i < n1; ++i) {
-        v1[i] = hull[i];
         if (hull[i] == nf) {
           origin_index = i;
           vd[i] = P2f{(float)ox, (float)oy};
         } else {
-          vd[i] = P2f{(float)fx[hull[i]], (float)fy[hull[i]]};
+          double x, y;
+          input_point(src[hull[i]], x, y);
+          vd[i] = P2f{(float)x, (float)y};
         }
       }
       double ix = ox, iy = oy;  // cc:200-216
@@ -150,9 +163,10 @@ __global__ __launch_bounds__(64) void k_build_corridors(int n, CorridorParams cp
         const uint64_t sz = (uint64_t)n1;
         const int last = (int)(((uint64_t)(int64_t)(origin_index - 1)) % sz);
         const int next = (int)(((uint64_t)(int64_t)(origin_index + 1)) % sz);
-        const int vl = v1[last], vn = v1[next];
-        const double lx = (vl == nf) ? ox : fx[vl], ly = (vl == nf) ? oy : fy[vl];
-        const double nx = (vn == nf) ? ox : fx[vn], ny = (vn == nf) ? oy : fy[vn];
+        const int vl = hull[last], vn = hull[next];
+        double lx = ox, ly = oy, nx = ox, ny = oy;
+        if (vl != nf) input_point(src[vl], lx, ly);
+        if (vn != nf) input_point(src[vn], nx, ny);
         const double dx = (lx + ox + nx) / 3 - ox;
         const double dy = (ly + oy + ny) / 3 - oy;
         const double d = sqrt(dx * dx + dy * dy);
@@ -178,7 +192,7 @@ __global__ __launch_bounds__(64) void k_build_corridors(int n, CorridorParams cp
           }
           int idx = v2[j];
           int guard = 0;
-          while (idx != v2[j1] && guard++ <= n1 && nt < kCorMaxPts + 1) {
+          while (idx != v2[j1] && guard++ <= n1 && nt < MAXP + 1) {
             const double c = (vd[idx].x - ix) * n0 + (vd[idx].y - iy) * nn1;
             const float cf = (float)c;
             dual[nt].x = n0 / cf;
@@ -238,8 +252,17 @@ __global__ __launch_bounds__(64) void k_build_corridors(int n, CorridorParams cp
 void launch_build_corridors(int n, const CorridorParams& cp, const double* knots, const double* points,
                             const int* count, int pmax, double* corridor, int* ccount, int cmax, int* n_failed,
                             hipStream_t st) {
-  hipLaunchKernelGGL(k_build_corridors, dim3((n + 63) / 64), dim3(64), 0, st, n, cp, knots, points, count, pmax,
-                     corridor, ccount, cmax, n_failed);
+  // Unused dynamic LDS caps the kernel at 16 waves per CU.  A lane's working set lives in scratch
+  // memory; with every wave slot filled (32 per CU) the scratch of the waves in flight (1.2 GB)
+  // streams through HBM on every access, at half that the kernel is 20 % faster (measured).
+  constexpr int lds_pad = 10000;
+  // two capacities: a lane's scratch working set scales with it
+  if (pmax + 8 <= 56)
+    hipLaunchKernelGGL(k_build_corridors<56>, dim3((n + 63) / 64), dim3(64), lds_pad, st, n, cp, knots, points,
+                       count, pmax, corridor, ccount, cmax, n_failed);
+  else
+    hipLaunchKernelGGL(k_build_corridors<kCorMaxPts>, dim3((n + 63) / 64), dim3(64), lds_pad, st, n, cp, knots,
+                       points, count, pmax, corridor, ccount, cmax, n_failed);
 }
 
 }  // namespace cilqr
