@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--compact-percent", type=int, default=-1, help="CILQR_OPT_COMPACTION value (tuning experiments)")
     ap.add_argument("--spec-threshold", type=int, default=-1, help="CILQR_OPT_SPEC_THRESHOLD value (tuning experiments)")
     ap.add_argument("--seq-rounds", type=int, default=-1, help="CILQR_OPT_SEQ_ROUNDS value (tuning experiments)")
+    ap.add_argument("--team-threshold", type=int, default=-1, help="CILQR_OPT_TEAM_THRESHOLD value (tuning experiments)")
     ap.add_argument("--pipeline", type=int, default=3,
                     help="after the timed region, also measure throughput with this many batches in flight "
                          "(one handle + stream + host thread each; 0/1 = skip; single-GPU runs only)")
@@ -97,6 +98,8 @@ def main():
         opt.set_option(api.OPT_SEQ_ROUNDS, args.seq_rounds)
     if args.spec_threshold >= 0:
         opt.set_option(api.OPT_SPEC_THRESHOLD, args.spec_threshold)
+    if args.team_threshold >= 0:
+        opt.set_option(api.OPT_TEAM_THRESHOLD, args.team_threshold)
 
     d_start = torch.from_numpy(sc["start"]).to(dev)
     d_coarse = torch.from_numpy(sc["coarse"]).to(dev)
