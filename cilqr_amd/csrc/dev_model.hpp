@@ -301,17 +301,19 @@ CILQR_DEV int nearest_from_cell(const DeviceState& s, const double* __restrict__
   if (cnt == kGridFullScan) return nearest_segment_scan(tab, n, px, py);
   double best = DBL_MAX;
   int bi = 0;
-  // compact loop (not unrolled: this function is inlined at every disc of three kernels and an
-  // unrolled 15-way test made them instruction-cache bound)
+  // Compact loop (not unrolled: this function is inlined at every disc of three kernels and an
+  // unrolled 15-way test made them instruction-cache bound).  The trip count is the longest list
+  // of the wave, tested with a ballot, so the loop is a scalar branch around straight-line
+  // predicated code instead of a divergent loop with its exec-mask bookkeeping; a lane past the
+  // end of its list tests row 0 and discards the result.
 #pragma unroll 1
-  for (int k = 1; k <= cnt; ++k) {
+  for (int k = 1; __builtin_amdgcn_ballot_w64(k <= cnt) != 0; ++k) {
     const unsigned word = (k < 4) ? w[0] : (k < 8) ? w[1] : (k < 12) ? w[2] : w[3];
-    const int seg = (int)((word >> ((k & 3) * 8)) & 0xffu);
+    const int seg = (k <= cnt) ? (int)((word >> ((k & 3) * 8)) & 0xffu) : 0;
     const double d2 = segment_dist2(tab + seg * kLaneFields, px, py);
-    if (d2 < best) {
-      best = d2;
-      bi = seg;
-    }
+    const bool take = (k <= cnt) && (d2 < best);
+    best = take ? d2 : best;
+    bi = take ? seg : bi;
   }
   return bi;
 }
