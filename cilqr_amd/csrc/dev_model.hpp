@@ -253,14 +253,20 @@ CILQR_DEV void dynamics_jacobian(const Params& p, const double* s, const double*
 // monotone; exact ties -- the shared end point of two consecutive segments -- stay ties, so the
 // strict '<' keeps the reference's "first index wins").
 CILQR_DEV double segment_dist2(const double* __restrict__ r, double px, double py) {
-  const double sx = r[3], sy = r[4], ux = r[5], uy = r[6], len = r[7];
+  double sx = r[3], sy = r[4], ux = r[5], uy = r[6], len = r[7], ex = r[8], ey = r[9];
+  // All seven values are requested before anything is computed (one LDS round trip per candidate):
+  // left alone, the compiler turns the case selection below into branches and sinks the loads of
+  // the end point into one of them, which puts a second dependent round trip and two exec-mask
+  // switches on the critical path of every candidate test.
+  asm volatile("" : "+v"(sx), "+v"(sy), "+v"(ux), "+v"(uy), "+v"(len), "+v"(ex), "+v"(ey));
   const double x0 = px - sx, y0 = py - sy;
-  const double d_start = x0 * x0 + y0 * y0;
+  double d_start = x0 * x0 + y0 * y0;
   const double proj = x0 * ux + y0 * uy;
-  const double x1 = px - r[8], y1 = py - r[9];
-  const double d_end = x1 * x1 + y1 * y1;
+  const double x1 = px - ex, y1 = py - ey;
+  double d_end = x1 * x1 + y1 * y1;
   const double c = x0 * uy - y0 * ux;
-  const double d_perp = c * c;
+  double d_perp = c * c;
+  asm volatile("" : "+v"(d_start), "+v"(d_end), "+v"(d_perp));   // three values, then selects
   // same case order as DistanceTo: degenerate, before the start, past the end, foot inside
   return (len <= kMathEps || proj <= 0.0) ? d_start : (proj >= len ? d_end : d_perp);
 }
