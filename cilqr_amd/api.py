@@ -123,7 +123,7 @@ def lib():
         L.cilqr_default_corridor_config.restype = None
         L.cilqr_build_corridors.argtypes = [C.c_void_p, C.POINTER(CorridorConfig), C.c_int32, C.c_int32, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
-                                            C.c_int32, C.POINTER(C.c_int32)]
+                                            C.c_int32, C.POINTER(C.c_int32), C.c_void_p]
         L.cilqr_lane_constraints.argtypes = [C.c_void_p, C.c_int32, C.c_double, C.c_int32, C.c_void_p, C.c_int32]
         L.cilqr_device_math.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
         L.cilqr_stage_load.argtypes = [C.c_void_p, C.POINTER(ProblemBatch)]
@@ -333,7 +333,8 @@ class BatchIlqrOptimizer:
                                                   1 if use_grid else 0, MEM_HOST), "nearest_lane")
         return left, right
 
-    def build_corridors(self, knots, points, point_count, cmax: int = 16, cfg: "CorridorConfig | None" = None):
+    def build_corridors(self, knots, points, point_count, cmax: int = 16, cfg: "CorridorConfig | None" = None,
+                        want_polygons: bool = False):
         """Corridor::BuildCorridorConstraints for a batch (corridor.cc:58-87): knots [B,K,3] = x, y, theta,
         points [B,K,P,2] obstacle corner points per knot, point_count [B,K].  Returns (corridor [B,K,cmax,3],
         corridor_count [B,K] int32 -- negative where a corridor could not be built --, n_failed)."""
@@ -346,17 +347,21 @@ class BatchIlqrOptimizer:
         cor = np.zeros((B, K, cmax, 3))
         ccnt = np.zeros((B, K), dtype=np.int32)
         nf = C.c_int32(0)
+        poly = np.zeros((B, K, cmax, 2)) if want_polygons else None
         self._chk(self.L.cilqr_build_corridors(self.h, C.byref(cfg), B, K, _ptr(knots), _ptr(points) if P else None,
                                                cnt.ctypes.data, P, _ptr(cor), ccnt.ctypes.data, cmax, MEM_HOST,
-                                               C.byref(nf)), "build_corridors")
+                                               C.byref(nf), _ptr(poly) if want_polygons else None), "build_corridors")
+        if want_polygons:
+            return cor, ccnt, int(nf.value), poly
         return cor, ccnt, int(nf.value)
 
     def build_corridors_raw(self, cfg, batch, n_knots, knots_ptr, points_ptr, count_ptr, max_points, corridor_ptr,
-                            ccount_ptr, cmax, memory):
+                            ccount_ptr, cmax, memory, polygons_ptr=None):
         """Pointer-level form (device or host memory); returns (rc, n_failed)."""
         nf = C.c_int32(0)
         rc = self.L.cilqr_build_corridors(self.h, C.byref(cfg), batch, n_knots, knots_ptr, points_ptr, count_ptr,
-                                          max_points, corridor_ptr, ccount_ptr, cmax, memory, C.byref(nf))
+                                          max_points, corridor_ptr, ccount_ptr, cmax, memory, C.byref(nf),
+                                          polygons_ptr)
         return rc, int(nf.value)
 
     def open_loop_rollout(self, x0, U):

@@ -85,7 +85,8 @@ __global__ __launch_bounds__(64) void k_build_corridors(int n, CorridorParams cp
                                                         const double* __restrict__ points,
                                                         const int* __restrict__ count, int pmax,
                                                         double* __restrict__ corridor, int* __restrict__ ccount,
-                                                        int cmax, int* __restrict__ n_failed) {
+                                                        int cmax, int* __restrict__ n_failed,
+                                                        double* __restrict__ polygons) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
   const double ox = knots[3 * t], oy = knots[3 * t + 1], theta = knots[3 * t + 2];
@@ -224,6 +225,10 @@ __global__ __launch_bounds__(64) void k_build_corridors(int n, CorridorParams cp
               qx = qx0;
               qy = qy0;
             }
+            if (polygons != nullptr && i < m) {
+              polygons[((size_t)t * cmax + i) * 2] = qx;
+              polygons[((size_t)t * cmax + i) * 2 + 1] = qy;
+            }
             if (i == 0) {
               qx0 = qx;
               qy0 = qy;
@@ -244,6 +249,8 @@ __global__ __launch_bounds__(64) void k_build_corridors(int n, CorridorParams cp
   {
     double* out = corridor + (size_t)t * cmax * 3;
     for (int i = 3 * m; i < 3 * cmax; ++i) out[i] = 0.0;   // rows past the count: zeros
+    if (polygons != nullptr)
+      for (int i = 2 * m; i < 2 * cmax; ++i) polygons[(size_t)t * cmax * 2 + i] = 0.0;
   }
   ccount[t] = code < 0 ? code : m;
   if (code < 0) atomicAdd(n_failed, 1);
@@ -251,7 +258,7 @@ __global__ __launch_bounds__(64) void k_build_corridors(int n, CorridorParams cp
 
 void launch_build_corridors(int n, const CorridorParams& cp, const double* knots, const double* points,
                             const int* count, int pmax, double* corridor, int* ccount, int cmax, int* n_failed,
-                            hipStream_t st) {
+                            double* polygons, hipStream_t st) {
   // Unused dynamic LDS caps the kernel at 16 waves per CU.  A lane's working set lives in scratch
   // memory; with every wave slot filled (32 per CU) the scratch of the waves in flight (1.2 GB)
   // streams through HBM on every access, at half that the kernel is 20 % faster (measured).
@@ -259,10 +266,10 @@ void launch_build_corridors(int n, const CorridorParams& cp, const double* knots
   // two capacities: a lane's scratch working set scales with it
   if (pmax + 8 <= 56)
     hipLaunchKernelGGL(k_build_corridors<56>, dim3((n + 63) / 64), dim3(64), lds_pad, st, n, cp, knots, points,
-                       count, pmax, corridor, ccount, cmax, n_failed);
+                       count, pmax, corridor, ccount, cmax, n_failed, polygons);
   else
     hipLaunchKernelGGL(k_build_corridors<kCorMaxPts>, dim3((n + 63) / 64), dim3(64), lds_pad, st, n, cp, knots,
-                       points, count, pmax, corridor, ccount, cmax, n_failed);
+                       points, count, pmax, corridor, ccount, cmax, n_failed, polygons);
 }
 
 }  // namespace cilqr

@@ -861,7 +861,7 @@ void cilqr_default_corridor_config(cilqr_corridor_config* c) {
 int cilqr_build_corridors(cilqr_handle h, const cilqr_corridor_config* cfg, int32_t batch, int32_t n_knots,
                           const double* knots, const double* points, const int32_t* point_count,
                           int32_t max_points, double* corridor, int32_t* corridor_count, int32_t cmax,
-                          int32_t memory, int32_t* n_failed) {
+                          int32_t memory, int32_t* n_failed, double* polygons) {
   if (h == nullptr || cfg == nullptr || knots == nullptr || point_count == nullptr || corridor == nullptr ||
       corridor_count == nullptr)
     return CILQR_ERR_NULL;                                          // corridor.cc:29-35
@@ -872,19 +872,20 @@ int cilqr_build_corridors(cilqr_handle h, const cilqr_corridor_config* cfg, int3
   HIP_TRY(hipSetDevice(h->device));
   const size_t n = (size_t)batch * n_knots;
   const size_t b_knots = n * 3 * 8, b_pts = n * (size_t)max_points * 2 * 8, b_cnt = n * 4;
-  const size_t b_cor = n * (size_t)cmax * 3 * 8;
+  const size_t b_cor = n * (size_t)cmax * 3 * 8, b_poly = polygons ? n * (size_t)cmax * 2 * 8 : 0;
   CorridorParams cp{cfg->max_diff_x, cfg->max_diff_y, cfg->radius, cfg->max_axis_x, cfg->max_axis_y};
   void *t_in = nullptr, *t_out = nullptr, *t_fail = nullptr;
   int rc = CILQR_OK;
   const double *d_knots = knots, *d_pts = points;
   const int* d_cnt = point_count;
   double* d_cor = corridor;
+  double* d_poly = polygons;
   int* d_ccnt = corridor_count;
   if (hipMalloc(&t_fail, 256) != hipSuccess) return CILQR_ERR_DEVICE;
   if (hipMemsetAsync(t_fail, 0, 4, h->stream) != hipSuccess) rc = CILQR_ERR_DEVICE;
   if (rc == CILQR_OK && memory == CILQR_MEM_HOST) {
     const size_t o_pts = (b_knots + 255) / 256 * 256, o_cnt = o_pts + (b_pts + 255) / 256 * 256;
-    if (hipMalloc(&t_in, o_cnt + b_cnt + 256) != hipSuccess || hipMalloc(&t_out, b_cor + 256 + b_cnt) != hipSuccess) {
+    if (hipMalloc(&t_in, o_cnt + b_cnt + 256) != hipSuccess || hipMalloc(&t_out, b_cor + 512 + b_cnt + b_poly) != hipSuccess) {
       rc = CILQR_ERR_DEVICE;
     } else {
       char* bi = static_cast<char*>(t_in);
@@ -898,16 +899,18 @@ int cilqr_build_corridors(cilqr_handle h, const cilqr_corridor_config* cfg, int3
       d_cnt = reinterpret_cast<const int*>(bi + o_cnt);
       d_cor = reinterpret_cast<double*>(bo);
       d_ccnt = reinterpret_cast<int*>(bo + (b_cor + 255) / 256 * 256);
+      if (polygons) d_poly = reinterpret_cast<double*>(bo + (b_cor + 255) / 256 * 256 + (b_cnt + 255) / 256 * 256);
     }
   }
   int failed = 0;
   if (rc == CILQR_OK) {
     launch_build_corridors((int)n, cp, d_knots, d_pts, d_cnt, max_points, d_cor, d_ccnt, cmax,
-                           static_cast<int*>(t_fail), h->stream);
+                           static_cast<int*>(t_fail), d_poly, h->stream);
     if (hipGetLastError() != hipSuccess) rc = CILQR_ERR_DEVICE;
     if (rc == CILQR_OK && memory == CILQR_MEM_HOST) {
       if (hipMemcpyAsync(corridor, d_cor, b_cor, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
-          hipMemcpyAsync(corridor_count, d_ccnt, b_cnt, hipMemcpyDeviceToHost, h->stream) != hipSuccess)
+          hipMemcpyAsync(corridor_count, d_ccnt, b_cnt, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+          (polygons && hipMemcpyAsync(polygons, d_poly, b_poly, hipMemcpyDeviceToHost, h->stream) != hipSuccess))
         rc = CILQR_ERR_DEVICE;
     }
     if (rc == CILQR_OK &&

@@ -190,7 +190,7 @@ struct CorridorParams {
 };
 void launch_build_corridors(int n, const CorridorParams& cp, const double* knots, const double* points,
                             const int* count, int pmax, double* corridor, int* ccount, int cmax, int* n_failed,
-                            hipStream_t st);
+                            double* polygons, hipStream_t st);
 void launch_device_math(int fn, int n, const double* in, double* out, hipStream_t st);
 void launch_rollout(const Params& p, int B, const double* x0, const double* U, double* X, hipStream_t st);
 // stage_read helpers: gather a batch-fastest tensor into problem-major order

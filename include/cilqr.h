@@ -231,11 +231,14 @@ void cilqr_default_corridor_config(cilqr_corridor_config* cfg);
  *   corridor_count [batch][n_knots]                 cilqr_problem_batch::corridor / corridor_count
  * A knot whose corridor cannot be built gets a negative count (-2: fewer than 4 usable points,
  * -3: more than cmax half-planes, -4: degenerate hull) and is counted in *n_failed; the reference
- * fails the whole Plan in that case (cc:78-81).  max_points <= 88.  `memory` applies to all arrays. */
+ * fails the whole Plan in that case (cc:78-81).  max_points <= 88.  `memory` applies to all arrays.
+ *   polygons       [batch][n_knots][cmax][2]        optional out (NULL to skip): the vertices of each
+ *                                                   corridor polygon (`convex_polygons`, cc:244-249),
+ *                                                   vertex i being the start of half-plane i */
 int cilqr_build_corridors(cilqr_handle h, const cilqr_corridor_config* cfg, int32_t batch, int32_t n_knots,
                           const double* knots, const double* points, const int32_t* point_count,
                           int32_t max_points, double* corridor, int32_t* corridor_count, int32_t cmax,
-                          int32_t memory, int32_t* n_failed);
+                          int32_t memory, int32_t* n_failed, double* polygons);
 
 /* LaneBoundarySample (corridor.cc:298-311) + CalLeftLaneConstraints / CalRightLaneConstraints
  * (cc:265-296) + HalfPlaneConstraint (cc:313-321), host only: boundary [n][2] -> rows [.][7] in the

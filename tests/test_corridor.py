@@ -219,3 +219,57 @@ def test_obstacles_to_trajectories_on_the_device(built):
     ref = oracle_reference(sc2, oracle_cfg_from(opt.cfg))
     assert_parity(host, ref, max_unstable_frac=0.3)
     opt.close()
+
+
+@pytest.mark.gpu
+def test_cpp_corridor_adapter_matches_oracle(built, tmp_path):
+    """planning::Corridor-shaped C++ adapter (include/cilqr/corridor.hpp), one trajectory, host
+    containers: half-planes and polygons against the oracle knot by knot, lane constraints equal
+    to the oracle's, error paths of Corridor::Plan (corridor.cc:24-35), stored point lists."""
+    import subprocess
+    from test_host import build_corridor_adapter_test
+    exe = build_corridor_adapter_test(tmp_path)
+    sc = scenario.generate("mix11", 3, seed=45, obstacle_points=True)
+    b = 1
+    K, P = sc["coarse"].shape[1], sc["obstacle_points"].shape[2]
+    road = scenario.build_road()
+    lb = np.stack(road.cartesian(road.s, scenario.LEFT_BOUND), 1)
+    rb = np.stack(road.cartesian(road.s, -scenario.RIGHT_BOUND), 1)
+    scene = tmp_path / "scene.bin"
+    knots = np.concatenate([(np.arange(K) * sc["dt"])[:, None], sc["coarse"][b, :, :3]], axis=1)
+    with open(scene, "wb") as f:
+        np.array([K, P, len(lb), len(rb)], np.int32).tofile(f)
+        np.ascontiguousarray(knots, np.float64).tofile(f)
+        np.ascontiguousarray(sc["obstacle_count"][b], np.int32).tofile(f)
+        np.ascontiguousarray(sc["obstacle_points"][b], np.float64).tofile(f)
+        np.ascontiguousarray(lb, np.float64).tofile(f)
+        np.ascontiguousarray(rb, np.float64).tofile(f)
+    out = tmp_path / "out.bin"
+    r = subprocess.run([str(exe), str(scene), str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    raw = open(out, "rb").read()
+    ok, n_left, n_right, errors_ok = np.frombuffer(raw[:16], np.int32)
+    assert ok == 1 and errors_ok == 1
+    counts = np.frombuffer(raw[16:16 + 4 * K], np.int32)
+    off = 16 + 4 * K
+    n_same = 0
+    for k in range(K):
+        m = counts[k]
+        planes = np.frombuffer(raw[off:off + m * 24], np.float64).reshape(m, 3); off += m * 24
+        poly = np.frombuffer(raw[off:off + m * 16], np.float64).reshape(m, 2); off += m * 16
+        n = sc["obstacle_count"][b, k]
+        pts = sc["obstacle_points"][b, k, :n]
+        ox, oy, th = sc["coarse"][b, k, :3]
+        _check_corridor(planes, ox, oy, pts)
+        ocons, opoly = orc.build_corridor(ox, oy, th, pts)
+        if len(ocons) == m:
+            n_same += 1
+            assert (np.abs(planes - ocons) / np.abs(ocons).max(axis=1, keepdims=True)).max() < 1e-5
+            assert np.abs(poly - opoly).max() < 1e-4
+    assert n_same >= K - 1
+    left = np.frombuffer(raw[off:off + n_left * 56], np.float64).reshape(n_left, 7); off += n_left * 56
+    right = np.frombuffer(raw[off:off + n_right * 56], np.float64).reshape(n_right, 7); off += n_right * 56
+    assert np.array_equal(left, orc.lane_constraints(lb, 5.0, True))
+    assert np.array_equal(right, orc.lane_constraints(rb, 5.0, False))
+    stored = np.frombuffer(raw[off:off + 4 * K], np.int32)
+    assert np.array_equal(stored, sc["obstacle_count"][b] + 8)      # AddCorridorPoints appends 8 box points

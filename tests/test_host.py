@@ -175,6 +175,22 @@ def build_adapter_test(tmp_path):
     return exe
 
 
+def build_corridor_adapter_test(tmp_path):
+    exe = tmp_path / "corridor_adapter_test"
+    cmd = ["g++", "-std=c++14", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "cpp", "corridor_adapter_test.cc"), "-o", str(exe),
+           "-L" + os.path.dirname(api.LIB_PATH), "-lcilqr_hip", "-Wl,-rpath," + os.path.dirname(api.LIB_PATH),
+           "-Wl,-rpath-link,/opt/rocm/lib"]
+    subprocess.check_call(cmd)
+    return exe
+
+
+def test_corridor_adapter_compiles_as_cxx14_against_the_c_abi(built, tmp_path):
+    """include/cilqr/corridor.hpp (the planning::Corridor call surface) builds with C++14 / g++ and
+    links against the C-ABI library only."""
+    assert build_corridor_adapter_test(tmp_path).exists()
+
+
 def test_cpp_adapter_compiles_as_cxx14_against_the_c_abi(built, tmp_path):
     """The drop-in header (include/cilqr/ilqr_optimizer.hpp) must build with the reference's own
     toolchain settings (C++14, g++, no HIP headers) and link against the C-ABI library only."""
