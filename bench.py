@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--batch", type=int, default=65536, help="problems per GPU")
     ap.add_argument("--scene", default="mix11")
     ap.add_argument("--seed", type=int, default=2)
-    ap.add_argument("--cpu-sample", type=int, default=1024, help="problems timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=3072, help="problems timed on the CPU oracle (0 = skip); 3072 scenes = about 15 s on one core")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
     ap.add_argument("--compact-percent", type=int, default=-1, help="CILQR_OPT_COMPACTION value (tuning experiments)")
     ap.add_argument("--spec-threshold", type=int, default=-1, help="CILQR_OPT_SPEC_THRESHOLD value (tuning experiments)")

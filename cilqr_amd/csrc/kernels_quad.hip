@@ -233,6 +233,36 @@ void launch_spec_cost(const DeviceState& s, const int* list, const int* n_ptr, i
   hipLaunchKernelGGL(k_spec_cost, g, dim3(256), lane_lds_bytes(s), st, s, list, n_ptr, n_max, r0);
 }
 
+// knot i of candidate alpha_r of the problems pending in round r
+__global__ __launch_bounds__(256) void k_round_cost(DeviceState s, int r, int n_max) {
+  extern __shared__ double lds[];
+  const int* __restrict__ list = s.pend + (size_t)r * s.Bcap;
+  const int n = (r == 0) ? active_count(s, n_max) : min(s.counters[r], n_max);
+  if ((int)(blockIdx.x * blockDim.x) >= n) return;
+  const double* lanes = stage_lanes(s, lds);
+  const int i = blockIdx.y;
+  const size_t cap = (size_t)s.spec_cap;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+    const int j = (r == 0) ? e : list[e];
+    const int slot = s.act[j];
+    if (s.acc_idx[slot] != -1) continue;
+    const double2* xb = s.Xs + ((size_t)r * s.p.K + i) * 3 * cap + j;
+    const double2 p0 = xb[0], p1 = xb[cap], p2 = xb[2 * cap];
+    const double x[6] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y};
+    double u[2] = {0.0, 0.0};
+    if (i < s.p.N) {
+      const double2 q = s.Us[((size_t)r * s.p.N + i) * cap + j];
+      u[0] = q.x; u[1] = q.y;
+    }
+    knot_cost_any(s, lanes, i, slot, x, u, s.parts + ((size_t)r * s.p.K + i) * kPartPairs * cap + j, cap);
+  }
+}
+
+void launch_round_cost(const DeviceState& s, int r, int n_max, int n_grid, hipStream_t st) {
+  dim3 g((n_grid + 255) / 256, s.p.K);
+  hipLaunchKernelGGL(k_round_cost, g, dim3(256), lane_lds_bytes(s), st, s, r, n_max);
+}
+
 __global__ __launch_bounds__(64) void k_reduce_only(DeviceState s, const int* __restrict__ list, int n) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;

@@ -112,6 +112,66 @@ CILQR_DEV void forward_problem(const DeviceState& s, int slot, double alpha) {
   forward_core(s, slot, alpha, OutSlot{s, s.cur[slot] ^ 1, slot});
 }
 
+// G rollouts of one problem at once (alpha_0 .. alpha_{G-1}) into the speculative arena at list
+// position j: the nominal trajectory and the gains of a step are loaded once for all of them, and
+// the G dynamics chains are independent, which fills the latency of each other.  Same arithmetic
+// per rollout as forward_core.
+template <int G>
+CILQR_DEV void forward_multi(const DeviceState& s, int slot, int j) {
+  const Params& p = s.p;
+  const int Bc = s.Bcap, N = p.N;
+  const int buf = s.cur[slot];
+  double x[G][6];
+  {
+    const double2* gp = s.goals + slot;
+    const double2 g0 = gp[0], g1 = gp[(size_t)Bc], g2 = gp[(size_t)2 * Bc];
+#pragma unroll
+    for (int r = 0; r < G; ++r) {
+      x[r][0] = g0.x; x[r][1] = g0.y; x[r][2] = g1.x; x[r][3] = g1.y; x[r][4] = g2.x; x[r][5] = g2.y;
+      OutSpec{s, r, j}.x(0, x[r]);
+    }
+  }
+  FwdStep pf[kFwdAhead];
+#pragma unroll
+  for (int d = 0; d < kFwdAhead; ++d)
+    if (d < N) load_fwd_step(s, buf, d, slot, pf[d]);
+  for (int i0 = 0; i0 < N; i0 += kFwdAhead) {
+#pragma unroll
+    for (int d = 0; d < kFwdAhead; ++d) {
+      const int i = i0 + d;
+      if (i < N) {
+        const FwdStep c = pf[d];
+        if (i + kFwdAhead < N) load_fwd_step(s, buf, i + kFwdAhead, slot, pf[d]);
+        const double xs[6] = {c.x0.x, c.x0.y, c.x1.x, c.x1.y, c.x2.x, c.x2.y};
+        const double us[2] = {c.u.x, c.u.y};
+#pragma unroll
+        for (int r = 0; r < G; ++r) {
+          double dx[6];
+#pragma unroll
+          for (int e = 0; e < 6; ++e) dx[e] = x[r][e] - xs[e];
+          double u[2];
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            double acc = c.kk[q * 3].x * dx[0];
+            acc += c.kk[q * 3].y * dx[1];
+            acc += c.kk[q * 3 + 1].x * dx[2];
+            acc += c.kk[q * 3 + 1].y * dx[3];
+            acc += c.kk[q * 3 + 2].x * dx[4];
+            acc += c.kk[q * 3 + 2].y * dx[5];
+            const double kff = (q == 0) ? c.kk[6].x : c.kk[6].y;
+            u[q] = (us[q] + acc) + kAlpha[r] * kff;                         // cc:407
+          }
+          u[1] = normalize_angle(u[1]);                                     // cc:408
+          const OutSpec out{s, r, j};
+          out.u(i, u);
+          dynamics(p, x[r], u, x[r]);
+          out.x(i + 1, x[r]);
+        }
+      }
+    }
+  }
+}
+
 // stage API: plain rollout of the listed slots with one alpha
 __global__ __launch_bounds__(64) void k_forward(DeviceState s, const int* __restrict__ list, int n,
                                                 double alpha, int skip_done) {
@@ -281,6 +341,90 @@ __global__ __launch_bounds__(256) void k_spec_copy(DeviceState s, const int* __r
   }
 }
 
+// ---- pre-rolled rounds: alpha_0 .. alpha_{G-1} of every active problem are rolled out in one pass
+// (forward_multi), then evaluated round by round: round r costs and tests only the problems that
+// rejected alpha_0 .. alpha_{r-1}.  The arena position of a problem is its position j in the active
+// list; pending lists 1 .. G-1 hold such positions, the last one (problems that rejected all G)
+// holds slots, which is what the speculative pass over the remaining step sizes takes.
+template <int G>
+__global__ __launch_bounds__(64) void k_multi_forward(DeviceState s, int n) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= active_count(s, n)) return;
+  const int slot = s.act[j];
+  if (s.gnorm[slot] < 1e-6 && s.lambda[slot] < 1e-5) {   // cc:235-241
+    s.status[s.pid[slot]] = 3;   // CILQR_ST_GNORM
+    s.acc_idx[slot] = -2;
+    return;
+  }
+  s.acc_idx[slot] = -1;
+  forward_multi<G>(s, slot, j);
+}
+
+// round r: total cost of candidate alpha_r (knot partials summed in index order), acceptance test
+// (cc:252-261); rejected -> pending list r + 1 (positions, or slots when `last`)
+__global__ __launch_bounds__(64) void k_round_pick(DeviceState s, int r, int n_max, int last) {
+  const int* __restrict__ list = s.pend + (size_t)r * s.Bcap;
+  const int n = (r == 0) ? active_count(s, n_max) : min(s.counters[r], n_max);
+  const size_t cap = (size_t)s.spec_cap;
+  const int K = s.p.K, N = s.p.N;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+    const int j = (r == 0) ? e : list[e];
+    const int slot = s.act[j];
+    if (s.acc_idx[slot] != -1) continue;   // left at the gradient-norm exit
+    double jj = 0.0, dx = 0.0, du = 0.0, cc = 0.0, lc = 0.0;
+    const double2* pb = s.parts + (size_t)r * K * kPartPairs * cap + j;
+    for (int i = 0; i < K; ++i) {
+      const double2* o = pb + (size_t)i * kPartPairs * cap;
+      const double2 a = o[0], b = o[cap], c = o[2 * cap];
+      jj += a.x;
+      dx += b.x;
+      cc += c.x;
+      lc += c.y;
+    }
+    for (int i = 0; i < N; ++i) {
+      const double2* o = pb + (size_t)i * kPartPairs * cap;
+      jj += o[0].y;
+      du += o[cap].y;
+    }
+    const double dyn = dx + du;
+    const double c5[5] = {jj + dyn + cc + lc, jj, dyn, cc, lc};
+    const double alpha = kAlpha[r];
+    const double dcost = s.cost_old[slot] - c5[0];                                  // cc:254
+    const double expected = -alpha * (s.dV[slot] + alpha * s.dV[(size_t)s.Bcap + slot]);  // cc:255
+    const double z = dcost / expected;                                              // cc:257
+#pragma unroll
+    for (int c = 0; c < 5; ++c) s.trial[(size_t)c * s.Bcap + slot] = c5[c];
+    if ((z > 1e-4 && z < 10.0) && dcost > 0.0) {                                    // cc:258
+      s.acc_idx[slot] = r;
+      s.dcost[slot] = dcost;
+      s.cur[slot] ^= 1;   // k_multi_copy fills the new current buffer
+    } else if (r + 1 < kNumAlpha) {
+      const int pos = atomicAdd(&s.counters[r + 1], 1);
+      s.pend[(size_t)(r + 1) * s.Bcap + pos] = last ? slot : j;
+    }
+  }
+}
+
+// the candidate accepted in a pre-rolled round becomes the iterate: one thread per (position, knot)
+__global__ __launch_bounds__(256) void k_multi_copy(DeviceState s, int n_max, int G) {
+  const int n = active_count(s, n_max);
+  const int i = blockIdx.y;
+  const size_t cap = (size_t)s.spec_cap;
+  const int K = s.p.K, N = s.p.N, Bc = s.Bcap;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+    const int slot = s.act[j];
+    const int acc = s.acc_idx[slot];
+    if (acc < 0 || acc >= G) continue;
+    const int nb = s.cur[slot];
+    const double2* xb = s.Xs + ((size_t)acc * K + i) * 3 * cap + j;
+    double2* o = s.X + ((size_t)nb * K + i) * 3 * Bc + slot;
+    o[0] = xb[0];
+    o[(size_t)Bc] = xb[cap];
+    o[(size_t)2 * Bc] = xb[2 * cap];
+    if (i < N) s.U[((size_t)nb * N + i) * Bc + slot] = s.Us[((size_t)acc * N + i) * cap + j];
+  }
+}
+
 static void launch_spec(const DeviceState& s, const int* list, const int* n_ptr, int n_max, int n_grid, int r0,
                         int open, hipStream_t st) {
   const int na = kNumAlpha - r0;
@@ -299,6 +443,28 @@ void launch_linesearch(const DeviceState& s, int n_act, int spec_threshold, int 
     return;
   }
   const int R = seq_rounds < 1 ? 1 : (seq_rounds > kNumAlpha ? kNumAlpha : seq_rounds);
+  if (R <= 4) {
+    // pre-rolled rounds: one pass rolls out alpha_0 .. alpha_{R-1} of every active problem
+    const dim3 gf((n_act + 63) / 64), bf(64);
+    if (R == 1) hipLaunchKernelGGL(k_multi_forward<1>, gf, bf, 0, st, s, n_act);
+    else if (R == 2) hipLaunchKernelGGL(k_multi_forward<2>, gf, bf, 0, st, s, n_act);
+    else if (R == 3) hipLaunchKernelGGL(k_multi_forward<3>, gf, bf, 0, st, s, n_act);
+    else hipLaunchKernelGGL(k_multi_forward<4>, gf, bf, 0, st, s, n_act);
+    for (int r = 0; r < R; ++r) {
+      // later rounds carry a fraction of the batch: shrink the grids, stride inside
+      const int shrink = (r == 0) ? 1 : (r == 1 ? 2 : 8);
+      const int n_grid = (n_act + shrink - 1) / shrink;
+      launch_round_cost(s, r, n_act, n_grid, st);
+      // one lane per pending problem (never strided: a lane sums a whole cost column)
+      hipLaunchKernelGGL(k_round_pick, dim3((n_act + 63) / 64), dim3(64), 0, st, s, r, n_act, (r + 1 == R) ? 1 : 0);
+    }
+    hipLaunchKernelGGL(k_multi_copy, dim3((n_act + 255) / 256, s.p.K), dim3(256), 0, st, s, n_act, R);
+    if (R < kNumAlpha) {
+      const int n_grid = (n_act + 3) / 4;
+      launch_spec(s, s.pend + (size_t)R * s.Bcap, s.counters + R, n_act, n_grid, R, 0, st);
+    }
+    return;
+  }
   hipLaunchKernelGGL(k_search_open, dim3((n_act + 63) / 64), dim3(64), 0, st, s, n_act);
   for (int r = 0; r < R; ++r) {
     // later rounds carry a fraction of the batch: shrink the cost grid, stride inside

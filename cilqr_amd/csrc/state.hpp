@@ -164,6 +164,7 @@ void launch_cost_knots(const DeviceState& s, const int* list, const int* n_ptr, 
                        int cand, int skip_done, hipStream_t st);
 void launch_spec_cost(const DeviceState& s, const int* list, const int* n_ptr, int n_max, int n_grid, int r0,
                       hipStream_t st);
+void launch_round_cost(const DeviceState& s, int r, int n_max, int n_grid, hipStream_t st);
 void launch_init_cost_commit(const DeviceState& s, int n, hipStream_t st);
 void launch_quadratize(const DeviceState& s, const int* list, int n, int only_upd, hipStream_t st);
 void launch_backward(const DeviceState& s, const int* list, int n, const double* lambda_override,
