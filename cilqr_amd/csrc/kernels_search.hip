@@ -346,6 +346,7 @@ __global__ __launch_bounds__(256) void k_spec_copy(DeviceState s, const int* __r
 // rejected alpha_0 .. alpha_{r-1}.  The arena position of a problem is its position j in the active
 // list; pending lists 1 .. G-1 hold such positions, the last one (problems that rejected all G)
 // holds slots, which is what the speculative pass over the remaining step sizes takes.
+constexpr int kMaxPreRolled = 6;   // more sequential rounds than this: the round-by-round rollouts below
 template <int G>
 __global__ __launch_bounds__(64) void k_multi_forward(DeviceState s, int n) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -443,13 +444,15 @@ void launch_linesearch(const DeviceState& s, int n_act, int spec_threshold, int 
     return;
   }
   const int R = seq_rounds < 1 ? 1 : (seq_rounds > kNumAlpha ? kNumAlpha : seq_rounds);
-  if (R <= 4) {
+  if (R <= kMaxPreRolled) {
     // pre-rolled rounds: one pass rolls out alpha_0 .. alpha_{R-1} of every active problem
     const dim3 gf((n_act + 63) / 64), bf(64);
     if (R == 1) hipLaunchKernelGGL(k_multi_forward<1>, gf, bf, 0, st, s, n_act);
     else if (R == 2) hipLaunchKernelGGL(k_multi_forward<2>, gf, bf, 0, st, s, n_act);
     else if (R == 3) hipLaunchKernelGGL(k_multi_forward<3>, gf, bf, 0, st, s, n_act);
-    else hipLaunchKernelGGL(k_multi_forward<4>, gf, bf, 0, st, s, n_act);
+    else if (R == 4) hipLaunchKernelGGL(k_multi_forward<4>, gf, bf, 0, st, s, n_act);
+    else if (R == 5) hipLaunchKernelGGL(k_multi_forward<5>, gf, bf, 0, st, s, n_act);
+    else hipLaunchKernelGGL(k_multi_forward<6>, gf, bf, 0, st, s, n_act);
     for (int r = 0; r < R; ++r) {
       // later rounds carry a fraction of the batch: shrink the grids, stride inside
       const int shrink = (r == 0) ? 1 : (r == 1 ? 2 : 8);
