@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--pipeline", type=int, default=3,
                     help="after the timed region, also measure throughput with this many batches in flight "
                          "(one handle + stream + host thread each; 0/1 = skip; single-GPU runs only)")
+    ap.add_argument("--end-to-end", action="store_true",
+                    help="extra (never `value`): obstacle points -> cilqr_build_corridors -> solve on the device")
     ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "backward_traffic.json"))
     args = ap.parse_args()
 
@@ -211,6 +213,48 @@ def main():
             c[0].close()
         opt.set_stream(torch.cuda.current_stream().cuda_stream)
 
+    # Extra (never `value`): the producer in front of the solve.  Obstacle corner
+    # points per knot -> cilqr_build_corridors -> cilqr_solve_batch, everything resident in HBM.
+    end_to_end = None
+    if world == 1 and args.end_to_end:
+        sc_p = scenario.generate(spec, B, seed=args.seed, first_problem=rank * B, workers=workers, obstacle_points=True)
+        P_ = sc_p["obstacle_points"].shape[2]
+        d_knots = torch.from_numpy(np.ascontiguousarray(sc_p["coarse"][:, :, :3])).to(dev)
+        d_pts = torch.from_numpy(sc_p["obstacle_points"]).to(dev)
+        d_pcnt = torch.from_numpy(sc_p["obstacle_count"]).to(dev)
+        e_cor = torch.zeros((B, K, cmax, 3), dtype=torch.float64, device=dev)
+        e_cnt = torch.zeros((B, K), dtype=torch.int32, device=dev)
+        ccfg = api.default_corridor_config()
+        prob_e = opt.make_problem(B, d_start.data_ptr(), d_coarse.data_ptr(), e_cor.data_ptr(), e_cnt.data_ptr(),
+                                  cmax, left.ctypes.data, right.ctypes.data, left.shape[0], right.shape[0],
+                                  api.MEM_DEVICE)
+        opt.set_profiling(False)
+        torch.cuda.synchronize()
+        times_c, times_s, failed = [], [], 0
+        for it_ in range(1 + max(2, args.steps // 2)):
+            t1 = time.perf_counter()
+            rc_, nf_ = opt.build_corridors_raw(ccfg, B, K, d_knots.data_ptr(), d_pts.data_ptr(), d_pcnt.data_ptr(), P_,
+                                               e_cor.data_ptr(), e_cnt.data_ptr(), cmax, api.MEM_DEVICE)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            if rc_ != api.OK or opt.solve_raw(prob_e, sol) != api.OK:
+                raise api.CilqrError(rc_, "in end-to-end step")
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            if it_ > 0:
+                times_c.append(t2 - t1)
+                times_s.append(t3 - t2)
+            failed = nf_
+        tc, ts = sum(times_c) / len(times_c), sum(times_s) / len(times_s)
+        end_to_end = {"value": round(B / (tc + ts), 1), "unit": "solves/s", "corridor_ms": round(tc * 1e3, 3),
+                      "solve_ms": round(ts * 1e3, 3), "steps": len(times_c), "corridors_failed": failed,
+                      "mean_obstacle_points": round(float(sc_p["obstacle_count"].mean()), 2),
+                      "mean_half_planes": round(float(e_cnt.double().mean().item()), 2),
+                      "note": "corridors built by k_build_corridors (sphere-flip construction) instead of the "
+                              "generator's simplified ones: a different, larger feasible set, hence another "
+                              "iteration count than the timed region"}
+        opt.set_profiling(not args.no_profile)
+
     # sanity: every problem must have terminated with a valid status
     st = o_st.cpu().numpy()
     nc = o_nc.cpu().numpy()
@@ -297,6 +341,7 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
             "pipelined": pipelined,
+            "end_to_end": end_to_end,
             "breakdown_ms_per_step": {k: round(prof_acc[k] / args.steps, 3)
                                       for k in ("quad_ms", "bwd_ms", "ls_ms", "other_ms", "total_ms")},
             "lockstep_iterations_per_step": prof_acc["iters"] / args.steps,
