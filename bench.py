@@ -135,11 +135,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Warm-up steps carry HIP events around every phase (the per-phase breakdown below; ~4 % slower);
+    # the timed steps only around the backward launches, which is what the roofline needs (< 1 %).
+    warm = dict(quad_ms=0.0, bwd_ms=0.0, ls_ms=0.0, other_ms=0.0, total_ms=0.0, steps=0)
     for _ in range(args.warmup):
         step()
+        if not args.no_profile:
+            p = opt.profile()
+            warm["quad_ms"] += p.quadratize_ms
+            warm["bwd_ms"] += p.backward_ms
+            warm["ls_ms"] += p.linesearch_ms
+            warm["other_ms"] += p.other_ms
+            warm["total_ms"] += p.total_ms
+            warm["steps"] += 1
     fence()
-    prof_acc = dict(bwd_ms=0.0, bwd_launches=0, bwd_steps=0, quad_ms=0.0, ls_ms=0.0, other_ms=0.0,
-                    total_ms=0.0, iters=0, full_ms=0.0, full_launches=0)
+    if not args.no_profile:
+        opt.set_profiling(2)
+    prof_acc = dict(bwd_ms=0.0, bwd_launches=0, bwd_steps=0, iters=0, full_ms=0.0, full_launches=0)
     t_start = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -147,10 +159,6 @@ def main():
         prof_acc["bwd_ms"] += p.backward_ms
         prof_acc["bwd_launches"] += p.backward_launches
         prof_acc["bwd_steps"] += p.backward_problem_steps
-        prof_acc["quad_ms"] += p.quadratize_ms
-        prof_acc["ls_ms"] += p.linesearch_ms
-        prof_acc["other_ms"] += p.other_ms
-        prof_acc["total_ms"] += p.total_ms
         prof_acc["iters"] += p.iterations
         prof_acc["full_ms"] += p.backward_full_ms
         prof_acc["full_launches"] += p.backward_full_launches
@@ -342,8 +350,10 @@ def main():
             "cpu_baseline": cpu,
             "pipelined": pipelined,
             "end_to_end": end_to_end,
-            "breakdown_ms_per_step": {k: round(prof_acc[k] / args.steps, 3)
-                                      for k in ("quad_ms", "bwd_ms", "ls_ms", "other_ms", "total_ms")},
+            # per-phase HIP-event times of the WARM-UP step(s), which run with events around every phase
+            "breakdown_ms_per_step": ({k: round(warm[k] / warm["steps"], 3)
+                                       for k in ("quad_ms", "bwd_ms", "ls_ms", "other_ms", "total_ms")}
+                                      if warm["steps"] else None),
             "lockstep_iterations_per_step": prof_acc["iters"] / args.steps,
             "mean_cost_rows": float(nc.mean()),
             "status_histogram": np.bincount(st, minlength=6).tolist(),

@@ -207,8 +207,9 @@ class BatchIlqrOptimizer:
         if rc != OK:
             raise CilqrError(rc, "in cilqr_set_option")
 
-    def set_profiling(self, on: bool):
-        self.L.cilqr_set_profiling(self.h, 1 if on else 0)
+    def set_profiling(self, on):
+        """False / 0: off; True / 1: every phase of every iteration; 2: the backward launches only."""
+        self.L.cilqr_set_profiling(self.h, int(on))
 
     def profile(self) -> Profile:
         p = Profile()

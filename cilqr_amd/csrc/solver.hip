@@ -66,6 +66,7 @@ struct cilqr_solver {
   int job_rc = CILQR_OK;
   // profiling
   bool profiling = false;
+  int profiling_level = 1;
   std::vector<hipEvent_t> ev;
   std::vector<hipEvent_t> iter_ev;  // one per lockstep iteration (count read-back)
   cilqr_profile prof;
@@ -208,8 +209,10 @@ struct Timer {  // event pairs, resolved after the final sync
   size_t next = 0;
   std::vector<int> kind;  // 0 quad, 1 backward, 2 linesearch, 3 other
   std::vector<char> full_flags, live_flags;  // per backward launch: covered the whole batch / had work
+  bool open = false;   // the last begin() recorded an event, so the matching end() must too
   int begin(int k) {
-    if (!h->profiling) return 0;
+    open = h->profiling && (h->profiling_level != 2 || k == 1);   // level 2: the backward launches only
+    if (!open) return 0;
     if (next + 2 > h->ev.size()) {
       const size_t old = h->ev.size();
       h->ev.resize(old + 64);
@@ -220,7 +223,8 @@ struct Timer {  // event pairs, resolved after the final sync
     return hipEventRecord(h->ev[next++], h->stream) == hipSuccess ? 0 : -1;
   }
   int end() {
-    if (!h->profiling) return 0;
+    if (!open) return 0;
+    open = false;
     return hipEventRecord(h->ev[next++], h->stream) == hipSuccess ? 0 : -1;
   }
   void resolve(cilqr_profile* p) {
@@ -241,7 +245,7 @@ struct Timer {  // event pairs, resolved after the final sync
         default: p->other_ms += ms; break;
       }
     }
-    if (!kind.empty()) {
+    if (!kind.empty() && h->profiling_level == 1) {
       float ms = 0.f;
       (void)hipEventElapsedTime(&ms, h->ev[0], h->ev[next - 1]);
       p->total_ms = ms;
@@ -444,6 +448,7 @@ int cilqr_set_option(cilqr_handle h, int32_t option, int64_t value) {
 int cilqr_set_profiling(cilqr_handle h, int32_t enable) {
   if (h == nullptr) return CILQR_ERR_NULL;
   h->profiling = enable != 0;
+  h->profiling_level = (enable == 2) ? 2 : 1;
   return CILQR_OK;
 }
 
