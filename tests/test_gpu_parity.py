@@ -388,6 +388,25 @@ def test_team_backward_is_bit_identical_to_one_lane_per_problem():
     opt.close()
 
 
+@pytest.mark.parametrize("N", [1, 2, 3, 5, 7])
+def test_short_horizons_empty_knots_and_single_segment_lanes(N):
+    """Horizons shorter than the rollout's prefetch depth (4 steps) and than a backward team's
+    pipeline, knots without any corridor plane, lane tables of one segment, batches of 1 / 3 / 65."""
+    import dataclasses
+    for B in (1, 3, 65):
+        spec = dataclasses.replace(scenario.SPECS["mix11"], n_steps=N)
+        sc = scenario.generate(spec, B, seed=300 + N)
+        sc["ccount"][:, ::2] = 0
+        if N == 5:
+            sc["left"] = np.ascontiguousarray(sc["left"][3:4])
+            sc["right"] = np.ascontiguousarray(sc["right"][3:4])
+        opt = _opt(sc)
+        g = opt.plan(sc)
+        ref = oracle_reference(sc, oracle_cfg_from(opt.cfg))
+        assert_parity(g, ref, max_unstable_frac=0.2, what=f"N={N} B={B}")
+        opt.close()
+
+
 def test_full_size_batch_properties():
     """BASELINE configs[2] size (B = 65536, N = 50): 256 distinct scenes tiled 256x.  Size-independent
     properties: every copy of a scene gives bit-identical output wherever it sits in the batch, all
