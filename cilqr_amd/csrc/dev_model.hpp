@@ -366,6 +366,8 @@ CILQR_DEV void store_u(const DeviceState& s, int buf, int i, int slot, const dou
 CILQR_DEV void reduce_cost(const DeviceState& s, int slot, double* c5) {
   const int Bc = s.Bcap, K = s.p.K, N = s.p.N;
   double j = 0.0, dx = 0.0, du = 0.0, cc = 0.0, lc = 0.0;
+  // loads of several knots in flight; the sums stay in knot order
+#pragma unroll 8
   for (int i = 0; i < K; ++i) {
     const double2* o = s.part + (size_t)i * kPartPairs * Bc + slot;
     const double2 a = o[0], b = o[(size_t)Bc], c = o[(size_t)2 * Bc];
@@ -374,6 +376,7 @@ CILQR_DEV void reduce_cost(const DeviceState& s, int slot, double* c5) {
     cc += c.x;
     lc += c.y;
   }
+#pragma unroll 8
   for (int i = 0; i < N; ++i) {   // control terms follow the state terms (cc:510-513)
     const double2* o = s.part + (size_t)i * kPartPairs * Bc + slot;
     j += o[0].y;

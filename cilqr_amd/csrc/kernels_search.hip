@@ -267,6 +267,8 @@ __global__ __launch_bounds__(64) void k_spec_reduce(DeviceState s, const int* __
     }
     double jj = 0.0, dx = 0.0, du = 0.0, cc = 0.0, lc = 0.0;
     const double2* pb = s.parts + (size_t)r * K * kPartPairs * cap + j;
+    // loads of several knots in flight; the sums stay in knot order
+#pragma unroll 8
     for (int i = 0; i < K; ++i) {
       const double2* o = pb + (size_t)i * kPartPairs * cap;
       const double2 a = o[0], b = o[cap], c = o[2 * cap];
@@ -275,6 +277,7 @@ __global__ __launch_bounds__(64) void k_spec_reduce(DeviceState s, const int* __
       cc += c.x;
       lc += c.y;
     }
+#pragma unroll 8
     for (int i = 0; i < N; ++i) {
       const double2* o = pb + (size_t)i * kPartPairs * cap;
       jj += o[0].y;
@@ -374,6 +377,8 @@ __global__ __launch_bounds__(64) void k_round_pick(DeviceState s, int r, int n_m
     if (s.acc_idx[slot] != -1) continue;   // left at the gradient-norm exit
     double jj = 0.0, dx = 0.0, du = 0.0, cc = 0.0, lc = 0.0;
     const double2* pb = s.parts + (size_t)r * K * kPartPairs * cap + j;
+    // loads of several knots in flight; the sums stay in knot order
+#pragma unroll 8
     for (int i = 0; i < K; ++i) {
       const double2* o = pb + (size_t)i * kPartPairs * cap;
       const double2 a = o[0], b = o[cap], c = o[2 * cap];
@@ -382,6 +387,7 @@ __global__ __launch_bounds__(64) void k_round_pick(DeviceState s, int r, int n_m
       cc += c.x;
       lc += c.y;
     }
+#pragma unroll 8
     for (int i = 0; i < N; ++i) {
       const double2* o = pb + (size_t)i * kPartPairs * cap;
       jj += o[0].y;
