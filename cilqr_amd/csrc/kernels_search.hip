@@ -302,9 +302,14 @@ __global__ __launch_bounds__(64) void k_spec_pick(DeviceState s, const int* __re
     const double cost_old = s.cost_old[slot], dV0 = s.dV[slot], dV1 = s.dV[(size_t)Bc + slot];
     int acc = -1, last = kNumAlpha - 1;
     double dcost = 0.0;
-    for (int r = r0; r < kNumAlpha; ++r) {
+    double tot[kNumAlpha];   // all totals requested at once, then tested in order
+#pragma unroll
+    for (int r = 0; r < kNumAlpha; ++r) tot[r] = (r >= r0) ? s.spec_tot[(size_t)r * 5 * cap + j] : 0.0;
+#pragma unroll
+    for (int r = 0; r < kNumAlpha; ++r) {
+      if (r < r0) continue;
       const double alpha = kAlpha[r];
-      dcost = cost_old - s.spec_tot[(size_t)r * 5 * cap + j];
+      dcost = cost_old - tot[r];
       const double expected = -alpha * (dV0 + alpha * dV1);
       const double z = dcost / expected;
       if ((z > 1e-4 && z < 10.0) && dcost > 0.0) {
