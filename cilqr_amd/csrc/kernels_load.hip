@@ -486,7 +486,7 @@ void launch_export_done(const DeviceState& s, int n_act, double* traj, hipStream
 // same values because they depend only on the iterate), and everything indexed by problem.
 __global__ __launch_bounds__(256) void k_compact(DeviceState a, DeviceState b, int n_max) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= min(a.counters[0], n_max)) return;   // counters[0]: survivors counted by k_update
+  if (j >= min(*a.n_next, n_max)) return;   // survivors counted by k_update
   const int i = blockIdx.y;   // knot
   const int K = a.p.K, N = a.p.N;
   const int src = a.act_next[j];

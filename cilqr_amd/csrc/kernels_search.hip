@@ -498,20 +498,38 @@ void launch_linesearch(const DeviceState& s, int n_act, int spec_threshold, int 
 }
 
 // per-problem bookkeeping after the line search (cc:272-308, 312-319) + next active list
-// start of a lockstep iteration: latch the active count the previous k_update produced (or the
-// batch size) where every kernel of this iteration can read it, and clear the list counters
-__global__ void k_begin_iteration(DeviceState s, int first_n) {
-  if (threadIdx.x == 0) s.counters[kCntActive] = (first_n >= 0) ? first_n : s.counters[0];
-  __syncthreads();
-  if (threadIdx.x < kCntActive) s.counters[threadIdx.x] = 0;
+// once per solve: the ring of active counts starts with the batch size, everything else at zero
+// (afterwards k_update's epilogue keeps the counters)
+__global__ void k_init_counters(DeviceState s, int first_n) {
+  if (threadIdx.x < 64) s.counters[threadIdx.x] = (threadIdx.x == kCntActive) ? first_n : 0;
 }
-void launch_begin_iteration(const DeviceState& s, int first_n, hipStream_t st) {
-  hipLaunchKernelGGL(k_begin_iteration, dim3(1), dim3(64), 0, st, s, first_n);
+void launch_init_counters(const DeviceState& s, int first_n, hipStream_t st) {
+  hipLaunchKernelGGL(k_init_counters, dim3(1), dim3(64), 0, st, s, first_n);
 }
 
-__global__ __launch_bounds__(256) void k_update(DeviceState s, int n) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= active_count(s, n)) return;
+// The last block to finish publishes the survivor count to the host (pinned memory: no copy
+// kernel), clears the pending-list counters and the ring entry of the iteration after next: the
+// bookkeeping between two lockstep iterations needs no kernel of its own.
+CILQR_DEV void update_epilogue(const DeviceState& s) {
+  __shared__ int last;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    last = (atomicAdd(&s.counters[kCntTicket], 1) == (int)gridDim.x - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (last && threadIdx.x == 0) {
+    const int total = atomicAdd(s.n_next, 0);
+    *s.h_count_dev = total;
+    *s.n_clear = 0;
+    s.counters[kCntTicket] = 0;
+#pragma unroll
+    for (int r = 0; r <= kNumAlpha; ++r) s.counters[r] = 0;
+    __threadfence_system();
+  }
+}
+
+CILQR_DEV void update_problem(const DeviceState& s, int j) {
   const int slot = s.act[j];
   const int pb = s.pid[slot];
   const Params& p = s.p;
@@ -564,10 +582,16 @@ __global__ __launch_bounds__(256) void k_update(DeviceState s, int n) {
   s.acc_idx[slot] = -1;
   s.done_now[slot] = done ? 1 : 0;
   if (!done) {
-    const int pos = atomicAdd(&s.counters[0], 1);
+    const int pos = atomicAdd(s.n_next, 1);
     s.act_next[pos] = slot;
   }
 }
+__global__ __launch_bounds__(256) void k_update(DeviceState s, int n) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < active_count(s, n)) update_problem(s, j);
+  update_epilogue(s);
+}
+
 void launch_update(const DeviceState& s, int n_act, hipStream_t st) {
   if (n_act == 0) return;
   hipLaunchKernelGGL(k_update, dim3((n_act + 255) / 256), dim3(256), 0, st, s, n_act);

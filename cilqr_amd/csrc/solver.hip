@@ -50,7 +50,8 @@ struct cilqr_solver {
   size_t out_stage_bytes = 0;
   double* lanes_raw = nullptr;  // device [2*smax][7]
   double* lambda_stage = nullptr;
-  int* h_count = nullptr;  // pinned
+  int* h_count = nullptr;  // pinned, written by k_update through h_count_dev
+  int* h_count_dev = nullptr;
   int B = 0;               // problems loaded
   int stage = 0;           // bit0 loaded, bit1 iterate, bit2 quadratized, bit3 gains
   int spec_threshold = 8192;  // active sets up to this size evaluate all 11 step sizes at once
@@ -378,7 +379,10 @@ int cilqr_create(const cilqr_config* cfg, int32_t device, int32_t batch_capacity
   if (rc == CILQR_OK) rc = dev_alloc(h, &h->lambda_stage, B);
   if (rc == CILQR_OK && hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess)
     rc = CILQR_ERR_DEVICE;
-  if (rc == CILQR_OK && hipHostMalloc(reinterpret_cast<void**>(&h->h_count), (size_t)(cfg->max_iter + 64) * sizeof(int)) != hipSuccess)
+  if (rc == CILQR_OK && hipHostMalloc(reinterpret_cast<void**>(&h->h_count), (size_t)(cfg->max_iter + 64) * sizeof(int),
+                                      hipHostMallocMapped) != hipSuccess)
+    rc = CILQR_ERR_DEVICE;
+  if (rc == CILQR_OK && hipHostGetDevicePointer(reinterpret_cast<void**>(&h->h_count_dev), h->h_count, 0) != hipSuccess)
     rc = CILQR_ERR_DEVICE;
   if (rc == CILQR_OK && hipMemset(d.cor, 0, K * cmax * 3 * B * sizeof(double)) != hipSuccess)
     rc = CILQR_ERR_DEVICE;
@@ -522,8 +526,7 @@ int cilqr_solve_batch(cilqr_handle h, const cilqr_problem_batch* in, cilqr_solut
     for (size_t i = old; i < h->iter_ev.size(); ++i)
       HIP_TRY(hipEventCreateWithFlags(&h->iter_ev[i], hipEventDisableTiming));
   }
-  d.n_dev = d.counters + kCntActive;
-  o.n_dev = d.n_dev;
+  launch_init_counters(d, B, st);
   int n_hint = B;   // upper bound of the active count of the iteration being enqueued
   int span = B;     // slots occupied in the current arena (upper bound)
   int it = 0;
@@ -534,7 +537,13 @@ int cilqr_solve_batch(cilqr_handle h, const cilqr_problem_batch* in, cilqr_solut
       n_hint = h->h_count[it - kLead];
       if (n_hint == 0) break;                          // iterations it-kLead+1 .. it-1 were no-ops
     }
-    launch_begin_iteration(d, it == 0 ? B : -1, st);
+    // iteration `it` reads entry it % 3 of the ring of active counts, counts its survivors into
+    // the next entry and clears the one after that
+    d.n_dev = d.counters + kCntActive + it % 3;
+    d.n_next = d.counters + kCntActive + (it + 1) % 3;
+    d.n_clear = d.counters + kCntActive + (it + 2) % 3;
+    d.h_count_dev = h->h_count_dev + it;
+    o.n_dev = d.n_dev; o.n_next = d.n_next; o.n_clear = d.n_clear; o.h_count_dev = d.h_count_dev;
     if (tm.begin(0)) return CILQR_ERR_DEVICE;
     launch_quadratize(d, d.act, n_hint, 1, st);        // cc:203-214
     if (tm.end() || tm.begin(1)) return CILQR_ERR_DEVICE;
@@ -546,7 +555,6 @@ int cilqr_solve_batch(cilqr_handle h, const cilqr_problem_batch* in, cilqr_solut
     launch_export_done(d, n_hint, o_traj, st);         // cc:238,285,303,319
     if (o_it) launch_export_iter_traj(d, d.act, n_hint, o_it, out->max_iter_trajs, st);
     if (tm.end()) return CILQR_ERR_DEVICE;
-    HIP_TRY(hipMemcpyAsync(h->h_count + it, d.counters, sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipEventRecord(h->iter_ev[it], st));
     if (h->compaction && (int64_t)100 * n_hint <= (int64_t)h->compact_percent * span) {
       // the survivors have thinned out: re-pack them densely (k_compact reads the exact count)

@@ -139,8 +139,14 @@ struct DeviceState {
   // Non-null inside the solve loop: the host runs a couple of iterations ahead of the GPU and only
   // knows an upper bound of the active count; kernels clamp to the device-side value.
   const int* n_dev;
+  // where k_update of the iteration in flight counts the survivors (the next iteration's n_dev), the
+  // ring entry it clears for the iteration after that, and the host-visible copy of the count
+  int* n_next;
+  int* n_clear;
+  int* h_count_dev;
 };
-constexpr int kCntActive = 32;
+constexpr int kCntActive = 32;   // [32..34]: ring of active counts, iteration it reads entry it % 3
+constexpr int kCntTicket = 40;   // blocks of k_update that have finished
 
 // ---- launchers (one per kernel family; all asynchronous on `st`) ----
 struct ProblemView {  // device pointers to the problem-major inputs
@@ -174,7 +180,7 @@ void launch_forward(const DeviceState& s, const int* list, int n, double alpha, 
                     hipStream_t st);
 // the 11-round line search of one lockstep iteration (forward/cost/accept with compaction)
 void launch_linesearch(const DeviceState& s, int n_act, int spec_threshold, int seq_rounds, hipStream_t st);
-void launch_begin_iteration(const DeviceState& s, int first_n, hipStream_t st);
+void launch_init_counters(const DeviceState& s, int first_n, hipStream_t st);
 void launch_update(const DeviceState& s, int n_act, hipStream_t st);
 // trajectories of the slots that finished in the last update -> traj[pid]
 void launch_export_done(const DeviceState& s, int n_act, double* traj, hipStream_t st);
