@@ -50,6 +50,27 @@ CILQR_DEV void load_chunk(const double* __restrict__ cor, int Bc, int c0, int cn
   }
 }
 
+// first chunk of a knot: requested before the plane count is known (its addresses do not depend on
+// it), masked once the count has arrived -- one dependent memory round trip less per knot
+CILQR_DEV void load_first_chunk(const double* __restrict__ cor, int Bc, int cmax, PlaneChunk& pc) {
+#pragma unroll
+  for (int k = 0; k < kPlaneChunk; ++k) {
+    const double* q = cor + (size_t)min(k, cmax - 1) * 3 * Bc;
+    pc.a[k] = q[0];
+    pc.b[k] = q[(size_t)Bc];
+    pc.c[k] = q[(size_t)2 * Bc];
+  }
+}
+CILQR_DEV void mask_first_chunk(int cnt, PlaneChunk& pc) {
+#pragma unroll
+  for (int k = 0; k < kPlaneChunk; ++k) {
+    const bool live = k < cnt;
+    pc.a[k] = live ? pc.a[k] : 0.0;
+    pc.b[k] = live ? pc.b[k] : 0.0;
+    pc.c[k] = live ? pc.c[k] : 1.0;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // cost partials of one knot.  x, u: the knot's state / control; out[0], out[stride], out[2*stride]
 // ---------------------------------------------------------------------------------------------
@@ -78,10 +99,11 @@ CILQR_DEV void knot_cost_core(const DeviceState& s, const double* __restrict__ l
   const double2* gp = s.goals + (size_t)i * 3 * Bc + slot;
   const double2 g0 = gp[0];
   const double gth = gp[(size_t)Bc].x;
-  const int cnt = s.ccnt[(size_t)i * Bc + slot];
   const double* __restrict__ cor = s.cor + (size_t)i * s.cmax * 3 * Bc + slot;
   PlaneChunk pc;
-  load_chunk(cor, Bc, 0, cnt, pc);
+  load_first_chunk(cor, Bc, s.cmax, pc);
+  const int cnt = s.ccnt[(size_t)i * Bc + slot];
+  mask_first_chunk(cnt, pc);
   // JCost cc:501-513
   const double ex = x[0] - g0.x, ey = x[1] - g0.y, eth = x[2] - gth;
   const double jx = p.w_x * (ex * ex) + p.w_y * (ey * ey) + p.w_theta * (eth * eth);
@@ -365,10 +387,11 @@ CILQR_DEV void knot_quadratize(const DeviceState& s, const double* __restrict__ 
   const double2* gp = s.goals + (size_t)i * 3 * Bc + slot;
   const double2 g0 = gp[0];
   const double gth = gp[(size_t)Bc].x;
-  const int cnt = s.ccnt[(size_t)i * Bc + slot];
   const double* __restrict__ cor = s.cor + (size_t)i * s.cmax * 3 * Bc + slot;
   PlaneChunk pc;
-  load_chunk(cor, Bc, 0, cnt, pc);
+  load_first_chunk(cor, Bc, s.cmax, pc);
+  const int cnt = s.ccnt[(size_t)i * Bc + slot];
+  mask_first_chunk(cnt, pc);
   Quad q;
   q.lx[0] = 2.0 * p.w_x * (x[0] - g0.x);           // cc:623-628
   q.lx[1] = 2.0 * p.w_y * (x[1] - g0.y);
