@@ -179,12 +179,13 @@ def _rect_nearest(ox, oy, cx, cy, cth, hl, hw):
 
 
 def _chunk_job(args):
-    spec, n, seed, first, road, want_points = args
-    return _generate_chunk(spec, n, seed, first, road, want_points)
+    spec, n, seed, first, road, want_points, want_scn = args
+    return _generate_chunk(spec, n, seed, first, road, want_points, want_scn)
 
 
 def generate(spec: SceneSpec | str, batch: int, seed: int = 0, first_problem: int = 0,
-             road: Road | None = None, chunk: int = 1024, workers: int = 0, obstacle_points: bool = False):
+             road: Road | None = None, chunk: int = 1024, workers: int = 0, obstacle_points: bool = False,
+             scenarios: bool = False):
     """Generate `batch` scenes; problem p uses RNG stream (seed, first_problem + p).
 
     workers > 1 spreads the chunks over a thread pool (results are identical).
@@ -194,12 +195,16 @@ def generate(spec: SceneSpec | str, batch: int, seed: int = 0, first_problem: in
     (Query{Static,Dynamic}ObstaclesPoints, environment.cpp:153-182): obstacle_points[B,K,4*O,2], the
     corner points of the obstacles alive at each knot's time (packed to the front), and
     obstacle_count[B,K] int32 -- the inputs of BatchIlqrOptimizer.build_corridors.
+    scenarios=True adds the scene itself in the vocabulary of the reference's messages (msg/*.msg):
+    "obstacle_pose"[B,O,K,3] (x, y, theta of every obstacle at every knot time), "obstacle_live"[B,O,K]
+    bool, "obstacle_half_size"[O,2] (half length, half width) -- what cilqr_amd.scene_io turns into
+    static polygons and dynamic obstacles with trajectories -- and "road" (the centre line).
     """
     if isinstance(spec, str):
         spec = SPECS[spec]
     road = road or build_road()
     left, right = lane_constraints(road)
-    jobs = [(spec, min(chunk, batch - c0), seed, first_problem + c0, road, obstacle_points)
+    jobs = [(spec, min(chunk, batch - c0), seed, first_problem + c0, road, obstacle_points, scenarios)
             for c0 in range(0, batch, chunk)]
     if workers > 1 and len(jobs) > 1:
         # threads, not processes: numpy releases the GIL inside its loops, and forking a process
@@ -209,8 +214,15 @@ def generate(spec: SceneSpec | str, batch: int, seed: int = 0, first_problem: in
             outs = list(pool.map(_chunk_job, jobs))
     else:
         outs = [_chunk_job(j) for j in jobs]
+    shared = {k: outs[0].pop(k) for k in list(outs[0]) if k in ("obstacle_half_size", "obstacle_kind")}
+    for o in outs[1:]:
+        for k in shared:
+            o.pop(k, None)
     out = {k: np.concatenate([o[k] for o in outs], axis=0) for k in outs[0]}
+    out.update(shared)
     out.update(left=left, right=right, n_steps=spec.n_steps, dt=spec.dt, cmax=spec.cmax)
+    if scenarios:
+        out["road"] = road
     return out
 
 
@@ -222,7 +234,8 @@ def _uniforms(seed, first, n, m):
     return out
 
 
-def _generate_chunk(spec: SceneSpec, B: int, seed: int, first: int, road: Road, want_points: bool = False):
+def _generate_chunk(spec: SceneSpec, B: int, seed: int, first: int, road: Road, want_points: bool = False,
+                    want_scn: bool = False):
     # Array convention inside: obstacle / candidate axes first, (problem, knot) last, so numpy's
     # inner loops run over B*K contiguous elements.
     N, dt = spec.n_steps, spec.dt
@@ -388,4 +401,10 @@ def _generate_chunk(spec: SceneSpec, B: int, seed: int, first: int, road: Road, 
         cnt = live.sum(axis=2).astype(np.int32)
         pts = np.where((np.arange(O * 4)[None, None, :] < cnt[:, :, None])[..., None], pts, 0.0)
         out.update(obstacle_points=np.ascontiguousarray(pts), obstacle_count=np.ascontiguousarray(cnt))
+    if want_scn:
+        pose = np.stack([o_x, o_y, np.broadcast_to(o_th, o_x.shape)], axis=-1).transpose(1, 0, 2, 3)   # [B,O,K,3]
+        out.update(obstacle_pose=np.ascontiguousarray(pose),
+                   obstacle_live=np.ascontiguousarray(np.broadcast_to(o_live, o_x.shape).transpose(1, 0, 2)),
+                   obstacle_half_size=np.stack([np.broadcast_to(hl, (O, 1, 1))[:, 0, 0], np.broadcast_to(hw, (O, 1, 1))[:, 0, 0]], axis=1),
+                   obstacle_kind=kind.copy())
     return out

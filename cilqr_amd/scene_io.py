@@ -1,0 +1,184 @@
+"""Scene wire format: a compact binary equivalent of what the reference moves between
+its scenario publisher and its planning node -- the six ROS messages under msg/ (CenterLine,
+CenterLinePoint, Obstacles, DynamicObstacle, DynamicObstacles, DynamicTrajectoryPoint) and the
+pickle {"center", "static", "dynamic"} of script/reference_publisher.py:232-236 -- plus the two
+things a replay of the optimizer needs on top (start state, coarse trajectory), so that a scene
+can be replayed bit for bit on the CPU oracle and on the GPU.
+
+A file holds ONE road and B scenes on it:
+
+    "CILQRSC1" | u32 version = 1 | u32 B | u32 K | f64 dt
+    u32 n_center | center[n_center][7] f64            CenterLinePoint: s x y theta kappa left_bound right_bound
+    per scene:
+      start[4] f64 (x y theta v) | coarse[K][6] f64 (x y theta v a delta)
+      u32 n_static  | per obstacle: u32 m | polygon[m][2] f64 (world frame)           Obstacles.msg
+      u32 n_dynamic | per obstacle: u32 m | polygon[m][2] f64 (body frame)            DynamicObstacle.msg
+                                  | u32 T | trajectory[T][4] f64 (time x y theta)     DynamicTrajectoryPoint.msg
+
+Everything little-endian.  `environment_points` and `road_barriers` restate the queries the reference's
+Environment answers from that data (algorithm/utils/environment.cpp:134-182, planning_node.cc:63-78):
+the obstacle corner points valid at a knot's time and the two road barriers -- the inputs of
+cilqr_build_corridors / cilqr_lane_constraints.
+"""
+from __future__ import annotations
+
+import dataclasses
+import struct
+
+import numpy as np
+
+MAGIC = b"CILQRSC1"
+K_MATH_EPS = 1e-10  # algorithm/math/vec2d.h:33
+
+
+@dataclasses.dataclass
+class DynamicObstacle:
+    polygon: np.ndarray      # [m,2] body frame
+    trajectory: np.ndarray   # [T,4] time, x, y, theta
+
+
+@dataclasses.dataclass
+class Scene:
+    start: np.ndarray                 # [4]
+    coarse: np.ndarray                # [K,6]
+    static: list                      # of [m,2] world-frame polygons
+    dynamic: list                     # of DynamicObstacle
+
+
+@dataclasses.dataclass
+class SceneFile:
+    dt: float
+    center: np.ndarray                # [n,7]
+    scenes: list
+
+
+def _rect(hl: float, hw: float) -> np.ndarray:
+    return np.array([[hl, hw], [hl, -hw], [-hl, -hw], [-hl, hw]], dtype=np.float64)
+
+
+def from_generator(sc: dict) -> SceneFile:
+    """Scenes of cilqr_amd.scenario.generate(..., scenarios=True) in the reference's vocabulary: an
+    obstacle that never moves becomes a static polygon (Obstacles.msg), the others a body-frame
+    polygon with the trajectory of the knots at which they exist (pedestrians enter and leave)."""
+    road = sc["road"]
+    from .scenario import LEFT_BOUND, RIGHT_BOUND
+    n = len(road.s)
+    center = np.stack([road.s, road.x, road.y, road.theta, road.kappa, np.full(n, LEFT_BOUND), np.full(n, RIGHT_BOUND)], 1)
+    pose, live, half, kind = sc["obstacle_pose"], sc["obstacle_live"], sc["obstacle_half_size"], sc["obstacle_kind"]
+    B, O, K = live.shape
+    t = np.arange(K) * sc["dt"]
+    scenes = []
+    for b in range(B):
+        static, dynamic = [], []
+        for o in range(O):
+            m = live[b, o]
+            if not m.any():
+                continue
+            body = _rect(*half[o])
+            if kind[o] == 2:      # static vehicle: one world-frame polygon
+                x, y, th = pose[b, o, 0]
+                R = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+                static.append(body @ R.T + [x, y])
+            else:
+                traj = np.concatenate([t[m, None], pose[b, o, m]], axis=1)
+                dynamic.append(DynamicObstacle(body, traj))
+        scenes.append(Scene(sc["start"][b].copy(), sc["coarse"][b].copy(), static, dynamic))
+    return SceneFile(float(sc["dt"]), center, scenes)
+
+
+def save(path: str, f: SceneFile) -> None:
+    K = f.scenes[0].coarse.shape[0] if f.scenes else 0
+    with open(path, "wb") as o:
+        o.write(MAGIC)
+        o.write(struct.pack("<IIId", 1, len(f.scenes), K, f.dt))
+        c = np.ascontiguousarray(f.center, dtype="<f8")
+        o.write(struct.pack("<I", c.shape[0]))
+        o.write(c.tobytes())
+        for s in f.scenes:
+            o.write(np.ascontiguousarray(s.start, dtype="<f8").tobytes())
+            o.write(np.ascontiguousarray(s.coarse, dtype="<f8").tobytes())
+            o.write(struct.pack("<I", len(s.static)))
+            for p in s.static:
+                o.write(struct.pack("<I", len(p)))
+                o.write(np.ascontiguousarray(p, dtype="<f8").tobytes())
+            o.write(struct.pack("<I", len(s.dynamic)))
+            for d in s.dynamic:
+                o.write(struct.pack("<I", len(d.polygon)))
+                o.write(np.ascontiguousarray(d.polygon, dtype="<f8").tobytes())
+                o.write(struct.pack("<I", len(d.trajectory)))
+                o.write(np.ascontiguousarray(d.trajectory, dtype="<f8").tobytes())
+
+
+def load(path: str) -> SceneFile:
+    raw = open(path, "rb").read()
+    if raw[:8] != MAGIC:
+        raise ValueError("not a CILQR scene file")
+    pos = 8
+    version, B, K, dt = struct.unpack_from("<IIId", raw, pos)
+    pos += 20
+    if version != 1:
+        raise ValueError(f"unsupported scene file version {version}")
+
+    def u32():
+        nonlocal pos
+        v, = struct.unpack_from("<I", raw, pos)
+        pos += 4
+        return v
+
+    def f64(*shape):
+        nonlocal pos
+        n = int(np.prod(shape))
+        a = np.frombuffer(raw, dtype="<f8", count=n, offset=pos).reshape(shape).copy()
+        pos += 8 * n
+        return a
+
+    center = f64(u32(), 7)
+    scenes = []
+    for _ in range(B):
+        start, coarse = f64(4), f64(K, 6)
+        static = [f64(u32(), 2) for _ in range(u32())]
+        dynamic = []
+        for _ in range(u32()):
+            poly = f64(u32(), 2)
+            dynamic.append(DynamicObstacle(poly, f64(u32(), 4)))
+        scenes.append(Scene(start, coarse, static, dynamic))
+    if pos != len(raw):
+        raise ValueError("trailing bytes in scene file")
+    return SceneFile(dt, center, scenes)
+
+
+def environment_points(scene: Scene, times) -> tuple:
+    """Environment::QueryStaticObstaclesPoints + QueryDynamicObstaclesPoints (environment.cpp:153-182,
+    is_multiple_sample = false) for every knot time: (points [K,P,2] padded with zeros, counts [K]).
+    A dynamic obstacle exists at time t when t lies within its trajectory (to 1e-10); its polygon is
+    the one of the first trajectory sample later than t - 1e-10 (std::upper_bound, cpp:143-146),
+    placed by that sample's pose (planning_node.cc:68-75)."""
+    per_knot = []
+    for t in times:
+        pts = [p for p in scene.static]
+        for d in scene.dynamic:
+            tt = d.trajectory[:, 0]
+            if tt[0] > t + K_MATH_EPS or tt[-1] < t - K_MATH_EPS:
+                continue
+            i = int(np.searchsorted(tt + K_MATH_EPS, t, side="right"))   # first sample with t < time + eps
+            i = min(i, len(tt) - 1)
+            _, x, y, th = d.trajectory[i]
+            R = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+            pts.append(d.polygon @ R.T + [x, y])
+        per_knot.append(np.concatenate(pts, axis=0) if pts else np.zeros((0, 2)))
+    P = max((len(p) for p in per_knot), default=0)
+    out = np.zeros((len(per_knot), P, 2))
+    cnt = np.zeros(len(per_knot), dtype=np.int32)
+    for k, p in enumerate(per_knot):
+        out[k, :len(p)] = p
+        cnt[k] = len(p)
+    return out, cnt
+
+
+def road_barriers(center: np.ndarray) -> tuple:
+    """left_road_barrier / right_road_barrier of the reference's Environment: the centre line shifted by
+    +left_bound / -right_bound along its normal (ReferenceLine::GetCartesian at every centre point)."""
+    x, y, th, lb, rb = center[:, 1], center[:, 2], center[:, 3], center[:, 5], center[:, 6]
+    left = np.stack([x - lb * np.sin(th), y + lb * np.cos(th)], 1)
+    right = np.stack([x + rb * np.sin(th), y - rb * np.cos(th)], 1)
+    return left, right

@@ -69,5 +69,24 @@ def main():
               f"{os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def make_scene_file():
+    """tests/golden/scenes_mix11_4.cqs (+ .json): the wire format of cilqr_amd/scene_io.py, pinned."""
+    import hashlib
+    import json
+    from cilqr_amd import scene_io
+    sc = scenario.generate("mix11", 4, seed=71, obstacle_points=True, scenarios=True)
+    f = scene_io.from_generator(sc)
+    path = os.path.join(HERE, "scenes_mix11_4.cqs")
+    scene_io.save(path, f)
+    raw = open(path, "rb").read()
+    K = sc["coarse"].shape[1]
+    meta = {"sha256": hashlib.sha256(raw).hexdigest(), "bytes": len(raw), "scenes": 4, "knots": K, "dt": sc["dt"],
+            "n_static": [len(s.static) for s in f.scenes], "n_dynamic": [len(s.dynamic) for s in f.scenes],
+            "points_per_knot": [scene_io.environment_points(s, np.arange(K) * sc["dt"])[1].tolist() for s in f.scenes],
+            "made_by": "tests/golden/make_golden.py (scene file section): scenario.generate('mix11', 4, seed=71, scenarios=True)"}
+    json.dump(meta, open(os.path.join(HERE, "scenes_mix11_4.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
     main()
+    make_scene_file()
