@@ -94,6 +94,41 @@ def test_committed_scene_file_is_stable():
                for a, b in zip(f.scenes, g.scenes))
 
 
+def test_cpp_reader_agrees_with_the_python_loader(tmp_path):
+    """include/cilqr/scene_file.hpp (header-only C++14) reads the same file: counts, checksums of every
+    array, the obstacle points of every knot time (its ObstaclePoints restates the same Environment
+    queries), the road barriers."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "scene_file_test"
+    subprocess.check_call(["g++", "-std=c++14", "-O2", "-Wall", "-Werror", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "scene_file_test.cc"), "-o", str(exe)])
+    path = os.path.join(root, "tests", "golden", "scenes_mix11_4.cqs")
+    out = subprocess.run([str(exe), path], capture_output=True, text=True, check=True).stdout.strip().split("\n")
+    g = scene_io.load(path)
+    n, nc, dt = out[0].split()
+    assert int(n) == len(g.scenes) and int(nc) == len(g.center) and float(dt) == g.dt
+    assert float(out[1]) == pytest.approx(float(g.center.sum()), rel=1e-13)
+    for line, sc in zip(out[2:2 + len(g.scenes)], g.scenes):
+        tok = line.split()
+        K = sc.coarse.shape[0]
+        assert [int(tok[0]), int(tok[1]), int(tok[2])] == [K, len(sc.static), len(sc.dynamic)]
+        assert float(tok[3]) == pytest.approx(float(sc.start.sum() + sc.coarse.sum()), rel=1e-13)
+        pts, cnt = scene_io.environment_points(sc, np.arange(K) * g.dt)
+        for k in range(K):
+            c, v = tok[4 + k].split(":")
+            assert int(c) == cnt[k]
+            want = float((pts[k, :cnt[k], 0] + 2.0 * pts[k, :cnt[k], 1]).sum())
+            assert float(v) == pytest.approx(want, rel=1e-12, abs=1e-9)
+    lb, rb = scene_io.road_barriers(g.center)
+    want = float((lb[:, 0] + 2 * lb[:, 1]).sum() - (rb[:, 0] + 2 * rb[:, 1]).sum())
+    assert float(out[-1]) == pytest.approx(want, rel=1e-12)
+    bad = tmp_path / "bad.cqs"
+    bad.write_bytes(open(path, "rb").read()[:-5])
+    assert subprocess.run([str(exe), str(bad)], capture_output=True).returncode == 1
+
+
 @pytest.mark.gpu
 def test_replay_from_file_on_the_gpu(built, tmp_path):
     """file -> Environment queries -> cilqr_build_corridors / cilqr_lane_constraints -> solve: the
