@@ -1,7 +1,9 @@
 #!/usr/bin/env python
-"""Times cilqr_build_corridors on device-resident inputs at the bench batch size and
+"""(Under tests/ because it times the CPU oracle beside the kernel; only tests/, smoke() and bench.py's
+cpu_baseline leg may use oracle/.)
+Times cilqr_build_corridors on device-resident inputs at the bench batch size and
 the CPU oracle beside it.
-    python tools/corridor_bench.py [batch] [scene-family]
+    python tests/corridor_bench.py [batch] [scene-family]
 Prints one JSON line: corridors/s on the GPU, on one CPU core (oracle), bytes moved per corridor."""
 import json
 import os

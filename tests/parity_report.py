@@ -1,10 +1,11 @@
 #!/usr/bin/env python
-"""Parity of the HIP path against the CPU oracle on a larger sample than the test suite uses: for every
+"""(Under tests/: it runs the CPU oracle.)
+Parity of the HIP path against the CPU oracle on a larger sample than the test suite uses: for every
 scene family, how many problems match within 1e-4 relative (status, iteration count, every Cost row,
 final trajectory), how many are ill-conditioned in the oracle itself (a 4e-16 relative perturbation
 of the inputs changes the ORACLE's result by more than 1e-5), and the largest deviation among the
 well-conditioned ones.  One JSON document on stdout.
-    python tools/parity_report.py [problems-per-family]"""
+    python tests/parity_report.py [problems-per-family]"""
 import json
 import os
 import sys
