@@ -325,7 +325,7 @@ def main():
             else:
                 roof = dict(agg, bound="hbm", kernel="cilqr::k_backward", peak=HBM_PEAK_GBS, unit="GB/s")
         cpu = None
-        if args.cpu_sample > 0:
+        if args.cpu_sample > 0 and world == 1:   # rank 0 at N = 1 only
             from oracle import oracle as orc
             ns = min(args.cpu_sample, B)
             sub = {k: (v[:ns] if isinstance(v, np.ndarray) and v.shape[:1] == (B,) else v) for k, v in sc.items()}
