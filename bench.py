@@ -127,7 +127,8 @@ def main():
         if rc != api.OK:
             raise api.CilqrError(rc, "in bench step")
         if use_dist:
-            return gather_results(o_traj, o_hist, o_nc, o_st, dst=0, densify=False)
+            # 8 of the 10 trajectory columns travel (time and kappa are functions of the others)
+            return gather_results(o_traj, o_hist, o_nc, o_st, dst=0, densify=False, derive=(cfg.dt, cfg.wheel_base))
         return None
 
     def fence():

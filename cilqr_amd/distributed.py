@@ -30,7 +30,7 @@ def shard_scene(scene: dict, rank: int, world: int) -> dict:
     return out
 
 
-def gather_results(traj, cost_hist, n_cost, status, dst: int = 0, densify: bool = True):
+def gather_results(traj, cost_hist, n_cost, status, dst: int = 0, densify: bool = True, derive=None):
     """ONE gather: every rank packs its results into a single flat fp64 tensor
     (trajectories | live cost-history rows, ragged | n_cost | status) and rank `dst` receives the
     blocks in rank order.  Only the n_cost[b] live rows of each problem's history travel (9 of
@@ -42,11 +42,19 @@ def gather_results(traj, cost_hist, n_cost, status, dst: int = 0, densify: bool 
     traj, n_cost, status, and the history either dense again (`cost_hist`, as many rows as the
     longest history; densify=True) or ragged as it travelled (`hist_rows` [sum n_cost, 5] in problem
     order, problem b's rows start at cumsum(n_cost)[b-1]; densify=False, no extra passes on rank 0).
+
+    derive=(dt, wheel_base): only the 8 independent columns of a trajectory point travel (x, y, theta, v,
+    a, delta, jerk, delta_rate -- SURVEY 8(e)); rank `dst` rebuilds column 0 (time = i dt) and column 7
+    (kappa = tan(delta) / wheel_base, TransformToTrajectory cc:771-791).  kappa is then recomputed with
+    torch's tan, which may differ from the device's in the last bit.
     """
     import torch
     import torch.distributed as dist
 
     world, rank = dist.get_world_size(), dist.get_rank()
+    full_F = traj.shape[2]
+    if derive is not None:
+        traj = traj[:, :, [1, 2, 3, 4, 5, 6, 8, 9]].contiguous()
     B, K, F = traj.shape
     C = cost_hist.shape[2]
     nc = n_cost.to(torch.int64)
@@ -71,7 +79,16 @@ def gather_results(traj, cost_hist, n_cost, status, dst: int = 0, densify: bool 
         trajs.append(p[:n_traj].reshape(B, K, F))
         ncs.append(p[n_traj + n_rows:n_traj + n_rows + B].to(n_cost.dtype))
         sts.append(p[n_traj + n_rows + B:].to(status.dtype))
-    out = {"traj": torch.cat(trajs), "n_cost": torch.cat(ncs), "status": torch.cat(sts)}
+    all_traj = torch.cat(trajs)
+    if derive is not None:
+        dt_, wb_ = derive
+        full = torch.empty((all_traj.shape[0], K, full_F), dtype=all_traj.dtype, device=all_traj.device)
+        full[:, :, 1:7] = all_traj[:, :, 0:6]
+        full[:, :, 8:10] = all_traj[:, :, 6:8]
+        full[:, :, 0] = torch.arange(K, dtype=all_traj.dtype, device=all_traj.device)[None, :] * dt_
+        full[:, :, 7] = torch.tan(all_traj[:, :, 5]) / wb_
+        all_traj = full
+    out = {"traj": all_traj, "n_cost": torch.cat(ncs), "status": torch.cat(sts)}
     if not densify:
         out["hist_rows"] = torch.cat([p[n_traj:n_traj + int(c.to(torch.int64).sum().item()) * C].reshape(-1, C)
                                       for p, c in zip(parts, ncs)])

@@ -144,9 +144,18 @@ _WORKER = textwrap.dedent("""
     if rank == 0:
         rows = np.concatenate([full["cost_hist"][b, :full["n_cost"][b]] for b in range(8)])
         assert np.array_equal(rag["hist_rows"].numpy(), rows) and np.array_equal(rag["traj"].numpy(), full["traj"])
+    # only the 8 independent columns of a trajectory point travel; time and kappa are rebuilt on rank 0
+    slim = gather_results(torch.from_numpy(r["traj"]), torch.from_numpy(r["cost_hist"]),
+                          torch.from_numpy(r["n_cost"]), torch.from_numpy(r["status"]), dst=0, densify=False,
+                          derive=(0.1, 1.0))
+    if rank == 0:
+        t = slim["traj"].numpy()
+        assert np.array_equal(t[:, :, [1, 2, 3, 4, 5, 6, 8, 9]], full["traj"][:, :, [1, 2, 3, 4, 5, 6, 8, 9]])
+        assert np.allclose(t[:, :, 0], full["traj"][:, :, 0], rtol=0, atol=1e-15)
+        assert np.allclose(t[:, :, 7], full["traj"][:, :, 7], rtol=1e-15, atol=1e-15)
         print("GATHER_OK")
     else:
-        assert out is None
+        assert out is None and slim is None
     dist.destroy_process_group()
 """)
 
