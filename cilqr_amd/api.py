@@ -22,7 +22,8 @@ OPT_SPEC_THRESHOLD = 1
 OPT_COMPACTION = 2
 OPT_SEQ_ROUNDS = 3
 OPT_TEAM_THRESHOLD = 4
-ST_RUNNING, ST_CONVERGED_ABS, ST_CONVERGED_REL, ST_GNORM, ST_UNSOLVED, ST_MAX_ITER = range(6)
+ST_RUNNING, ST_CONVERGED_ABS, ST_CONVERGED_REL, ST_GNORM, ST_UNSOLVED, ST_MAX_ITER, ST_NO_CORRIDOR = range(7)
+ABI_VERSION = 2
 
 T_GOALS, T_CORRIDOR, T_LANES, T_X, T_U, T_XCAND, T_UCAND, T_A, T_B, T_LX, T_LU, T_LXX, T_LUU, \
     T_KFB, T_KFF, T_DV, T_GNORM = range(17)
@@ -61,6 +62,7 @@ class SolutionBatch(C.Structure):
         ("memory", C.c_int32), ("max_iter_trajs", C.c_int32), ("traj", C.c_void_p),
         ("cost_hist", C.c_void_p), ("n_cost", C.c_void_p), ("status", C.c_void_p),
         ("n_iter", C.c_void_p), ("iter_trajs", C.c_void_p), ("n_iter_trajs", C.c_void_p),
+        ("alpha_trace", C.c_void_p),
     ]
 
 
@@ -253,8 +255,10 @@ class BatchIlqrOptimizer:
                             _ptr(a["right"]) if a["right"].size else None)
         return prob, a
 
-    def plan(self, scene: dict, max_iter_trajs: int = 0, check: bool = True):
-        """scene: dict from cilqr_amd.scenario.generate (problem-major numpy arrays)."""
+    def plan(self, scene: dict, max_iter_trajs: int = 0, check: bool = True, alpha_trace: bool = False):
+        """scene: dict from cilqr_amd.scenario.generate (problem-major numpy arrays).
+        alpha_trace=True adds "alpha_trace" [B, max_iter] int8: the accepted step-size index of every
+        iteration (-1 all rejected, -2 left before the line search, -3 not run)."""
         prob, keep = self._host_problem(scene)
         B, K, M = prob.batch, self.K, self.cfg.max_iter
         traj = np.zeros((B, K, 10))
@@ -264,8 +268,9 @@ class BatchIlqrOptimizer:
         n_iter = np.zeros(B, np.int32)
         it = np.zeros((B, max_iter_trajs, K, 10)) if max_iter_trajs else None
         n_it = np.zeros(B, np.int32) if max_iter_trajs else None
+        at = np.full((B, M), -3, np.int8) if alpha_trace else None
         sol = SolutionBatch(MEM_HOST, max_iter_trajs, _ptr(traj), _ptr(hist), _ptr(n_cost), _ptr(status),
-                            _ptr(n_iter), _ptr(it), _ptr(n_it))
+                            _ptr(n_iter), _ptr(it), _ptr(n_it), _ptr(at))
         rc = self.solve_raw(prob, sol)
         del keep
         if rc != OK:
@@ -273,11 +278,8 @@ class BatchIlqrOptimizer:
                 raise CilqrError(rc, "in cilqr_solve_batch")
             return dict(rc=rc)
         self.B = B
-        # rows >= n_cost are unspecified by the ABI: zero them for convenience
-        mask = np.arange(M + 1)[None, :] >= n_cost[:, None]
-        hist[mask] = 0.0
         return dict(rc=rc, traj=traj, cost_hist=hist, n_cost=n_cost, status=status, n_iter=n_iter,
-                    iter_trajs=it, n_iter_trajs=n_it)
+                    iter_trajs=it, n_iter_trajs=n_it, alpha_trace=at)
 
     # ---- stages ----
     def _chk(self, rc, what):

@@ -32,8 +32,10 @@ struct P2f {
 };
 
 // strictly convex hull of p[0..n): indices into p, counter-clockwise (y up) from the
-// lexicographically smallest point; `order` and `h` are caller-provided work arrays
-// (n and 2n + 2 entries).  Returns the number of hull vertices.
+// lexicographically smallest point; `order` and `h` are caller-provided work arrays of n and 2n
+// entries (exact predicates keep at most n + 1 on the stack; with float32 rounding a nearly
+// collinear point can survive in both chains, and 2n - 1 pushes is the hard bound).  Returns the
+// number of hull vertices.
 __device__ int hull_indices(const P2f* p, int n, unsigned char* order, unsigned char* h) {
   // stable sort by (x, y) through ranks: rank(i) = number of points that sort before point i.
   // n^2 comparisons, but the loads of the inner loop do not depend on each other (an insertion
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(64) void k_build_corridors(int n, CorridorParams cp
   // are remembered by their index in the input list and re-read (or re-derived) when needed.
   P2f flip[MAXP + 1], vd[MAXP + 1];
   P2f* dual = flip;
-  unsigned char src[MAXP], order[MAXP + 1], hull[MAXP + 3], v2[MAXP + 1];
+  unsigned char src[MAXP], order[MAXP + 1], hull[2 * (MAXP + 1)], v2[MAXP + 1];
   int code = 0;
   int nf = 0;
   double safe_radius = cp.radius;
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(64) void k_build_corridors(int n, CorridorParams cp
   } else {
     flip[nf] = P2f{0.0f, 0.0f};
     const int n1 = hull_indices(flip, nf + 1, order, hull);  // cc:184
-    if (n1 < 3) {
+    if (n1 < 3 || n1 > nf + 1) {   // more vertices than points: float32 predicates disagreed (degenerate)
       code = -4;
     } else {
       // star-shaped polygon through the visible points cc:186-198
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(64) void k_build_corridors(int n, CorridorParams cp
         iy = 0.99 * safe_radius * dy / d + oy;
       }
       const int n2 = hull_indices(vd, n1, order, hull);  // cc:218
-      if (n2 < 3) {
+      if (n2 < 3 || n2 > n1) {
         code = -4;
       } else {
         for (int j = 0; j < n2; ++j) v2[j] = hull[j];
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(64) void k_build_corridors(int n, CorridorParams cp
           }
         }
         const int n3 = hull_indices(dual, nt, order, hull);  // cc:241-242
-        if (n3 < 3) {
+        if (n3 < 3 || n3 > nt) {
           code = -4;
         } else if (n3 > cmax) {
           code = -3;

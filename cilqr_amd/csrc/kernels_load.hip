@@ -13,33 +13,46 @@ namespace cilqr {
 // [K][cmax][3][Bcap].  One block = 64 problems x one knot, transposed through LDS so both the
 // HBM reads (runs of cmax_in*3 doubles) and the writes (64 consecutive slots) are contiguous.
 // ---------------------------------------------------------------------------------------------
+constexpr int kLoadPlaneChunk = 16;   // planes per LDS tile: 64 x (48 + 1) doubles = 24.5 KiB for any cmax
 __global__ __launch_bounds__(256) void k_load_corridor(DeviceState s, int B, ProblemView in) {
-  extern __shared__ double tile[];  // [64][row + 1]
+  __shared__ double tile[64 * (kLoadPlaneChunk * 3 + 1)];
   const int i = blockIdx.y;
   const int b0 = blockIdx.x * 64;
   const int row = in.cmax_in * 3;
-  const int ld = row + 1;
+  constexpr int ld = kLoadPlaneChunk * 3 + 1;
   const int nb = min(64, B - b0);
-  for (int e = threadIdx.x; e < nb * row; e += blockDim.x) {
-    const int pb = e / row, off = e - pb * row;
-    tile[pb * ld + off] = in.corridor[((size_t)(b0 + pb) * s.p.K + i) * row + off];
-  }
-  __syncthreads();
   const int pb = threadIdx.x & 63;
-  if (pb >= nb) return;
   const int slot = b0 + pb;
-  const int cnt = max(0, min(in.ccount[(size_t)slot * s.p.K + i], min(s.cmax, in.cmax_in)));
-  if ((threadIdx.x >> 6) == 0) s.ccnt[(size_t)i * s.Bcap + slot] = cnt;
-  for (int c = threadIdx.x >> 6; c < cnt; c += 4) {
-    double a = tile[pb * ld + c * 3 + 0];
-    double b = tile[pb * ld + c * 3 + 1];
-    double cc = tile[pb * ld + c * 3 + 2];
-    cc = cc - s.p.shrink_corridor * (a * a + b * b) / hypot(a, b);   // cc:448
-    const double nrm = hypot(hypot(a, b), cc);                       // cc:479
-    double* o = s.cor + ((size_t)(i * s.cmax + c) * 3) * s.Bcap + slot;
-    o[0] = a / nrm;
-    o[(size_t)s.Bcap] = b / nrm;
-    o[(size_t)2 * s.Bcap] = cc / nrm;
+  int cnt = 0;
+  if (pb < nb) {
+    const int raw = in.ccount[(size_t)slot * s.p.K + i];
+    // A negative count is a knot whose corridor could not be built (cilqr_build_corridors codes -2..-4):
+    // the reference aborts the whole Plan there (corridor.cc:78-81), so the problem is flagged and
+    // never optimised (k_load_goals ran before this kernel and set status = 0).
+    if (raw < 0 && (threadIdx.x >> 6) == 0) s.status[slot] = 6;   // CILQR_ST_NO_CORRIDOR
+    cnt = max(0, min(raw, min(s.cmax, in.cmax_in)));
+    if ((threadIdx.x >> 6) == 0) s.ccnt[(size_t)i * s.Bcap + slot] = cnt;
+  }
+  for (int c0 = 0; c0 < in.cmax_in; c0 += kLoadPlaneChunk) {
+    const int w = min(kLoadPlaneChunk, in.cmax_in - c0) * 3;   // doubles of this chunk per problem
+    __syncthreads();
+    for (int e = threadIdx.x; e < nb * w; e += blockDim.x) {
+      const int q = e / w, off = e - q * w;
+      tile[q * ld + off] = in.corridor[((size_t)(b0 + q) * s.p.K + i) * row + c0 * 3 + off];
+    }
+    __syncthreads();
+    if (pb >= nb) continue;
+    for (int c = c0 + (threadIdx.x >> 6); c < min(cnt, c0 + kLoadPlaneChunk); c += 4) {
+      double a = tile[pb * ld + (c - c0) * 3 + 0];
+      double b = tile[pb * ld + (c - c0) * 3 + 1];
+      double cc = tile[pb * ld + (c - c0) * 3 + 2];
+      cc = cc - s.p.shrink_corridor * (a * a + b * b) / hypot(a, b);   // cc:448
+      const double nrm = hypot(hypot(a, b), cc);                       // cc:479
+      double* o = s.cor + ((size_t)(i * s.cmax + c) * 3) * s.Bcap + slot;
+      o[0] = a / nrm;
+      o[(size_t)s.Bcap] = b / nrm;
+      o[(size_t)2 * s.Bcap] = cc / nrm;
+    }
   }
 }
 
@@ -223,11 +236,11 @@ void launch_device_math(int fn, int n, const double* in, double* out, hipStream_
 
 void launch_load(const DeviceState& s, int B, const ProblemView& in, const double* lanes_raw,
                  hipStream_t st) {
-  const int ld = in.cmax_in * 3 + 1;
-  dim3 g((B + 63) / 64, s.p.K);
-  hipLaunchKernelGGL(k_load_corridor, g, dim3(256), 64 * ld * sizeof(double), st, s, B, in);
+  // goals first: it resets the per-problem state that k_load_corridor may flag (status 6)
   const int n = B * s.p.K;
   hipLaunchKernelGGL(k_load_goals, dim3((n + 255) / 256), dim3(256), 0, st, s, B, in);
+  dim3 g((B + 63) / 64, s.p.K);
+  hipLaunchKernelGGL(k_load_corridor, g, dim3(256), 0, st, s, B, in);
   hipLaunchKernelGGL(k_load_lanes, dim3(1), dim3(512), 0, st, s, lanes_raw);
   launch_build_lane_grid(s, st);
 }
@@ -555,7 +568,7 @@ void launch_export_iter_traj(const DeviceState& s, const int* list, int n, doubl
 // cost history + counters, problem-major.  Rows >= n_cost are left untouched.
 __global__ void k_export_hist(DeviceState s, int B, double* __restrict__ hist, int* __restrict__ n_cost,
                               int* __restrict__ status, int* __restrict__ n_iter,
-                              int* __restrict__ n_iter_trajs) {
+                              int* __restrict__ n_iter_trajs, signed char* __restrict__ alpha_trace) {
   const int slot = blockIdx.x * blockDim.x + threadIdx.x;
   if (slot >= B) return;
   const int nc = s.n_cost[slot];
@@ -569,11 +582,16 @@ __global__ void k_export_hist(DeviceState s, int B, double* __restrict__ hist, i
 #pragma unroll
       for (int c = 0; c < 5; ++c) o[r * 5 + c] = s.hist[((size_t)r * 5 + c) * s.Bcap + slot];
   }
+  if (alpha_trace) {   // [B][max_iter]; iterations that never ran: -3
+    signed char* o = alpha_trace + (size_t)slot * s.p.max_iter;
+    const int ni = s.iter[slot];
+    for (int r = 0; r < s.p.max_iter; ++r) o[r] = (r < ni) ? s.atrace[(size_t)r * s.Bcap + slot] : (signed char)-3;
+  }
 }
 void launch_export_hist(const DeviceState& s, int B, double* cost_hist, int* n_cost, int* status,
-                        int* n_iter, int* n_iter_trajs, hipStream_t st) {
+                        int* n_iter, int* n_iter_trajs, signed char* alpha_trace, hipStream_t st) {
   hipLaunchKernelGGL(k_export_hist, dim3((B + 255) / 256), dim3(256), 0, st, s, B, cost_hist, n_cost,
-                     status, n_iter, n_iter_trajs);
+                     status, n_iter, n_iter_trajs, alpha_trace);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -172,6 +172,19 @@ CILQR_DEV void forward_multi(const DeviceState& s, int slot, int j) {
   }
 }
 
+// Leaves the iteration before the line search (acc_idx = -2 must then be set by ONE lane of the
+// problem): gradient-norm exit (cc:235-241), or a problem that was never admissible (a knot without
+// corridor, status 6 -- the reference aborts such a Plan before Optimize, corridor.cc:78-81).
+CILQR_DEV bool leaves_before_search(const DeviceState& s, int slot, bool write) {
+  const int pb = s.pid[slot];
+  if (s.status[pb] == 6) return true;
+  if (s.gnorm[slot] < 1e-6 && s.lambda[slot] < 1e-5) {   // cc:235-241
+    if (write) s.status[pb] = 3;   // CILQR_ST_GNORM
+    return true;
+  }
+  return false;
+}
+
 // stage API: plain rollout of the listed slots with one alpha
 __global__ __launch_bounds__(64) void k_forward(DeviceState s, const int* __restrict__ list, int n,
                                                 double alpha, int skip_done) {
@@ -192,8 +205,7 @@ __global__ __launch_bounds__(64) void k_search_open(DeviceState s, int n) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= active_count(s, n)) return;
   const int slot = s.act[j];
-  if (s.gnorm[slot] < 1e-6 && s.lambda[slot] < 1e-5) {
-    s.status[s.pid[slot]] = 3;   // CILQR_ST_GNORM
+  if (leaves_before_search(s, slot, true)) {
     s.acc_idx[slot] = -2;
     return;
   }
@@ -240,11 +252,10 @@ __global__ __launch_bounds__(64) void k_spec_forward(DeviceState s, const int* _
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
     const int slot = list[j];
     if (open) {
-      if (s.gnorm[slot] < 1e-6 && s.lambda[slot] < 1e-5) {   // cc:235-241
-        if (r == 0) {
-          s.status[s.pid[slot]] = 3;
-          s.acc_idx[slot] = -2;
-        }
+      // status is only written by the r == 0 lanes, and only from 0 to 3: the other step sizes' lanes
+      // read 0 or 3 and come to the same verdict through the gradient norm
+      if (leaves_before_search(s, slot, r == 0)) {
+        if (r == 0) s.acc_idx[slot] = -2;
         continue;
       }
       if (r == 0) s.acc_idx[slot] = -1;
@@ -360,8 +371,7 @@ __global__ __launch_bounds__(64) void k_multi_forward(DeviceState s, int n) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= active_count(s, n)) return;
   const int slot = s.act[j];
-  if (s.gnorm[slot] < 1e-6 && s.lambda[slot] < 1e-5) {   // cc:235-241
-    s.status[s.pid[slot]] = 3;   // CILQR_ST_GNORM
+  if (leaves_before_search(s, slot, true)) {
     s.acc_idx[slot] = -2;
     return;
   }
@@ -536,10 +546,13 @@ CILQR_DEV void update_problem(const DeviceState& s, int j) {
   bool done = false;
   int st = s.status[pb];
   s.emit[slot] = 0;
-  if (st == 3) {
+  const int it0 = s.iter[pb];
+  if (st == 3 || st == 6) {
     done = true;
+    s.atrace[(size_t)it0 * s.Bcap + pb] = (signed char)-2;
   } else {
     const int a = s.acc_idx[slot];
+    s.atrace[(size_t)it0 * s.Bcap + pb] = (signed char)a;
     const double lam = s.lambda[slot], dl = s.dlambda[slot];
     if (a >= 0) {
       const double ndl = fmin(dl / 1.6, 1.0 / 1.6);                                // cc:273
@@ -572,7 +585,7 @@ CILQR_DEV void update_problem(const DeviceState& s, int j) {
       }
     }
   }
-  const int it = s.iter[pb] + 1;
+  const int it = it0 + 1;
   s.iter[pb] = it;
   if (!done && it >= p.max_iter) {                                                 // cc:312
     st = 5;

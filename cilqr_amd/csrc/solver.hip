@@ -351,6 +351,7 @@ int cilqr_create(const cilqr_config* cfg, int32_t device, int32_t batch_capacity
   ALLOC(lambda, B); ALLOC(dlambda, B); ALLOC(cost_old, B); ALLOC(dcost, B);
   ALLOC(iter, B); ALLOC(status, B); ALLOC(n_cost, B); ALLOC(upd, B); ALLOC(acc_idx, B);
   ALLOC(n_iter_trajs, B); ALLOC(emit, B); ALLOC(pid, B); ALLOC(done_now, B);
+  ALLOC(atrace, (size_t)cfg->max_iter * B);
   d.spec_cap = (int)B;   // every active problem can have all 11 candidates in flight (4 GB at B = 65536)
   ALLOC(Xs, (size_t)kNumAlpha * K * 3 * d.spec_cap);
   ALLOC(Us, (size_t)kNumAlpha * N * d.spec_cap);
@@ -383,8 +384,6 @@ int cilqr_create(const cilqr_config* cfg, int32_t device, int32_t batch_capacity
                                       hipHostMallocMapped) != hipSuccess)
     rc = CILQR_ERR_DEVICE;
   if (rc == CILQR_OK && hipHostGetDevicePointer(reinterpret_cast<void**>(&h->h_count_dev), h->h_count, 0) != hipSuccess)
-    rc = CILQR_ERR_DEVICE;
-  if (rc == CILQR_OK && hipMemset(d.cor, 0, K * cmax * 3 * B * sizeof(double)) != hipSuccess)
     rc = CILQR_ERR_DEVICE;
   if (rc != CILQR_OK) {
     cilqr_destroy(h);
@@ -496,10 +495,12 @@ int cilqr_solve_batch(cilqr_handle h, const cilqr_problem_batch* in, cilqr_solut
   // output staging when the caller's buffers live in host memory
   double* o_traj = out->traj; double* o_hist = out->cost_hist; double* o_it = out->iter_trajs;
   int* o_nc = out->n_cost; int* o_st = out->status; int* o_ni = out->n_iter; int* o_nit = out->n_iter_trajs;
+  signed char* o_at = reinterpret_cast<signed char*>(out->alpha_trace);
   const size_t n_traj = (size_t)B * K * 10, n_hist = (size_t)B * (M + 1) * 5;
   const size_t n_it = out->iter_trajs ? (size_t)B * out->max_iter_trajs * K * 10 : 0;
+  const size_t n_at = out->alpha_trace ? (size_t)B * M : 0;
   if (out->memory == CILQR_MEM_HOST) {
-    const size_t bytes = (n_traj + n_hist + n_it) * 8 + (size_t)4 * B * 4 + 1024;
+    const size_t bytes = (n_traj + n_hist + n_it) * 8 + (size_t)4 * B * 4 + n_at + 1024;
     rc = grow(&h->out_stage, &h->out_stage_bytes, bytes);
     if (rc != CILQR_OK) return rc;
     double* p = static_cast<double*>(h->out_stage);
@@ -508,6 +509,10 @@ int cilqr_solve_batch(cilqr_handle h, const cilqr_problem_batch* in, cilqr_solut
     o_it = out->iter_trajs ? p : nullptr; p += n_it;
     int* q = reinterpret_cast<int*>(p);
     o_nc = q; o_st = q + B; o_ni = q + 2 * B; o_nit = q + 3 * B;
+    o_at = out->alpha_trace ? reinterpret_cast<signed char*>(q + 4 * B) : nullptr;
+    // the staging buffer is reused between solves: rows the kernels do not write (cost rows
+    // >= n_cost, iterates >= n_iter_trajs) must reach the caller as zeros, not as an earlier solve's data
+    HIP_TRY(hipMemsetAsync(o_hist, 0, (n_hist + n_it) * 8, h->stream));
   }
 
   launch_init_guess(d, B, st);                         // cc:169
@@ -591,12 +596,12 @@ int cilqr_solve_batch(cilqr_handle h, const cilqr_problem_batch* in, cilqr_solut
   }
   h->prof.iterations = it;
   if (tm.begin(3)) return CILQR_ERR_DEVICE;
-  launch_export_hist(h->ds, B, o_hist, o_nc, o_st, o_ni, o_nit, st);
+  launch_export_hist(h->ds, B, o_hist, o_nc, o_st, o_ni, o_nit, o_at, st);
   if (tm.end()) return CILQR_ERR_DEVICE;
   HIP_TRY(hipGetLastError());
   if (out->memory == CILQR_MEM_HOST) {
     HIP_TRY(hipMemcpyAsync(out->traj, o_traj, n_traj * 8, hipMemcpyDeviceToHost, st));
-    // rows >= n_cost are unspecified on the device side; copy everything, the host masks
+    // rows >= n_cost were zero-filled above
     HIP_TRY(hipMemcpyAsync(out->cost_hist, o_hist, n_hist * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(out->n_cost, o_nc, (size_t)B * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(out->status, o_st, (size_t)B * 4, hipMemcpyDeviceToHost, st));
@@ -605,10 +610,14 @@ int cilqr_solve_batch(cilqr_handle h, const cilqr_problem_batch* in, cilqr_solut
       HIP_TRY(hipMemcpyAsync(out->iter_trajs, o_it, n_it * 8, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipMemcpyAsync(out->n_iter_trajs, o_nit, (size_t)B * 4, hipMemcpyDeviceToHost, st));
     }
+    if (out->alpha_trace) HIP_TRY(hipMemcpyAsync(out->alpha_trace, o_at, n_at, hipMemcpyDeviceToHost, st));
   }
   HIP_TRY(hipStreamSynchronize(st));
   tm.resolve(&h->prof);
-  h->stage = 1 | 2 | 4 | 8;
+  // Survivor re-packing ping-pongs the working set between the two arenas, so after a solve the
+  // slots of arena A no longer hold the loaded batch in problem order: the stage entry points
+  // refuse to run (CILQR_ERR_STATE) until cilqr_stage_load is called again.
+  h->stage = 0;
   return CILQR_OK;
 }
 

@@ -121,6 +121,8 @@ struct DeviceState {
   int* acc_idx;      // accepted alpha index of this iteration, -1 = none yet, -2 = left the line search
   int* n_iter_trajs;
   int* emit;         // iterate to append to iter_trajs this iteration
+  // [max_iter][Bcap] by PROBLEM: accepted alpha index of every iteration (-1 all rejected, -2 gradient-norm exit)
+  signed char* atrace;
 
   // speculative line search (all 11 step sizes at once) for small active sets: candidates and
   // cost partials indexed by [alpha][...][list position], capacity spec_cap list entries
@@ -189,7 +191,7 @@ void launch_compact(const DeviceState& src, const DeviceState& dst, int n_max, h
 void launch_export_iter_traj(const DeviceState& s, const int* list, int n, double* iter_trajs,
                              int max_iter_trajs, hipStream_t st);
 void launch_export_hist(const DeviceState& s, int B, double* cost_hist, int* n_cost, int* status,
-                        int* n_iter, int* n_iter_trajs, hipStream_t st);
+                        int* n_iter, int* n_iter_trajs, signed char* alpha_trace, hipStream_t st);
 // corridor producer (kernels_corridor.hip)
 constexpr int kCorMaxPts = 96;   // obstacle points of one knot + the 8 box points
 struct CorridorParams {

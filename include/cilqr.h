@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define CILQR_ABI_VERSION 1
+#define CILQR_ABI_VERSION 2
 
 #define CILQR_NX 6  /* state  (x, y, theta, v, a, delta)   vehicle_model.h:11 */
 #define CILQR_NU 2  /* control (jerk, delta_rate)           vehicle_model.h:12 */
@@ -63,6 +63,10 @@ extern "C" {
 #define CILQR_ST_GNORM 3         /* gnorm < 1e-6 && lambda < 1e-5        cc:236     */
 #define CILQR_ST_UNSOLVED 4      /* lambda > 1e11                        cc:302     */
 #define CILQR_ST_MAX_ITER 5      /* iter == max_iter_num                 cc:312     */
+#define CILQR_ST_NO_CORRIDOR 6   /* corridor_count < 0 at some knot: the corridor producer failed there
+                                    (cilqr_build_corridors codes); the reference aborts the whole Plan
+                                    (corridor.cc:78-81, trajectory_planner.cpp:49-57).  The problem is not
+                                    optimised: traj = the init guess, n_cost = 1, n_iter = 1 */
 
 #define CILQR_MEM_HOST 0
 #define CILQR_MEM_DEVICE 1
@@ -95,7 +99,8 @@ typedef struct cilqr_problem_batch {
   const double* start;           /* [B][4]  x, y, theta, velocity  (cc:151) */
   const double* coarse;          /* [B][K][6]  x, y, theta, velocity, a, delta  (cc:148) */
   const double* corridor;        /* [B][K][cmax][3]  a, b, c with "a x + b y < c"  (corridor.h:19-21) */
-  const int32_t* corridor_count; /* [B][K]  live planes per knot */
+  const int32_t* corridor_count; /* [B][K]  live planes per knot; negative = no corridor at that knot
+                                    (the problem ends with CILQR_ST_NO_CORRIDOR) */
   int32_t n_left, n_right;       /* lane segments, shared by the whole batch */
   const double* left_lane;       /* [n_left][7]  HOST memory */
   const double* right_lane;      /* [n_right][7] HOST memory */
@@ -106,12 +111,17 @@ typedef struct cilqr_solution_batch {
   int32_t memory;                /* CILQR_MEM_* of every pointer below */
   int32_t max_iter_trajs;        /* capacity per problem of iter_trajs */
   double* traj;                  /* [B][K][10] */
-  double* cost_hist;             /* [B][max_iter+1][5]; rows >= n_cost[b] are left untouched */
+  double* cost_hist;             /* [B][max_iter+1][5]; rows >= n_cost[b]: zero (CILQR_MEM_HOST) or left
+                                    untouched (CILQR_MEM_DEVICE) */
   int32_t* n_cost;               /* [B] */
   int32_t* status;               /* [B] CILQR_ST_* */
   int32_t* n_iter;               /* [B] iterations started */
   double* iter_trajs;            /* [B][max_iter_trajs][K][10]: init guess + accepted non-final iterates (cc:170,294) */
   int32_t* n_iter_trajs;         /* [B] number that would have been produced (may exceed the capacity) */
+  int8_t* alpha_trace;           /* optional (NULL to skip) [B][max_iter]: per iteration of Optimize() the index
+                                    into the step-size list (cc:197) that the line search accepted, -1 = all
+                                    eleven rejected (cc:296-308), -2 = left before the line search
+                                    (gradient-norm exit cc:235-241, or status 6), -3 = iteration not run */
 } cilqr_solution_batch;
 
 /* Per-solve kernel timing, filled when profiling is on (cilqr_set_profiling). */
@@ -173,7 +183,9 @@ int cilqr_solve_batch(cilqr_handle h, const cilqr_problem_batch* in, cilqr_solut
 int cilqr_submit(cilqr_handle h, const cilqr_problem_batch* in, cilqr_solution_batch* out);
 int cilqr_wait(cilqr_handle h);
 
-/* ---- stage entry points (operate on the handle's device state, whole batch) ---- */
+/* ---- stage entry points (operate on the handle's device state, whole batch) ----
+ * A cilqr_solve_batch / cilqr_submit on the same handle invalidates the staged state: call
+ * cilqr_stage_load again afterwards (CILQR_ERR_STATE otherwise). */
 int cilqr_stage_load(cilqr_handle h, const cilqr_problem_batch* in);
 int cilqr_stage_init_guess(cilqr_handle h);
 /* overwrite the current iterate: X [B][K][6], U [B][N][2] */

@@ -177,12 +177,17 @@ class IlqrOptimizerT {
     out.n_iter = &n_iter;
     out.iter_trajs = iters.data();
     out.n_iter_trajs = &n_it;
+    out.alpha_trace = nullptr;
     const int rc = cilqr_solve_batch(handle_, &in, &out);
     if (rc != CILQR_OK) {
       std::fprintf(stderr, "cilqr_solve_batch failed: %s\n", cilqr_error_string(rc));
       return false;
     }
     status_ = status;
+    if (status == CILQR_ST_NO_CORRIDOR) {   // a knot without corridor: the reference's pipeline stops before
+      std::fprintf(stderr, "ilqr input constraints error\n");   // Optimize (trajectory_planner.cpp:49-57)
+      return false;
+    }
     for (int r = 0; r < n_cost; ++r) {
       const double* c = &hist[static_cast<size_t>(r) * CILQR_COST_FIELDS];
       cost_.push_back(Cost(c[0], c[1], c[2], c[3], c[4]));

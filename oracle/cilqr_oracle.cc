@@ -32,6 +32,7 @@ namespace {
 constexpr int NX = 6;  // vm.h:11
 constexpr int NU = 2;  // vm.h:12
 constexpr double kMathEpsilon = 1e-10;  // vec2d.h:33
+constexpr int kTraceCols = 10;  // columns of the per-iteration trace, see cilqr_oracle.h
 
 // math_utils.cpp:53-59
 inline double NormalizeAngle(double angle) {
@@ -636,10 +637,22 @@ struct Oracle {
     return std::abs(a - b) / s;
   }
 
+  // Re-entry into the loop of Optimize() for the step-by-step parity tests: instead of the init guess
+  // the solve starts from a given iterate with the given regularisation state, at iteration `iter`,
+  // and (stop_after_accept) returns as soon as one iteration was accepted.
+  struct Warm {
+    const double* X;
+    const double* U;
+    double lambda, dlambda;
+    int iter;
+    bool stop_after_accept;
+  };
+
   // ---- cc:154-320 ----
   int Plan(double* traj, double* cost_hist, int* n_cost_out, int* status_out, int* n_iter_out,
            double* iter_trajs, int max_iter_trajs, int* n_iter_trajs_out, double* trace,
-           double* min_margin_out) const {
+           double* min_margin_out, const Warm* warm = nullptr, double* U_out = nullptr,
+           double* lambda_out = nullptr) const {
     std::vector<double> X(K * 6), U(N * 2), Xo(K * 6), Uo(N * 2);
     std::vector<double> A(N * 36), B(N * 12), lx(K * 6), lu(N * 2), lxx(K * 36), luu(N * 4);
     std::vector<double> Ks(N * 12), ks(N * 2);
@@ -653,7 +666,12 @@ struct Oracle {
       std::memcpy(cost_hist + n_cost * 5, c5, 5 * sizeof(double));
       ++n_cost;
     };
-    InitGuess(X.data(), U.data());                         // cc:169
+    if (warm) {
+      std::memcpy(X.data(), warm->X, X.size() * sizeof(double));
+      std::memcpy(U.data(), warm->U, U.size() * sizeof(double));
+    } else {
+      InitGuess(X.data(), U.data());                       // cc:169
+    }
     push_iter_traj(X.data(), U.data());                    // cc:170
     double cost_data[5];
     double cost_old = TotalCost(X.data(), U.data(), cost_data);  // cc:172
@@ -666,6 +684,9 @@ struct Oracle {
                                           0.0158, 0.0079, 0.0040, 0.0020, 0.0010};   // cc:197
     double dV[2];
     int iter = 0;
+    if (warm) { lambda = warm->lambda; dlambda = warm->dlambda; iter = warm->iter; }
+    const int iter_first = iter;
+    bool stopped = false;
     for (; iter < cfg.max_iter; ++iter) {
       if (updated) {                                                               // cc:203-214
         Quadratize(X.data(), U.data(), A.data(), B.data(), lx.data(), lu.data(), lxx.data(), luu.data());
@@ -675,36 +696,46 @@ struct Oracle {
                ks.data(), dV);                                                     // cc:218 (never diverges)
       const double gnorm = GradNorm(ks.data(), U.data());                          // cc:235
       if (trace) {
-        double* t = trace + iter * 8;
+        double* t = trace + (iter - iter_first) * kTraceCols;
         t[0] = -1; t[1] = lambda; t[2] = dV[0]; t[3] = dV[1]; t[4] = 0; t[5] = 0; t[6] = 0; t[7] = gnorm;
+        t[8] = 0; t[9] = 0;
       }
-      margin = std::min(margin, RelMargin(gnorm, gnorm_min));
-      if (gnorm < gnorm_min && lambda < 1e-5) { status = ORACLE_ST_GNORM; ++iter; break; } // cc:236-241
+      // smallest relative distance of this iteration's decisions to their thresholds
+      double it_margin = (lambda < 1e-5) ? RelMargin(gnorm, gnorm_min) : std::numeric_limits<double>::infinity();
+      if (gnorm < gnorm_min && lambda < 1e-5) {                                    // cc:236-241
+        margin = std::min(margin, it_margin);
+        if (trace) { trace[(iter - iter_first) * kTraceCols + 0] = -2; trace[(iter - iter_first) * kTraceCols + 8] = it_margin; }
+        status = ORACLE_ST_GNORM; ++iter; break;
+      }
       bool done = false;
-      int acc_idx = -1;
+      int acc_idx = -1, n_trials = 0;
       for (int ai = 0; ai < 11; ++ai) {                                            // cc:246-265
+        ++n_trials;
         const double alpha = alpha_list[ai];
         Forward(alpha, X.data(), U.data(), Ks.data(), ks.data(), Xo.data(), Uo.data());
         cost_new = TotalCost(Xo.data(), Uo.data(), cost_data);
         dcost = cost_old - cost_new;
         const double expected = -alpha * (dV[0] + alpha * dV[1]);
         z = dcost / expected;
-        margin = std::min(margin, RelMargin(z, beta_min));
-        margin = std::min(margin, RelMargin(z, beta_max));
-        margin = std::min(margin, std::abs(dcost) / std::max(std::abs(cost_old), 1e-300));
+        it_margin = std::min(it_margin, RelMargin(z, beta_min));
+        it_margin = std::min(it_margin, RelMargin(z, beta_max));
+        it_margin = std::min(it_margin, std::abs(dcost) / std::max(std::abs(cost_old), 1e-300));
         if ((z > beta_min && z < beta_max) && dcost > 0.0) { done = true; acc_idx = ai; break; }
       }
+      if (done) {
+        it_margin = std::min(it_margin, RelMargin(dcost, cfg.abs_cost_tol));
+        it_margin = std::min(it_margin, RelMargin(dcost / cost_old, cfg.rel_cost_tol));
+      }
+      margin = std::min(margin, it_margin);
       if (trace) {
-        double* t = trace + iter * 8;
-        t[0] = acc_idx; t[4] = cost_new; t[5] = dcost; t[6] = z;
+        double* t = trace + (iter - iter_first) * kTraceCols;
+        t[0] = acc_idx; t[4] = cost_new; t[5] = dcost; t[6] = z; t[8] = it_margin; t[9] = n_trials;
       }
       if (done) {
         X.swap(Xo); U.swap(Uo);
         dlambda = std::fmin(dlambda / ratio, 1.0 / ratio);                         // cc:273
         lambda = lambda * dlambda * (lambda > reg_min);                            // cc:275
         updated = true;
-        margin = std::min(margin, RelMargin(dcost, cfg.abs_cost_tol));
-        margin = std::min(margin, RelMargin(dcost / cost_old, cfg.rel_cost_tol));
         if (dcost < cfg.abs_cost_tol || dcost / cost_old < cfg.rel_cost_tol) {     // cc:281-293
           push_cost(cost_data);
           status = (dcost < cfg.abs_cost_tol) ? ORACLE_ST_CONVERGED_ABS : ORACLE_ST_CONVERGED_REL;
@@ -714,14 +745,17 @@ struct Oracle {
         push_iter_traj(X.data(), U.data());                                        // cc:294
         cost_old = cost_new;
         push_cost(cost_data);
+        if (warm && warm->stop_after_accept) { ++iter; stopped = true; break; }
       } else {
         dlambda = std::fmax(dlambda * ratio, ratio);                               // cc:298
         lambda = std::fmax(lambda * dlambda, reg_min);                             // cc:299
         if (lambda > reg_max) { status = ORACLE_ST_UNSOLVED; ++iter; break; }      // cc:302-307
       }
     }
-    if (status == ORACLE_ST_RUNNING) status = ORACLE_ST_MAX_ITER;                  // cc:312-319
+    if (status == ORACLE_ST_RUNNING && (!stopped || iter >= cfg.max_iter)) status = ORACLE_ST_MAX_ITER;  // cc:312-319
     ToTrajectory(X.data(), U.data(), traj);
+    if (U_out) std::memcpy(U_out, U.data(), U.size() * sizeof(double));
+    if (lambda_out) { lambda_out[0] = lambda; lambda_out[1] = dlambda; }
     *n_cost_out = n_cost;
     *status_out = status;
     if (n_iter_out) *n_iter_out = iter;
@@ -779,6 +813,20 @@ int oracle_plan(void* h, double* traj, double* cost_hist, int* n_cost, int* stat
   if (!o->has_problem) return -1;
   return o->Plan(traj, cost_hist, n_cost, status, n_iter, iter_trajs, max_iter_trajs, n_iter_trajs,
                  trace, min_margin);
+}
+
+/* Step-by-step replay: Optimize() re-entered at iteration `iter` from the iterate (X, U) with the
+ * regularisation state (lambda, dlambda); runs until one iteration is accepted (or the solve ends).
+ * cost_hist row 0 = TotalCost(X, U), row 1 = the accepted trial (if any); trace rows count from the
+ * first replayed iteration; lambda_out = (lambda, dlambda) afterwards. */
+int oracle_replay(void* h, const double* X, const double* U, double lambda, double dlambda, int iter,
+                  double* traj, double* cost_hist, int* n_cost, int* status, int* n_iter, double* trace,
+                  double* lambda_out) {
+  Oracle* o = static_cast<Oracle*>(h);
+  if (!o->has_problem) return -1;
+  Oracle::Warm w{X, U, lambda, dlambda, iter, true};
+  return o->Plan(traj, cost_hist, n_cost, status, n_iter, nullptr, 0, nullptr, trace, nullptr, &w, nullptr,
+                 lambda_out);
 }
 
 void oracle_get_constraints(void* h, double* goals, double* corridor, double* left_abc,
@@ -853,13 +901,18 @@ void oracle_barrier_hessian(void* h, double g, const double* dg, const double* d
 }
 
 /* Batch driver: B independent Plan() calls, single thread.  seconds (nullable) receives the
- * steady_clock time of the set_problem+plan span (what the reference times at cc:82-93). */
-int oracle_solve_batch(const oracle_config* c, int B, const double* start, const double* coarse,
-                       const double* corridor, const int* ccount, int cmax, const double* left,
-                       int n_left, const double* right, int n_right, double* traj, double* cost_hist,
-                       int* n_cost, int* status, int* n_iter, double* min_margin, double* seconds) {
+ * steady_clock time of the set_problem+plan span (what the reference times at cc:82-93).
+ * alpha_trace / iter_margin (nullable, [B][max_iter]): per iteration the accepted alpha index (-1 all
+ * rejected, -2 gradient-norm exit, -3 iteration not run) and the trace's decision margin. */
+int oracle_solve_batch_trace(const oracle_config* c, int B, const double* start, const double* coarse,
+                             const double* corridor, const int* ccount, int cmax, const double* left,
+                             int n_left, const double* right, int n_right, double* traj, double* cost_hist,
+                             int* n_cost, int* status, int* n_iter, double* min_margin, double* seconds,
+                             signed char* alpha_trace, double* iter_margin) {
   Oracle* o = static_cast<Oracle*>(oracle_create(c));
-  const int K = o->K;
+  const int K = o->K, M = c->max_iter;
+  const bool want_trace = alpha_trace != nullptr || iter_margin != nullptr;
+  std::vector<double> trace(want_trace ? (size_t)M * kTraceCols : 0);
   const auto t0 = std::chrono::steady_clock::now();
   int rc = 0;
   for (int b = 0; b < B; ++b) {
@@ -867,15 +920,29 @@ int oracle_solve_batch(const oracle_config* c, int B, const double* start, const
                        corridor + (size_t)b * K * cmax * 3, ccount + (size_t)b * K, cmax, left, n_left,
                        right, n_right);
     if (rc != 0) break;
-    rc = o->Plan(traj + (size_t)b * K * 10, cost_hist + (size_t)b * (c->max_iter + 1) * 5, n_cost + b,
-                 status + b, n_iter ? n_iter + b : nullptr, nullptr, 0, nullptr, nullptr,
+    int iters = 0;
+    rc = o->Plan(traj + (size_t)b * K * 10, cost_hist + (size_t)b * (M + 1) * 5, n_cost + b,
+                 status + b, &iters, nullptr, 0, nullptr, want_trace ? trace.data() : nullptr,
                  min_margin ? min_margin + b : nullptr);
     if (rc != 0) break;
+    if (n_iter) n_iter[b] = iters;
+    for (int i = 0; i < M && want_trace; ++i) {
+      if (alpha_trace) alpha_trace[(size_t)b * M + i] = (i < iters) ? (signed char)trace[(size_t)i * kTraceCols] : -3;
+      if (iter_margin) iter_margin[(size_t)b * M + i] = (i < iters) ? trace[(size_t)i * kTraceCols + 8] : 0.0;
+    }
   }
   const auto t1 = std::chrono::steady_clock::now();
   if (seconds) *seconds = std::chrono::duration<double>(t1 - t0).count();
   delete o;
   return rc;
+}
+
+int oracle_solve_batch(const oracle_config* c, int B, const double* start, const double* coarse,
+                       const double* corridor, const int* ccount, int cmax, const double* left,
+                       int n_left, const double* right, int n_right, double* traj, double* cost_hist,
+                       int* n_cost, int* status, int* n_iter, double* min_margin, double* seconds) {
+  return oracle_solve_batch_trace(c, B, start, coarse, corridor, ccount, cmax, left, n_left, right, n_right,
+                                  traj, cost_hist, n_cost, status, n_iter, min_margin, seconds, nullptr, nullptr);
 }
 
 }  // extern "C"

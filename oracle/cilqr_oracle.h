@@ -63,12 +63,23 @@ int oracle_set_problem(void* h, const double* start4, const double* coarse, int 
  * traj: K x (time,x,y,theta,v,a,delta,kappa,jerk,delta_rate)  (cc:771-791)
  * cost_hist: (max_iter+1) x (total,target,dynamic,corridor,lane) (h:14-27)
  * iter_trajs (nullable): up to max_iter_trajs x K x 10, init guess + accepted non-final iterates
- * trace (nullable): max_iter x 8: (accepted alpha index or -1, lambda used in Backward,
- *   dV0, dV1, cost_new of last trial, dcost, z, gnorm)
+ * trace (nullable): max_iter x 10: (accepted alpha index, -1 = all eleven rejected, -2 = gradient-norm
+ *   exit; lambda used in Backward; dV0; dV1; cost_new of last trial; dcost; z; gnorm; smallest relative
+ *   distance of this iteration's accept / converge / exit tests to their thresholds; trials evaluated)
  * min_margin (nullable): smallest relative distance of any accept/converge decision to its threshold */
 int oracle_plan(void* h, double* traj, double* cost_hist, int* n_cost, int* status, int* n_iter,
                 double* iter_trajs, int max_iter_trajs, int* n_iter_trajs, double* trace,
                 double* min_margin);
+
+/* Step-by-step replay for the parity tests: Optimize() re-entered at iteration `iter` from the iterate
+ * X [K][6], U [N][2] with regularisation state (lambda, dlambda); runs until ONE iteration is accepted or
+ * the solve ends (status stays ORACLE_ST_RUNNING when it stopped after a non-converging accept).
+ * cost_hist row 0 = TotalCost(X, U), row 1 = the accepted trial; n_iter = index of the next iteration;
+ * trace rows (10 columns, see oracle_plan) count from the first replayed iteration;
+ * traj = the iterate afterwards; lambda_out[2] = (lambda, dlambda) afterwards. */
+int oracle_replay(void* h, const double* X, const double* U, double lambda, double dlambda, int iter,
+                  double* traj, double* cost_hist, int* n_cost, int* status, int* n_iter, double* trace,
+                  double* lambda_out);
 
 /* ---- stage entry points (same arithmetic as inside oracle_plan) ---- */
 void oracle_get_constraints(void* h, double* goals /*K*6*/, double* corridor /*K*cmax*3*/,
@@ -99,6 +110,14 @@ int oracle_solve_batch(const oracle_config* c, int B, const double* start, const
                        const double* corridor, const int* ccount, int cmax, const double* left,
                        int n_left, const double* right, int n_right, double* traj, double* cost_hist,
                        int* n_cost, int* status, int* n_iter, double* min_margin, double* seconds);
+/* Same, plus per iteration ([B][max_iter], nullable): the accepted alpha index (-1 = all eleven
+ * rejected, -2 = gradient-norm exit, -3 = iteration not run) and the smallest relative distance of
+ * that iteration's tests to their thresholds (trace column 8). */
+int oracle_solve_batch_trace(const oracle_config* c, int B, const double* start, const double* coarse,
+                             const double* corridor, const int* ccount, int cmax, const double* left,
+                             int n_left, const double* right, int n_right, double* traj, double* cost_hist,
+                             int* n_cost, int* status, int* n_iter, double* min_margin, double* seconds,
+                             signed char* alpha_trace, double* iter_margin);
 
 #ifdef __cplusplus
 }

@@ -112,7 +112,7 @@ class Oracle:
         hist = np.zeros((M + 1, 5))
         n_cost, status, n_iter, n_it = C.c_int(), C.c_int(), C.c_int(), C.c_int()
         it = np.zeros((max_iter_trajs, K, 10)) if max_iter_trajs else None
-        trace = np.zeros((M, 8)) if want_trace else None
+        trace = np.zeros((M, 10)) if want_trace else None
         margin = C.c_double()
         rc = self.L.oracle_plan(self.h, _p(traj), _p(hist), C.byref(n_cost), C.byref(status),
                                 C.byref(n_iter), _p(it), C.c_int(max_iter_trajs), C.byref(n_it),
@@ -121,6 +121,28 @@ class Oracle:
                     n_iter=n_iter.value, iter_trajs=it, n_iter_trajs=n_it.value,
                     trace=trace[:n_iter.value] if trace is not None else None,
                     min_margin=margin.value)
+
+    def replay(self, X, U, lam: float, dlam: float, it: int):
+        """Optimize() re-entered at iteration `it` from the iterate (X, U) with regularisation state
+        (lam, dlam): runs until one iteration is accepted or the solve ends.  Returns dict(cost0 = cost
+        row of (X, U), cost1 = accepted row or None, traj = iterate afterwards [K,10], status, n_iter
+        = next iteration index, decisions = accepted alpha index per replayed iteration (-1 rejected,
+        -2 gradient-norm exit), margins, lam, dlam afterwards)."""
+        X, U = _f64(X), _f64(U)
+        K, M = self.K, self.cfg.max_iter
+        traj = np.zeros((K, 10))
+        hist = np.zeros((M + 1, 5))
+        n_cost, status, n_iter = C.c_int(), C.c_int(), C.c_int()
+        trace = np.zeros((max(1, M - it), 10))
+        lo = np.zeros(2)
+        rc = self.L.oracle_replay(self.h, _p(X), _p(U), C.c_double(lam), C.c_double(dlam), C.c_int(it), _p(traj),
+                                  _p(hist), C.byref(n_cost), C.byref(status), C.byref(n_iter), _p(trace), _p(lo))
+        if rc != 0:
+            raise RuntimeError("oracle_replay: no problem set")
+        n = n_iter.value - it
+        return dict(cost0=hist[0].copy(), cost1=hist[1].copy() if n_cost.value > 1 else None, traj=traj,
+                    status=status.value, n_iter=n_iter.value, decisions=trace[:n, 0].astype(int),
+                    margins=trace[:n, 8].copy(), lam=float(lo[0]), dlam=float(lo[1]))
 
     # ---- stages ----
     def constraints(self):
@@ -215,8 +237,10 @@ def segment_distance(seg4, px, py) -> float:
     return lib().oracle_segment_distance(_p(seg4), C.c_double(px), C.c_double(py))
 
 
-def solve_batch(scene: dict, cfg: OracleConfig | None = None, want_margin: bool = True):
-    """Loop of independent Plan() calls over a problem-major scene dict (scenario.generate)."""
+def solve_batch(scene: dict, cfg: OracleConfig | None = None, want_margin: bool = True, want_trace: bool = False):
+    """Loop of independent Plan() calls over a problem-major scene dict (scenario.generate).
+    want_trace adds alpha_trace [B, max_iter] int8 (accepted alpha index per iteration, -1 all rejected,
+    -2 gradient-norm exit, -3 not run) and iter_margin [B, max_iter] (decision margins)."""
     start, coarse = _f64(scene["start"]), _f64(scene["coarse"])
     corridor = _f64(scene["corridor"])
     ccount = np.ascontiguousarray(scene["ccount"], dtype=np.int32)
@@ -232,13 +256,16 @@ def solve_batch(scene: dict, cfg: OracleConfig | None = None, want_margin: bool 
     n_iter = np.zeros(B, np.int32)
     margin = np.zeros(B) if want_margin else None
     sec = C.c_double()
-    rc = lib().oracle_solve_batch(C.byref(cfg), C.c_int(B), _p(start), _p(coarse), _p(corridor),
-                                  _p(ccount, C.c_int), C.c_int(corridor.shape[2]), _p(left),
-                                  C.c_int(left.shape[0]), _p(right), C.c_int(right.shape[0]), _p(traj),
-                                  _p(hist), _p(n_cost, C.c_int), _p(status, C.c_int),
-                                  _p(n_iter, C.c_int), _p(margin), C.byref(sec))
+    atrace = np.full((B, M), -3, np.int8) if want_trace else None
+    imargin = np.zeros((B, M)) if want_trace else None
+    rc = lib().oracle_solve_batch_trace(C.byref(cfg), C.c_int(B), _p(start), _p(coarse), _p(corridor),
+                                        _p(ccount, C.c_int), C.c_int(corridor.shape[2]), _p(left),
+                                        C.c_int(left.shape[0]), _p(right), C.c_int(right.shape[0]), _p(traj),
+                                        _p(hist), _p(n_cost, C.c_int), _p(status, C.c_int),
+                                        _p(n_iter, C.c_int), _p(margin), C.byref(sec),
+                                        _p(atrace, C.c_byte), _p(imargin))
     return dict(rc=rc, traj=traj, cost_hist=hist, n_cost=n_cost, status=status, n_iter=n_iter,
-                min_margin=margin, seconds=sec.value)
+                min_margin=margin, seconds=sec.value, alpha_trace=atrace, iter_margin=imargin)
 
 
 CORRIDOR_CFG = (25.0, 25.0, 150.0, 10.0, 10.0)   # max_diff_x/y, radius, max_axis_x/y (planner_config.h:75-86)

@@ -8,7 +8,7 @@ obstacle points -> corridors -> CILQR solve chain on the device."""
 import numpy as np
 import pytest
 
-from parity_util import assert_parity, oracle_cfg_from, oracle_reference
+from parity_util import assert_parity, assert_steps, oracle_cfg_from, oracle_reference
 from cilqr_amd import api, scenario
 from oracle import oracle as orc
 
@@ -214,10 +214,24 @@ def test_obstacles_to_trajectories_on_the_device(built):
     assert opt.solve_raw(prob, sol) == api.OK
     torch.cuda.synchronize()
     sc2 = dict(sc, corridor=cor_h, ccount=cnt_h)
-    host = opt.plan(sc2)
+    host = opt.plan(sc2, max_iter_trajs=48, alpha_trace=True)
     assert np.array_equal(o_traj.cpu().numpy(), host["traj"]) and np.array_equal(o_st.cpu().numpy(), host["status"])
     ref = oracle_reference(sc2, oracle_cfg_from(opt.cfg))
-    assert_parity(host, ref, max_unstable_frac=0.3)
+    assert_parity(host, ref, max_unstable_frac=0.125)
+    assert_steps(host, sc2, oracle_cfg_from(opt.cfg), what="corridors built on the device")
+    # a knot whose corridor could not be built (negative count, what cilqr_build_corridors writes on
+    # failure) takes its problem out of the solve with CILQR_ST_NO_CORRIDOR -- the reference aborts such a
+    # Plan (corridor.cc:78-81) -- and leaves every other problem's result untouched, bit for bit
+    cnt_bad = cnt_h.copy()
+    cnt_bad[5, 7] = -2
+    cnt_bad[40, 0] = -4
+    bad = opt.plan(dict(sc, corridor=cor_h, ccount=cnt_bad), alpha_trace=True)
+    assert bad["status"][5] == api.ST_NO_CORRIDOR and bad["status"][40] == api.ST_NO_CORRIDOR
+    assert bad["n_cost"][5] == 1 and bad["n_iter"][5] == 1 and bad["alpha_trace"][5, 0] == -2
+    keep = np.ones(B, bool)
+    keep[[5, 40]] = False
+    for k in ("traj", "cost_hist", "n_cost", "status", "n_iter", "alpha_trace"):
+        assert np.array_equal(bad[k][keep], host[k][keep]), k
     opt.close()
 
 

@@ -11,13 +11,20 @@ import os
 import numpy as np
 import pytest
 
-from parity_util import REL_TOL, assert_parity, oracle_cfg_from, oracle_reference, rel_err
+from parity_util import (REL_TOL, assert_parity, assert_steps, cost_err, oracle_cfg_from, oracle_reference, rel_err,
+                         traj_err)
 from cilqr_amd import api, scenario
 from oracle import oracle as orc
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 STAGE_TOL = 1e-9
+ITER_CAP = 48   # iterates kept per problem for the step-by-step replay (longer solves: decisions and costs only)
+
+
+def _plan(opt, sc, **kw):
+    """A solve with everything the parity rules look at: iterates and the per-iteration decisions."""
+    return opt.plan(sc, max_iter_trajs=ITER_CAP, alpha_trace=True, **kw)
 
 
 def _opt(sc, B=None, **cfg_over):
@@ -100,18 +107,78 @@ def test_open_loop_rollout():
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("family,B,seed", [("ped6", 200, 41), ("mix11", 333, 42), ("dyn20", 96, 43), ("demo80", 64, 44)])
 def test_full_solve_parity(family, B, seed):
-    """Per-iteration Cost history, final trajectory, status and iteration counts vs the oracle."""
+    """Whole solves vs the oracle (status, iteration count, accepted step size of every iteration, every
+    Cost row, final trajectory: 1e-4 on every oracle-stable problem; stability = 8 oracle re-runs at a
+    4e-16 input perturbation) AND every single step of every problem, stable or not, replayed in the
+    oracle from the HIP path's own iterate (1e-8).  Unstable shares of these scene sets, which depend on
+    the oracle alone: 5.0 / 3.9 / 2.1 / 9.4 %."""
     sc = scenario.generate(family, B, seed=seed)
     opt = _opt(sc)
-    g = opt.plan(sc)
-    ref = oracle_reference(sc, oracle_cfg_from(opt.cfg), n_perturb=3, eps=1e-13)
-    # the 80-step demo scenes are chaotic in the oracle itself more often than the 50-step families
-    frac = 0.3 if family == "demo80" else 0.15
-    rep = assert_parity(g, ref, what=f"{family} B={B}", max_unstable_frac=frac)
-    st = ref["stable"]
-    assert np.array_equal(g["n_iter"][st], ref["n_iter"][st])
-    assert rep["n_stable"] >= (1.0 - frac) * B
-    print(f"\n[{family}] {rep}")
+    g = _plan(opt, sc)
+    ocfg = oracle_cfg_from(opt.cfg)
+    ref = oracle_reference(sc, ocfg)
+    rep = assert_parity(g, ref, what=f"{family} B={B}")
+    steps = assert_steps(g, sc, ocfg, what=f"{family} B={B}")
+    print(f"\n[{family}] whole solves {rep}\n[{family}] steps {steps}")
+    opt.close()
+
+
+def test_parity_report():
+    """The large-sample comparison (tests/parity_report.py: 1024 scenes of each family), run by the driver:
+    no oracle-stable problem differs, the unstable share stays under 10 %, no step fails its replay and
+    under 1 % of the steps are excused as discontinuous in the oracle.  The report goes to
+    gpurun_out/parity_report.json when that directory exists (copied to profiles/ by hand)."""
+    import json
+    from parity_report import build_report
+    rep = build_report(1024)
+    out_dir = os.path.join(os.path.dirname(HERE), "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "parity_report.json"), "w") as f:
+            json.dump(rep, f, indent=1)
+    for fam, r in rep["families"].items():
+        assert not r["stable_but_different"], (fam, r["stable_but_different"][:10])
+        assert r["oracle_unstable"] <= 0.10 * r["problems"], (fam, r["oracle_unstable"])
+        assert r["steps"]["n_failed"] == 0, (fam, r["steps"]["failed"][:5])
+        assert r["steps"]["excused_discontinuous_in_oracle"] <= 0.01 * r["steps"]["replayed"], (fam, r["steps"])
+
+
+def test_wide_corridors_and_stage_state_after_a_solve():
+    """cmax above 42 (the corridor producer can emit up to 64 planes per knot; the load kernel tiles its
+    LDS transpose so any cmax fits), and the handle's staged state is invalid after a solve: the stage
+    entry points must refuse to run until cilqr_stage_load is called again."""
+    sc = scenario.generate("mix11", 40, seed=77)
+    B, K, c0 = 40, sc["n_steps"] + 1, sc["cmax"]
+    wide = 50
+    cor = np.zeros((B, K, wide, 3))
+    cor[:, :, :c0] = sc["corridor"]
+    cnt = sc["ccount"].copy()
+    rng = np.random.default_rng(3)
+    for b in range(0, B, 2):                      # far-away copies of the live planes: up to 50 per knot
+        for i in range(0, K, 3):
+            n0 = int(cnt[b, i])
+            extra = int(rng.integers(20, wide - n0 + 1))
+            src = rng.integers(0, n0, extra)
+            pl = cor[b, i, src].copy()
+            pl[:, 2] += (3.0 + 20.0 * rng.random(extra)) * np.hypot(pl[:, 0], pl[:, 1])
+            cor[b, i, n0:n0 + extra] = pl
+            cnt[b, i] = n0 + extra
+    sc2 = dict(sc, corridor=cor, ccount=cnt, cmax=wide)
+    assert cnt.max() > 42
+    opt = _opt(sc2)
+    g = _plan(opt, sc2)
+    ocfg = oracle_cfg_from(opt.cfg)
+    ref = oracle_reference(sc2, ocfg)
+    assert_parity(g, ref, max_unstable_frac=0.15, what="wide corridors")
+    assert_steps(g, sc2, ocfg, what="wide corridors")
+    L, h = opt.L, opt.h
+    assert L.cilqr_stage_init_guess(h) == api.ERR_STATE and L.cilqr_stage_quadratize(h) == api.ERR_STATE
+    cost = np.zeros((B, 5))
+    assert L.cilqr_stage_total_cost(h, cost.ctypes.data, api.MEM_HOST) == api.ERR_STATE
+    x = np.zeros((B, K, 6))
+    assert L.cilqr_stage_read(h, api.T_X, x.ctypes.data, api.MEM_HOST) == api.ERR_STATE
+    opt.stage_load(sc2)
+    opt.stage_init_guess()
+    opt.stage_quadratize()                        # works again after a load
     opt.close()
 
 
@@ -126,13 +193,13 @@ def test_golden_fixtures_through_the_c_abi():
         assert np.array_equal(r["n_iter"], g["ref_n_iter"])
         for b in range(sc["start"].shape[0]):
             nc = int(g["ref_n_cost"][b])
-            assert rel_err(r["cost_hist"][b, :nc], g["ref_cost_hist"][b, :nc]) < REL_TOL
-            assert rel_err(r["traj"][b], g["ref_traj"][b]) < REL_TOL
+            assert cost_err(r["cost_hist"][b, :nc], g["ref_cost_hist"][b, :nc]) < REL_TOL
+            assert traj_err(r["traj"][b], g["ref_traj"][b]) < REL_TOL
         # iter_trajs of the first scene: init guess + accepted non-final iterates (cc:170,294)
         n_it = int(g["st_n_iter_trajs"])
         assert r["n_iter_trajs"][0] == n_it
         k = min(n_it, 8)
-        assert rel_err(r["iter_trajs"][0, :k], g["st_iter_trajs"][:k]) < REL_TOL
+        assert traj_err(r["iter_trajs"][0, :k], g["st_iter_trajs"][:k]) < REL_TOL
         opt.close()
 
 
@@ -145,14 +212,17 @@ def test_exit_paths(over, expect):
     """Every exit of Optimize() (max-iter, abs tol, lambda > 1e11 / gnorm) agrees with the oracle."""
     sc = scenario.generate("ped6", 48, seed=51)
     opt = _opt(sc, **over)
-    g = opt.plan(sc)
-    ref = oracle_reference(sc, oracle_cfg_from(opt.cfg), n_perturb=2, eps=1e-13)
-    # with both tolerances at 0 the solver iterates into the rounding-noise plateau, where accept /
-    # reject decisions are not determined at fp64 level: those problems are excused via the
-    # oracle's own decision margins
+    g = _plan(opt, sc)
+    ocfg = oracle_cfg_from(opt.cfg)
+    ref = oracle_reference(sc, ocfg)
+    # With both tolerances at 0 the solver iterates into the rounding-noise plateau, where accept /
+    # reject decisions hang on the last bits of a cost difference: 12 of these 48 problems (25 %) are
+    # not reproducible by the oracle itself there (1 and 5 of 48 for the other two configurations), and
+    # single steps are excused more often -- but every step still has to replay or be shown unstable.
     noisy = over.get("rel_cost_tol", 1.0) == 0.0 and over.get("abs_cost_tol", 1.0) == 0.0
-    assert_parity(g, ref, max_unstable_frac=1.0 if noisy else 0.5, what=str(over),
-                  margin_tol=1e-6 if noisy else 0.0)
+    assert_parity(g, ref, max_unstable_frac=0.35 if noisy else 0.125, what=str(over))
+    steps = assert_steps(g, sc, ocfg, what=str(over), max_excused_frac=0.25 if noisy else 0.02)
+    print(f"\n{over}: steps {steps}")
     if expect is not None:
         assert (g["status"] == expect).sum() >= 1
     else:
@@ -166,9 +236,10 @@ def test_ragged_counts_single_problem_and_odd_batches():
     # ragged corridor: drop to the 4 box planes on some knots, keep everything on others
     sc["ccount"][::3, ::2] = 4
     full = _opt(sc)
-    g = full.plan(sc)
-    ref = oracle_reference(sc, oracle_cfg_from(full.cfg), n_perturb=2, eps=1e-13)
+    g = _plan(full, sc)
+    ref = oracle_reference(sc, oracle_cfg_from(full.cfg))
     assert_parity(g, ref, what="ragged")
+    assert_steps(g, sc, oracle_cfg_from(full.cfg), what="ragged")
     # problems are independent: any sub-batch (1, 63, 65) gives bit-identical results
     for lo, hi in [(7, 8), (0, 63), (65, 130)]:
         sub = {k: (v[lo:hi] if isinstance(v, np.ndarray) and v.shape[:1] == (130,) else v) for k, v in sc.items()}
@@ -401,9 +472,10 @@ def test_short_horizons_empty_knots_and_single_segment_lanes(N):
             sc["left"] = np.ascontiguousarray(sc["left"][3:4])
             sc["right"] = np.ascontiguousarray(sc["right"][3:4])
         opt = _opt(sc)
-        g = opt.plan(sc)
+        g = _plan(opt, sc)
         ref = oracle_reference(sc, oracle_cfg_from(opt.cfg))
-        assert_parity(g, ref, max_unstable_frac=0.2, what=f"N={N} B={B}")
+        assert_parity(g, ref, max_unstable_frac=0.0, what=f"N={N} B={B}")   # every one of them is stable
+        assert_steps(g, sc, oracle_cfg_from(opt.cfg), what=f"N={N} B={B}")
         opt.close()
 
 
@@ -418,7 +490,7 @@ def test_full_size_batch_properties():
           for k, v in base.items()}
     B = 256 * rep
     opt = _opt(sc)
-    g = opt.plan(sc)
+    g = opt.plan(sc, alpha_trace=True)
     assert ((g["status"] >= 1) & (g["status"] <= 5)).all()
     tr = g["traj"].reshape(rep, 256, *g["traj"].shape[1:])
     assert np.array_equal(tr, np.broadcast_to(tr[:1], tr.shape))
@@ -428,7 +500,7 @@ def test_full_size_batch_properties():
     for b in range(256):
         assert np.all(np.diff(tot[b, :g["n_cost"][b]]) < 0)
     first = {k: v[:256] for k, v in g.items() if isinstance(v, np.ndarray)}
-    ref = oracle_reference(base, oracle_cfg_from(opt.cfg), n_perturb=3, eps=1e-13)
+    ref = oracle_reference(base, oracle_cfg_from(opt.cfg))
     assert_parity(first, ref, what="full-size batch")
     assert B == 65536
     opt.close()
@@ -548,8 +620,8 @@ def test_cpp_adapter_plan_matches_oracle(tmp_path):
     cost = body[K * 10:K * 10 + n_cost * 5].reshape(n_cost, 5)
     it0 = body[K * 10 + n_cost * 5:].reshape(K, 10)
     assert n_cost == g["ref_n_cost"][b] and n_it == n_cost - 1
-    assert rel_err(cost, g["ref_cost_hist"][b, :n_cost]) < REL_TOL
-    assert rel_err(traj, g["ref_traj"][b]) < REL_TOL
+    assert cost_err(cost, g["ref_cost_hist"][b, :n_cost]) < REL_TOL
+    assert traj_err(traj, g["ref_traj"][b]) < REL_TOL
     o = orc.Oracle(n_steps=K - 1)
     o.set_problem(g["start"][b], g["coarse"][b], g["corridor"][b], g["ccount"][b], g["left"], g["right"])
     X, U = o.init_guess()
@@ -568,10 +640,12 @@ def test_nondefault_configuration_parity(over):
     the reference defaults)."""
     sc = scenario.generate("mix11", 72, seed=97)
     opt = _opt(sc, **over)
-    g = opt.plan(sc)
-    ref = oracle_reference(sc, oracle_cfg_from(opt.cfg), n_perturb=2, eps=1e-13)
-    rep = assert_parity(g, ref, max_unstable_frac=0.35, what=str(over))
-    assert rep["n_stable"] >= 40
+    g = _plan(opt, sc)
+    ref = oracle_reference(sc, oracle_cfg_from(opt.cfg))
+    # not reproducible by the oracle itself under these five configurations: 4 / 8 / 6 / 1 / 11 of the 72 scenes
+    rep = assert_parity(g, ref, max_unstable_frac=0.16, what=str(over))
+    assert_steps(g, sc, oracle_cfg_from(opt.cfg), what=str(over))
+    assert rep["n_stable"] >= 60
     # the stages too, on one problem
     opt.stage_load(sc)
     opt.stage_init_guess()

@@ -1,0 +1,87 @@
+"""The comparison rules of tests/parity_util.py, exercised on the CPU with the oracle standing in
+for the HIP path: the step-by-step replay must accept the oracle's own solves bit for bit (every exit
+path), follow a decision history that is not the oracle's, and catch a tampered result."""
+import numpy as np
+import pytest
+
+import parity_util as pu
+from cilqr_amd import scenario
+from oracle import oracle as orc
+
+
+def oracle_as_gpu(sc, cfg, cap=64):
+    """A dict shaped like BatchIlqrOptimizer.plan(..., max_iter_trajs=cap, alpha_trace=True)."""
+    B, K, M = sc["coarse"].shape[0], sc["coarse"].shape[1], cfg.max_iter
+    out = dict(traj=np.zeros((B, K, 10)), cost_hist=np.zeros((B, M + 1, 5)), n_cost=np.zeros(B, np.int32),
+               status=np.zeros(B, np.int32), n_iter=np.zeros(B, np.int32), iter_trajs=np.zeros((B, cap, K, 10)),
+               n_iter_trajs=np.zeros(B, np.int32), alpha_trace=np.full((B, M), -3, np.int8))
+    for b in range(B):
+        o = orc.Oracle(cfg)
+        assert o.set_problem(sc["start"][b], sc["coarse"][b], sc["corridor"][b], sc["ccount"][b], sc["left"], sc["right"]) == 0
+        r = o.plan(max_iter_trajs=cap, want_trace=True)
+        out["traj"][b], out["cost_hist"][b] = r["traj"], r["cost_hist"]
+        out["n_cost"][b], out["status"][b], out["n_iter"][b] = r["n_cost"], r["status"], r["n_iter"]
+        out["iter_trajs"][b], out["n_iter_trajs"][b] = r["iter_trajs"], r["n_iter_trajs"]
+        out["alpha_trace"][b, :r["n_iter"]] = r["trace"][:, 0].astype(np.int8)
+    return out
+
+
+@pytest.mark.parametrize("over", [dict(), dict(max_iter=3), dict(rel_cost_tol=0.0, abs_cost_tol=5.0),
+                                  dict(rel_cost_tol=0.0, abs_cost_tol=0.0, max_iter=40)])
+def test_replay_reproduces_the_oracle_step_by_step(over):
+    sc = scenario.generate("mix11", 12, seed=17)
+    cfg = orc.default_config(sc["n_steps"], **over)
+    g = oracle_as_gpu(sc, cfg)
+    rep = pu.check_steps(g, sc, cfg, tol=0.0)          # its own solve: every step bit for bit
+    assert rep["steps"] >= 12 and rep["tight"] == rep["steps"] and not rep["failed"] and rep["excused"] == 0
+    assert rep["worst"] == 0.0
+    # the batch driver's trace agrees with the per-problem one
+    r = orc.solve_batch(sc, cfg, want_trace=True)
+    assert np.array_equal(r["alpha_trace"], g["alpha_trace"]) and np.array_equal(r["n_iter"], g["n_iter"])
+    n_pass, fails = pu.compare_solutions(g, r, tol=0.0)
+    assert n_pass == 12 and not fails
+
+
+def test_replay_catches_a_tampered_result():
+    sc = scenario.generate("mix11", 4, seed=18)
+    cfg = orc.default_config(sc["n_steps"])
+    g = oracle_as_gpu(sc, cfg)
+    bad = {k: v.copy() for k, v in g.items()}
+    bad["cost_hist"][1, 1, 3] *= 1.0 + 1e-6            # one Cost entry of one accepted row
+    rep = pu.check_steps(bad, sc, cfg)
+    assert [f[0] for f in rep["failed"]] == [1] * len(rep["failed"]) and rep["failed"]
+    bad = {k: v.copy() for k, v in g.items()}
+    b = int(np.argmax(g["n_iter_trajs"] >= 3))
+    bad["iter_trajs"][b, 2, 10, 1] += 1e-5             # one state of one intermediate iterate
+    rep = pu.check_steps(bad, sc, cfg)
+    assert rep["failed"] and all(f[0] == b for f in rep["failed"])
+    bad = {k: v.copy() for k, v in g.items()}
+    it = int(np.argmax(bad["alpha_trace"][0] >= 0))
+    bad["alpha_trace"][0, it] += 1                      # a different step size than the oracle accepts
+    rep = pu.check_steps(bad, sc, cfg)
+    assert rep["failed"] and rep["failed"][0][0] == 0
+
+
+def test_error_measures_scale_per_column():
+    ref = np.zeros((5, 10))
+    ref[:, 1] = 100.0      # x
+    ref[:, 6] = 0.05       # delta
+    a = ref.copy()
+    a[2, 6] += 5e-6        # 1e-4 of the column scale
+    assert pu.traj_err(a, ref) == pytest.approx(1e-4)
+    a = ref.copy()
+    a[2, 1] += 5e-6        # the same absolute error on a 100 m coordinate
+    assert pu.traj_err(a, ref) == pytest.approx(5e-8)
+    row = np.array([100.0, 60.0, 39.0, 1.0, 1e-9])
+    assert pu.cost_err(row * (1 + 1e-6), row) == pytest.approx(1e-6)
+    r2 = row.copy()
+    r2[4] = 2e-9           # a vanishing component is measured against 1e-3 of the row's mass
+    assert pu.cost_err(r2, row) < 1e-7
+
+
+def test_stability_mask_uses_the_documented_perturbation():
+    assert pu.PERTURB_EPS == 4e-16 and pu.N_PERTURB >= 8 and pu.MAX_UNSTABLE_FRAC <= 0.10
+    sc = scenario.generate("mix11", 48, seed=19)
+    ref = pu.oracle_reference(sc, orc.default_config(sc["n_steps"]))
+    assert ref["stable"].sum() >= 40 and ref["alpha_trace"].shape == (48, 200)
+    assert np.all(ref["spread"][ref["stable"]] <= pu.STABLE_TOL)
