@@ -908,7 +908,7 @@ int oracle_solve_batch_trace(const oracle_config* c, int B, const double* start,
                              const double* corridor, const int* ccount, int cmax, const double* left,
                              int n_left, const double* right, int n_right, double* traj, double* cost_hist,
                              int* n_cost, int* status, int* n_iter, double* min_margin, double* seconds,
-                             signed char* alpha_trace, double* iter_margin) {
+                             signed char* alpha_trace, double* iter_margin, double* problem_seconds) {
   Oracle* o = static_cast<Oracle*>(oracle_create(c));
   const int K = o->K, M = c->max_iter;
   const bool want_trace = alpha_trace != nullptr || iter_margin != nullptr;
@@ -916,6 +916,7 @@ int oracle_solve_batch_trace(const oracle_config* c, int B, const double* start,
   const auto t0 = std::chrono::steady_clock::now();
   int rc = 0;
   for (int b = 0; b < B; ++b) {
+    const auto tb = std::chrono::steady_clock::now();
     rc = o->SetProblem(start + (size_t)b * 4, coarse + (size_t)b * K * 6, K,
                        corridor + (size_t)b * K * cmax * 3, ccount + (size_t)b * K, cmax, left, n_left,
                        right, n_right);
@@ -925,6 +926,8 @@ int oracle_solve_batch_trace(const oracle_config* c, int B, const double* start,
                  status + b, &iters, nullptr, 0, nullptr, want_trace ? trace.data() : nullptr,
                  min_margin ? min_margin + b : nullptr);
     if (rc != 0) break;
+    if (problem_seconds)   // the span the reference times around Plan (ilqr_optimizer.cc:82-93)
+      problem_seconds[b] = std::chrono::duration<double>(std::chrono::steady_clock::now() - tb).count();
     if (n_iter) n_iter[b] = iters;
     for (int i = 0; i < M && want_trace; ++i) {
       if (alpha_trace) alpha_trace[(size_t)b * M + i] = (i < iters) ? (signed char)trace[(size_t)i * kTraceCols] : -3;
@@ -942,7 +945,8 @@ int oracle_solve_batch(const oracle_config* c, int B, const double* start, const
                        int n_left, const double* right, int n_right, double* traj, double* cost_hist,
                        int* n_cost, int* status, int* n_iter, double* min_margin, double* seconds) {
   return oracle_solve_batch_trace(c, B, start, coarse, corridor, ccount, cmax, left, n_left, right, n_right,
-                                  traj, cost_hist, n_cost, status, n_iter, min_margin, seconds, nullptr, nullptr);
+                                  traj, cost_hist, n_cost, status, n_iter, min_margin, seconds, nullptr, nullptr,
+                                  nullptr);
 }
 
 }  // extern "C"

@@ -112,12 +112,13 @@ int oracle_solve_batch(const oracle_config* c, int B, const double* start, const
                        int* n_cost, int* status, int* n_iter, double* min_margin, double* seconds);
 /* Same, plus per iteration ([B][max_iter], nullable): the accepted alpha index (-1 = all eleven
  * rejected, -2 = gradient-norm exit, -3 = iteration not run) and the smallest relative distance of
- * that iteration's tests to their thresholds (trace column 8). */
+ * that iteration's tests to their thresholds (trace column 8); problem_seconds ([B], nullable): the
+ * steady_clock time of every single solve. */
 int oracle_solve_batch_trace(const oracle_config* c, int B, const double* start, const double* coarse,
                              const double* corridor, const int* ccount, int cmax, const double* left,
                              int n_left, const double* right, int n_right, double* traj, double* cost_hist,
                              int* n_cost, int* status, int* n_iter, double* min_margin, double* seconds,
-                             signed char* alpha_trace, double* iter_margin);
+                             signed char* alpha_trace, double* iter_margin, double* problem_seconds);
 
 #ifdef __cplusplus
 }

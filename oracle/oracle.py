@@ -237,7 +237,8 @@ def segment_distance(seg4, px, py) -> float:
     return lib().oracle_segment_distance(_p(seg4), C.c_double(px), C.c_double(py))
 
 
-def solve_batch(scene: dict, cfg: OracleConfig | None = None, want_margin: bool = True, want_trace: bool = False):
+def solve_batch(scene: dict, cfg: OracleConfig | None = None, want_margin: bool = True, want_trace: bool = False,
+                want_times: bool = False):
     """Loop of independent Plan() calls over a problem-major scene dict (scenario.generate).
     want_trace adds alpha_trace [B, max_iter] int8 (accepted alpha index per iteration, -1 all rejected,
     -2 gradient-norm exit, -3 not run) and iter_margin [B, max_iter] (decision margins)."""
@@ -258,14 +259,16 @@ def solve_batch(scene: dict, cfg: OracleConfig | None = None, want_margin: bool 
     sec = C.c_double()
     atrace = np.full((B, M), -3, np.int8) if want_trace else None
     imargin = np.zeros((B, M)) if want_trace else None
+    ptimes = np.zeros(B) if want_times else None
     rc = lib().oracle_solve_batch_trace(C.byref(cfg), C.c_int(B), _p(start), _p(coarse), _p(corridor),
                                         _p(ccount, C.c_int), C.c_int(corridor.shape[2]), _p(left),
                                         C.c_int(left.shape[0]), _p(right), C.c_int(right.shape[0]), _p(traj),
                                         _p(hist), _p(n_cost, C.c_int), _p(status, C.c_int),
                                         _p(n_iter, C.c_int), _p(margin), C.byref(sec),
-                                        _p(atrace, C.c_byte), _p(imargin))
+                                        _p(atrace, C.c_byte), _p(imargin), _p(ptimes))
     return dict(rc=rc, traj=traj, cost_hist=hist, n_cost=n_cost, status=status, n_iter=n_iter,
-                min_margin=margin, seconds=sec.value, alpha_trace=atrace, iter_margin=imargin)
+                min_margin=margin, seconds=sec.value, alpha_trace=atrace, iter_margin=imargin,
+                problem_seconds=ptimes)
 
 
 CORRIDOR_CFG = (25.0, 25.0, 150.0, 10.0, 10.0)   # max_diff_x/y, radius, max_axis_x/y (planner_config.h:75-86)
