@@ -147,6 +147,7 @@ def main():
     torch.cuda.synchronize()   # inputs uploaded and outputs zero-filled before the solvers' own streams start
 
     prof_acc = dict(bwd_ms=0.0, bwd_launches=0, bwd_steps=0, iters=0, full_ms=0.0, full_launches=0)
+    last_gather = [None]
 
     def collect(c, timed):
         rc = c.opt.wait()
@@ -163,7 +164,7 @@ def main():
             prof_acc["full_launches"] += p.backward_full_launches
         if use_dist:
             # 8 of the 10 trajectory columns travel (time and kappa are functions of the others)
-            gather_results(c.traj, c.hist, c.nc, c.st, dst=0, densify=False, derive=(cfg.dt, cfg.wheel_base))
+            last_gather[0] = gather_results(c.traj, c.hist, c.nc, c.st, dst=0, densify=False, derive=(cfg.dt, cfg.wheel_base))
 
     def run_steps(n, timed):
         for s_ in range(n):
@@ -208,6 +209,64 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+
+    # Extra (never `value`): the same gather through the C-ABI (cilqr_comm_* / cilqr_gather_results: librccl
+    # called directly, no PyTorch), checked against the torch.distributed gather of the timed region.  Guarded
+    # by a watchdog: a multi-rank send / recv cannot be rehearsed on a 1-GPU box.
+    cabi = None
+    if use_dist:
+        import threading
+        res = {}
+
+        def run_cabi():
+            try:
+                ids = [api.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(ids, src=0)
+                opt.comm_create(ids[0], rank, world)
+                g = None
+                if rank == 0:
+                    g = dict(traj=torch.zeros((world * B, K, 10), dtype=torch.float64, device=dev),
+                             hist=torch.zeros((world * B, M + 1, 5), dtype=torch.float64, device=dev),
+                             nc=torch.zeros(world * B, dtype=torch.int32, device=dev),
+                             st=torch.zeros(world * B, dtype=torch.int32, device=dev))
+                    gsol = api.SolutionBatch(api.MEM_DEVICE, 0, g["traj"].data_ptr(), g["hist"].data_ptr(),
+                                             g["nc"].data_ptr(), g["st"].data_ptr(), None, None, None)
+                torch.cuda.synchronize()
+                dist.barrier()
+                times = []
+                for _ in range(3):
+                    t1 = time.perf_counter()
+                    rc_ = opt.gather_results_raw(B, ctx[0].sol, 0, gsol if rank == 0 else None)
+                    times.append(time.perf_counter() - t1)
+                    if rc_ != api.OK:
+                        raise api.CilqrError(rc_, "in cilqr_gather_results")
+                res["ms"] = round(1e3 * min(times), 3)
+                if rank == 0:
+                    tg = last_gather[0]
+                    res["ranks"] = world
+                    # the torch path rebuilds kappa with torch.tan, the C-ABI with the device's tan (as the solver
+                    # does): compare the 8 travelling columns bit for bit, kappa to an ulp
+                    cols = [1, 2, 3, 4, 5, 6, 8, 9]
+                    res["identical_to_torch_gather"] = bool(
+                        torch.equal(g["traj"][:, :, cols], tg["traj"][:, :, cols]) and torch.equal(g["nc"], tg["n_cost"])
+                        and torch.equal(g["st"], tg["status"])
+                        and torch.equal(g["hist"][torch.arange(M + 1, device=dev)[None, :] < g["nc"][:, None].long()],
+                                        tg["hist_rows"])
+                        and bool(torch.allclose(g["traj"][:, :, 7], tg["traj"][:, :, 7], rtol=1e-15, atol=0.0)))
+                    res["rank0_block_identical_to_local"] = bool(torch.equal(g["traj"][:B], ctx[0].traj))
+                opt.comm_destroy()
+                res["ok"] = True
+            except Exception as e:   # noqa: BLE001
+                res["ok"] = False
+                res["error"] = repr(e)
+
+        th = threading.Thread(target=run_cabi, daemon=True)
+        th.start()
+        th.join(120.0)
+        cabi = dict(res) if not th.is_alive() else {"ok": False, "error": "no return within 120 s"}
+        hung = th.is_alive()
+    else:
+        hung = False
 
     # sequential form: two more steps back to back on one handle, no events
     seq = None
@@ -389,6 +448,7 @@ def main():
                               "note": "one batch in flight: the same solve called back to back, nothing overlapped"}
                              if seq else None),
             "results_identical_across_handles": same,
+            "c_abi_gather": cabi,
             "end_to_end": end_to_end,
             # per-phase HIP-event times of the calibration step (one batch alone, events around every phase)
             "breakdown_ms_per_step": ({k: round(single[k], 3) for k in ("quad_ms", "bwd_ms", "ls_ms", "other_ms", "total_ms")}
@@ -399,6 +459,10 @@ def main():
             "scene_generation_s": round(t_gen, 1),
             "device_bytes": sum(c.opt.device_bytes() for c in ctx),
         }
+    if hung:   # a stuck collective cannot be torn down: print the line and leave
+        if rank == 0:
+            os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        os._exit(0)
     for c in ctx:
         c.opt.close()
     if use_dist:

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("CILQR_LIB") or os.path.join(_HERE, "lib", "libcilqr_h
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "cilqr.h")
 
 OK = 0
-ERR_NULL, ERR_CONSTRAINTS, ERR_KNOTS, ERR_CAPACITY, ERR_DEVICE, ERR_ARG, ERR_STATE = -1, -2, -3, -4, -5, -6, -7
+ERR_NULL, ERR_CONSTRAINTS, ERR_KNOTS, ERR_CAPACITY, ERR_DEVICE, ERR_ARG, ERR_STATE, ERR_NO_PATH = -1, -2, -3, -4, -5, -6, -7, -8
 MEM_HOST, MEM_DEVICE = 0, 1
 OPT_SPEC_THRESHOLD = 1
 OPT_COMPACTION = 2
@@ -72,6 +72,24 @@ class CorridorConfig(C.Structure):
                 ("max_axis_x", C.c_double), ("max_axis_y", C.c_double), ("lane_segment_length", C.c_double)]
 
 
+class DpConfig(C.Structure):
+    """Live fields of PlannerConfig / VehicleParam for the DP coarse planner (include/cilqr.h)."""
+    _fields_ = [(n, C.c_double) for n in (
+        "tf", "delta_t", "dp_nominal_velocity", "dp_w_obstacle", "dp_w_lateral", "dp_w_lateral_change",
+        "dp_w_lateral_velocity_change", "dp_w_longitudinal_velocity_bias", "dp_w_longitudinal_velocity_change",
+        "front_hang_length", "wheel_base", "rear_hang_length", "width", "max_velocity")]
+
+
+class SceneStruct(C.Structure):
+    _fields_ = [("center", C.c_void_p), ("n_center", C.c_int32), ("n_static", C.c_int32),
+                ("static_points", C.c_void_p), ("static_counts", C.c_void_p), ("n_dynamic", C.c_int32),
+                ("reserved0", C.c_int32), ("dynamic_polygon_points", C.c_void_p), ("dynamic_polygon_counts", C.c_void_p),
+                ("dynamic_trajectories", C.c_void_p), ("dynamic_trajectory_counts", C.c_void_p)]
+
+
+COARSE_FIELDS = 9   # time, s, x, y, theta, kappa, velocity, a, delta
+
+
 class Profile(C.Structure):
     _fields_ = [
         ("iterations", C.c_int32), ("backward_launches", C.c_int32), ("backward_ms", C.c_double),
@@ -88,7 +106,10 @@ EXPORTS = [
     "cilqr_stage_total_cost", "cilqr_stage_quadratize", "cilqr_stage_backward", "cilqr_stage_forward",
     "cilqr_stage_read", "cilqr_stage_nearest_lane", "cilqr_open_loop_rollout", "cilqr_error_string",
     "cilqr_default_corridor_config", "cilqr_build_corridors", "cilqr_lane_constraints",
+    "cilqr_default_dp_config", "cilqr_dp_plan", "cilqr_road_barriers",
+    "cilqr_comm_unique_id", "cilqr_comm_create", "cilqr_comm_destroy", "cilqr_comm_info", "cilqr_gather_results",
 ]
+UNIQUE_ID_BYTES = 128
 
 _LIB = None
 
@@ -140,6 +161,16 @@ def lib():
                                                C.c_int32, C.c_int32]
         L.cilqr_open_loop_rollout.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.c_int32]
+        L.cilqr_default_dp_config.argtypes = [C.POINTER(DpConfig)]
+        L.cilqr_default_dp_config.restype = None
+        L.cilqr_dp_plan.argtypes = [C.POINTER(DpConfig), C.POINTER(SceneStruct), C.c_void_p, C.c_void_p, C.c_int32]
+        L.cilqr_road_barriers.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]
+        L.cilqr_comm_unique_id.argtypes = [C.c_void_p]
+        L.cilqr_comm_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
+        L.cilqr_comm_destroy.argtypes = [C.c_void_p]
+        L.cilqr_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.cilqr_gather_results.argtypes = [C.c_void_p, C.c_int32, C.POINTER(SolutionBatch), C.c_int32,
+                                           C.POINTER(SolutionBatch)]
         _LIB = L
     return _LIB
 
@@ -237,6 +268,18 @@ class BatchIlqrOptimizer:
         out = np.empty_like(x)
         self._chk(self.L.cilqr_device_math(self.h, fn, x.size, _ptr(x), _ptr(out)), "device_math")
         return out
+
+    # ---- multi-GPU: one process per GPU, one RCCL gather of the results (include/cilqr.h) ----
+    def comm_create(self, unique_id: bytes, rank: int, world: int):
+        buf = (C.c_uint8 * UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
+        self._chk(self.L.cilqr_comm_create(self.h, buf, rank, world), "comm_create")
+
+    def comm_destroy(self):
+        self._chk(self.L.cilqr_comm_destroy(self.h), "comm_destroy")
+
+    def gather_results_raw(self, batch: int, local: SolutionBatch, root: int, gathered: "SolutionBatch | None") -> int:
+        return self.L.cilqr_gather_results(self.h, batch, C.byref(local), root,
+                                           C.byref(gathered) if gathered is not None else None)
 
     # ---- numpy (host memory) interface ----
     def _host_problem(self, scene: dict):
@@ -373,6 +416,55 @@ class BatchIlqrOptimizer:
         X = np.zeros((B, self.K, 6))
         self._chk(self.L.cilqr_open_loop_rollout(self.h, B, _ptr(x0), _ptr(U), _ptr(X), MEM_HOST), "rollout")
         return X
+
+
+def default_dp_config(**over) -> DpConfig:
+    c = DpConfig()
+    lib().cilqr_default_dp_config(C.byref(c))
+    for k, v in over.items():
+        setattr(c, k, v)
+    return c
+
+
+def dp_plan(flat: dict, start3, cfg: "DpConfig | None" = None):
+    """DpPlanner::Plan through the C-ABI (host only).  `flat` = cilqr_amd.scene_io.flatten_scene(center, scene);
+    returns (found, coarse [K, 9] = time s x y theta kappa velocity a delta); found = False is the
+    reference's "DP failed" (every sampled path collides), coarse is filled all the same."""
+    cfg = cfg or default_dp_config()
+    K = max(1, int(cfg.tf / cfg.delta_t + 1)) if cfg.delta_t > 0 else 1
+    keep = {k: np.ascontiguousarray(v) for k, v in flat.items()}
+    sc = SceneStruct(keep["center"].ctypes.data, keep["center"].shape[0], len(keep["static_counts"]),
+                     keep["static_points"].ctypes.data, keep["static_counts"].ctypes.data,
+                     len(keep["dynamic_polygon_counts"]), 0, keep["dynamic_polygon_points"].ctypes.data,
+                     keep["dynamic_polygon_counts"].ctypes.data, keep["dynamic_trajectories"].ctypes.data,
+                     keep["dynamic_trajectory_counts"].ctypes.data)
+    start = _f64(start3)
+    coarse = np.zeros((K, COARSE_FIELDS))
+    rc = lib().cilqr_dp_plan(C.byref(cfg), C.byref(sc), start.ctypes.data, coarse.ctypes.data, K)
+    if rc not in (OK, ERR_NO_PATH):
+        raise CilqrError(rc, "in cilqr_dp_plan")
+    return rc == OK, coarse
+
+
+def road_barriers(center):
+    """Environment::set_reference (environment.cpp:20-43): left / right road barriers [n, 2] sampled every 0.1 m of
+    station from the centre line [m, 7] -- what Corridor::Plan builds its lane constraints from."""
+    c = _f64(center)
+    cap = int((c[-1, 0] - c[0, 0]) / 0.1) + 8
+    left, right = np.zeros((cap, 2)), np.zeros((cap, 2))
+    n = lib().cilqr_road_barriers(c.ctypes.data, c.shape[0], left.ctypes.data, right.ctypes.data, cap)
+    if n < 0:
+        raise CilqrError(n, "in cilqr_road_barriers")
+    return left[:n].copy(), right[:n].copy()
+
+
+def comm_unique_id() -> bytes:
+    """ncclGetUniqueId through the C-ABI (rank 0; ship the 128 bytes to the other ranks)."""
+    buf = (C.c_uint8 * UNIQUE_ID_BYTES)()
+    rc = lib().cilqr_comm_unique_id(buf)
+    if rc != OK:
+        raise CilqrError(rc, "in cilqr_comm_unique_id")
+    return bytes(buf)
 
 
 def default_corridor_config() -> CorridorConfig:

@@ -14,64 +14,13 @@
 #include <new>
 #include <vector>
 
-#include "../../include/cilqr.h"
-#include "state.hpp"
+#include "solver_priv.hpp"
 
 using namespace cilqr;
 
-#define HIP_TRY(expr)                                                              \
-  do {                                                                             \
-    hipError_t e_ = (expr);                                                        \
-    if (e_ != hipSuccess) {                                                        \
-      std::snprintf(g_last_hip_error, sizeof(g_last_hip_error), "%s -> %s", #expr, \
-                    hipGetErrorString(e_));                                        \
-      return CILQR_ERR_DEVICE;                                                     \
-    }                                                                              \
-  } while (0)
+void cilqr_comm_release(cilqr_solver* h);   // comm.hip
 
-static thread_local char g_last_hip_error[256] = "";
-
-struct cilqr_solver {
-  cilqr_config cfg;
-  int device = 0;
-  int Bcap = 0, capacity = 0, cmax = 0, smax = 0;
-  DeviceState ds;      // arena A (also what the stage API works on)
-  DeviceState twin;    // arena B: only the fields k_compact moves are its own, the rest alias ds
-  bool compaction = true;
-  int compact_percent = 75;  // re-pack when the survivors fill at most this share of the occupied slots
-  hipStream_t own_stream = nullptr;
-  hipStream_t stream = nullptr;
-  std::vector<void*> allocs;
-  int64_t bytes = 0;
-  // staging (lazily grown): problem-major copies of host inputs / outputs on the device
-  void* in_stage = nullptr;
-  size_t in_stage_bytes = 0;
-  void* out_stage = nullptr;
-  size_t out_stage_bytes = 0;
-  double* lanes_raw = nullptr;  // device [2*smax][7]
-  double* lambda_stage = nullptr;
-  int* h_count = nullptr;  // pinned, written by k_update through h_count_dev
-  int* h_count_dev = nullptr;
-  int B = 0;               // problems loaded
-  int stage = 0;           // bit0 loaded, bit1 iterate, bit2 quadratized, bit3 gains
-  int spec_threshold = 8192;  // active sets up to this size evaluate all 11 step sizes at once
-  int team_threshold = 4096;  // active sets up to this size run the backward pass with 8 lanes per problem
-  int seq_rounds = 4;         // larger sets: this many round-by-round trials, then the rest at once
-  // asynchronous submit / wait: one worker thread per handle, one job in flight
-  std::thread worker;
-  std::mutex mu;
-  std::condition_variable cv;
-  bool worker_started = false, job_pending = false, job_done = false, quit = false;
-  cilqr_problem_batch job_in;
-  cilqr_solution_batch job_out;
-  int job_rc = CILQR_OK;
-  // profiling
-  bool profiling = false;
-  int profiling_level = 1;
-  std::vector<hipEvent_t> ev;
-  std::vector<hipEvent_t> iter_ev;  // one per lockstep iteration (count read-back)
-  cilqr_profile prof;
-};
+thread_local char g_last_hip_error[256] = "";
 
 namespace {
 
@@ -270,6 +219,7 @@ const char* cilqr_error_string(int code) {
     case CILQR_ERR_DEVICE: return g_last_hip_error[0] ? g_last_hip_error : "HIP runtime error";
     case CILQR_ERR_ARG: return "invalid argument";
     case CILQR_ERR_STATE: return "stage called out of order";
+    case CILQR_ERR_NO_PATH: return "DP failed";
     default: return "unknown error";
   }
 }
@@ -406,6 +356,7 @@ int cilqr_destroy(cilqr_handle h) {
   }
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  cilqr_comm_release(h);
   for (void* p : h->allocs) (void)hipFree(p);
   if (h->in_stage) (void)hipFree(h->in_stage);
   if (h->out_stage) (void)hipFree(h->out_stage);

@@ -147,6 +147,10 @@ class SceneSpec:
     v_range: tuple = (6.0, 12.0)
     s0_range: tuple = (2.0, 80.0)
     n_candidates: int = 8
+    # obstacles the chosen coarse path passes closer than this are dropped from the scene (the DP planner
+    # only returns collision-free paths); below disc_radius + safe_margin = 1.21 m the shrunk corridor plane
+    # of a kept obstacle lies beyond the coarse path: barriers in the relaxed region at the init guess
+    min_clearance: float = MIN_CLEARANCE
 
 
 SPECS = {
@@ -161,6 +165,11 @@ SPECS = {
     # configs[4]: 100-step horizon, 20 dynamic obstacles
     "dyn20": SceneSpec(n_steps=100, n_pedestrians=12, n_dynamic=8, n_static=0, cmax=24,
                        v_range=(5.0, 9.0), s0_range=(2.0, 60.0)),
+    # configs[4] as BASELINE words it ("constrained-ILQR barrier active"): the same scenes, but
+    # obstacles down to 0.6 m from the coarse path stay -- their corridor planes, shrunk by 1.21 m, cut
+    # across the coarse path, so corridor barriers sit in the relaxed region at the init guess
+    "dyn20x": SceneSpec(n_steps=100, n_pedestrians=12, n_dynamic=8, n_static=0, cmax=24,
+                        v_range=(5.0, 9.0), s0_range=(2.0, 60.0), min_clearance=0.6),
 }
 
 
@@ -328,7 +337,7 @@ def _generate_chunk(spec: SceneSpec, B: int, seed: int, first: int, road: Road, 
     # the DP planner only returns collision-free coarse paths (dp_planner.cpp:88-133): an obstacle
     # the chosen path cannot clear by MIN_CLEARANCE is dropped from the scene
     o_clear = o_clear_c[best, :, bi].T                             # [O,B]
-    o_live = o_live & (o_clear >= MIN_CLEARANCE)[:, :, None]
+    o_live = o_live & (o_clear >= spec.min_clearance)[:, :, None]
     l_t = l_c[best, bi]                                            # [B,K]
     x_t = ex_c - l_t * sin_e
     y_t = ey_c + l_t * cos_e
@@ -408,3 +417,43 @@ def _generate_chunk(spec: SceneSpec, B: int, seed: int, first: int, road: Road, 
                    obstacle_half_size=np.stack([np.broadcast_to(hl, (O, 1, 1))[:, 0, 0], np.broadcast_to(hw, (O, 1, 1))[:, 0, 0]], axis=1),
                    obstacle_kind=kind.copy())
     return out
+
+
+def generate_dp(spec: SceneSpec | str, batch: int, seed: int = 0, first_problem: int = 0, workers: int = 8,
+                dp_config=None):
+    """Scenes whose coarse trajectory comes from the DP coarse planner (the reference's own producer,
+    algorithm/planner/dp_planner.cpp, through the C-ABI's cilqr_dp_plan) instead of this module's smooth
+    best-clearance pick: every obstacle stays in the scene (the planner avoids them itself), the start state is the
+    generator's, and the coarse trajectory carries the kinks of the 5-layer piecewise-linear (s, l) path.
+
+    Returns dict(start[B,4], coarse[B,K,6] (x, y, theta, v, a, delta), dp[B,K,9] (the planner's full rows), found[B]
+    bool ("DP failed" where False), obstacle_points[B,K,P,2], obstacle_count[B,K], left, right, n_steps, dt, cmax,
+    scene_file).  There is no `corridor`: it is built from the obstacle points by cilqr_build_corridors
+    (BatchIlqrOptimizer.build_corridors), as Corridor::Plan does behind the reference's DP."""
+    from concurrent.futures import ThreadPoolExecutor
+    from . import api, scene_io
+    if isinstance(spec, str):
+        spec = SPECS[spec]
+    spec = dataclasses.replace(spec, min_clearance=-1.0)
+    sc = generate(spec, batch, seed=seed, first_problem=first_problem, workers=workers, obstacle_points=True,
+                  scenarios=True)
+    sf = scene_io.from_generator(sc)
+    cfg = dp_config or api.default_dp_config(tf=spec.n_steps * spec.dt, delta_t=spec.dt)
+
+    def one(b):
+        flat = scene_io.flatten_scene(sf.center, sf.scenes[b])
+        return api.dp_plan(flat, sc["start"][b, :3], cfg)
+
+    with ThreadPoolExecutor(max(1, workers)) as pool:
+        outs = list(pool.map(one, range(batch)))
+    dp = np.stack([o[1] for o in outs])
+    found = np.array([o[0] for o in outs], dtype=bool)
+    # a plan that stands still for a whole layer has 0 / 0 curvature (ComputePathProfile divides by the station
+    # difference of neighbouring points): as unusable as a failed plan
+    found &= np.isfinite(dp).all(axis=(1, 2))
+    coarse = np.ascontiguousarray(dp[:, :, [2, 3, 4, 6, 7, 8]])        # x, y, theta, velocity, a, delta (cc:148)
+    for b in range(batch):                                              # the scene file replays what was solved
+        sf.scenes[b].coarse = coarse[b].copy()
+    return dict(start=sc["start"], coarse=coarse, dp=dp, found=found, obstacle_points=sc["obstacle_points"],
+                obstacle_count=sc["obstacle_count"], left=sc["left"], right=sc["right"], n_steps=spec.n_steps,
+                dt=spec.dt, cmax=spec.cmax, scene_file=sf)

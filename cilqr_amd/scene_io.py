@@ -163,8 +163,9 @@ def environment_points(scene: Scene, times) -> tuple:
             i = int(np.searchsorted(tt + K_MATH_EPS, t, side="right"))   # first sample with t < time + eps
             i = min(i, len(tt) - 1)
             _, x, y, th = d.trajectory[i]
-            R = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
-            pts.append(d.polygon @ R.T + [x, y])
+            c, s = np.cos(th), np.sin(th)     # Pose::transform (pose.h:40-46): x + rx cos - ry sin, in that order
+            pts.append(np.stack([x + d.polygon[:, 0] * c - d.polygon[:, 1] * s,
+                                 y + d.polygon[:, 0] * s + d.polygon[:, 1] * c], axis=1))
         per_knot.append(np.concatenate(pts, axis=0) if pts else np.zeros((0, 2)))
     P = max((len(p) for p in per_knot), default=0)
     out = np.zeros((len(per_knot), P, 2))
@@ -182,3 +183,17 @@ def road_barriers(center: np.ndarray) -> tuple:
     left = np.stack([x - lb * np.sin(th), y + lb * np.cos(th)], 1)
     right = np.stack([x + rb * np.sin(th), y - rb * np.cos(th)], 1)
     return left, right
+
+
+def flatten_scene(center: np.ndarray, scene: Scene) -> dict:
+    """The scene as the C-ABI's `cilqr_scene` takes it (include/cilqr.h): polygons and trajectories back to back."""
+    def cat(arrs, width):
+        return np.ascontiguousarray(np.concatenate(arrs, axis=0) if arrs else np.zeros((0, width)), dtype=np.float64)
+    return dict(
+        center=np.ascontiguousarray(center, dtype=np.float64),
+        static_points=cat([np.asarray(p, float).reshape(-1, 2) for p in scene.static], 2),
+        static_counts=np.asarray([len(p) for p in scene.static], dtype=np.int32),
+        dynamic_polygon_points=cat([np.asarray(d.polygon, float).reshape(-1, 2) for d in scene.dynamic], 2),
+        dynamic_polygon_counts=np.asarray([len(d.polygon) for d in scene.dynamic], dtype=np.int32),
+        dynamic_trajectories=cat([np.asarray(d.trajectory, float).reshape(-1, 4) for d in scene.dynamic], 4),
+        dynamic_trajectory_counts=np.asarray([len(d.trajectory) for d in scene.dynamic], dtype=np.int32))

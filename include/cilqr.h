@@ -55,6 +55,7 @@ extern "C" {
 #define CILQR_ERR_DEVICE (-5)       /* HIP runtime error or no gfx950 device */
 #define CILQR_ERR_ARG (-6)          /* invalid argument value */
 #define CILQR_ERR_STATE (-7)        /* stage called before the stage it depends on */
+#define CILQR_ERR_NO_PATH (-8)      /* cilqr_dp_plan: every sampled path collides ("DP failed", trajectory_planner.cpp:32-35) */
 
 /* per-problem termination status (exits of Optimize(), cc:154-320) */
 #define CILQR_ST_RUNNING 0
@@ -271,6 +272,67 @@ int cilqr_device_math(cilqr_handle h, int32_t fn, int32_t n, const double* in, d
 /* X[b][0] = x0[b]; X[b][i+1] = Dynamics(X[b][i], U[b][i]).  x0 [B][6], U [B][N][2], X [B][K][6] */
 int cilqr_open_loop_rollout(cilqr_handle h, int32_t batch, const double* x0, const double* U,
                             double* X, int32_t memory);
+
+/* ---- coarse trajectory: the producer of `coarse` / `start`, host only ----
+ * DpPlanner::Plan (algorithm/planner/dp_planner.cpp:135-281): 5 x 7 x 10 (time, station, lateral) sampling DP in
+ * the Frenet frame of the centre line with collision checks against the scene, then ComputePathProfile
+ * (algorithm/utils/discrete_points_math.cc:27-176).  C++ callers use include/cilqr/dp_planner.hpp directly;
+ * include/cilqr/trajectory_planner.hpp chains it with the corridor producer and the solve
+ * (TrajectoryPlanner::Plan, algorithm/planner/trajectory_planner.cpp:28-162). */
+#define CILQR_COARSE_FIELDS 9   /* time, s, x, y, theta, kappa, velocity, a, delta */
+typedef struct cilqr_dp_config {   /* PlannerConfig planner_config.h:94-133 + VehicleParam vehicle_param.h:26-46 */
+  double tf, delta_t;
+  double dp_nominal_velocity, dp_w_obstacle, dp_w_lateral, dp_w_lateral_change, dp_w_lateral_velocity_change;
+  double dp_w_longitudinal_velocity_bias, dp_w_longitudinal_velocity_change;
+  double front_hang_length, wheel_base, rear_hang_length, width, max_velocity;
+} cilqr_dp_config;
+void cilqr_default_dp_config(cilqr_dp_config* cfg);
+/* A scene in the vocabulary of the reference's messages (the files under msg/), flattened; HOST memory. */
+typedef struct cilqr_scene {
+  const double* center;                 /* [n_center][7]  CenterLinePoint: s x y theta kappa left_bound right_bound */
+  int32_t n_center;
+  int32_t n_static;
+  const double* static_points;          /* [sum static_counts][2]  world-frame polygons, back to back (Obstacles.msg) */
+  const int32_t* static_counts;         /* [n_static] */
+  int32_t n_dynamic;
+  int32_t reserved0;
+  const double* dynamic_polygon_points;     /* [sum dynamic_polygon_counts][2]  body-frame polygons (DynamicObstacle.msg) */
+  const int32_t* dynamic_polygon_counts;    /* [n_dynamic] */
+  const double* dynamic_trajectories;       /* [sum dynamic_trajectory_counts][4]  time x y theta (DynamicTrajectoryPoint.msg) */
+  const int32_t* dynamic_trajectory_counts; /* [n_dynamic] */
+} cilqr_scene;
+/* Environment::set_reference (algorithm/utils/environment.cpp:20-43), host only: the left / right road barriers -- the
+ * centre line evaluated every 0.1 m of station and shifted by +left_bound / -right_bound along its normal -- that
+ * Corridor::Plan samples its lane constraints from (corridor.cc:43-51; the `boundary` input of
+ * cilqr_lane_constraints).  left / right [max_points][2]; returns the number of points or a negative error code. */
+int cilqr_road_barriers(const double* center, int32_t n_center, double* left, double* right, int32_t max_points);
+/* start3 = x, y, theta (dp_planner.cpp:135-141); coarse [n_knots][CILQR_COARSE_FIELDS], n_knots = tf / delta_t + 1.
+ * Returns CILQR_OK, or CILQR_ERR_NO_PATH when every sampled path collides (coarse is filled all the same, as in
+ * the reference, whose caller then stops: trajectory_planner.cpp:32-35). */
+int cilqr_dp_plan(const cilqr_dp_config* cfg, const cilqr_scene* scene, const double* start3, double* coarse,
+                  int32_t n_knots);
+
+/* ---- multi-GPU (nothing in the single-process reference to replace) ----
+ * One process per GPU.  Problems are independent: rank r solves a contiguous block of `batch` problems with
+ * its own handle and no communication; ONE gather then moves the results to a root rank through RCCL
+ * (grouped ncclSend / ncclRecv, point-to-point over xGMI).  librccl.so.1 is loaded on the first call --
+ * libcilqr_hip.so does not link against it.
+ *   rank 0:      cilqr_comm_unique_id(id)  ->  ship the 128 bytes to every rank (any transport)
+ *   every rank:  cilqr_comm_create(h, id, rank, world)          (collective: ncclCommInitRank)
+ *   every step:  cilqr_solve_batch(h, ...)  then  cilqr_gather_results(h, batch, &local, root, &gathered)
+ * Travelling per rank: 8 of the 10 trajectory columns (time and kappa are rebuilt on the root with the
+ * expressions of TransformToTrajectory, ilqr_optimizer.cc:771-791 -- bit-identical to a local export),
+ * the LIVE Cost rows only (n_cost[b] of the max_iter + 1), n_cost, status, n_iter.
+ * `local` and `gathered` must be CILQR_MEM_DEVICE; `gathered` (root only, NULL elsewhere) holds
+ * world * batch problems in rank order: traj [world*batch][K][10], cost_hist [world*batch][max_iter+1][5]
+ * (rows >= n_cost untouched), n_cost, status, n_iter (optional).  iter_trajs / alpha_trace do not travel. */
+#define CILQR_UNIQUE_ID_BYTES 128
+int cilqr_comm_unique_id(uint8_t* id /* [CILQR_UNIQUE_ID_BYTES] */);
+int cilqr_comm_create(cilqr_handle h, const uint8_t* id, int32_t rank, int32_t world);
+int cilqr_comm_destroy(cilqr_handle h);
+int cilqr_comm_info(cilqr_handle h, int32_t* rank, int32_t* world);
+int cilqr_gather_results(cilqr_handle h, int32_t batch, const cilqr_solution_batch* local, int32_t root,
+                         cilqr_solution_batch* gathered);
 
 const char* cilqr_error_string(int code);
 

@@ -1,0 +1,678 @@
+// include/cilqr/dp_planner.hpp -- header-only C++14: the coarse-trajectory producer in front of the
+// CILQR solve, host side.
+//
+// What it restates (behaviour, not code) from the reference:
+//   DpPlanner               algorithm/planner/dp_planner.{h,cpp}: 5 x 7 x 10 (time, station, lateral) sampling DP in
+//                           the Frenet frame of the centre line -- GetCost cpp:88-133, GetCollisionCost cpp:44-86,
+//                           Plan cpp:135-281, InterpolateLinearly cpp:283-320
+//   ComputePathProfile      algorithm/utils/discrete_points_math.cc:27-176 (finite-difference heading / s / v / a / kappa)
+//   reference-line queries  algorithm/utils/discretized_trajectory.cpp: EvaluateStation :117-128, GetProjection
+//                           :165-197, GetCartesian :199-203, LinearInterpolateTrajectory :66-89, math::slerp
+//   Environment             algorithm/utils/environment.cpp: set_reference :20-43 (road barriers every 0.1 m),
+//                           CheckStaticCollision :45-80, CheckDynamicCollision :113-130, CheckOptimizationCollision :92-111
+//   geometry                Polygon2d::HasOverlap(Box2d) polygon2d.cpp:150-164, Polygon2d::IsPointIn :120-140,
+//                           Box2d::IsPointIn box2d.cpp:123-129, VehicleParam disc positions vehicle_param.h:76-95
+//
+// Every number is produced by the reference's expressions in the reference's order (the DP compares costs with
+// '<', so a different rounding could pick another cell); what differs is the bookkeeping around them: the point count
+// of a layer's path segment is computed once, the last point of the parent's segment in closed form instead of
+// rebuilding the whole segment, obstacle polygons are placed once per trajectory sample with their bounding boxes, and
+// the lateral offsets of a cell are cached.  tests/test_dp_planner.py holds it to the line-by-line restatement in
+// oracle/dp_oracle.cc, bit for bit.
+//
+// Quirks kept: the DP-local epsilon of 1e-3 next to the geometry epsilon of 1e-10 (cpp:25 vs vec2d.h:33); the loop
+// that counts a segment's points accumulates t += delta_t in floating point (cpp:288-298); GetDiscPositions returns
+// (front, rear) into variables named (rear, front) (environment.cpp:100-101) -- harmless, both discs are tested;
+// a dynamic obstacle whose last sample time equals the query time dereferences end() in the reference
+// (environment.cpp:119-125): here the last sample is used.
+#ifndef CILQR_DP_PLANNER_HPP_
+#define CILQR_DP_PLANNER_HPP_
+
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <limits>
+#include <utility>
+#include <vector>
+
+namespace cilqr {
+
+constexpr int kDpNT = 5;    // dp_planner.h:27-29
+constexpr int kDpNS = 7;
+constexpr int kDpNL = 10;
+
+// live fields of PlannerConfig (planner_config.h:88-133) and VehicleParam (vehicle_param.h:26-46) for this stage
+struct DpConfig {
+  double tf = 8.0;
+  double delta_t = 0.1;
+  double dp_nominal_velocity = 10.0;
+  double dp_w_obstacle = 1000.0;
+  double dp_w_lateral = 0.1;
+  double dp_w_lateral_change = 0.5;
+  double dp_w_lateral_velocity_change = 1.0;
+  double dp_w_longitudinal_velocity_bias = 10.0;
+  double dp_w_longitudinal_velocity_change = 1.0;
+  double front_hang_length = 0.96;
+  double wheel_base = 1.0;
+  double rear_hang_length = 0.929;
+  double width = 1.942;
+  double max_velocity = 20.0;
+};
+
+struct DpPoint2 {
+  double x, y;
+};
+
+// TrajectoryPoint fields the coarse trajectory carries (discretized_trajectory.h:26-43)
+struct CoarsePoint {
+  double time = 0.0, s = 0.0, x = 0.0, y = 0.0, theta = 0.0, kappa = 0.0, velocity = 0.0, a = 0.0, delta = 0.0;
+};
+
+namespace dp_detail {
+
+constexpr double kGeomEps = 1e-10;   // math::kMathEpsilon, vec2d.h:33
+constexpr double kDpEps = 1e-3;      // dp_planner.cpp:25
+
+inline double NormalizeAngle(double angle) {   // math_utils.cpp:53-59
+  double a = std::fmod(angle + M_PI, 2.0 * M_PI);
+  if (a < 0.0) a += 2.0 * M_PI;
+  return a - M_PI;
+}
+
+inline double Slerp(double a0, double t0, double a1, double t1, double t) {   // math_utils.h:208-225
+  if (std::abs(t1 - t0) <= kGeomEps) return NormalizeAngle(a0);
+  const double a0_n = NormalizeAngle(a0);
+  const double a1_n = NormalizeAngle(a1);
+  double d = a1_n - a0_n;
+  if (d > M_PI) d = d - 2 * M_PI;
+  else if (d < -M_PI) d = d + 2 * M_PI;
+  const double r = (t - t0) / (t1 - t0);
+  const double a = a0_n + d * r;
+  return NormalizeAngle(a);
+}
+
+template <int N>
+inline std::array<double, N> LinSpaced(double start, double end) {   // math_utils.h:245-254
+  std::array<double, N> res;
+  const double step = (end - start) / (N - 1);
+  for (int i = 0; i < N; ++i) res[i] = start + step * i;
+  return res;
+}
+
+}  // namespace dp_detail
+
+// ---- the centre line (CenterLinePoint: s x y theta kappa left_bound right_bound) -------------------------------
+struct RefPoint {
+  double s = 0.0, x = 0.0, y = 0.0, theta = 0.0, kappa = 0.0, left_bound = 0.0, right_bound = 0.0;
+};
+
+class ReferenceLine {
+ public:
+  ReferenceLine() = default;
+  explicit ReferenceLine(const std::vector<std::array<double, 7>>& center) {
+    pts_.resize(center.size());
+    for (size_t i = 0; i < center.size(); ++i) {
+      const auto& c = center[i];
+      pts_[i] = RefPoint{c[0], c[1], c[2], c[3], c[4], c[5], c[6]};
+    }
+  }
+  const std::vector<RefPoint>& points() const { return pts_; }
+  bool empty() const { return pts_.size() < 2; }
+
+  // discretized_trajectory.cpp:117-128 (+ :33-47, :66-89)
+  RefPoint EvaluateStation(double station) const {
+    size_t it;
+    if (station >= pts_.back().s) {
+      it = pts_.size() - 1;
+    } else if (station < pts_.front().s) {
+      it = 0;
+    } else {
+      size_t lo = 0, hi = pts_.size();   // first point with s >= station
+      while (lo < hi) {
+        const size_t mid = (lo + hi) / 2;
+        if (pts_[mid].s < station) lo = mid + 1;
+        else hi = mid;
+      }
+      it = lo;
+    }
+    if (it == 0) it = 1;
+    return Interpolate(pts_[it - 1], pts_[it], station);
+  }
+
+  DpPoint2 GetCartesian(double station, double lateral) const {   // cpp:199-203
+    const RefPoint ref = EvaluateStation(station);
+    return DpPoint2{ref.x - lateral * std::sin(ref.theta), ref.y + lateral * std::cos(ref.theta)};
+  }
+
+  // (station, lateral) of a point, cpp:165-197
+  DpPoint2 GetProjection(double px, double py) const {
+    size_t idx = 0;
+    double nearest = std::numeric_limits<double>::max();
+    for (size_t i = 0; i < pts_.size(); ++i) {
+      const double dx = pts_[i].x - px, dy = pts_[i].y - py;
+      const double d = dx * dx + dy * dy;
+      if (d < nearest) {
+        idx = i;
+        nearest = d;
+      }
+    }
+    RefPoint proj = pts_[idx];
+    const size_t i0 = idx > 0 ? idx - 1 : 0;
+    const size_t i1 = std::min(pts_.size() - 1, idx + 1);
+    if (i0 < i1) {
+      const double v0x = px - pts_[i0].x, v0y = py - pts_[i0].y;
+      const double v1x = pts_[i1].x - pts_[i0].x, v1y = pts_[i1].y - pts_[i0].y;
+      const double v1_norm = std::sqrt(v1x * v1x + v1y * v1y);
+      const double dot = v0x * v1x + v0y * v1y;
+      const double delta_s = dot / v1_norm;
+      proj = Interpolate(pts_[i0], pts_[i1], pts_[i0].s + delta_s);
+    }
+    const double nr_x = px - proj.x, nr_y = py - proj.y;
+    const double lateral = std::copysign(std::hypot(nr_x, nr_y), nr_y * std::cos(proj.theta) - nr_x * std::sin(proj.theta));
+    return DpPoint2{proj.s, lateral};
+  }
+
+ private:
+  static RefPoint Interpolate(const RefPoint& p0, const RefPoint& p1, double s) {   // cpp:66-89
+    const double s0 = p0.s, s1 = p1.s;
+    if (std::abs(s1 - s0) < dp_detail::kGeomEps) return p0;
+    RefPoint pt;
+    const double weight = (s - s0) / (s1 - s0);
+    pt.s = s;
+    pt.x = (1 - weight) * p0.x + weight * p1.x;
+    pt.y = (1 - weight) * p0.y + weight * p1.y;
+    pt.theta = dp_detail::Slerp(p0.theta, p0.s, p1.theta, p1.s, s);
+    pt.kappa = (1 - weight) * p0.kappa + weight * p1.kappa;
+    pt.left_bound = (1 - weight) * p0.left_bound + weight * p1.left_bound;
+    pt.right_bound = (1 - weight) * p0.right_bound + weight * p1.right_bound;
+    return pt;
+  }
+  std::vector<RefPoint> pts_;
+};
+
+// ---- the scene as the reference's Environment holds it ------------------------------------------------------------
+class DpEnvironment {
+ public:
+  struct Poly {   // a placed polygon with its bounding box (Polygon2d::BuildFromPoints, polygon2d.cpp:240-257)
+    std::vector<DpPoint2> pts;
+    double min_x, max_x, min_y, max_y;
+  };
+  struct Dynamic {
+    std::vector<double> time;
+    std::vector<Poly> poly;   // one per trajectory sample (PlanningNode::DynamicObstaclesCallback, planning_node.cc:63-78)
+  };
+
+  DpEnvironment() = default;
+  DpEnvironment(const DpConfig& cfg, const ReferenceLine& ref) : cfg_(cfg), ref_(ref) {
+    const double length = cfg.wheel_base + cfg.rear_hang_length + cfg.front_hang_length;   // vehicle_param.h:80-85
+    radius_ = std::hypot(0.25 * length, 0.5 * cfg.width);
+    r2x_ = 0.25 * length - cfg.rear_hang_length;
+    f2x_ = 0.75 * length - cfg.rear_hang_length;
+    // set_reference, environment.cpp:20-43: both road barriers sampled every 0.1 m, sorted by x
+    constexpr double kSampleStep = 0.1;
+    const double start_s = ref_.points().front().s, back_s = ref_.points().back().s;
+    const int sample_points = int((back_s - start_s) / kSampleStep);
+    for (int i = 0; i <= sample_points; ++i) {
+      const double s = start_s + i * kSampleStep;
+      const RefPoint r = ref_.EvaluateStation(s);
+      barrier_.push_back(ref_.GetCartesian(s, r.left_bound));
+      barrier_.push_back(ref_.GetCartesian(s, -r.right_bound));
+    }
+    std::stable_sort(barrier_.begin(), barrier_.end(), [](const DpPoint2& a, const DpPoint2& b) { return a.x < b.x; });
+  }
+
+  const ReferenceLine& reference() const { return ref_; }
+
+  void AddStatic(const std::vector<DpPoint2>& world_polygon) { statics_.push_back(MakePoly(world_polygon)); }
+
+  // body-frame polygon + trajectory (time, x, y, theta): one placed polygon per sample (Pose::transform)
+  void AddDynamic(const std::vector<DpPoint2>& body_polygon, const std::vector<std::array<double, 4>>& trajectory) {
+    Dynamic d;
+    for (const auto& tp : trajectory) {
+      const double c = std::cos(tp[3]), s = std::sin(tp[3]);
+      std::vector<DpPoint2> w;
+      for (const auto& v : body_polygon)   // Pose::transform, pose.h:40-46: x + rx cos - ry sin, in that order
+        w.push_back(DpPoint2{tp[1] + v.x * c - v.y * s, tp[2] + v.x * s + v.y * c});
+      d.time.push_back(tp[0]);
+      d.poly.push_back(MakePoly(w));
+    }
+    if (!d.time.empty()) dynamics_.push_back(std::move(d));
+  }
+
+  // the same obstacle given as the reference's Environment holds it: one world-frame polygon per trajectory sample
+  void AddDynamicPlaced(const std::vector<double>& times, const std::vector<std::vector<DpPoint2>>& world_polygons) {
+    Dynamic d;
+    for (size_t i = 0; i < times.size() && i < world_polygons.size(); ++i) {
+      d.time.push_back(times[i]);
+      d.poly.push_back(MakePoly(world_polygons[i]));
+    }
+    if (!d.time.empty()) dynamics_.push_back(std::move(d));
+  }
+
+  // environment.cpp:92-111 (collision_buffer = 0)
+  bool CheckOptimizationCollision(double time, double x, double y, double theta) const {
+    const double ct = std::cos(theta), st = std::sin(theta);
+    const double ax = x + f2x_ * ct, ay = y + f2x_ * st;   // vehicle_param.h:88-95
+    const double bx = x + r2x_ * ct, by = y + r2x_ * st;
+    return StaticCollision(bx, by) || StaticCollision(ax, ay) || DynamicCollision(time, bx, by) ||
+           DynamicCollision(time, ax, ay);
+  }
+
+ private:
+  static Poly MakePoly(const std::vector<DpPoint2>& p) {
+    Poly q;
+    q.pts = p;
+    q.min_x = q.max_x = p[0].x;
+    q.min_y = q.max_y = p[0].y;
+    for (const auto& v : p) {
+      q.min_x = std::min(q.min_x, v.x);
+      q.max_x = std::max(q.max_x, v.x);
+      q.min_y = std::min(q.min_y, v.y);
+      q.max_y = std::max(q.max_y, v.y);
+    }
+    return q;
+  }
+
+  // axis-aligned square of half side radius_ centred at (cx, cy), as Box2d(AABox2d) (box2d.cpp:93-105)
+  struct Square {
+    double cx, cy, h, min_x, max_x, min_y, max_y;
+  };
+  Square MakeSquare(double cx, double cy) const {
+    return Square{cx, cy, radius_, cx - radius_, cx + radius_, cy - radius_, cy + radius_};
+  }
+  static bool SquareHasPoint(const Square& b, const DpPoint2& p) {   // Box2d::IsPointIn, heading 0 (box2d.cpp:123-129)
+    const double x0 = p.x - b.cx, y0 = p.y - b.cy;
+    const double dx = std::abs(x0 * 1.0 + y0 * 0.0);
+    const double dy = std::abs(-x0 * 0.0 + y0 * 1.0);
+    return dx <= b.h + dp_detail::kGeomEps && dy <= b.h + dp_detail::kGeomEps;
+  }
+  static bool PolyHasPoint(const Poly& q, double px, double py) {   // Polygon2d::IsPointIn, polygon2d.cpp:120-140
+    if (px < q.min_x || px > q.max_x || py < q.min_y || py > q.max_y) return false;
+    const int n = (int)q.pts.size();
+    int j = n - 1, c = 0;
+    for (int i = 0; i < n; ++i) {
+      if ((q.pts[i].y > py) != (q.pts[j].y > py)) {
+        // CrossProd(point, points_[i], points_[j]) = (pi - p) x (pj - p)
+        const double side = (q.pts[i].x - px) * (q.pts[j].y - py) - (q.pts[j].x - px) * (q.pts[i].y - py);
+        if (q.pts[i].y < q.pts[j].y ? side > 0.0 : side < 0.0) ++c;
+      }
+      j = i;
+    }
+    return (c & 1) != 0;
+  }
+  static bool Overlap(const Poly& q, const Square& b) {   // Polygon2d::HasOverlap(Box2d), polygon2d.cpp:150-164
+    if (b.max_x < q.min_x || b.min_x > q.max_x || b.max_y < q.min_y || b.min_y > q.max_y) return false;
+    for (const auto& p : q.pts)
+      if (SquareHasPoint(b, p)) return true;
+    // AABox2d::GetAllCorners order (aabox2d.cpp:63-71)
+    return PolyHasPoint(q, b.cx + b.h, b.cy - b.h) || PolyHasPoint(q, b.cx + b.h, b.cy + b.h) ||
+           PolyHasPoint(q, b.cx - b.h, b.cy + b.h) || PolyHasPoint(q, b.cx - b.h, b.cy - b.h);
+  }
+
+  bool StaticCollision(double cx, double cy) const {   // environment.cpp:45-80
+    const Square b = MakeSquare(cx, cy);
+    for (const auto& q : statics_)
+      if (Overlap(q, b)) return true;
+    if (barrier_.empty()) return false;
+    if (b.max_x < barrier_.front().x || b.min_x > barrier_.back().x) return false;
+    auto upper = [&](double val) {   // first barrier point with val < point.x
+      size_t lo = 0, hi = barrier_.size();
+      while (lo < hi) {
+        const size_t mid = (lo + hi) / 2;
+        if (val < barrier_[mid].x) hi = mid;
+        else lo = mid + 1;
+      }
+      return lo;
+    };
+    size_t first = upper(b.min_x);
+    const size_t last = upper(b.max_x);
+    if (first > 0) --first;
+    for (size_t i = first; i < last; ++i)
+      if (SquareHasPoint(b, barrier_[i])) return true;
+    return false;
+  }
+
+  bool DynamicCollision(double time, double cx, double cy) const {   // environment.cpp:113-130
+    const Square b = MakeSquare(cx, cy);
+    for (const auto& d : dynamics_) {
+      if (d.time.front() > time || d.time.back() < time) continue;
+      size_t i = 0;   // first sample with time < sample time (std::upper_bound)
+      while (i < d.time.size() && !(time < d.time[i])) ++i;
+      if (i >= d.time.size()) i = d.time.size() - 1;   // the reference dereferences end() here
+      if (Overlap(d.poly[i], b)) return true;
+    }
+    return false;
+  }
+
+  DpConfig cfg_;
+  ReferenceLine ref_;
+  double radius_ = 0.0, r2x_ = 0.0, f2x_ = 0.0;
+  std::vector<DpPoint2> barrier_;
+  std::vector<Poly> statics_;
+  std::vector<Dynamic> dynamics_;
+};
+
+// ---- ComputePathProfile, discrete_points_math.cc:27-176 ---------------------------------------------------------
+inline bool ComputePathProfile(double dt, const std::vector<std::pair<double, double>>& xy, std::vector<double>* headings,
+                               std::vector<double>* accumulated_s, std::vector<double>* speeds,
+                               std::vector<double>* accelerations, std::vector<double>* kappas) {
+  headings->clear();
+  accumulated_s->clear();
+  speeds->clear();
+  accelerations->clear();
+  kappas->clear();
+  if (xy.size() < 2) return false;
+  const std::size_t n = xy.size();
+  std::vector<double> dxs(n), dys(n), xds(n), yds(n), xdds(n), ydds(n);
+  for (std::size_t i = 0; i < n; ++i) {
+    if (i == 0) {
+      dxs[i] = xy[i + 1].first - xy[i].first;
+      dys[i] = xy[i + 1].second - xy[i].second;
+    } else if (i == n - 1) {
+      dxs[i] = xy[i].first - xy[i - 1].first;
+      dys[i] = xy[i].second - xy[i - 1].second;
+    } else {
+      dxs[i] = 0.5 * (xy[i + 1].first - xy[i - 1].first);
+      dys[i] = 0.5 * (xy[i + 1].second - xy[i - 1].second);
+    }
+  }
+  for (std::size_t i = 0; i < n; ++i) headings->push_back(std::atan2(dys[i], dxs[i]));
+  double distance = 0.0;
+  accumulated_s->push_back(distance);
+  double fx = xy[0].first, fy = xy[0].second;
+  for (std::size_t i = 1; i < n; ++i) {
+    const double nx = xy[i].first, ny = xy[i].second;
+    const double seg = std::sqrt((fx - nx) * (fx - nx) + (fy - ny) * (fy - ny));
+    accumulated_s->push_back(seg + distance);
+    distance += seg;
+    fx = nx;
+    fy = ny;
+  }
+  const std::vector<double>& acc = *accumulated_s;
+  for (std::size_t i = 1; i < n; ++i) speeds->push_back((acc[i] - acc[i - 1]) / dt);
+  speeds->push_back(speeds->back());
+  for (std::size_t i = 1; i < speeds->size(); ++i) accelerations->push_back(((*speeds)[i] - (*speeds)[i - 1]) / dt);
+  accelerations->push_back(accelerations->back());
+  for (std::size_t i = 0; i < n; ++i) {
+    if (i == 0) {
+      xds[i] = (xy[i + 1].first - xy[i].first) / (acc[i + 1] - acc[i]);
+      yds[i] = (xy[i + 1].second - xy[i].second) / (acc[i + 1] - acc[i]);
+    } else if (i == n - 1) {
+      xds[i] = (xy[i].first - xy[i - 1].first) / (acc[i] - acc[i - 1]);
+      yds[i] = (xy[i].second - xy[i - 1].second) / (acc[i] - acc[i - 1]);
+    } else {
+      xds[i] = (xy[i + 1].first - xy[i - 1].first) / (acc[i + 1] - acc[i - 1]);
+      yds[i] = (xy[i + 1].second - xy[i - 1].second) / (acc[i + 1] - acc[i - 1]);
+    }
+  }
+  for (std::size_t i = 0; i < n; ++i) {
+    if (i == 0) {
+      xdds[i] = (xds[i + 1] - xds[i]) / (acc[i + 1] - acc[i]);
+      ydds[i] = (yds[i + 1] - yds[i]) / (acc[i + 1] - acc[i]);
+    } else if (i == n - 1) {
+      xdds[i] = (xds[i] - xds[i - 1]) / (acc[i] - acc[i - 1]);
+      ydds[i] = (yds[i] - yds[i - 1]) / (acc[i] - acc[i - 1]);
+    } else {
+      xdds[i] = (xds[i + 1] - xds[i - 1]) / (acc[i + 1] - acc[i - 1]);
+      ydds[i] = (yds[i + 1] - yds[i - 1]) / (acc[i + 1] - acc[i - 1]);
+    }
+  }
+  for (std::size_t i = 0; i < n; ++i) {
+    const double a = xds[i], b = yds[i];
+    kappas->push_back((a * ydds[i] - b * xdds[i]) / (std::sqrt(a * a + b * b) * (a * a + b * b) + 1e-6));
+  }
+  return true;
+}
+
+// ---- the DP ------------------------------------------------------------------------------------------------------
+class DpPlanner {
+ public:
+  DpPlanner(const DpConfig& config, const DpEnvironment* env) : env_(env), cfg_(config), unit_time_(config.tf / kDpNT) {
+    time_ = dp_detail::LinSpaced<kDpNT>(unit_time_, cfg_.tf);                          // cpp:29-34
+    station_ = dp_detail::LinSpaced<kDpNS>(0, unit_time_ * cfg_.max_velocity);
+    lateral_ = dp_detail::LinSpaced<kDpNL - 1>(0, 1);
+    safe_margin_ = cfg_.width / 2 * 1.5;
+    for (int t = 0; t < kDpNT; ++t) nseg_[t] = CountSegmentPoints(t);
+  }
+
+  // false = no collision-free path (min cost >= dp_w_obstacle); `result` is filled either way, as in the reference
+  bool Plan(double start_x, double start_y, double start_theta, std::vector<CoarsePoint>* result) {
+    const ReferenceLine& ref = env_->reference();
+    const DpPoint2 sl = ref.GetProjection(start_x, start_y);
+    start_s_ = sl.x;
+    start_l_ = sl.y;
+    (void)start_theta;
+    for (auto& layer : cells_)
+      for (auto& row : layer)
+        for (auto& c : row) c = Cell();
+    for (int i = 0; i < kDpNS; ++i)                                                    // first layer, cpp:155-161
+      for (int j = 0; j < kDpNL; ++j) {
+        const auto tup = GetCost(-1, -1, -1, 0, i, j);
+        cells_[0][i][j].current_s = tup.first;
+        cells_[0][i][j].cost = tup.second;
+      }
+    for (int i = 0; i < kDpNT - 1; ++i)                                                // cpp:164-184
+      for (int j = 0; j < kDpNS; ++j)
+        for (int k = 0; k < kDpNL; ++k)
+          for (int m = 0; m < kDpNS; ++m)
+            for (int n = 0; n < kDpNL; ++n) {
+              const auto tup = GetCost(i, j, k, i + 1, m, n);
+              const double cur_cost = cells_[i][j][k].cost + tup.second;
+              if (cur_cost < cells_[i + 1][m][n].cost) {
+                Cell& c = cells_[i + 1][m][n];
+                c.cost = cur_cost;
+                c.current_s = tup.first;
+                c.parent_s = j;
+                c.parent_l = k;
+                c.lat_valid = false;
+              }
+            }
+    double min_cost = std::numeric_limits<double>::max();                              // cpp:187-198
+    int min_s = 0, min_l = 0;
+    for (int i = 0; i < kDpNS; ++i)
+      for (int j = 0; j < kDpNL; ++j)
+        if (cells_[kDpNT - 1][i][j].cost < min_cost) {
+          min_s = i;
+          min_l = j;
+          min_cost = cells_[kDpNT - 1][i][j].cost;
+        }
+    struct Way {
+      int s, l;
+      Cell cell;
+    };
+    Way way[kDpNT];
+    for (int i = kDpNT - 1; i >= 0; --i) {                                             // cpp:203-208
+      way[i] = Way{min_s, min_l, cells_[i][min_s][min_l]};
+      min_s = way[i].cell.parent_s;   // every cell of a layer >= 1 has a parent (the first candidate always improves
+      min_l = way[i].cell.parent_l;   // on the initial cost), so the indices stay valid down to layer 0
+    }
+    // interpolation, cpp:217-244
+    const size_t n_data = (size_t)(cfg_.tf / cfg_.delta_t + 1);
+    std::vector<CoarsePoint> data(n_data);
+    double last_l = start_l_, last_s = start_s_;
+    std::vector<std::pair<double, double>> xy_points;
+    size_t n = 0;
+    for (int i = 0; i < kDpNT; ++i) {
+      const double parent_s = i > 0 ? way[i - 1].cell.current_s : start_s_;
+      const std::vector<DpPoint2> segment = InterpolateLinearly(parent_s, way[i].cell.parent_l, i, way[i].s, way[i].l);
+      for (size_t j = 0; j < segment.size(); ++j) {
+        const double dl = segment[j].y - last_l;
+        const double ds = std::max(segment[j].x - last_s, dp_detail::kDpEps);
+        last_l = segment[j].y;
+        last_s = segment[j].x;
+        const DpPoint2 xy = ref.GetCartesian(segment[j].x, segment[j].y);
+        const RefPoint tp = ref.EvaluateStation(segment[j].x);
+        if (n < n_data) {
+          data[n].time = cfg_.delta_t * n;
+          data[n].s = segment[j].x;
+          data[n].x = xy.x;
+          data[n].y = xy.y;
+          data[n].theta = tp.theta + std::atan((dl / ds) / (1 - tp.kappa * segment[j].y));
+        }
+        xy_points.emplace_back(xy.x, xy.y);
+        ++n;
+      }
+    }
+    std::vector<double> headings, acc_s, speeds, accels, kappas;
+    ComputePathProfile(cfg_.delta_t, xy_points, &headings, &acc_s, &speeds, &accels, &kappas);
+    for (size_t i = 0; i < xy_points.size() && i < n_data; ++i) {                      // cpp:253-275
+      data[i].kappa = kappas[i];
+      data[i].delta = std::atan(data[i].kappa * cfg_.wheel_base);
+      data[i].velocity = speeds[i];
+      data[i].a = accels[i];
+    }
+    *result = std::move(data);
+    return min_cost < cfg_.dp_w_obstacle;
+  }
+
+  int segment_points(int layer) const { return nseg_[layer]; }
+
+ private:
+  struct Cell {
+    double cost = std::numeric_limits<double>::max();
+    double current_s = std::numeric_limits<double>::min();
+    int parent_s = -1, parent_l = -1;
+    double lat = 0.0;       // GetLateralOffset(current_s, own lateral index), cached
+    bool lat_valid = false;
+  };
+
+  int CountSegmentPoints(int cur_t) const {   // the counting loop of InterpolateLinearly, cpp:287-299
+    int nseg = 0;
+    for (double t = 0.0; t < cfg_.tf + cfg_.delta_t - dp_detail::kGeomEps; t += cfg_.delta_t) {
+      if (cur_t == 0) {
+        if (t > 0.0 - dp_detail::kDpEps && t < unit_time_ + dp_detail::kDpEps) ++nseg;
+      } else {
+        if (t > time_[cur_t] - unit_time_ + dp_detail::kGeomEps && t < time_[cur_t] + dp_detail::kGeomEps) ++nseg;
+      }
+    }
+    return nseg;
+  }
+
+  double GetLateralOffset(double s, int l_ind) const {   // dp_planner.h:84-92
+    if (l_ind == kDpNL - 1) return 0.0;
+    const RefPoint ref = env_->reference().EvaluateStation(s);
+    const double lb = -ref.right_bound + safe_margin_;
+    const double ub = ref.left_bound - safe_margin_;
+    return lb + (ub - lb) * lateral_[l_ind];
+  }
+  double CellLateral(int t, int s, int l) {
+    Cell& c = cells_[t][s][l];
+    if (!c.lat_valid) {
+      c.lat = GetLateralOffset(c.current_s, l);
+      c.lat_valid = true;
+    }
+    return c.lat;
+  }
+
+  // start of a segment: the parent's (station, lateral), or the start state when there is no parent
+  void SegmentStart(double parent_s, int parent_l_ind, double* p_s, double* p_l) const {
+    *p_l = start_l_;
+    *p_s = start_s_;
+    if (parent_l_ind >= 0) {
+      *p_s = parent_s;
+      *p_l = GetLateralOffset(*p_s, parent_l_ind);
+    }
+  }
+
+  std::vector<DpPoint2> InterpolateLinearly(double parent_s, int parent_l_ind, int cur_t, int cur_s_ind,
+                                            int cur_l_ind) const {   // cpp:283-320
+    const int nseg = nseg_[cur_t];
+    std::vector<DpPoint2> result(nseg);
+    double p_s, p_l;
+    SegmentStart(parent_s, parent_l_ind, &p_s, &p_l);
+    const double cur_s = p_s + station_[cur_s_ind];
+    const double cur_l = GetLateralOffset(cur_s, cur_l_ind);
+    const double s_step = station_[cur_s_ind] / nseg;
+    const double l_step = (cur_l - p_l) / nseg;
+    for (int i = 0; i < nseg; ++i) result[i] = DpPoint2{p_s + i * s_step, p_l + i * l_step};
+    return result;
+  }
+
+  double GetCollisionCost(int pt, int ps, int pl, int ct, int cs, int cl) {   // cpp:44-86
+    const ReferenceLine& ref = env_->reference();
+    double parent_s = start_s_, grandparent_s = start_s_;
+    double last_l = start_l_, last_s = start_s_;
+    if (pt >= 0) {
+      const Cell& cell = cells_[pt][ps][pl];
+      parent_s = cell.current_s;
+      if (pt > 0) grandparent_s = cells_[pt - 1][cell.parent_s][cell.parent_l].current_s;
+      // last point of the parent's own segment, InterpolateLinearly(grandparent_s, cell.parent_l, pt, ps, pl).back()
+      const int nprev = nseg_[pt];
+      double g_s, g_l;
+      SegmentStart(grandparent_s, cell.parent_l, &g_s, &g_l);
+      const double prev_cur_s = g_s + station_[ps];
+      const double prev_cur_l = GetLateralOffset(prev_cur_s, pl);
+      const double s_step = station_[ps] / nprev;
+      const double l_step = (prev_cur_l - g_l) / nprev;
+      last_s = g_s + (nprev - 1) * s_step;
+      last_l = g_l + (nprev - 1) * l_step;
+    }
+    const std::vector<DpPoint2> path = InterpolateLinearly(parent_s, pl, ct, cs, cl);
+    const int nseg = (int)path.size();
+    for (int i = 0; i < nseg; ++i) {
+      const DpPoint2& pt_ = path[i];
+      const double dl = pt_.y - last_l;
+      const double ds = std::max(pt_.x - last_s, dp_detail::kDpEps);
+      last_l = pt_.y;
+      last_s = pt_.x;
+      const RefPoint r = ref.EvaluateStation(pt_.x);
+      const double lb = std::min(0.0, -r.right_bound + safe_margin_);
+      const double ub = std::max(0.0, r.left_bound - safe_margin_);
+      if (pt_.y < lb - dp_detail::kDpEps || pt_.y > ub + dp_detail::kDpEps) return cfg_.dp_w_obstacle;
+      // GetCartesian(pt.x, pt.y) evaluates the same station: same RefPoint
+      const double cx = r.x - pt_.y * std::sin(r.theta), cy = r.y + pt_.y * std::cos(r.theta);
+      const double heading = r.theta + std::atan((dl / ds) / (1 - r.kappa * pt_.y));
+      const double parent_time = pt < 0 ? 0.0 : time_[pt];
+      const double time = parent_time + i * (unit_time_ / nseg);
+      if (env_->CheckOptimizationCollision(time, cx, cy, heading)) return cfg_.dp_w_obstacle;
+    }
+    return 0.0;
+  }
+
+  std::pair<double, double> GetCost(int pt, int ps, int pl, int ct, int cs, int cl) {   // cpp:88-133
+    double parent_s = start_s_, grandparent_s = start_s_;
+    double parent_l = start_l_, grandparent_l = start_l_;
+    if (pt >= 0) {
+      const Cell& cell = cells_[pt][ps][pl];
+      parent_s = cell.current_s;
+      parent_l = CellLateral(pt, ps, pl);
+      if (pt >= 1) {
+        grandparent_s = cells_[pt - 1][cell.parent_s][cell.parent_l].current_s;
+        grandparent_l = CellLateral(pt - 1, cell.parent_s, cell.parent_l);
+      }
+    }
+    const double cur_s = parent_s + station_[cs];
+    const double cur_l = GetLateralOffset(cur_s, cl);
+    const double ds1 = cur_s - parent_s;
+    const double dl1 = cur_l - parent_l;
+    const double ds0 = parent_s - grandparent_s;
+    const double dl0 = parent_l - grandparent_l;
+    const double cost_obstacle = GetCollisionCost(pt, ps, pl, ct, cs, cl);
+    if (cost_obstacle >= cfg_.dp_w_obstacle) return std::make_pair(cur_s, cfg_.dp_w_obstacle);
+    const double cost_lateral = std::fabs(cur_l);
+    const double cost_lateral_change = std::fabs(parent_l - cur_l) / (station_[cs] + dp_detail::kDpEps);
+    const double cost_lateral_change_t = std::fabs(dl1 - dl0) / unit_time_;
+    const double cost_longitudinal_velocity = std::fabs(ds1 / unit_time_ - cfg_.dp_nominal_velocity);
+    const double cost_longitudinal_velocity_change = std::fabs((ds1 - ds0) / unit_time_);
+    const double delta_cost = (cfg_.dp_w_lateral * cost_lateral + cfg_.dp_w_lateral_change * cost_lateral_change +
+                               cfg_.dp_w_lateral_velocity_change * cost_lateral_change_t +
+                               cfg_.dp_w_longitudinal_velocity_bias * cost_longitudinal_velocity +
+                               cfg_.dp_w_longitudinal_velocity_change * cost_longitudinal_velocity_change);
+    return std::make_pair(cur_s, delta_cost);
+  }
+
+  const DpEnvironment* env_;
+  DpConfig cfg_;
+  double unit_time_;
+  std::array<double, kDpNT> time_;
+  std::array<double, kDpNS> station_;
+  std::array<double, kDpNL - 1> lateral_;
+  double safe_margin_ = 0.0;
+  int nseg_[kDpNT];
+  double start_s_ = 0.0, start_l_ = 0.0;
+  Cell cells_[kDpNT][kDpNS][kDpNL];
+};
+
+}  // namespace cilqr
+
+#endif  // CILQR_DP_PLANNER_HPP_

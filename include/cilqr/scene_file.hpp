@@ -47,7 +47,8 @@ struct Scene {
       while (i + 1 < d.trajectory.size() && !(time < d.trajectory[i][0] + kEps)) ++i;
       const double x = d.trajectory[i][1], y = d.trajectory[i][2], th = d.trajectory[i][3];
       const double c = std::cos(th), s = std::sin(th);
-      for (const auto& v : d.polygon) out.push_back(ScenePoint2{v.x * c - v.y * s + x, v.x * s + v.y * c + y});
+      for (const auto& v : d.polygon)   // Pose::transform (pose.h:40-46): x + rx cos - ry sin, in that order
+        out.push_back(ScenePoint2{x + v.x * c - v.y * s, y + v.x * s + v.y * c});
     }
     return out;
   }

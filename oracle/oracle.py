@@ -33,7 +33,7 @@ class OracleConfig(C.Structure):
 
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("cilqr_oracle.cc", "corridor_oracle.cc")]
+    srcs = [os.path.join(_HERE, f) for f in ("cilqr_oracle.cc", "corridor_oracle.cc", "dp_oracle.cc")]
     if force or not os.path.exists(so) or any(
             os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so) for src in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
@@ -297,3 +297,33 @@ def lane_constraints(boundary, segment_length=5.0, is_left=True, max_rows=4096):
     if m < 0:
         raise ValueError(m)
     return rows[:m].copy()
+
+
+DP_CFG_FIELDS = ("tf", "delta_t", "dp_nominal_velocity", "dp_w_obstacle", "dp_w_lateral", "dp_w_lateral_change",
+                 "dp_w_lateral_velocity_change", "dp_w_longitudinal_velocity_bias", "dp_w_longitudinal_velocity_change",
+                 "front_hang_length", "wheel_base", "rear_hang_length", "width", "max_velocity")
+DP_CFG_DEFAULT = (8.0, 0.1, 10.0, 1000.0, 0.1, 0.5, 1.0, 10.0, 1.0, 0.96, 1.0, 0.929, 1.942, 20.0)   # planner_config.h:94-133
+
+
+def dp_plan(flat: dict, start3, **over):
+    """DpPlanner::Plan, line-by-line restatement (oracle/dp_oracle.cc).  `flat`: the scene flattened as by
+    cilqr_amd.scene_io.flatten_scene (plain arrays; this module imports nothing from the product).
+    Returns (found, coarse [K, 9] = time s x y theta kappa velocity a delta)."""
+    cfg = dict(zip(DP_CFG_FIELDS, DP_CFG_DEFAULT))
+    cfg.update(over)
+    c = _f64([cfg[k] for k in DP_CFG_FIELDS])
+    K = int(cfg["tf"] / cfg["delta_t"] + 1)
+    a = {k: np.ascontiguousarray(v) for k, v in flat.items()}
+    coarse = np.zeros((K, 9))
+    start = _f64(start3)
+    L = lib()
+    L.oracle_dp_plan.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    rc = L.oracle_dp_plan(c.ctypes.data, a["center"].ctypes.data, a["center"].shape[0], a["static_points"].ctypes.data,
+                          a["static_counts"].ctypes.data, len(a["static_counts"]), a["dynamic_polygon_points"].ctypes.data,
+                          a["dynamic_polygon_counts"].ctypes.data, a["dynamic_trajectories"].ctypes.data,
+                          a["dynamic_trajectory_counts"].ctypes.data, len(a["dynamic_polygon_counts"]),
+                          start.ctypes.data, coarse.ctypes.data, K)
+    if rc < 0:
+        raise ValueError(rc)
+    return rc == 1, coarse

@@ -20,8 +20,8 @@ What "parity" means here (DESIGN.md section 5 has the long form):
    One step is not a long chain, so STEP_TOL = 1e-8 relative applies -- except where the step
    itself is discontinuous in the oracle (nearest-lane-segment switches, barrier branch switches,
    tan poles of a wild trial): a step that fails STEP_TOL is excused only if the oracle's own
-   result for that step changes by more than STEP_TOL / 10 (or its decisions flip) under a 4e-16
-   perturbation of the iterate it starts from, or if the first decision that differs is one whose
+   result for that step -- the cost of the iterate included -- changes by more than STEP_TOL / 10 (or
+   its decisions flip) under a 4e-16 perturbation of the iterate it starts from (8 samples), or if the first decision that differs is one whose
    test sat within KNIFE_EDGE = 1e-9 (relative) of its threshold in the oracle (only seen when both
    cost tolerances are 0 and the solver iterates on in the rounding-noise plateau, where accepted
    cost decreases are ~1e-13 of the cost).  The excused share of steps is bounded.
@@ -215,7 +215,7 @@ def _step_matches(r, seg, gpu_status_after, cost_row0, cost_row1, next_traj, tol
     return True, worst, ""
 
 
-def check_steps(gpu: dict, scene: dict, ocfg, problems=None, tol=STEP_TOL, eps=PERTURB_EPS, n_perturb=3,
+def check_steps(gpu: dict, scene: dict, ocfg, problems=None, tol=STEP_TOL, eps=PERTURB_EPS, n_perturb=8,
                 seed=777):
     """Replay every step of the listed problems (default: all) in the oracle, starting each step from
     the HIP path's own iterate.  `gpu` must come from plan(..., max_iter_trajs=cap, alpha_trace=True).
@@ -279,6 +279,7 @@ def check_steps(gpu: dict, scene: dict, ocfg, problems=None, tol=STEP_TOL, eps=P
                     rp = o.replay(X * (1.0 + eps * rng.standard_normal(X.shape)),
                                   U * (1.0 + eps * rng.standard_normal(U.shape)), lam, dlam, it)
                     if (not np.array_equal(rp["decisions"], r["decisions"]) or rp["status"] != r["status"]
+                            or cost_err(rp["cost0"], r["cost0"]) > tol / 10
                             or (r["cost1"] is not None and (cost_err(rp["cost1"], r["cost1"]) > tol / 10
                                                             or traj_err(rp["traj"], r["traj"]) > tol / 10))):
                         unstable = True

@@ -182,6 +182,64 @@ def test_wide_corridors_and_stage_state_after_a_solve():
     opt.close()
 
 
+@pytest.mark.parametrize("family,seed,min_share", [("dyn20", 43, 0.9), ("dyn20x", 46, 1.0)])
+def test_config4_barriers_are_active_at_the_init_guess(family, seed, min_share):
+    """BASELINE configs[4] is "constrained-ILQR barrier active" (at least one corridor / lane barrier
+    in the relaxed region at the init guess).  From the device's own init guess and shrunk + normalised planes:
+    the share of problems with a barrier argument g > -eps (RelaxBarrierFunction's relaxed branch,
+    barrier_function.h:104-113) at some (knot, disc, plane); then the solve itself against the oracle.  "dyn20x"
+    keeps every obstacle down to 0.6 m from the coarse path, so all of its problems start inside a barrier."""
+    B = 96
+    sc = scenario.generate(family, B, seed=seed)
+    opt = _opt(sc)
+    opt.stage_load(sc)
+    opt.stage_init_guess()
+    X, cor = opt.read(api.T_X), opt.read(api.T_CORRIDOR)
+    cfg = opt.cfg
+    Ld = (cfg.front_hang + cfg.wheel_base + cfg.rear_hang) / cfg.num_of_disc
+    off = np.array([Ld * (j - 0.5) - cfg.rear_hang for j in range(cfg.num_of_disc)])       # cc:556-565
+    px = X[:, :, 0, None] + off * np.cos(X[:, :, 2, None])                                   # [B,K,D]
+    py = X[:, :, 1, None] + off * np.sin(X[:, :, 2, None])
+    g = cor[..., 0, None] * px[:, :, None, :] + cor[..., 1, None] * py[:, :, None, :] - cor[..., 2, None]   # [B,K,C,D]
+    live = np.arange(cor.shape[2])[None, None, :, None] < sc["ccount"][:, :, None, None]
+    relaxed = ((g > -cfg.barrier_eps) & live).reshape(B, -1).sum(axis=1)
+    share = float((relaxed > 0).mean())
+    print(f"\n[{family}] problems with a relaxed corridor barrier at the init guess: {share:.2f}, "
+          f"relaxed terms per problem: mean {relaxed.mean():.0f}")
+    assert share >= min_share
+    cost0 = opt.stage_total_cost()
+    assert np.median(cost0[:, 3]) > 100.0            # the corridor component dominates the initial cost
+    g_ = _plan(opt, sc)
+    ocfg = oracle_cfg_from(cfg)
+    ref = oracle_reference(sc, ocfg)
+    assert_parity(g_, ref, what=family)
+    assert_steps(g_, sc, ocfg, what=family)
+    opt.close()
+
+
+def test_exit_paths_at_batch_scale():
+    """UNSOLVED / MAX_ITER / converged exits with thousands of problems in lockstep (compaction, the team backward
+    kernel and the speculative line search all switch on and off while problems leave through different exits):
+    256 distinct "dyn20x" scenes tiled 32x with the tolerances at 0 and 24 iterations -- every copy bit-identical,
+    statuses and iteration counts of the distinct scenes equal to the oracle's on its stable problems."""
+    base = scenario.generate("dyn20x", 256, seed=93)
+    rep = 32
+    sc = {k: (np.tile(v, (rep,) + (1,) * (v.ndim - 1)) if isinstance(v, np.ndarray) and v.shape[:1] == (256,) else v)
+          for k, v in base.items()}
+    opt = _opt(sc, max_iter=24, abs_cost_tol=0.5, rel_cost_tol=0.0)
+    g = opt.plan(sc, alpha_trace=True)
+    for k in ("traj", "n_cost", "status", "n_iter", "alpha_trace"):
+        v = g[k].reshape(rep, 256, *g[k].shape[1:])
+        assert np.array_equal(v, np.broadcast_to(v[:1], v.shape)), k
+    hist = np.bincount(g["status"][:256], minlength=7)
+    print(f"\nstatus histogram of the 256 distinct scenes: {hist.tolist()}")
+    assert hist[api.ST_MAX_ITER] > 0 and hist[api.ST_CONVERGED_ABS] > 0
+    first = {k: v[:256] for k, v in g.items() if isinstance(v, np.ndarray)}
+    ref = oracle_reference(base, oracle_cfg_from(opt.cfg))
+    assert_parity(first, ref, max_unstable_frac=0.15, what="exit paths at batch scale")
+    opt.close()
+
+
 def test_golden_fixtures_through_the_c_abi():
     for path in sorted(glob.glob(os.path.join(HERE, "golden", "*.npz"))):
         g = np.load(path)
@@ -320,6 +378,52 @@ def test_device_memory_interface_and_stream():
     hist = o_hist.cpu().numpy()
     for b in range(B):
         assert np.array_equal(hist[b, :host["n_cost"][b]], host["cost_hist"][b, :host["n_cost"][b]])
+    opt.close()
+
+
+def test_gather_results_through_the_c_abi_single_rank():
+    """cilqr_comm_* / cilqr_gather_results (librccl loaded with dlopen, no PyTorch involved in the exchange) with a
+    one-rank communicator -- all a 1-GPU box can hold: RCCL initialises, the results are packed (8 trajectory
+    columns, live Cost rows only), unpacked on the root and equal the local results bit for bit (time and kappa
+    rebuilt), rows past n_cost stay untouched.  State errors mirror the rest of the ABI."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    sc = scenario.generate("mix11", 150, seed=160)
+    B, K = 150, sc["n_steps"] + 1
+    opt = _opt(sc)
+    M = opt.cfg.max_iter
+    t = {k: torch.from_numpy(np.ascontiguousarray(sc[k])).to(dev) for k in ("start", "coarse", "corridor", "ccount")}
+    loc = dict(traj=torch.zeros((B, K, 10), dtype=torch.float64, device=dev), hist=torch.zeros((B, M + 1, 5), dtype=torch.float64, device=dev),
+               nc=torch.zeros(B, dtype=torch.int32, device=dev), st=torch.zeros(B, dtype=torch.int32, device=dev),
+               ni=torch.zeros(B, dtype=torch.int32, device=dev))
+    gat = {k: torch.full_like(v, -7) for k, v in loc.items()}
+    left, right = np.ascontiguousarray(sc["left"]), np.ascontiguousarray(sc["right"])
+    torch.cuda.synchronize()
+    prob = opt.make_problem(B, t["start"].data_ptr(), t["coarse"].data_ptr(), t["corridor"].data_ptr(), t["ccount"].data_ptr(),
+                            sc["cmax"], left.ctypes.data, right.ctypes.data, left.shape[0], right.shape[0], api.MEM_DEVICE)
+
+    def sol(d):
+        return api.SolutionBatch(api.MEM_DEVICE, 0, d["traj"].data_ptr(), d["hist"].data_ptr(), d["nc"].data_ptr(),
+                                 d["st"].data_ptr(), d["ni"].data_ptr(), None, None)
+
+    assert opt.solve_raw(prob, sol(loc)) == api.OK
+    assert opt.gather_results_raw(B, sol(loc), 0, sol(gat)) == api.ERR_STATE         # no communicator yet
+    uid = api.comm_unique_id()
+    assert len(uid) == api.UNIQUE_ID_BYTES
+    opt.comm_create(uid, 0, 1)
+    with pytest.raises(api.CilqrError):
+        opt.comm_create(uid, 0, 1)                                                    # one communicator per handle
+    assert opt.gather_results_raw(B, sol(loc), 1, sol(gat)) == api.ERR_ARG           # root outside the world
+    assert opt.gather_results_raw(B, sol(loc), 0, None) == api.ERR_NULL              # the root needs a destination
+    assert opt.gather_results_raw(B, sol(loc), 0, sol(gat)) == api.OK
+    torch.cuda.synchronize()
+    for k in ("traj", "nc", "st", "ni"):
+        assert torch.equal(gat[k], loc[k]), k
+    live = torch.arange(M + 1, device=dev)[None, :] < loc["nc"][:, None].long()
+    assert torch.equal(gat["hist"][live], loc["hist"][live])
+    assert bool((gat["hist"][~live] == -7).all())                                     # rows >= n_cost untouched
+    opt.comm_destroy()
+    assert opt.L.cilqr_comm_destroy(opt.h) == api.ERR_STATE
     opt.close()
 
 
