@@ -52,12 +52,16 @@ CILQR_DEV double normalize_angle(double angle) {
 
 // 1 / g for normal finite g != 0: hardware estimate + two Newton steps (6 instructions; the
 // IEEE-exact division sequence is 12)
+#ifdef CILQR_REF_ORDER   // test-only build (ref_order.hpp): IEEE division and the library's sin / cos / tan
+CILQR_DEV double fast_rcp(double g) { return 1.0 / g; }
+#else
 CILQR_DEV double fast_rcp(double g) {
   double r = __builtin_amdgcn_rcp(g);
   r = fma(fma(-g, r, 1.0), r, r);
   r = fma(fma(-g, r, 1.0), r, r);
   return r;
 }
+#endif
 
 // log(x * 2^e2) for normal finite x > 0.  Classic argument reduction x = 2^k (1 + f),
 // sqrt(1/2) <= 1 + f < sqrt(2), s = f / (2 + f), log(1 + f) = f - f^2/2 + s (f^2/2 + R(s^2)) with
@@ -89,6 +93,13 @@ CILQR_DEV double log_pos(double x, int e2) {
 // sin and cos of x for |x| <= 1e5 (the states keep every angle wrapped to [-pi, pi)): three-step
 // Cody-Waite reduction by pi/2 with fma, then the kernel polynomials of fdlibm k_sin.c / k_cos.c
 // on |r| <= pi/4.  ~35 instructions against ~160 for the library sincos(), error about 1 ulp.
+#ifdef CILQR_REF_ORDER
+CILQR_DEV void lean_sincos(double x, double* sn, double* cs) {
+  *sn = sin(x);
+  *cs = cos(x);
+}
+CILQR_DEV double lean_tan(double x) { return tan(x); }
+#else
 CILQR_DEV void lean_sincos(double x, double* sn, double* cs) {
   constexpr double two_over_pi = 6.36619772367581382433e-01;
   constexpr double pio2_hi = 1.5707963267948966, pio2_lo = 6.123233995736766e-17, pio2_lo2 = -1.4973849048591698e-33;
@@ -118,6 +129,14 @@ CILQR_DEV double lean_tan(double x) {
   lean_sincos(x, &s, &c);
   return s * fast_rcp(c);
 }
+#endif
+// x / wheel_base as the reference writes it (vehicle_model.cc:59-82, 131); the product build multiplies by the
+// reciprocal, which is the same number for the reference's wheel_base = 1
+#ifdef CILQR_REF_ORDER
+#define CILQR_OVER_L(p, x) ((x) / (p).wheel_base)
+#else
+#define CILQR_OVER_L(p, x) ((x) * (p).inv_wheel_base)
+#endif
 
 // ---- relaxed log barrier, barrier_function.h:104-140 ----
 // value(g) = g < -eps ? -r log(-g) : r/2 (((-g - 2 eps)/eps)^2 - 1) - r log(eps)
@@ -186,7 +205,7 @@ CILQR_DEV void dyn_continuous(const Params& p, const double* s, const double* u,
   lean_sincos(theta, &sn, &cs);
   r[0] = v * cs;
   r[1] = v * sn;
-  r[2] = v * lean_tan(delta) * p.inv_wheel_base;
+  r[2] = CILQR_OVER_L(p, v * lean_tan(delta));
   r[3] = s[4];
   r[4] = u[0];
   r[5] = u[1];
@@ -219,14 +238,14 @@ struct DynJac {
   double b21;
 };
 CILQR_DEV void dynamics_jacobian(const Params& p, const double* s, const double* u, DynJac& J) {
-  const double iL = p.inv_wheel_base, dt = p.dt;
+  const double dt = p.dt;
   const double v = s[3];
   const double theta = normalize_angle(s[2]);
   const double delta = normalize_angle(s[5]);
   const double a = s[4];
   const double delta_rate = u[1];
   const double tan_delta = lean_tan(delta);
-  const double theta_mid = theta + 0.5 * dt * v * tan_delta * iL;
+  const double theta_mid = theta + CILQR_OVER_L(p, 0.5 * dt * v * tan_delta);
   const double tan_dr = lean_tan(delta + 0.5 * dt * delta_rate);
   double sin_m, cos_m;
   lean_sincos(theta_mid, &sin_m, &cos_m);
@@ -235,17 +254,17 @@ CILQR_DEV void dynamics_jacobian(const Params& p, const double* s, const double*
   const double v_tdr = v * (tdr2 + 1);
   const double vm = 0.5 * a * dt + v;
   J.a02 = -dt * vm * sin_m;
-  J.a03 = dt * cos_m - 0.5 * dt * dt * vm * sin_m * tan_delta * iL;
+  J.a03 = dt * cos_m - CILQR_OVER_L(p, 0.5 * dt * dt * vm * sin_m * tan_delta);
   J.a04 = 0.5 * dt * dt * cos_m;
-  J.a05 = -0.5 * dt * dt * v * vm * (td2 + 1) * sin_m * iL;
+  J.a05 = CILQR_OVER_L(p, -0.5 * dt * dt * v * vm * (td2 + 1) * sin_m);
   J.a12 = dt * vm * cos_m;
-  J.a13 = dt * sin_m + 0.5 * dt * dt * vm * cos_m * tan_delta * iL;
+  J.a13 = dt * sin_m + CILQR_OVER_L(p, 0.5 * dt * dt * vm * cos_m * tan_delta);
   J.a14 = 0.5 * dt * dt * sin_m;
-  J.a15 = 0.5 * dt * dt * v * vm * (td2 + 1) * cos_m * iL;
-  J.a23 = dt * tan_dr * iL;
-  J.a24 = 0.5 * dt * dt * tan_dr * iL;
-  J.a25 = dt * v_tdr * iL;
-  J.b21 = 0.5 * dt * dt * v * (tdr2 + 1) * iL;
+  J.a15 = CILQR_OVER_L(p, 0.5 * dt * dt * v * vm * (td2 + 1) * cos_m);
+  J.a23 = CILQR_OVER_L(p, dt * tan_dr);
+  J.a24 = CILQR_OVER_L(p, 0.5 * dt * dt * tan_dr);
+  J.a25 = CILQR_OVER_L(p, dt * v_tdr);
+  J.b21 = CILQR_OVER_L(p, 0.5 * dt * dt * v * (tdr2 + 1));
 }
 
 // ---- nearest lane segment (first minimum wins), cc:605-618 + line_segment2d.cpp:61-75 ----
@@ -271,6 +290,14 @@ CILQR_DEV double segment_dist2(const double* __restrict__ r, double px, double p
   return (len <= kMathEps || proj <= 0.0) ? d_start : (proj >= len ? d_end : d_perp);
 }
 
+// Squared distances order like distances, with one exception that is left as it is.  The reference compares
+// DISTANCES (hypot / |cross|, line_segment2d.cpp:61-75): two squared distances one or two ulp apart have the same
+// square root, which its strict '<' treats as a tie (first index wins).  That happens on a strip ~1e-7 m wide along
+// the normal through a segment end point (perpendicular distance to one segment against the end-point distance to its
+// neighbour); there this search returns the strictly nearer segment and the reference the earlier one.  Measured
+// alternatives (k_cost_knots at full batch, 481 us as is): comparing the roots inside a 4-ulp window, inline +34 %,
+// out of line +18 %; a plain 2-ulp margin costs nothing but only moves the disagreement to the fuzzy edge of the
+// strip.  The parity tests recognise the case (an exact tie of the oracle's own distances) and say so.
 CILQR_DEV int nearest_segment_scan(const double* __restrict__ tab, int n, double px, double py) {
   double best = DBL_MAX;
   int bi = 0;
@@ -362,30 +389,9 @@ CILQR_DEV void store_u(const DeviceState& s, int buf, int i, int slot, const dou
   s.U[((size_t)buf * s.p.N + i) * s.Bcap + slot] = make_double2(u[0], u[1]);
 }
 
-// sum of the knot partials in index order -> trial[5] (total, J, dynamics, corridor, lane)
-CILQR_DEV void reduce_cost(const DeviceState& s, int slot, double* c5) {
-  const int Bc = s.Bcap, K = s.p.K, N = s.p.N;
-  double j = 0.0, dx = 0.0, du = 0.0, cc = 0.0, lc = 0.0;
-  // loads of several knots in flight; the sums stay in knot order
-#pragma unroll 8
-  for (int i = 0; i < K; ++i) {
-    const double2* o = s.part + (size_t)i * kPartPairs * Bc + slot;
-    const double2 a = o[0], b = o[(size_t)Bc], c = o[(size_t)2 * Bc];
-    j += a.x;
-    dx += b.x;
-    cc += c.x;
-    lc += c.y;
-  }
-#pragma unroll 8
-  for (int i = 0; i < N; ++i) {   // control terms follow the state terms (cc:510-513)
-    const double2* o = s.part + (size_t)i * kPartPairs * Bc + slot;
-    j += o[0].y;
-    du += o[(size_t)Bc].y;
-  }
-  const double dyn = dx + du;                      // cc:550
-  c5[0] = j + dyn + cc + lc;                       // cc:429
-  c5[1] = j; c5[2] = dyn; c5[3] = cc; c5[4] = lc;
-}
-
+// sum of the knot partials in index order -> c5 (total, J, dynamics, corridor, lane).  `cand`: which buffer of the
+// slot the partials were computed on (0 = the iterate, 1 = the candidate) -- only the test-only reference-order build
+// needs it, which re-evaluates the whole cost from that trajectory instead of summing partials.
+CILQR_DEV void reduce_cost(const DeviceState& s, int slot, int cand, double* c5);
 
 }  // namespace cilqr

@@ -16,7 +16,7 @@
 // Per-knot cost partials go to `part`; a per-problem pass sums them over knots in index order.
 // Sums over (disc, plane) are therefore re-associated with respect to the reference's running
 // sums; every individual term is computed with the reference's expression.
-#include "dev_model.hpp"
+#include "cost_reduce.hpp"
 
 namespace cilqr {
 
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(64) void k_reduce_only(DeviceState s, const int* __
   if (j >= n) return;
   const int slot = list ? list[j] : j;
   double c5[5];
-  reduce_cost(s, slot, c5);
+  reduce_cost(s, slot, 0, c5);
 #pragma unroll
   for (int c = 0; c < 5; ++c) s.trial[(size_t)c * s.Bcap + slot] = c5[c];
 }
@@ -503,6 +503,53 @@ CILQR_DEV void knot_quadratize(const DeviceState& s, const double* __restrict__ 
   o[(size_t)16 * Bc] = make_double2(q.huu[0], q.huu[1]);
 }
 
+#ifdef CILQR_REF_ORDER
+// test-only: the knot's quadratisation in the reference's operation order (ref_order.hpp), same storage layout
+CILQR_DEV void knot_quadratize_ref(const DeviceState& s, int buf, int i, int slot) {
+  const Params& p = s.p;
+  const int Bc = s.Bcap;
+  const bool term = (i == p.N);
+  double x[6], u[2] = {0.0, 0.0};
+  load_x(s, buf, i, slot, x);
+  if (!term) load_u(s, buf, i, slot, u);
+  Quad q;
+  reforder::knot_quadratize(s, i, slot, x, u, q.lx, q.lu, q.h, q.hd, q.huu);
+  if (term) {
+    double2* o = s.term + slot;
+    o[0] = make_double2(q.lx[0], q.lx[1]);
+    o[(size_t)Bc] = make_double2(q.lx[2], q.lx[3]);
+    o[(size_t)2 * Bc] = make_double2(q.lx[4], q.lx[5]);
+    o[(size_t)3 * Bc] = make_double2(q.h[0], q.h[1]);
+    o[(size_t)4 * Bc] = make_double2(q.h[2], q.h[3]);
+    o[(size_t)5 * Bc] = make_double2(q.h[4], q.h[5]);
+    o[(size_t)6 * Bc] = make_double2(q.h[6], q.h[7]);
+    o[(size_t)7 * Bc] = make_double2(q.h[8], q.hd[0]);
+    o[(size_t)8 * Bc] = make_double2(q.hd[1], q.hd[2]);
+    return;
+  }
+  DynJac J;
+  dynamics_jacobian(p, x, u, J);
+  double2* o = s.lin + (size_t)i * kLinPairs * Bc + slot;
+  o[(size_t)0 * Bc] = make_double2(J.a02, J.a03);
+  o[(size_t)1 * Bc] = make_double2(J.a04, J.a05);
+  o[(size_t)2 * Bc] = make_double2(J.a12, J.a13);
+  o[(size_t)3 * Bc] = make_double2(J.a14, J.a15);
+  o[(size_t)4 * Bc] = make_double2(J.a23, J.a24);
+  o[(size_t)5 * Bc] = make_double2(J.a25, J.b21);
+  o[(size_t)6 * Bc] = make_double2(q.lx[0], q.lx[1]);
+  o[(size_t)7 * Bc] = make_double2(q.lx[2], q.lx[3]);
+  o[(size_t)8 * Bc] = make_double2(q.lx[4], q.lx[5]);
+  o[(size_t)9 * Bc] = make_double2(q.lu[0], q.lu[1]);
+  o[(size_t)10 * Bc] = make_double2(q.h[0], q.h[1]);
+  o[(size_t)11 * Bc] = make_double2(q.h[2], q.h[3]);
+  o[(size_t)12 * Bc] = make_double2(q.h[4], q.h[5]);
+  o[(size_t)13 * Bc] = make_double2(q.h[6], q.h[7]);
+  o[(size_t)14 * Bc] = make_double2(q.h[8], q.hd[0]);
+  o[(size_t)15 * Bc] = make_double2(q.hd[1], q.hd[2]);
+  o[(size_t)16 * Bc] = make_double2(q.huu[0], q.huu[1]);
+}
+#endif
+
 __global__ __launch_bounds__(256) void k_quadratize(DeviceState s, const int* __restrict__ list, int n,
                                                     int only_upd) {
   extern __shared__ double lds[];
@@ -513,8 +560,13 @@ __global__ __launch_bounds__(256) void k_quadratize(DeviceState s, const int* __
   if (j >= n) return;
   const int slot = list ? list[j] : j;
   if (only_upd && !s.upd[slot]) return;
+#ifdef CILQR_REF_ORDER
+  (void)lanes;
+  knot_quadratize_ref(s, s.cur[slot], blockIdx.y, slot);
+#else
   if (s.p.num_of_disc == 5) knot_quadratize<5>(s, lanes, s.cur[slot], blockIdx.y, slot);
   else knot_quadratize<0>(s, lanes, s.cur[slot], blockIdx.y, slot);
+#endif
 }
 
 void launch_quadratize(const DeviceState& s, const int* list, int n, int only_upd, hipStream_t st) {

@@ -11,7 +11,7 @@
 //   [reduce + accept test, or roll out alpha_{r+1} and join pending list r+1] -> cost -> ...
 // The first passing list index wins, as in the sequential loop.  Pending lists are compacted
 // with wave-aggregated atomics; their order only affects coalescing, never results.
-#include "dev_model.hpp"
+#include "cost_reduce.hpp"
 
 namespace cilqr {
 
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(64) void k_search_round(DeviceState s, int r, int n
     const int slot = list[j];
     if (s.acc_idx[slot] != -1) continue;   // left at the gradient-norm exit
     double c5[5];
-    reduce_cost(s, slot, c5);
+    reduce_cost(s, slot, 1, c5);
     const double alpha = kAlpha[r];
     const double dcost = s.cost_old[slot] - c5[0];                                  // cc:254
     const double expected = -alpha * (s.dV[slot] + alpha * s.dV[(size_t)s.Bcap + slot]);  // cc:255
@@ -276,6 +276,14 @@ __global__ __launch_bounds__(64) void k_spec_reduce(DeviceState s, const int* __
     if (open) {   // acc_idx is written by the r == 0 lanes of k_spec_forward, already complete here
       if (s.acc_idx[slot] != -1) continue;
     }
+    double* t = s.spec_tot + (size_t)r * 5 * cap + j;
+#ifdef CILQR_REF_ORDER
+    double c5[5];
+    spec_total_cost(s, slot, r, j, c5);
+    t[0] = c5[0];
+    t[cap] = c5[1]; t[2 * cap] = c5[2]; t[3 * cap] = c5[3]; t[4 * cap] = c5[4];
+    (void)K; (void)N;
+#else
     double jj = 0.0, dx = 0.0, du = 0.0, cc = 0.0, lc = 0.0;
     const double2* pb = s.parts + (size_t)r * K * kPartPairs * cap + j;
     // loads of several knots in flight; the sums stay in knot order
@@ -295,9 +303,9 @@ __global__ __launch_bounds__(64) void k_spec_reduce(DeviceState s, const int* __
       du += o[cap].y;
     }
     const double dyn = dx + du;
-    double* t = s.spec_tot + (size_t)r * 5 * cap + j;
     t[0] = jj + dyn + cc + lc;
     t[cap] = jj; t[2 * cap] = dyn; t[3 * cap] = cc; t[4 * cap] = lc;
+#endif
   }
 }
 
@@ -390,6 +398,11 @@ __global__ __launch_bounds__(64) void k_round_pick(DeviceState s, int r, int n_m
     const int j = (r == 0) ? e : list[e];
     const int slot = s.act[j];
     if (s.acc_idx[slot] != -1) continue;   // left at the gradient-norm exit
+#ifdef CILQR_REF_ORDER
+    double c5[5];
+    spec_total_cost(s, slot, r, j, c5);
+    (void)K; (void)N; (void)cap;
+#else
     double jj = 0.0, dx = 0.0, du = 0.0, cc = 0.0, lc = 0.0;
     const double2* pb = s.parts + (size_t)r * K * kPartPairs * cap + j;
     // loads of several knots in flight; the sums stay in knot order
@@ -410,6 +423,7 @@ __global__ __launch_bounds__(64) void k_round_pick(DeviceState s, int r, int n_m
     }
     const double dyn = dx + du;
     const double c5[5] = {jj + dyn + cc + lc, jj, dyn, cc, lc};
+#endif
     const double alpha = kAlpha[r];
     const double dcost = s.cost_old[slot] - c5[0];                                  // cc:254
     const double expected = -alpha * (s.dV[slot] + alpha * s.dV[(size_t)s.Bcap + slot]);  // cc:255

@@ -68,14 +68,41 @@ def family_report(family, seed, nb, lib_path=None):
     }
 
 
-def build_report(n=1024, families=FAMILIES):
+def build_report(n=1024, families=FAMILIES, with_reference_order=True):
+    """Product library against the oracle, and -- in a child process, because a process holds one libcilqr_hip --
+    the TEST-ONLY build of the same kernels with the cost / quadratisation arithmetic in the reference's operation
+    order and the library's log / sin / cos / tan (cilqr_amd/csrc/ref_order.hpp, lib/libcilqr_hip_reforder.so).  The
+    share of problems that differ from the oracle in THAT build is what the reference's ill-conditioning costs any
+    implementation with another libm; the product's share on top of it is what its re-associations add."""
     import torch  # noqa: F401  (one HIP runtime per process: torch's first)
     report = {"tolerance_whole_solves": 1e-4, "tolerance_steps": 1e-8, "problems_per_family": n, "families": {}}
     for family, seed in families:
         report["families"][family] = family_report(family, seed, n)
+    if with_reference_order:
+        import subprocess
+        lib = os.path.join(ROOT, "cilqr_amd", "lib", "libcilqr_hip_reforder.so")
+        if not os.path.exists(lib):
+            report["reference_order_build"] = {"error": f"{lib} is missing (make -C cilqr_amd/csrc reforder)"}
+        else:
+            env = dict(os.environ, CILQR_LIB=lib)
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), str(n), "--plain"], env=env, capture_output=True, text=True)
+            if r.returncode != 0:
+                report["reference_order_build"] = {"error": r.stderr[-2000:]}
+            else:
+                sub = json.loads(r.stdout)
+                report["reference_order_build"] = {"library": os.path.relpath(lib, ROOT), "families": sub["families"]}
+        rob = report["reference_order_build"].get("families")
+        if rob:
+            # the comparison the two builds are there for: problems (of all, stable or not) that do not match the oracle
+            report["mismatch_share_all_problems"] = {
+                fam: {"product_build": round(1.0 - report["families"][fam]["match_within_tolerance"] / report["families"][fam]["problems"], 4),
+                      "reference_order_build": round(1.0 - rob[fam]["match_within_tolerance"] / rob[fam]["problems"], 4),
+                      "oracle_unstable_share": round(report["families"][fam]["oracle_unstable"] / report["families"][fam]["problems"], 4)}
+                for fam in report["families"] if fam in rob}
     return report
 
 
 if __name__ == "__main__":
-    n_ = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-    print(json.dumps(build_report(n_), indent=1))
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    n_ = int(args[0]) if args else 1024
+    print(json.dumps(build_report(n_, with_reference_order="--plain" not in sys.argv), indent=1))

@@ -24,7 +24,10 @@ What "parity" means here (DESIGN.md section 5 has the long form):
    its decisions flip) under a 4e-16 perturbation of the iterate it starts from (8 samples), or if the first decision that differs is one whose
    test sat within KNIFE_EDGE = 1e-9 (relative) of its threshold in the oracle (only seen when both
    cost tolerances are 0 and the solver iterates on in the rounding-noise plateau, where accepted
-   cost decreases are ~1e-13 of the cost).  The excused share of steps is bounded.
+   cost decreases are ~1e-13 of the cost), or if the iterate sits on an exact tie of the reference's own
+   nearest-lane-segment distances (`lane_tie`: the reference keeps the earlier segment, the kernels' squared
+   distances the strictly nearer one -- same plateau runs only: iterates come to rest on those strips because the
+   lane cost jumps there).  The excused share of steps is bounded.
 
 Error measure: every trajectory column is scaled by the largest magnitude of that column in the
 reference trajectory (theta, delta, kappa, delta_rate are O(0.1) quantities: a floor of 1.0 would
@@ -215,6 +218,33 @@ def _step_matches(r, seg, gpu_status_after, cost_row0, cost_row1, next_traj, tol
     return True, worst, ""
 
 
+def lane_tie(scene: dict, ocfg, X) -> bool:
+    """Does some disc point of trajectory X [K,6] have two lane segments at the SAME distance in the reference's own
+    arithmetic (LineSegment2d::DistanceTo: hypot to an end point, |cross| to the foot, line_segment2d.cpp:61-75)?
+    The reference's strict '<' then keeps the earlier segment (FindNeastLaneSegment, ilqr_optimizer.cc:605-618) while
+    the kernels, which compare squared distances, keep the strictly nearer one: the two lane costs differ by a jump.
+    It happens on strips ~1e-7 m wide along the normals through the segment end points -- and iterates do come to
+    rest there, because the lane cost is discontinuous exactly there (different segments carry different planes)."""
+    L = (ocfg.front_hang + ocfg.wheel_base + ocfg.rear_hang) / ocfg.num_of_disc
+    off = np.array([L * (j - 0.5) - ocfg.rear_hang for j in range(ocfg.num_of_disc)])
+    px = (X[:, 0, None] + off * np.cos(X[:, 2, None])).ravel()
+    py = (X[:, 1, None] + off * np.sin(X[:, 2, None])).ravel()
+    for tab in (scene["left"], scene["right"]):
+        sx, sy, ex, ey = tab[:, 3], tab[:, 4], tab[:, 5], tab[:, 6]
+        ln = np.hypot(ex - sx, ey - sy)
+        ux, uy = (ex - sx) / ln, (ey - sy) / ln
+        x0, y0 = px[:, None] - sx[None], py[:, None] - sy[None]
+        proj = x0 * ux[None] + y0 * uy[None]
+        x1, y1 = px[:, None] - ex[None], py[:, None] - ey[None]
+        cross = x0 * uy[None] - y0 * ux[None]
+        d = np.where(proj <= 0.0, np.hypot(x0, y0), np.where(proj >= ln[None], np.hypot(x1, y1), np.abs(cross)))
+        d2 = np.where(proj <= 0.0, x0 * x0 + y0 * y0, np.where(proj >= ln[None], x1 * x1 + y1 * y1, cross * cross))
+        # first minimum of the distances (the reference) against first minimum of the squared distances (the kernels)
+        if np.any(np.argmin(d, axis=1) != np.argmin(d2, axis=1)):
+            return True
+    return False
+
+
 def check_steps(gpu: dict, scene: dict, ocfg, problems=None, tol=STEP_TOL, eps=PERTURB_EPS, n_perturb=8,
                 seed=777):
     """Replay every step of the listed problems (default: all) in the oracle, starting each step from
@@ -224,7 +254,7 @@ def check_steps(gpu: dict, scene: dict, ocfg, problems=None, tol=STEP_TOL, eps=P
     cap = gpu["iter_trajs"].shape[1]
     rng = np.random.default_rng(seed)
     problems = range(B) if problems is None else problems
-    out = dict(steps=0, tight=0, excused=0, knife_edge=0, failed=[], worst=0.0, truncated=0, errors=[])
+    out = dict(steps=0, tight=0, excused=0, knife_edge=0, lane_tie=0, failed=[], worst=0.0, truncated=0, errors=[])
     o = orc.Oracle(ocfg)
     for b in problems:
         assert o.set_problem(scene["start"][b], scene["coarse"][b], scene["corridor"][b], scene["ccount"][b],
@@ -274,6 +304,10 @@ def check_steps(gpu: dict, scene: dict, ocfg, problems=None, tol=STEP_TOL, eps=P
                 if 0 <= jd < len(r["margins"]) and r["margins"][jd] < KNIFE_EDGE:
                     unstable = True
                     out["knife_edge"] += 1
+                # or does the iterate (or the one the step arrives at) sit on a nearest-lane-segment tie?
+                if not unstable and (lane_tie(scene, ocfg, X) or (nxt is not None and lane_tie(scene, ocfg, np.asarray(nxt)[:, 1:7]))):
+                    unstable = True
+                    out["lane_tie"] += 1
                 # or is the step itself discontinuous in the oracle?
                 for _ in range(0 if unstable else n_perturb):
                     rp = o.replay(X * (1.0 + eps * rng.standard_normal(X.shape)),
