@@ -69,7 +69,8 @@ class SolutionBatch(C.Structure):
 class CorridorConfig(C.Structure):
     """CorridorConfig of the reference (algorithm/params/planner_config.h:75-86)."""
     _fields_ = [("max_diff_x", C.c_double), ("max_diff_y", C.c_double), ("radius", C.c_double),
-                ("max_axis_x", C.c_double), ("max_axis_y", C.c_double), ("lane_segment_length", C.c_double)]
+                ("max_axis_x", C.c_double), ("max_axis_y", C.c_double), ("lane_segment_length", C.c_double),
+                ("is_multiple_sample", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class DpConfig(C.Structure):

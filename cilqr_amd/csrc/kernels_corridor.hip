@@ -36,7 +36,8 @@ struct P2f {
 // entries (exact predicates keep at most n + 1 on the stack; with float32 rounding a nearly
 // collinear point can survive in both chains, and 2n - 1 pushes is the hard bound).  Returns the
 // number of hull vertices.
-__device__ int hull_indices(const P2f* p, int n, unsigned char* order, unsigned char* h) {
+template <typename Idx>
+__device__ int hull_indices(const P2f* p, int n, Idx* order, Idx* h) {
   // stable sort by (x, y) through ranks: rank(i) = number of points that sort before point i.
   // n^2 comparisons, but the loads of the inner loop do not depend on each other (an insertion
   // sort is a chain of dependent memory round trips, which is what a lane of this kernel waits on).
@@ -47,7 +48,7 @@ __device__ int hull_indices(const P2f* p, int n, unsigned char* order, unsigned 
       const P2f r = p[j];
       rank += (r.x < q.x || (r.x == q.x && (r.y < q.y || (r.y == q.y && j < i)))) ? 1 : 0;
     }
-    order[rank] = (unsigned char)i;
+    order[rank] = (Idx)i;
   }
   auto cross = [&](int o, int a, int b) {
     const float ax = p[a].x - p[o].x, ay = p[a].y - p[o].y;
@@ -68,9 +69,10 @@ __device__ int hull_indices(const P2f* p, int n, unsigned char* order, unsigned 
   if (k == 2 && p[h[0]].x == p[h[1]].x && p[h[0]].y == p[h[1]].y) k = 1;
   return k;
 }
-__device__ void make_clockwise(unsigned char* h, int k) {
+template <typename Idx>
+__device__ void make_clockwise(Idx* h, int k) {
   for (int a = 1, b = k - 1; a < b; ++a, --b) {
-    const unsigned char t = h[a];
+    const Idx t = h[a];
     h[a] = h[b];
     h[b] = t;
   }
@@ -82,7 +84,7 @@ __device__ void make_clockwise(unsigned char* h, int k) {
 // the count zeroed), ccount [n]
 // (m >= 3 half-planes, or -1 no points, -2 fewer than 4 flipped points, -3 more than cmax
 // half-planes, -4 degenerate hull); *n_failed counts the knots with a negative code.
-template <int MAXP>
+template <int MAXP, typename Idx>
 __global__ __launch_bounds__(64) void k_build_corridors(int n, CorridorParams cp, const double* __restrict__ knots,
                                                         const double* __restrict__ points,
                                                         const int* __restrict__ count, int pmax,
@@ -97,35 +99,38 @@ __global__ __launch_bounds__(64) void k_build_corridors(int n, CorridorParams cp
   // are remembered by their index in the input list and re-read (or re-derived) when needed.
   P2f flip[MAXP + 1], vd[MAXP + 1];
   P2f* dual = flip;
-  unsigned char src[MAXP], order[MAXP + 1], hull[2 * (MAXP + 1)], v2[MAXP + 1];
+  Idx src[MAXP], order[MAXP + 1], hull[2 * (MAXP + 1)], v2[MAXP + 1];
   int code = 0;
   int nf = 0;
   double safe_radius = cp.radius;
   const int np = min(max(count[t], 0), pmax);
   const double* pp = points + (size_t)t * pmax * 2;
-  // box points of AddCorridorPoints (cc:89-120, is_multiple_sample = false: both ends of each edge)
+  // box points of AddCorridorPoints (cc:89-120): both ends of each edge, or six samples per edge
   const double ch = cos(theta), sh = sin(theta);
   const double dx1 = ch * cp.max_axis_x, dy1 = sh * cp.max_axis_x;
   const double dx2 = sh * cp.max_axis_y, dy2 = -ch * cp.max_axis_y;
-  auto input_point = [&](int i, double& x, double& y) {   // obstacle points, then the 8 box points
+  const int per_edge = cp.per_edge, nbox = 4 * cp.per_edge;
+  const double ratio_step = 1.0 / (per_edge == 2 ? 1.0 : 5.0);
+  auto input_point = [&](int i, double& x, double& y) {   // obstacle points, then the box points
     if (i < np) {
       x = pp[2 * i];
       y = pp[2 * i + 1];
     } else {
       // corners: +dx1 +dx2, +dx1 -dx2, -dx1 -dx2, -dx1 +dx2; edge e runs from corner e to e + 1
-      const int e = (i - np) >> 1, second = (i - np) & 1;
+      const int e = (i - np) / per_edge, kth = (i - np) - e * per_edge;
       const int k0 = e, k1 = (e + 1) & 3;
       const double s1a = (k0 < 2) ? 1.0 : -1.0, s2a = (k0 == 0 || k0 == 3) ? 1.0 : -1.0;
       const double s1b = (k1 < 2) ? 1.0 : -1.0, s2b = (k1 == 0 || k1 == 3) ? 1.0 : -1.0;
       const double ax = ox + s1a * dx1 + s2a * dx2, ay = oy + s1a * dy1 + s2a * dy2;
       const double bx = ox + s1b * dx1 + s2b * dx2, by = oy + s1b * dy1 + s2b * dy2;
-      const double ratio = second ? 1.0 : 0.0;
+      double ratio = 0.0;   // the reference's loop variable: ratio += ratio_step, in floating point (cc:113)
+      for (int q = 0; q < kth; ++q) ratio += ratio_step;
       x = ax * (1 - ratio) + bx * ratio;
       y = ay * (1 - ratio) + by * ratio;
     }
   };
   {
-    for (int i = 0; i < np + 8; ++i) {
+    for (int i = 0; i < np + nbox; ++i) {
       double x, y;
       input_point(i, x, y);
       // filter cc:136-149 and sphere flip cc:154-177
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(64) void k_build_corridors(int n, CorridorParams cp
       const double norm2 = sqrt(dx * dx + dy * dy);
       if (fabs(norm2) < kEps) continue;
       if (norm2 < cp.radius) safe_radius = norm2;
-      src[nf] = (unsigned char)i;
+      src[nf] = (Idx)i;
       flip[nf].x = (float)(dx + 2 * (cp.radius - norm2) * dx / norm2);
       flip[nf].y = (float)(dy + 2 * (cp.radius - norm2) * dy / norm2);
       ++nf;
@@ -266,12 +271,16 @@ void launch_build_corridors(int n, const CorridorParams& cp, const double* knots
   // streams through HBM on every access, at half that the kernel is 20 % faster (measured).
   constexpr int lds_pad = 10000;
   // two capacities: a lane's scratch working set scales with it
-  if (pmax + 8 <= 56)
-    hipLaunchKernelGGL(k_build_corridors<56>, dim3((n + 63) / 64), dim3(64), lds_pad, st, n, cp, knots, points,
-                       count, pmax, corridor, ccount, cmax, n_failed, polygons);
-  else
-    hipLaunchKernelGGL(k_build_corridors<kCorMaxPts>, dim3((n + 63) / 64), dim3(64), lds_pad, st, n, cp, knots,
+  const int need = pmax + 4 * cp.per_edge;
+  if (need <= 56)
+    hipLaunchKernelGGL((k_build_corridors<56, unsigned char>), dim3((n + 63) / 64), dim3(64), lds_pad, st, n, cp, knots,
                        points, count, pmax, corridor, ccount, cmax, n_failed, polygons);
+  else if (need <= 96)
+    hipLaunchKernelGGL((k_build_corridors<96, unsigned char>), dim3((n + 63) / 64), dim3(64), lds_pad, st, n, cp, knots,
+                       points, count, pmax, corridor, ccount, cmax, n_failed, polygons);
+  else   // is_multiple_sample scenes: six samples per obstacle edge and per box edge
+    hipLaunchKernelGGL((k_build_corridors<kCorMaxPts, unsigned short>), dim3((n + 63) / 64), dim3(64), lds_pad, st, n, cp,
+                       knots, points, count, pmax, corridor, ccount, cmax, n_failed, polygons);
 }
 
 }  // namespace cilqr

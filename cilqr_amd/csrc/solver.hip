@@ -829,6 +829,8 @@ void cilqr_default_corridor_config(cilqr_corridor_config* c) {
   c->max_diff_x = 25.0; c->max_diff_y = 25.0; c->radius = 150.0;   // planner_config.h:77-79
   c->max_axis_x = 10.0; c->max_axis_y = 10.0;                      // planner_config.h:81-82
   c->lane_segment_length = 5.0;                                    // planner_config.h:85
+  c->is_multiple_sample = 0;                                       // planner_config.h:76
+  c->reserved0 = 0;
 }
 
 int cilqr_build_corridors(cilqr_handle h, const cilqr_corridor_config* cfg, int32_t batch, int32_t n_knots,
@@ -840,13 +842,14 @@ int cilqr_build_corridors(cilqr_handle h, const cilqr_corridor_config* cfg, int3
     return CILQR_ERR_NULL;                                          // corridor.cc:29-35
   if (points == nullptr && max_points > 0) return CILQR_ERR_NULL;
   if (batch <= 0 || n_knots <= 0 || cmax < 3 || max_points < 0) return CILQR_ERR_ARG;   // empty trajectory cc:24-27
-  if (max_points + 8 > kCorMaxPts) return CILQR_ERR_CAPACITY;
+  if (max_points + (cfg->is_multiple_sample ? 24 : 8) > kCorMaxPts) return CILQR_ERR_CAPACITY;
   if (memory != CILQR_MEM_HOST && memory != CILQR_MEM_DEVICE) return CILQR_ERR_ARG;
   HIP_TRY(hipSetDevice(h->device));
   const size_t n = (size_t)batch * n_knots;
   const size_t b_knots = n * 3 * 8, b_pts = n * (size_t)max_points * 2 * 8, b_cnt = n * 4;
   const size_t b_cor = n * (size_t)cmax * 3 * 8, b_poly = polygons ? n * (size_t)cmax * 2 * 8 : 0;
-  CorridorParams cp{cfg->max_diff_x, cfg->max_diff_y, cfg->radius, cfg->max_axis_x, cfg->max_axis_y};
+  CorridorParams cp{cfg->max_diff_x, cfg->max_diff_y, cfg->radius, cfg->max_axis_x, cfg->max_axis_y,
+                    cfg->is_multiple_sample ? 6 : 2};
   void *t_in = nullptr, *t_out = nullptr, *t_fail = nullptr;
   int rc = CILQR_OK;
   const double *d_knots = knots, *d_pts = points;

@@ -193,9 +193,10 @@ void launch_export_iter_traj(const DeviceState& s, const int* list, int n, doubl
 void launch_export_hist(const DeviceState& s, int B, double* cost_hist, int* n_cost, int* status,
                         int* n_iter, int* n_iter_trajs, signed char* alpha_trace, hipStream_t st);
 // corridor producer (kernels_corridor.hip)
-constexpr int kCorMaxPts = 96;   // obstacle points of one knot + the 8 box points
+constexpr int kCorMaxPts = 320;  // obstacle points of one knot + the 8 (24) box points
 struct CorridorParams {
   double max_diff_x, max_diff_y, radius, max_axis_x, max_axis_y;   // planner_config.h:75-86
+  int per_edge;   // box points per edge: 2 (both ends), or 6 with is_multiple_sample (corridor.cc:110-118)
 };
 void launch_build_corridors(int n, const CorridorParams& cp, const double* knots, const double* points,
                             const int* count, int pmax, double* corridor, int* ccount, int cmax, int* n_failed,

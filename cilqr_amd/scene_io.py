@@ -147,15 +147,35 @@ def load(path: str) -> SceneFile:
     return SceneFile(dt, center, scenes)
 
 
-def environment_points(scene: Scene, times) -> tuple:
+def sample_points(polygon: np.ndarray) -> np.ndarray:
+    """Polygon2d::sample_points (algorithm/math/polygon2d.cpp:259-271): six points per edge (ratio = 0, 0.2, ... with
+    the reference's floating-point accumulation), edges in the counter-clockwise order BuildFromPoints leaves
+    (polygon2d.cpp:212-220: a clockwise input is reversed first)."""
+    p = np.asarray(polygon, float)
+    area = sum((p[i - 1, 0] - p[0, 0]) * (p[i, 1] - p[0, 1]) - (p[i - 1, 1] - p[0, 1]) * (p[i, 0] - p[0, 0]) for i in range(1, len(p)))
+    if area < 0:
+        p = p[::-1]
+    out = []
+    for i in range(len(p)):
+        q = p[(i + 1) % len(p)]
+        ratio = 0.0
+        while ratio < 1.0 + K_MATH_EPS:
+            out.append([p[i, 0] * (1 - ratio) + q[0] * ratio, p[i, 1] * (1 - ratio) + q[1] * ratio])
+            ratio += 1.0 / 5.0
+    return np.asarray(out)
+
+
+def environment_points(scene: Scene, times, multiple_sample: bool = False) -> tuple:
     """Environment::QueryStaticObstaclesPoints + QueryDynamicObstaclesPoints (environment.cpp:153-182,
     is_multiple_sample = false) for every knot time: (points [K,P,2] padded with zeros, counts [K]).
     A dynamic obstacle exists at time t when t lies within its trajectory (to 1e-10); its polygon is
     the one of the first trajectory sample later than t - 1e-10 (std::upper_bound, cpp:143-146),
-    placed by that sample's pose (planning_node.cc:68-75)."""
+    placed by that sample's pose (planning_node.cc:68-75).  multiple_sample: the polygons' sample points
+    (is_multiple_sample, environment.cpp:163,178) instead of their corners."""
+    pick = sample_points if multiple_sample else (lambda p: p)
     per_knot = []
     for t in times:
-        pts = [p for p in scene.static]
+        pts = [pick(p) for p in scene.static]
         for d in scene.dynamic:
             tt = d.trajectory[:, 0]
             if tt[0] > t + K_MATH_EPS or tt[-1] < t - K_MATH_EPS:
@@ -164,8 +184,8 @@ def environment_points(scene: Scene, times) -> tuple:
             i = min(i, len(tt) - 1)
             _, x, y, th = d.trajectory[i]
             c, s = np.cos(th), np.sin(th)     # Pose::transform (pose.h:40-46): x + rx cos - ry sin, in that order
-            pts.append(np.stack([x + d.polygon[:, 0] * c - d.polygon[:, 1] * s,
-                                 y + d.polygon[:, 0] * s + d.polygon[:, 1] * c], axis=1))
+            pts.append(pick(np.stack([x + d.polygon[:, 0] * c - d.polygon[:, 1] * s,
+                                      y + d.polygon[:, 0] * s + d.polygon[:, 1] * c], axis=1)))
         per_knot.append(np.concatenate(pts, axis=0) if pts else np.zeros((0, 2)))
     P = max((len(p) for p in per_knot), default=0)
     out = np.zeros((len(per_knot), P, 2))
@@ -197,3 +217,77 @@ def flatten_scene(center: np.ndarray, scene: Scene) -> dict:
         dynamic_polygon_counts=np.asarray([len(d.polygon) for d in scene.dynamic], dtype=np.int32),
         dynamic_trajectories=cat([np.asarray(d.trajectory, float).reshape(-1, 4) for d in scene.dynamic], 4),
         dynamic_trajectory_counts=np.asarray([len(d.trajectory) for d in scene.dynamic], dtype=np.int32))
+
+
+# ---------------------------------------------------------------------------------------------
+# the reference's own scene artefact: reference.pickle
+# ---------------------------------------------------------------------------------------------
+# script/reference_publisher.py:232-236 dumps {"center": CenterLine, "static": Obstacles | None, "dynamic":
+# DynamicObstacles | None} -- ROS message objects (genpy.Message: __slots__ in the field order of msg/*.msg and
+# geometry_msgs, pickled as the list of slot values) -- with Python 2's text pickle; script/pickle_publisher.py:24-55
+# replays it.  Reading it needs neither rospy nor the generated message modules: the unpickler below maps exactly
+# these message classes to slot-ordered stand-ins and refuses everything else.
+_MSG_SLOTS = {
+    "CenterLine": ("points",),                                                   # msg/CenterLine.msg
+    "CenterLinePoint": ("s", "x", "y", "theta", "kappa", "left_bound", "right_bound"),   # msg/CenterLinePoint.msg
+    "Obstacles": ("obstacles",),                                                 # msg/Obstacles.msg
+    "DynamicObstacles": ("obstacles",),                                          # msg/DynamicObstacles.msg
+    "DynamicObstacle": ("polygon", "trajectory"),                                # msg/DynamicObstacle.msg
+    "DynamicTrajectoryPoint": ("time", "x", "y", "theta"),                       # msg/DynamicTrajectoryPoint.msg
+    "Polygon": ("points",),                                                      # geometry_msgs/Polygon
+    "Point32": ("x", "y", "z"),                                                  # geometry_msgs/Point32
+}
+_MSG_MODULES = ("planning.msg", "geometry_msgs.msg")
+_STUBS = {}
+
+
+def _stub(name):
+    if name not in _STUBS:
+        slots = _MSG_SLOTS[name]
+
+        def __setstate__(self, state, _slots=slots):           # genpy.Message.__setstate__: slot values in order
+            for k, v in zip(_slots, state):
+                setattr(self, k, v)
+
+        _STUBS[name] = type(name, (object,), {"__setstate__": __setstate__, "_slots": slots})
+    return _STUBS[name]
+
+
+def _reference_unpickler(f):
+    import pickle
+
+    class U(pickle.Unpickler):
+        def find_class(self, module, name):
+            if module.split("._")[0] in _MSG_MODULES and name in _MSG_SLOTS:
+                return _stub(name)
+            if (module, name) in (("copy_reg", "_reconstructor"), ("copyreg", "_reconstructor")):
+                import copyreg
+                return copyreg._reconstructor
+            if (module, name) in (("__builtin__", "object"), ("builtins", "object")):
+                return object
+            raise pickle.UnpicklingError(f"{module}.{name} is not part of a reference scene pickle")
+
+    return U(f, encoding="latin1")
+
+
+def from_reference_pickle(path: str, start=(0.0, 0.0, 0.0, 10.0), dt: float = 0.1) -> SceneFile:
+    """The reference's reference.pickle -> a one-scene SceneFile (save() then gives the .cqs that
+    include/cilqr/scene_file.hpp and the DP planner read).  `start` defaults to the state PlanningNode hard-codes
+    (x = y = theta = 0, v = 10: algorithm/planning_node.cc:24-30); the scene carries no coarse trajectory (K = 0):
+    that is what cilqr_dp_plan produces from it."""
+    with open(path, "rb") as f:
+        ref = _reference_unpickler(f).load()
+    if not isinstance(ref, dict) or "center" not in ref:
+        raise ValueError("not a reference scene pickle: no 'center'")
+    center = np.array([[getattr(p, k) for k in _MSG_SLOTS["CenterLinePoint"]] for p in ref["center"].points], dtype=np.float64)
+    static = []
+    if ref.get("static") is not None:
+        for poly in ref["static"].obstacles:                     # Obstacles.msg: geometry_msgs/Polygon[], world frame
+            static.append(np.array([[q.x, q.y] for q in poly.points], dtype=np.float64))
+    dynamic = []
+    if ref.get("dynamic") is not None:
+        for ob in ref["dynamic"].obstacles:
+            poly = np.array([[q.x, q.y] for q in ob.polygon.points], dtype=np.float64)      # body frame
+            traj = np.array([[t.time, t.x, t.y, t.theta] for t in ob.trajectory], dtype=np.float64).reshape(-1, 4)
+            dynamic.append(DynamicObstacle(poly, traj))
+    return SceneFile(float(dt), center, [Scene(np.asarray(start, dtype=np.float64), np.zeros((0, 6)), static, dynamic)])

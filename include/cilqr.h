@@ -227,12 +227,16 @@ int cilqr_stage_nearest_lane(cilqr_handle h, int32_t n, const double* xy, int32_
 
 /* ---- corridor producer: the inputs of cilqr_problem_batch from obstacle points ---- */
 
-/* CorridorConfig, algorithm/params/planner_config.h:75-86 (is_multiple_sample = false only) */
+/* CorridorConfig, algorithm/params/planner_config.h:75-86 */
 typedef struct cilqr_corridor_config {
   double max_diff_x, max_diff_y;   /* obstacle points farther than this from the knot are ignored */
   double radius;                   /* sphere-flip radius */
   double max_axis_x, max_axis_y;   /* half extents of the box added around every knot */
   double lane_segment_length;      /* LaneBoundarySample spacing */
+  int32_t is_multiple_sample;      /* 0: both ends of every box edge (8 points); 1: six samples per box edge (24
+                                      points, corridor.cc:110-118) -- the caller then passes the obstacles' sample
+                                      points (Polygon2d::sample_points, polygon2d.cpp:259-271) instead of their corners */
+  int32_t reserved0;
 } cilqr_corridor_config;
 void cilqr_default_corridor_config(cilqr_corridor_config* cfg);
 
@@ -247,7 +251,8 @@ void cilqr_default_corridor_config(cilqr_corridor_config* cfg);
  *   corridor_count [batch][n_knots]                 cilqr_problem_batch::corridor / corridor_count
  * A knot whose corridor cannot be built gets a negative count (-2: fewer than 4 usable points,
  * -3: more than cmax half-planes, -4: degenerate hull) and is counted in *n_failed; the reference
- * fails the whole Plan in that case (cc:78-81).  max_points <= 88.  `memory` applies to all arrays.
+ * fails the whole Plan in that case (cc:78-81).  max_points + 8 (24 with is_multiple_sample) <= 320.  `memory`
+ * applies to all arrays.
  *   polygons       [batch][n_knots][cmax][2]        optional out (NULL to skip): the vertices of each
  *                                                   corridor polygon (`convex_polygons`, cc:244-249),
  *                                                   vertex i being the start of half-plane i */

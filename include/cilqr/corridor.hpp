@@ -30,8 +30,8 @@
 //     built, or a lane barrier with fewer than two sampled points (corridor.cc:24-53, 78-81).
 //   * points_for_corridors() keeps the per-knot point lists INCLUDING the eight box points that
 //     AddCorridorPoints appends (cc:76-77).
-//   * is_multiple_sample = true (five samples per box edge and per obstacle edge) is not
-//     implemented by the kernel: Plan returns false for it.
+//   * is_multiple_sample = true: the environment is asked for the obstacles' sample points and the box gets
+//     six samples per edge (cc:110-118), as in the reference; up to 296 obstacle points per knot.
 //   * cv::convexHull is replaced by the library's own float32 hull: the SET of half-planes of a
 //     knot is the reference's wherever no three points are collinear to float32 rounding; their
 //     ORDER may start at a different vertex.
@@ -98,7 +98,6 @@ class CorridorT {
     points_for_corridors_.clear();
     corridor_constraints->clear();
     convex_polygons->clear();
-    if (config_.is_multiple_sample) return false;
     std::vector<Vec2d> static_pts;
     env_->QueryStaticObstaclesPoints(&static_pts, config_.is_multiple_sample);              // cc:66-68
     const auto& pts = trajectory.trajectory();
@@ -126,6 +125,8 @@ class CorridorT {
     cc.max_diff_x = config_.max_diff_x; cc.max_diff_y = config_.max_diff_y; cc.radius = config_.radius;
     cc.max_axis_x = config_.max_axis_x; cc.max_axis_y = config_.max_axis_y;
     cc.lane_segment_length = config_.lane_segment_length;
+    cc.is_multiple_sample = config_.is_multiple_sample ? 1 : 0;
+    cc.reserved0 = 0;
     std::vector<double> cor((size_t)K * kMaxPlanes * 3), poly((size_t)K * kMaxPlanes * 2);
     std::vector<int32_t> ccount(K);
     int32_t failed = 0;
@@ -157,10 +158,12 @@ class CorridorT {
     const double dx2 = sh * config_.max_axis_y, dy2 = -ch * config_.max_axis_y;
     const double cx[4] = {x + dx1 + dx2, x + dx1 - dx2, x - dx1 - dx2, x - dx1 + dx2};
     const double cy[4] = {y + dy1 + dy2, y + dy1 - dy2, y - dy1 - dy2, y - dy1 + dy2};
+    const double kSampleMultiple = config_.is_multiple_sample ? 5.0 : 1.0;              // cc:110-118
+    const double ratio_step = 1.0 / kSampleMultiple;
     for (int i = 0; i < 4; ++i) {
       const int n = (i + 1) % 4;
-      points->push_back(Vec2d(cx[i], cy[i]));
-      points->push_back(Vec2d(cx[n], cy[n]));
+      for (double ratio = 0.0; ratio < 1.0 + 1e-10; ratio += ratio_step)
+        points->push_back(Vec2d(cx[i] * (1 - ratio) + cx[n] * ratio, cy[i] * (1 - ratio) + cy[n] * ratio));
     }
   }
 

@@ -77,7 +77,9 @@ extern "C" {
 
 // cfg: max_diff_x, max_diff_y, radius, max_axis_x, max_axis_y   (planner_config.h:75-86)
 // pts: n obstacle points (x, y) valid at this knot's time (Environment::Query*ObstaclesPoints).
-// Appends the 8 box points (AddCorridorPoints, is_multiple_sample = false) and builds the corridor.
+// Appends the box points (AddCorridorPoints: both ends of every edge, or six samples per edge when cfg[5] =
+// is_multiple_sample is set) and builds the corridor.  cfg = max_diff_x, max_diff_y, radius, max_axis_x, max_axis_y,
+// is_multiple_sample.
 // Outputs: cons[.][3] = (a, b, c) with a x + b y <= c; poly[.][2] the polygon vertices.
 // Returns the number of half-planes, or -1 (no points), -2 (fewer than 4 flipped points), -3 (more
 // than max_out half-planes), -4 (degenerate hull).
@@ -96,7 +98,8 @@ int oracle_build_corridor(double ox, double oy, double theta, const double* pts,
     const double dx2 = sh * max_axis_y, dy2 = -ch * max_axis_y;
     const double cx[4] = {ox + dx1 + dx2, ox + dx1 - dx2, ox - dx1 - dx2, ox - dx1 + dx2};
     const double cy[4] = {oy + dy1 + dy2, oy + dy1 - dy2, oy - dy1 - dy2, oy - dy1 + dy2};
-    const double ratio_step = 1.0 / 1.0;
+    const double kSampleMultiple = (cfg[5] != 0.0) ? 5.0 : 1.0;   // cc:110, is_multiple_sample
+    const double ratio_step = 1.0 / kSampleMultiple;
     for (int i = 0; i < 4; ++i) {
       const int nx = (i + 1) % 4;
       for (double ratio = 0.0; ratio < 1.0 + kMathEpsilon; ratio += ratio_step) {

@@ -146,6 +146,70 @@ def test_build_corridors_matches_oracle(built, family, B, seed):
     opt.close()
 
 
+def test_sample_points_of_a_polygon():
+    """Polygon2d::sample_points: six samples per edge, both end points included (so every corner appears twice),
+    counter-clockwise edge order whatever the input orientation."""
+    from cilqr_amd import scene_io
+    sq = np.array([[0.0, 0.0], [2.0, 0.0], [2.0, 1.0], [0.0, 1.0]])
+    a, b = scene_io.sample_points(sq), scene_io.sample_points(sq[::-1])
+    assert a.shape == (24, 2) and np.array_equal(a[0], sq[0]) and np.array_equal(a[5], sq[1]) and np.array_equal(a[6], sq[1])
+    assert np.allclose(a[1], [0.4, 0.0]) and np.allclose(a[3], [1.2000000000000002, 0.0])
+    assert sorted(map(tuple, np.round(a, 12))) == sorted(map(tuple, np.round(b, 12)))
+    # the oracle's box with is_multiple_sample: 24 box points, same corridor as the 8-point box without obstacles
+    c8, _ = orc.build_corridor(3.0, -2.0, 0.4, np.zeros((0, 2)))
+    c24, _ = orc.build_corridor(3.0, -2.0, 0.4, np.zeros((0, 2)), cfg=(25.0, 25.0, 150.0, 10.0, 10.0, 1.0))
+    assert len(c8) == len(c24) == 4
+
+
+@pytest.mark.gpu
+def test_build_corridors_with_multiple_sample_points(built):
+    """is_multiple_sample = true (CorridorConfig, planner_config.h:76): six samples per obstacle edge
+    (Environment::Query*ObstaclesPoints with the flag, environment.cpp:153-182) and per box edge (corridor.cc:110-118);
+    up to ~290 points per knot, the wide instantiation of the kernel, against the oracle knot by knot."""
+    from cilqr_amd import scene_io
+    sc = scenario.generate("mix11", 6, seed=47, scenarios=True)
+    sf = scene_io.from_generator(sc)
+    B, K = 6, sc["n_steps"] + 1
+    t = np.arange(K) * sc["dt"]
+    per = [scene_io.environment_points(sf.scenes[b], t, multiple_sample=True) for b in range(B)]
+    P = max(p[0].shape[1] for p in per)
+    pts = np.zeros((B, K, P, 2))
+    cnt = np.zeros((B, K), np.int32)
+    for b, (p, c) in enumerate(per):
+        pts[b, :, :p.shape[1]] = p
+        cnt[b] = c
+    assert P > 96 and cnt.max() > 96
+    opt = _opt(sc)
+    cfg = api.default_corridor_config()
+    cfg.is_multiple_sample = 1
+    knots = sc["coarse"][:, :, :3]
+    cor, ccnt, nf = opt.build_corridors(knots, pts, cnt, cmax=32, cfg=cfg)
+    assert nf == 0 and (ccnt >= 3).all()
+    ocfg = (25.0, 25.0, 150.0, 10.0, 10.0, 1.0)
+    same = 0
+    worst = 0.0
+    for b in range(B):
+        for k in range(K):
+            cons, _ = orc.build_corridor(*knots[b, k], pts[b, k, :cnt[b, k]], cfg=ocfg, max_out=32)
+            m = ccnt[b, k]
+            _check_corridor(cor[b, k, :m], knots[b, k, 0], knots[b, k, 1], pts[b, k, :cnt[b, k]])
+            if len(cons) == m:
+                same += 1
+                scale = np.abs(cons).max(axis=1, keepdims=True)
+                worst = max(worst, float((np.abs(cor[b, k, :m] - cons) / scale).max()))
+    assert same >= 0.99 * B * K and worst < 1e-5, (same, worst)
+    # and the corridors are no larger than the ones from the corners alone (more points can only cut more)
+    cfg0 = api.default_corridor_config()
+    p0 = [scene_io.environment_points(sf.scenes[b], t) for b in range(B)]
+    P0 = max(p[0].shape[1] for p in p0)
+    pts0 = np.zeros((B, K, P0, 2)); cnt0 = np.zeros((B, K), np.int32)
+    for b, (p, c) in enumerate(p0):
+        pts0[b, :, :p.shape[1]] = p; cnt0[b] = c
+    cor0, ccnt0, nf0 = opt.build_corridors(knots, pts0, cnt0, cmax=32, cfg=cfg0)
+    assert nf0 == 0
+    opt.close()
+
+
 @pytest.mark.gpu
 def test_build_corridors_failure_codes_and_arguments(built):
     sc = scenario.generate("ped6", 4, seed=43, obstacle_points=True)
@@ -171,7 +235,7 @@ def test_build_corridors_failure_codes_and_arguments(built):
                                    api.MEM_HOST)[0] == api.ERR_NULL
     assert opt.build_corridors_raw(c, 0, 51, k.ctypes.data, None, i32.ctypes.data, 0, out.ctypes.data,
                                    i32.ctypes.data, 16, api.MEM_HOST)[0] == api.ERR_ARG      # empty trajectory cc:24-27
-    assert opt.build_corridors_raw(c, 4, 51, k.ctypes.data, k.ctypes.data, i32.ctypes.data, 89, out.ctypes.data,
+    assert opt.build_corridors_raw(c, 4, 51, k.ctypes.data, k.ctypes.data, i32.ctypes.data, 313, out.ctypes.data,
                                    i32.ctypes.data, 16, api.MEM_HOST)[0] == api.ERR_CAPACITY
     opt.close()
 

@@ -1,10 +1,14 @@
 """Scene wire format (cilqr_amd/scene_io.py): round trip, and the restated Environment
 queries against what the generator computes directly."""
+import os
+
 import numpy as np
 import pytest
 
 from cilqr_amd import api, scenario, scene_io
 from oracle import oracle as orc
+
+HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def _scene_file(B=6, seed=61, family="mix11"):
@@ -162,3 +166,37 @@ def test_replay_from_file_on_the_gpu(built, tmp_path):
     for k in ("traj", "cost_hist", "n_cost", "status"):
         assert np.array_equal(a[k], b[k]), k
     opt.close()
+
+
+def test_reference_pickle_import(tmp_path):
+    """scene_io.from_reference_pickle reads the reference's own scene artefact -- reference.pickle of
+    script/reference_publisher.py:232-236: {"center", "static", "dynamic"} ROS messages in a Python 2 text pickle --
+    without rospy (tests/golden/reference_scene.pickle, written by make_reference_pickle.py in that layout), converts
+    it to a .cqs that round-trips exactly, refuses pickles that name anything but those message classes, and the DP
+    coarse planner plans on it from the state the reference's node starts in."""
+    import pickle
+    from cilqr_amd import api
+    src = os.path.join(HERE, "golden", "reference_scene.pickle")
+    sf = scene_io.from_reference_pickle(src)
+    assert sf.center.shape[1] == 7 and len(sf.center) == 391 and np.all(np.diff(sf.center[:, 0]) > 0)
+    assert np.allclose(sf.center[:, 5], 2.5) and np.allclose(sf.center[:, 6], 6.0)          # reference_publisher.py:25-26
+    sc = sf.scenes[0]
+    assert len(sc.static) == 1 and len(sc.dynamic) == 8 and sc.coarse.shape == (0, 6)
+    assert np.array_equal(sc.start, [0.0, 0.0, 0.0, 10.0])                                   # planning_node.cc:24-30
+    assert all(p.shape == (4, 2) for p in sc.static) and all(d.polygon.shape == (4, 2) for d in sc.dynamic)
+    assert all(d.trajectory.shape[1] == 4 and np.all(np.diff(d.trajectory[:, 0]) > 0) for d in sc.dynamic)
+    # Point32 coordinates are float32 in the message: they arrive as such
+    assert all(np.array_equal(p, p.astype(np.float32).astype(np.float64)) for p in sc.static)
+    path = tmp_path / "ref.cqs"
+    scene_io.save(str(path), sf)
+    back = scene_io.load(str(path))
+    assert np.array_equal(back.center, sf.center) and len(back.scenes) == 1
+    assert all(np.array_equal(a, b) for a, b in zip(back.scenes[0].static, sc.static))
+    assert all(np.array_equal(a.trajectory, b.trajectory) and np.array_equal(a.polygon, b.polygon)
+               for a, b in zip(back.scenes[0].dynamic, sc.dynamic))
+    ok, coarse = api.dp_plan(scene_io.flatten_scene(sf.center, sc), sc.start[:3])
+    assert ok and coarse.shape == (81, 9) and np.isfinite(coarse).all() and coarse[-1, 1] > 40.0
+    evil = tmp_path / "evil.pickle"
+    evil.write_bytes(b"cos\nsystem\n(S'true'\ntR.")
+    with pytest.raises(pickle.UnpicklingError):
+        scene_io.from_reference_pickle(str(evil))
