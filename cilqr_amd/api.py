@@ -54,6 +54,8 @@ class ProblemBatch(C.Structure):
         ("start", C.c_void_p), ("coarse", C.c_void_p), ("corridor", C.c_void_p),
         ("corridor_count", C.c_void_p), ("n_left", C.c_int32), ("n_right", C.c_int32),
         ("left_lane", C.c_void_p), ("right_lane", C.c_void_p),
+        ("n_lane_groups", C.c_int32), ("reserved1", C.c_int32), ("lane_group_start", C.c_void_p),
+        ("lane_group_left", C.c_void_p), ("lane_group_right", C.c_void_p),
     ]
 
 
@@ -297,6 +299,17 @@ class BatchIlqrOptimizer:
                             a["left"].shape[0], a["right"].shape[0],
                             _ptr(a["left"]) if a["left"].size else None,
                             _ptr(a["right"]) if a["right"].size else None)
+        groups = scene.get("lane_groups")
+        if groups is not None:
+            # per-problem lane tables: [(first problem, left rows, right rows), ...]; scene["left"] / ["right"] hold the
+            # groups' tables back to back
+            a["g_start"] = np.asarray([g[0] for g in groups] + [B], dtype=np.int32)
+            a["g_left"] = np.asarray([g[1] for g in groups], dtype=np.int32)
+            a["g_right"] = np.asarray([g[2] for g in groups], dtype=np.int32)
+            prob.n_lane_groups = len(groups)
+            prob.lane_group_start = a["g_start"].ctypes.data
+            prob.lane_group_left = a["g_left"].ctypes.data
+            prob.lane_group_right = a["g_right"].ctypes.data
         return prob, a
 
     def plan(self, scene: dict, max_iter_trajs: int = 0, check: bool = True, alpha_trace: bool = False):

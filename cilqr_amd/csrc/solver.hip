@@ -79,6 +79,7 @@ void fill_params(const cilqr_config& c, Params* p) {
 int check_problem(const cilqr_solver* h, const cilqr_problem_batch* in) {
   if (in == nullptr) return CILQR_ERR_NULL;
   if (in->batch <= 0) return CILQR_ERR_ARG;
+  if (in->n_lane_groups > 1) return CILQR_ERR_ARG;   // grouped lane tables: cilqr_solve_batch only (one table per load)
   if (in->corridor == nullptr || in->corridor_count == nullptr || in->left_lane == nullptr ||
       in->right_lane == nullptr || in->n_left <= 0 || in->n_right <= 0 || in->cmax <= 0)
     return CILQR_ERR_CONSTRAINTS;                                 // cc:68-73
@@ -417,7 +418,62 @@ int64_t cilqr_device_bytes(cilqr_handle h) {
   return h->bytes + (int64_t)h->in_stage_bytes + (int64_t)h->out_stage_bytes;
 }
 
+static int solve_core(cilqr_handle h, const cilqr_problem_batch* in, cilqr_solution_batch* out);
+
 int cilqr_solve_batch(cilqr_handle h, const cilqr_problem_batch* in, cilqr_solution_batch* out) {
+  if (h == nullptr || out == nullptr) return CILQR_ERR_NULL;
+  if (in == nullptr || in->n_lane_groups <= 1) return solve_core(h, in, out);
+  // problems grouped by lane table: one solve per group on contiguous sub-ranges of every array
+  if (in->lane_group_start == nullptr || in->lane_group_left == nullptr || in->lane_group_right == nullptr ||
+      in->left_lane == nullptr || in->right_lane == nullptr)
+    return CILQR_ERR_CONSTRAINTS;
+  if (in->lane_group_start[0] != 0 || in->lane_group_start[in->n_lane_groups] != in->batch) return CILQR_ERR_ARG;
+  const size_t K = (size_t)in->n_knots, M1 = (size_t)h->cfg.max_iter + 1;
+  size_t lrow = 0, rrow = 0;
+  cilqr_profile acc;
+  std::memset(&acc, 0, sizeof(acc));
+  for (int g = 0; g < in->n_lane_groups; ++g) {
+    const int b0 = in->lane_group_start[g], b1 = in->lane_group_start[g + 1];
+    if (b1 < b0 || in->lane_group_left[g] <= 0 || in->lane_group_right[g] <= 0) return CILQR_ERR_ARG;
+    if (b1 > b0) {
+      cilqr_problem_batch pi = *in;
+      pi.n_lane_groups = 0;
+      pi.batch = b1 - b0;
+      pi.start = in->start ? in->start + (size_t)b0 * 4 : nullptr;
+      pi.coarse = in->coarse ? in->coarse + (size_t)b0 * K * 6 : nullptr;
+      pi.corridor = in->corridor ? in->corridor + (size_t)b0 * K * in->cmax * 3 : nullptr;
+      pi.corridor_count = in->corridor_count ? in->corridor_count + (size_t)b0 * K : nullptr;
+      pi.n_left = in->lane_group_left[g];
+      pi.n_right = in->lane_group_right[g];
+      pi.left_lane = in->left_lane + lrow * CILQR_LANE_FIELDS;
+      pi.right_lane = in->right_lane + rrow * CILQR_LANE_FIELDS;
+      cilqr_solution_batch po = *out;
+      po.traj = out->traj ? out->traj + (size_t)b0 * K * CILQR_TRAJ_FIELDS : nullptr;
+      po.cost_hist = out->cost_hist ? out->cost_hist + (size_t)b0 * M1 * CILQR_COST_FIELDS : nullptr;
+      po.n_cost = out->n_cost ? out->n_cost + b0 : nullptr;
+      po.status = out->status ? out->status + b0 : nullptr;
+      po.n_iter = out->n_iter ? out->n_iter + b0 : nullptr;
+      po.iter_trajs = out->iter_trajs ? out->iter_trajs + (size_t)b0 * out->max_iter_trajs * K * CILQR_TRAJ_FIELDS : nullptr;
+      po.n_iter_trajs = out->n_iter_trajs ? out->n_iter_trajs + b0 : nullptr;
+      po.alpha_trace = out->alpha_trace ? out->alpha_trace + (size_t)b0 * h->cfg.max_iter : nullptr;
+      const int rc = solve_core(h, &pi, &po);
+      if (rc != CILQR_OK) return rc;
+      acc.iterations += h->prof.iterations;
+      acc.backward_launches += h->prof.backward_launches;
+      acc.backward_ms += h->prof.backward_ms; acc.quadratize_ms += h->prof.quadratize_ms;
+      acc.linesearch_ms += h->prof.linesearch_ms; acc.other_ms += h->prof.other_ms; acc.total_ms += h->prof.total_ms;
+      acc.backward_problem_steps += h->prof.backward_problem_steps;
+      acc.backward_full_launches += h->prof.backward_full_launches;
+      acc.backward_full_ms += h->prof.backward_full_ms;
+    }
+    lrow += (size_t)in->lane_group_left[g];
+    rrow += (size_t)in->lane_group_right[g];
+  }
+  h->prof = acc;
+  return CILQR_OK;
+}
+
+static int solve_core(cilqr_handle h, const cilqr_problem_batch* in, cilqr_solution_batch* out) {
   if (h == nullptr || out == nullptr) return CILQR_ERR_NULL;
   if (out->traj == nullptr || out->cost_hist == nullptr || out->n_cost == nullptr || out->status == nullptr)
     return CILQR_ERR_NULL;                                                     // cc:64-66

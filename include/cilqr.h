@@ -105,6 +105,16 @@ typedef struct cilqr_problem_batch {
   int32_t n_left, n_right;       /* lane segments, shared by the whole batch */
   const double* left_lane;       /* [n_left][7]  HOST memory */
   const double* right_lane;      /* [n_right][7] HOST memory */
+  /* Per-problem lane tables (every Plan call of the reference carries its own lane constraints,
+   * ilqr_optimizer.h:41-48).  n_lane_groups = 0 or 1: the one table above serves the whole batch.  Otherwise the
+   * problems come grouped by table: group g is problems [lane_group_start[g], lane_group_start[g + 1]) and uses the
+   * next lane_group_left[g] rows of left_lane and lane_group_right[g] rows of right_lane (the tables lie back to
+   * back; n_left / n_right are then ignored).  The groups are solved one after the other on the handle. */
+  int32_t n_lane_groups;
+  int32_t reserved1;
+  const int32_t* lane_group_start;   /* [n_lane_groups + 1], HOST memory, lane_group_start[0] = 0, last = batch */
+  const int32_t* lane_group_left;    /* [n_lane_groups] rows */
+  const int32_t* lane_group_right;   /* [n_lane_groups] rows */
 } cilqr_problem_batch;
 
 /* Outputs of Plan + cost().  iter_trajs is optional (NULL to skip). */

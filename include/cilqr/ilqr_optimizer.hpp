@@ -161,6 +161,11 @@ class IlqrOptimizerT {
     in.n_right = static_cast<int32_t>(right_lane_cons.size());
     in.left_lane = left.data();
     in.right_lane = right.data();
+    in.n_lane_groups = 0;
+    in.reserved1 = 0;
+    in.lane_group_start = nullptr;
+    in.lane_group_left = nullptr;
+    in.lane_group_right = nullptr;
 
     const int max_it = cfg_.max_iter + 1;
     std::vector<double> traj(static_cast<size_t>(K) * CILQR_TRAJ_FIELDS);

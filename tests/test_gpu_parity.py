@@ -381,6 +381,39 @@ def test_device_memory_interface_and_stream():
     opt.close()
 
 
+def test_per_problem_lane_tables_as_groups():
+    """Every Plan call of the reference carries its own lane constraints (ilqr_optimizer.h:41-48); a batch carries them
+    as groups of problems that share a table (cilqr_problem_batch::n_lane_groups).  Two tables over the same road
+    (boundaries sampled every 5 m and every 7 m -- different segments, different planes): the grouped solve equals
+    the two separate solves bit for bit, each group matches the oracle run with ITS table, and the tables do differ."""
+    sc = scenario.generate("mix11", 60, seed=170)
+    road = scenario.build_road()
+    left7, right7 = scenario.lane_constraints(road, seg_len=7.0)
+    n0 = 25
+    part = lambda lo, hi, l, r: dict(sc, **{k: sc[k][lo:hi] for k in ("start", "coarse", "corridor", "ccount")}, left=l, right=r)
+    a, b = part(0, n0, sc["left"], sc["right"]), part(n0, 60, left7, right7)
+    grouped = dict(sc, left=np.concatenate([sc["left"], left7]), right=np.concatenate([sc["right"], right7]),
+                   lane_groups=[(0, len(sc["left"]), len(sc["right"])), (n0, len(left7), len(right7))])
+    opt = _opt(sc, B=60)
+    opt.close()
+    opt = api.BatchIlqrOptimizer(api.default_config(sc["n_steps"]), batch_capacity=60, cmax=sc["cmax"], max_lane_segments=128)
+    g = _plan(opt, grouped)
+    ga, gb = _plan(opt, a), _plan(opt, b)
+    for k in ("traj", "cost_hist", "n_cost", "status", "n_iter", "alpha_trace", "iter_trajs"):
+        assert np.array_equal(g[k][:n0], ga[k]) and np.array_equal(g[k][n0:], gb[k]), k
+    ocfg = oracle_cfg_from(opt.cfg)
+    for sub_, res in ((a, ga), (b, gb)):
+        ref = oracle_reference(sub_, ocfg)
+        assert_parity(res, ref, max_unstable_frac=0.15, what="lane groups")
+        assert_steps(res, sub_, ocfg, what="lane groups")
+    shared = _plan(opt, part(n0, 60, sc["left"], sc["right"]))
+    assert not np.array_equal(shared["traj"], gb["traj"])            # the second table is a different constraint set
+    # the stage API works on one table
+    prob, keep = opt._host_problem(grouped)
+    assert opt.L.cilqr_stage_load(opt.h, C.byref(prob)) == api.ERR_ARG
+    opt.close()
+
+
 def test_gather_results_through_the_c_abi_single_rank():
     """cilqr_comm_* / cilqr_gather_results (librccl loaded with dlopen, no PyTorch involved in the exchange) with a
     one-rank communicator -- all a 1-GPU box can hold: RCCL initialises, the results are packed (8 trajectory
