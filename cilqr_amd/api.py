@@ -36,7 +36,7 @@ DENSE_DOUBLES_TERMINAL = 44
 class Config(C.Structure):
     _fields_ = [
         ("n_steps", C.c_int32), ("num_of_disc", C.c_int32), ("max_iter", C.c_int32),
-        ("reserved0", C.c_int32), ("dt", C.c_double), ("safe_margin", C.c_double),
+        ("init_guess", C.c_int32), ("dt", C.c_double), ("safe_margin", C.c_double),
         ("w_jerk", C.c_double), ("w_delta_rate", C.c_double), ("w_x", C.c_double),
         ("w_y", C.c_double), ("w_theta", C.c_double), ("w_v", C.c_double), ("w_a", C.c_double),
         ("w_delta", C.c_double), ("abs_cost_tol", C.c_double), ("rel_cost_tol", C.c_double),
@@ -55,7 +55,7 @@ class ProblemBatch(C.Structure):
         ("corridor_count", C.c_void_p), ("n_left", C.c_int32), ("n_right", C.c_int32),
         ("left_lane", C.c_void_p), ("right_lane", C.c_void_p),
         ("n_lane_groups", C.c_int32), ("reserved1", C.c_int32), ("lane_group_start", C.c_void_p),
-        ("lane_group_left", C.c_void_p), ("lane_group_right", C.c_void_p),
+        ("lane_group_left", C.c_void_p), ("lane_group_right", C.c_void_p), ("coarse_station", C.c_void_p),
     ]
 
 
@@ -93,6 +93,16 @@ class SceneStruct(C.Structure):
 COARSE_FIELDS = 9   # time, s, x, y, theta, kappa, velocity, a, delta
 
 
+class TrackerConfig(C.Structure):
+    """TrackerConfig of the reference (algorithm/params/planner_config.h:18-43) for init_guess = INIT_TRACKER."""
+    _fields_ = [(n, C.c_double) for n in ("weight_l", "weight_theta", "weight_delta", "weight_delta_rate", "preview_time",
+                                          "weight_s", "weight_v", "weight_a", "weight_j", "sumulation_dt", "dt", "tolerance")] + \
+               [("max_num_iteration", C.c_int32), ("reserved0", C.c_int32)]
+
+
+INIT_IQR, INIT_TRACKER = 0, 1
+
+
 class Profile(C.Structure):
     _fields_ = [
         ("iterations", C.c_int32), ("backward_launches", C.c_int32), ("backward_ms", C.c_double),
@@ -109,7 +119,8 @@ EXPORTS = [
     "cilqr_stage_total_cost", "cilqr_stage_quadratize", "cilqr_stage_backward", "cilqr_stage_forward",
     "cilqr_stage_read", "cilqr_stage_nearest_lane", "cilqr_open_loop_rollout", "cilqr_error_string",
     "cilqr_default_corridor_config", "cilqr_build_corridors", "cilqr_lane_constraints",
-    "cilqr_default_dp_config", "cilqr_dp_plan", "cilqr_road_barriers",
+    "cilqr_default_dp_config", "cilqr_dp_plan", "cilqr_road_barriers", "cilqr_default_tracker_config",
+    "cilqr_set_tracker_config",
     "cilqr_comm_unique_id", "cilqr_comm_create", "cilqr_comm_destroy", "cilqr_comm_info", "cilqr_gather_results",
 ]
 UNIQUE_ID_BYTES = 128
@@ -167,6 +178,9 @@ def lib():
         L.cilqr_default_dp_config.argtypes = [C.POINTER(DpConfig)]
         L.cilqr_default_dp_config.restype = None
         L.cilqr_dp_plan.argtypes = [C.POINTER(DpConfig), C.POINTER(SceneStruct), C.c_void_p, C.c_void_p, C.c_int32]
+        L.cilqr_default_tracker_config.argtypes = [C.POINTER(TrackerConfig)]
+        L.cilqr_default_tracker_config.restype = None
+        L.cilqr_set_tracker_config.argtypes = [C.c_void_p, C.POINTER(TrackerConfig)]
         L.cilqr_road_barriers.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]
         L.cilqr_comm_unique_id.argtypes = [C.c_void_p]
         L.cilqr_comm_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
@@ -243,6 +257,14 @@ class BatchIlqrOptimizer:
         if rc != OK:
             raise CilqrError(rc, "in cilqr_set_option")
 
+    def set_tracker_config(self, **over):
+        """Override fields of the tracker init guess's configuration (reference defaults otherwise)."""
+        c = TrackerConfig()
+        self.L.cilqr_default_tracker_config(C.byref(c))
+        for k, v in over.items():
+            setattr(c, k, v)
+        self._chk(self.L.cilqr_set_tracker_config(self.h, C.byref(c)), "set_tracker_config")
+
     def set_profiling(self, on):
         """False / 0: off; True / 1: every phase of every iteration; 2: the backward launches only."""
         self.L.cilqr_set_profiling(self.h, int(on))
@@ -299,6 +321,9 @@ class BatchIlqrOptimizer:
                             a["left"].shape[0], a["right"].shape[0],
                             _ptr(a["left"]) if a["left"].size else None,
                             _ptr(a["right"]) if a["right"].size else None)
+        if scene.get("coarse_station") is not None:      # stations of the coarse points (tracker init guess)
+            a["station"] = _f64(scene["coarse_station"])
+            prob.coarse_station = a["station"].ctypes.data
         groups = scene.get("lane_groups")
         if groups is not None:
             # per-problem lane tables: [(first problem, left rows, right rows), ...]; scene["left"] / ["right"] hold the

@@ -82,11 +82,15 @@ __global__ __launch_bounds__(256) void k_load_goals(DeviceState s, int B, Proble
     s.pid[slot] = slot;
     s.done_now[slot] = 0;
     s.act[slot] = slot;
+    const double* c = in.coarse + (size_t)slot * K * 6;   // the tracker init guess follows the coarse trajectory itself
+    s.coarse0[slot] = make_double2(c[0], c[1]);
+    s.coarse0[(size_t)s.Bcap + slot] = make_double2(c[2], c[3]);
   } else {
     const double* c = in.coarse + ((size_t)slot * K + i) * 6;
 #pragma unroll
     for (int e = 0; e < 6; ++e) g[e] = c[e];
   }
+  if (in.station != nullptr) s.cstation[(size_t)i * s.Bcap + slot] = in.station[(size_t)slot * K + i];
   double2* o = s.goals + (size_t)i * 3 * s.Bcap + slot;
   o[0] = make_double2(g[0], g[1]);
   o[(size_t)s.Bcap] = make_double2(g[2], g[3]);

@@ -101,8 +101,11 @@ int do_load(cilqr_solver* h, const cilqr_problem_batch* in) {
   pv.cmax_in = in->cmax;
   const size_t n_start = (size_t)B * 4, n_coarse = (size_t)B * K * 6,
                n_cor = (size_t)B * K * in->cmax * 3, n_cnt = (size_t)B * K;
+  const bool want_station = h->cfg.init_guess == CILQR_INIT_TRACKER && in->coarse_station != nullptr;
+  const size_t n_sta = want_station ? (size_t)B * K : 0;
+  pv.station = nullptr;
   if (in->memory == CILQR_MEM_HOST) {
-    const size_t bytes = (n_start + n_coarse + n_cor) * sizeof(double) + n_cnt * sizeof(int) + 1024;
+    const size_t bytes = (n_start + n_coarse + n_cor + n_sta) * sizeof(double) + n_cnt * sizeof(int) + 1024;
     const int g = grow(&h->in_stage, &h->in_stage_bytes, bytes);
     if (g != CILQR_OK) return g;
     double* d = static_cast<double*>(h->in_stage);
@@ -112,12 +115,18 @@ int do_load(cilqr_solver* h, const cilqr_problem_batch* in) {
     pv.coarse = d; d += n_coarse;
     HIP_TRY(hipMemcpyAsync(d, in->corridor, n_cor * 8, hipMemcpyHostToDevice, h->stream));
     pv.corridor = d; d += n_cor;
+    if (want_station) {
+      HIP_TRY(hipMemcpyAsync(d, in->coarse_station, n_sta * 8, hipMemcpyHostToDevice, h->stream));
+      pv.station = d; d += n_sta;
+    }
     HIP_TRY(hipMemcpyAsync(d, in->corridor_count, n_cnt * 4, hipMemcpyHostToDevice, h->stream));
     pv.ccount = reinterpret_cast<const int*>(d);
   } else {
     pv.start = in->start; pv.coarse = in->coarse; pv.corridor = in->corridor;
     pv.ccount = in->corridor_count;
+    if (want_station) pv.station = in->coarse_station;
   }
+  h->tracker.have_station = want_station ? 1 : 0;
   HIP_TRY(hipMemcpyAsync(h->lanes_raw, in->left_lane, (size_t)in->n_left * 7 * 8, hipMemcpyHostToDevice,
                          h->stream));
   HIP_TRY(hipMemcpyAsync(h->lanes_raw + (size_t)in->n_left * 7, in->right_lane,
@@ -231,6 +240,7 @@ int cilqr_default_config(cilqr_config* c, int32_t n_steps) {
   c->n_steps = n_steps;
   c->num_of_disc = 5;       // planner_config.h:58
   c->max_iter = 200;        // :63
+  c->init_guess = CILQR_INIT_IQR;   // cc:168-169
   c->dt = 0.1;              // :94
   c->safe_margin = 0.2;     // :59
   c->w_jerk = 1; c->w_delta_rate = 1;               // :46-47
@@ -251,6 +261,7 @@ int cilqr_create(const cilqr_config* cfg, int32_t device, int32_t batch_capacity
                  int32_t max_lane_segments, cilqr_handle* out) {
   if (cfg == nullptr || out == nullptr) return CILQR_ERR_NULL;
   *out = nullptr;
+  if (cfg->init_guess != CILQR_INIT_IQR && cfg->init_guess != CILQR_INIT_TRACKER) return CILQR_ERR_ARG;
   if (cfg->n_steps < 1 || cfg->num_of_disc < 1 || cfg->num_of_disc > CILQR_MAX_DISCS ||
       cfg->max_iter < 1 || batch_capacity < 1 || cmax < 1 || max_lane_segments < 1 ||
       max_lane_segments > CILQR_MAX_LANE_SEGMENTS || !(cfg->dt > 0.0) || !(cfg->barrier_t > 0.0) ||
@@ -279,6 +290,11 @@ int cilqr_create(const cilqr_config* cfg, int32_t device, int32_t batch_capacity
   d.Bcap = Bc;
   d.cmax = cmax;
   fill_params(*cfg, &d.p);
+  {
+    cilqr_tracker_config tc;
+    cilqr_default_tracker_config(&tc);
+    (void)cilqr_set_tracker_config(h, &tc);
+  }
   const size_t N = cfg->n_steps, K = N + 1, B = Bc;
   int rc = CILQR_OK;
 #define ALLOC(field, count) \
@@ -287,6 +303,8 @@ int cilqr_create(const cilqr_config* cfg, int32_t device, int32_t batch_capacity
   ALLOC(U, 2 * N * B);
   ALLOC(cur, B);
   ALLOC(goals, K * 3 * B);
+  ALLOC(coarse0, 2 * B);
+  ALLOC(cstation, K * B);
   ALLOC(cor, K * cmax * 3 * B);
   ALLOC(ccnt, K * B);
   ALLOC(lanes, (size_t)2 * max_lane_segments * kLaneFields);
@@ -398,6 +416,26 @@ int cilqr_set_option(cilqr_handle h, int32_t option, int64_t value) {
     default:
       return CILQR_ERR_ARG;
   }
+}
+
+void cilqr_default_tracker_config(cilqr_tracker_config* c) {
+  if (c == nullptr) return;
+  c->weight_l = 1e-1; c->weight_theta = 1e-12; c->weight_delta = 1e-12; c->weight_delta_rate = 0.1; c->preview_time = 0.2;   // :18-25
+  c->weight_s = 5.0 * 1e-1; c->weight_v = 1e-12; c->weight_a = 1e-12; c->weight_j = 0.1;                                     // :27-34
+  c->sumulation_dt = 0.01; c->dt = 0.1; c->tolerance = 0.01; c->max_num_iteration = 150;                                    // :37-40
+  c->reserved0 = 0;
+}
+
+int cilqr_set_tracker_config(cilqr_handle h, const cilqr_tracker_config* c) {
+  if (h == nullptr || c == nullptr) return CILQR_ERR_NULL;
+  if (!(c->sumulation_dt > 0.0) || !(c->dt > 0.0) || !(c->tolerance >= 0.0) || c->max_num_iteration < 1) return CILQR_ERR_ARG;
+  TrackerParams& t = h->tracker;
+  t.weight_l = c->weight_l; t.weight_theta = c->weight_theta; t.weight_delta = c->weight_delta;
+  t.weight_delta_rate = c->weight_delta_rate; t.preview_time = c->preview_time;
+  t.weight_s = c->weight_s; t.weight_v = c->weight_v; t.weight_a = c->weight_a; t.weight_j = c->weight_j;
+  t.sim_dt = c->sumulation_dt; t.dt = c->dt; t.tolerance = c->tolerance; t.max_num_iteration = c->max_num_iteration;
+  t.have_station = 0;
+  return CILQR_OK;
 }
 
 int cilqr_set_profiling(cilqr_handle h, int32_t enable) {
@@ -522,7 +560,8 @@ static int solve_core(cilqr_handle h, const cilqr_problem_batch* in, cilqr_solut
     HIP_TRY(hipMemsetAsync(o_hist, 0, (n_hist + n_it) * 8, h->stream));
   }
 
-  launch_init_guess(d, B, st);                         // cc:169
+  if (h->cfg.init_guess == CILQR_INIT_TRACKER) launch_init_guess_tracker(d, h->tracker, B, st);   // cc:168 (InitGuess)
+  else launch_init_guess(d, B, st);                    // cc:169
   launch_cost_only(d, nullptr, B, 0, st);              // cc:172
   launch_init_cost_commit(d, B, st);                   // cc:170,173
   if (o_it) launch_export_iter_traj(d, nullptr, B, o_it, out->max_iter_trajs, st);
@@ -686,7 +725,8 @@ int cilqr_stage_init_guess(cilqr_handle h) {
   if (h == nullptr) return CILQR_ERR_NULL;
   if (!(h->stage & 1)) return CILQR_ERR_STATE;
   HIP_TRY(hipSetDevice(h->device));
-  launch_init_guess(h->ds, h->B, h->stream);
+  if (h->cfg.init_guess == CILQR_INIT_TRACKER) launch_init_guess_tracker(h->ds, h->tracker, h->B, h->stream);
+  else launch_init_guess(h->ds, h->B, h->stream);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
   h->stage = 1 | 2;

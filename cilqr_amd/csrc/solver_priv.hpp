@@ -68,4 +68,5 @@ struct cilqr_solver {
   std::vector<hipEvent_t> iter_ev;  // one per lockstep iteration (count read-back)
   cilqr_profile prof;
   cilqr_comm* comm = nullptr;   // multi-GPU results gather (cilqr_comm_create)
+  cilqr::TrackerParams tracker;   // CILQR_INIT_TRACKER
 };

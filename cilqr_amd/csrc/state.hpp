@@ -72,6 +72,15 @@ struct Params {
   double shrink_lane;          // disc_radius                 (cc:463)
 };
 
+// TrackerConfig (planner_config.h:18-43): the alternative init guess of kernels_tracker.hip
+struct TrackerParams {
+  double weight_l, weight_theta, weight_delta, weight_delta_rate, preview_time;
+  double weight_s, weight_v, weight_a, weight_j;
+  double sim_dt, dt, tolerance;
+  int max_num_iteration;
+  int have_station;   // cstation was filled from the caller's stations (else: chord length, computed by the kernel)
+};
+
 struct DeviceState {
   int Bcap;  // arena capacity (slots)
   int cmax;
@@ -82,6 +91,8 @@ struct DeviceState {
   double2* U;      // [2][N][Bcap]
   int* cur;        // [Bcap] which X/U buffer is the current iterate
   double2* goals;  // [K][3][Bcap]
+  double2* coarse0;   // [2][Bcap] (x, y) (theta, v) of the coarse trajectory's first point (goals[0] is the start state)
+  double* cstation;   // [K][Bcap] stations of the coarse trajectory (tracker init guess only)
   double* cor;     // [K][cmax][3][Bcap]
   int* ccnt;       // [K][Bcap]
   double* lanes;   // [nl+nr][kLaneFields]
@@ -154,6 +165,7 @@ constexpr int kCntTicket = 40;   // blocks of k_update that have finished
 struct ProblemView {  // device pointers to the problem-major inputs
   const double* start;
   const double* coarse;
+  const double* station;   // [B][K] or nullptr
   const double* corridor;
   const int* ccount;
   int cmax_in;
@@ -165,6 +177,7 @@ void launch_build_lane_grid(const DeviceState& s, hipStream_t st);
 void launch_nearest_lane(const DeviceState& s, int n, const double* xy, int* left, int* right, int use_grid,
                          hipStream_t st);
 void launch_init_guess(const DeviceState& s, int B, hipStream_t st);
+void launch_init_guess_tracker(const DeviceState& s, const TrackerParams& tp, int B, hipStream_t st);
 void launch_set_trajectory(const DeviceState& s, int B, const double* X, const double* U, hipStream_t st);
 // cost of buffer (cur ^ cand) for the n listed slots -> trial[], no accept logic
 void launch_cost_only(const DeviceState& s, const int* list, int n, int cand, hipStream_t st);

@@ -69,6 +69,9 @@ extern "C" {
                                     (corridor.cc:78-81, trajectory_planner.cpp:49-57).  The problem is not
                                     optimised: traj = the init guess, n_cost = 1, n_iter = 1 */
 
+#define CILQR_INIT_IQR 0
+#define CILQR_INIT_TRACKER 1
+
 #define CILQR_MEM_HOST 0
 #define CILQR_MEM_DEVICE 1
 
@@ -78,7 +81,9 @@ typedef struct cilqr_config {
   int32_t n_steps;       /* N; knots K = N+1 = floor(horizon/dt + 1)  (cc:22) */
   int32_t num_of_disc;   /* planner_config.h:58 */
   int32_t max_iter;      /* :63 */
-  int32_t reserved0;
+  int32_t init_guess;    /* CILQR_INIT_IQR (0): iqr, what the reference runs (cc:169, 793-842); CILQR_INIT_TRACKER (1):
+                            InitGuess through the closed-loop Tracker (cc:107-139, tracker.cc), the alternative the
+                            reference keeps commented out at cc:168 and recommends in README.md:61-67 */
   double dt;             /* delta_t, :94 */
   double safe_margin;    /* :59 */
   double w_jerk, w_delta_rate, w_x, w_y, w_theta, w_v, w_a, w_delta; /* Weights :45-55 */
@@ -115,6 +120,10 @@ typedef struct cilqr_problem_batch {
   const int32_t* lane_group_start;   /* [n_lane_groups + 1], HOST memory, lane_group_start[0] = 0, last = batch */
   const int32_t* lane_group_left;    /* [n_lane_groups] rows */
   const int32_t* lane_group_right;   /* [n_lane_groups] rows */
+  /* CILQR_INIT_TRACKER only: stations of the coarse trajectory's points ([B][K], same memory as `coarse`; TrajectoryPoint::s,
+   * which the tracker's projection interpolates along: discretized_trajectory.cpp:165-197).  NULL: the accumulated
+   * chord length of the coarse points is used. */
+  const double* coarse_station;
 } cilqr_problem_batch;
 
 /* Outputs of Plan + cost().  iter_trajs is optional (NULL to skip). */
@@ -185,6 +194,18 @@ int cilqr_get_profile(cilqr_handle h, cilqr_profile* out);
 int64_t cilqr_device_bytes(cilqr_handle h);
 
 int cilqr_solve_batch(cilqr_handle h, const cilqr_problem_batch* in, cilqr_solution_batch* out);
+
+/* TrackerConfig / LateralTrackerConfig / LongitudinalTrackerConfig (algorithm/params/planner_config.h:18-43) for
+ * CILQR_INIT_TRACKER; cilqr_create starts from the reference's defaults. */
+typedef struct cilqr_tracker_config {
+  double weight_l, weight_theta, weight_delta, weight_delta_rate, preview_time;   /* lateral  :18-25 */
+  double weight_s, weight_v, weight_a, weight_j;                                  /* longitudinal :27-34 */
+  double sumulation_dt, dt, tolerance;                                            /* :37-39 */
+  int32_t max_num_iteration;                                                      /* :40 */
+  int32_t reserved0;
+} cilqr_tracker_config;
+void cilqr_default_tracker_config(cilqr_tracker_config* cfg);
+int cilqr_set_tracker_config(cilqr_handle h, const cilqr_tracker_config* cfg);
 
 /* Asynchronous form of cilqr_solve_batch: submit returns at once (the structs are copied, the
  * arrays they point to must stay valid), wait blocks for the result code.  One job in flight per

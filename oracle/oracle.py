@@ -33,7 +33,7 @@ class OracleConfig(C.Structure):
 
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("cilqr_oracle.cc", "corridor_oracle.cc", "dp_oracle.cc")]
+    srcs = [os.path.join(_HERE, f) for f in ("cilqr_oracle.cc", "corridor_oracle.cc", "dp_oracle.cc", "tracker_oracle.cc")]
     if force or not os.path.exists(so) or any(
             os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so) for src in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
@@ -327,3 +327,43 @@ def dp_plan(flat: dict, start3, **over):
     if rc < 0:
         raise ValueError(rc)
     return rc == 1, coarse
+
+
+TRACKER_CFG_FIELDS = ("weight_l", "weight_theta", "weight_delta", "weight_delta_rate", "preview_time", "weight_s", "weight_v",
+                      "weight_a", "weight_j", "sumulation_dt", "dt", "tolerance", "max_num_iteration", "wheel_base",
+                      "delta_min", "delta_max", "delta_rate_min", "delta_rate_max", "jerk_min", "jerk_max",
+                      "min_acceleration", "max_acceleration")
+_D40 = 40.0 / 180 * np.pi
+TRACKER_CFG_DEFAULT = (1e-1, 1e-12, 1e-12, 0.1, 0.2, 5.0 * 1e-1, 1e-12, 1e-12, 0.1, 0.01, 0.1, 0.01, 150, 1.0,   # planner_config.h:18-43
+                       -_D40, _D40, -_D40 / 3.0, _D40 / 3.0, -10.0, 10.0, -5.0, 5.0)                              # vehicle_param.h:31-64
+
+
+def chord_stations(coarse_xy):
+    """Stations of a coarse trajectory when the caller has none: accumulated chord length of its points."""
+    d = np.hypot(np.diff(coarse_xy[:, 0]), np.diff(coarse_xy[:, 1]))
+    out = np.zeros(len(coarse_xy))
+    for i in range(1, len(out)):
+        out[i] = out[i - 1] + d[i - 1]
+    return out
+
+
+def tracker_init_guess(start4, coarse, station=None, knot_dt=0.1, **over):
+    """IlqrOptimizer::InitGuess through Tracker::Plan (oracle/tracker_oracle.cc).  coarse [K,6] = x y theta v a delta,
+    station [K] (default: chord length).  Returns (X [K,6], U [K-1,2], min_margin); raises when the tracker fails."""
+    cfg = dict(zip(TRACKER_CFG_FIELDS, TRACKER_CFG_DEFAULT))
+    cfg.update(over)
+    c = _f64([cfg[k] for k in TRACKER_CFG_FIELDS])
+    coarse = _f64(coarse)
+    K = coarse.shape[0]
+    st = _f64(chord_stations(coarse) if station is None else station)
+    s4 = _f64(start4)
+    X, U = np.zeros((K, 6)), np.zeros((K - 1, 2))
+    m = C.c_double()
+    L = lib()
+    L.oracle_tracker_init_guess.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p,
+                                            C.c_void_p, C.POINTER(C.c_double)]
+    rc = L.oracle_tracker_init_guess(c.ctypes.data, s4.ctypes.data, coarse.ctypes.data, st.ctypes.data, K, knot_dt,
+                                     X.ctypes.data, U.ctypes.data, C.byref(m))
+    if rc != 0:
+        raise ValueError("tracker failed")
+    return X, U, m.value

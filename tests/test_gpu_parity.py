@@ -414,6 +414,60 @@ def test_per_problem_lane_tables_as_groups():
     opt.close()
 
 
+def test_tracker_init_guess():
+    """CILQR_INIT_TRACKER: IlqrOptimizer::InitGuess through the closed-loop Tracker (ilqr_optimizer.cc:107-139,
+    tracker.cc) -- the alternative init guess the reference keeps commented out (cc:168) and recommends
+    (README.md:61-67).  The device's init guess against oracle/tracker_oracle.cc with the stations of the DP planner's
+    coarse trajectories and with chord-length stations, then whole solves started from it, every step replayed in the
+    oracle from the device's own iterates.  A problem is left out of the stage comparison when one of the oracle's DARE
+    loops stopped within 1e-9 (relative) of its tolerance: one iteration more or less changes the gains by ~1e-2."""
+    g = scenario.generate_dp("demo80", 24, seed=180, workers=8)
+    ok = np.nonzero(g["found"])[0]
+    assert len(ok) >= 12
+    take = lambda a: np.ascontiguousarray(a[ok])
+    B, K = len(ok), 81
+    for with_station in (True, False):
+        sc = dict(start=take(g["start"]), coarse=take(g["coarse"]), left=g["left"], right=g["right"], n_steps=80, cmax=16)
+        if with_station:
+            sc["coarse_station"] = take(g["dp"][:, :, 1])
+        # corridors for the solve: a plain box around every knot (the init guess does not read them)
+        th = sc["coarse"][:, :, 2]
+        n = np.stack([np.stack([np.cos(th), np.sin(th)], -1), np.stack([-np.cos(th), -np.sin(th)], -1),
+                      np.stack([-np.sin(th), np.cos(th)], -1), np.stack([np.sin(th), -np.cos(th)], -1)], 2)   # [B,K,4,2]
+        c = (n * sc["coarse"][:, :, None, :2]).sum(-1) + 10.0
+        sc["corridor"] = np.zeros((B, K, 16, 3))
+        sc["corridor"][:, :, :4, :2] = n
+        sc["corridor"][:, :, :4, 2] = c
+        sc["ccount"] = np.full((B, K), 4, np.int32)
+        cfg = api.default_config(80, init_guess=api.INIT_TRACKER)
+        opt = api.BatchIlqrOptimizer(cfg, batch_capacity=B, cmax=16, max_lane_segments=64)
+        opt.stage_load(sc)
+        opt.stage_init_guess()
+        X, U = opt.read(api.T_X), opt.read(api.T_U)
+        compared = 0
+        for b in range(B):
+            oX, oU, margin = orc.tracker_init_guess(sc["start"][b], sc["coarse"][b], sc.get("coarse_station", [None] * B)[b])
+            if margin < 1e-9:
+                continue
+            compared += 1
+            assert traj_err(X[b], oX) < STAGE_TOL and traj_err(U[b], oU) < STAGE_TOL, (b, with_station)
+        assert compared >= B - 2
+        # the tracker follows the coarse path far better than iqr's open-loop-ish rollout: lower initial cost
+        cost_tr = opt.stage_total_cost()[:, 0]
+        iq = api.BatchIlqrOptimizer(api.default_config(80), batch_capacity=B, cmax=16, max_lane_segments=64)
+        iq.stage_load(sc)
+        iq.stage_init_guess()
+        assert np.median(cost_tr) < np.median(iq.stage_total_cost()[:, 0])
+        iq.close()
+        res = _plan(opt, sc)
+        assert ((res["status"] >= 1) & (res["status"] <= 5)).all()
+        assert traj_err(res["iter_trajs"][:, 0, :, 1:7], X) == 0.0            # iter_trajs[0] is the init guess (cc:170)
+        assert_steps(res, sc, oracle_cfg_from(opt.cfg), what=f"tracker init guess, stations {with_station}")
+        opt.close()
+    with pytest.raises(api.CilqrError):
+        api.BatchIlqrOptimizer(api.default_config(50, init_guess=7), batch_capacity=4)
+
+
 def test_gather_results_through_the_c_abi_single_rank():
     """cilqr_comm_* / cilqr_gather_results (librccl loaded with dlopen, no PyTorch involved in the exchange) with a
     one-rank communicator -- all a 1-GPU box can hold: RCCL initialises, the results are packed (8 trajectory
