@@ -59,6 +59,10 @@ def main():
     ap.add_argument("--team-threshold", type=int, default=-1, help="CILQR_OPT_TEAM_THRESHOLD value (tuning experiments)")
     ap.add_argument("--pipeline", type=int, default=3,
                     help="batches in flight during the timed region (handles, each with its own stream and host thread); 1 = sequential")
+    ap.add_argument("--coarse", default="generator", choices=["generator", "dp"],
+                    help="where the coarse trajectories come from: the generator's smooth best-clearance pick, or the DP coarse "
+                         "planner (cilqr_dp_plan: the reference's own producer, kinked paths) with corridors built from the "
+                         "obstacle points by cilqr_build_corridors; 512 distinct scenes tiled to the batch")
     ap.add_argument("--end-to-end", action="store_true",
                     help="extra (never `value`): obstacle points -> cilqr_build_corridors -> solve on the device")
     ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "backward_traffic.json"))
@@ -101,7 +105,26 @@ def main():
     B, N, K, cmax = args.batch, spec.n_steps, spec.n_steps + 1, spec.cmax
     t0 = time.time()
     workers = max(1, min(32, (os.cpu_count() or 8) // max(1, world)))
-    sc = scenario.generate(spec, B, seed=args.seed, first_problem=rank * B, workers=workers)
+    dp_info = None
+    if args.coarse == "dp":
+        # second scene source: DP coarse planner -> corridor producer -> the same solve
+        n_distinct = min(512, B)
+        gdp = scenario.generate_dp(spec, n_distinct, seed=args.seed, first_problem=rank * n_distinct, workers=workers)
+        keep = np.nonzero(gdp["found"])[0]
+        small = api.BatchIlqrOptimizer(api.default_config(spec.n_steps), device=local_rank, batch_capacity=len(keep), cmax=spec.cmax)
+        knots = np.ascontiguousarray(gdp["coarse"][keep][:, :, :3])
+        cor, ccnt, nfail = small.build_corridors(knots, gdp["obstacle_points"][keep], gdp["obstacle_count"][keep], cmax=spec.cmax)
+        small.close()
+        good = keep[(ccnt >= 0).all(axis=1)]
+        sel = np.isin(keep, good)
+        reps = (B + len(good) - 1) // len(good)
+        tile = lambda a: np.ascontiguousarray(np.tile(a, (reps,) + (1,) * (a.ndim - 1))[:B])
+        sc = dict(start=tile(gdp["start"][good]), coarse=tile(gdp["coarse"][good]), corridor=tile(cor[sel]), ccount=tile(ccnt[sel]),
+                  left=gdp["left"], right=gdp["right"], n_steps=spec.n_steps, dt=spec.dt, cmax=spec.cmax)
+        dp_info = {"distinct_scenes": int(len(good)), "dp_failed_or_standing": int(n_distinct - len(keep)),
+                   "corridor_failed": int(len(keep) - len(good)), "mean_half_planes": round(float(ccnt[sel].mean()), 2)}
+    else:
+        sc = scenario.generate(spec, B, seed=args.seed, first_problem=rank * B, workers=workers)
     t_gen = time.time() - t0
 
     cfg = api.default_config(N)
@@ -441,6 +464,8 @@ def main():
                                    f"{spec.n_dynamic} moving + {spec.n_static} static vehicles), reference road, "
                                    f"seed {args.seed}",
                        "batch_per_gpu": B, "n_steps": N, "cmax": cmax, "batches_in_flight": P,
+                       "coarse_trajectories": ("DP coarse planner (cilqr_dp_plan) + cilqr_build_corridors" if dp_info else "scene generator"),
+                       "dp_scene_source": dp_info,
                        "results_gather": "rccl" if use_dist else "none", "rccl_ranks": rccl_ranks},
             "roofline": roof,
             "cpu_baseline": cpu,

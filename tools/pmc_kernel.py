@@ -35,6 +35,9 @@ def main():
         if i < 6 or i % 20 == 0:
             print(d, v.get("grid"), " ".join(f"{v.get(n, 0.0):.6g}" for n in names))
     print("SUM", len(by), " ".join(f"{tot[n]:.6g}" for n in names))
+    # one k_load_goals dispatch per solve: how many solves the capture holds
+    n = c.execute(f"select count(distinct dispatch_id) from counters_collection where {kcol} like '%k_load_goals%'").fetchone()[0]
+    print("SOLVES", n)
 
 
 if __name__ == "__main__":
