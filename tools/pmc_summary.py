@@ -21,7 +21,7 @@ def main():
     rows = c.execute(f"select {kcol}, counter_name, sum(value), count(*) from {view} group by {kcol}, counter_name").fetchall()
     agg = {}
     for k, cn, v, n in rows:
-        agg.setdefault(k.split("(")[0].replace("cilqr::", ""), {})[cn] = (v, n)
+        agg.setdefault(k.split("(")[0].replace("void ", "").replace("cilqr::", ""), {})[cn] = (v, n)
     names = sorted({cn for d in agg.values() for cn in d})
     print(f"{'kernel':28s} {'disp':>6s} " + " ".join(f"{n[:18]:>18s}" for n in names))
     for k, d in sorted(agg.items(), key=lambda kv: -max(v[0] for v in kv[1].values())):

@@ -43,4 +43,6 @@ python bench.py --coarse dp --cpu-sample 0 > "$out/${tag}_bench_dp_coarse.json" 
 python bench.py --scene demo80 --coarse dp --cpu-sample 0 > "$out/${tag}_bench_dp_coarse_demo80.json" 2> "$out/dp80.err"
 python bench.py --end-to-end --cpu-sample 0 > "$out/${tag}_bench_end_to_end.json" 2> "$out/e2e.err"
 python tools/pcie_rate.py > "$out/${tag}_pcie_inclusive.json" 2> "$out/pcie.err"
-ls -la "$out"
+# the raw captures stay on the box: only summaries travel back (gpurun_out/ is capped at 64 MiB)
+rm -rf "$out"/kt3 "$out"/kt1 "$out"/pmc_*_FETCH_SIZE "$out"/pmc_*_WRITE_SIZE "$out"/pmc_all_[0-9]
+du -sh "$out"; ls -la "$out"; tail -3 "$out"/*.err
