@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--spec-threshold", type=int, default=-1, help="CILQR_OPT_SPEC_THRESHOLD value (tuning experiments)")
     ap.add_argument("--seq-rounds", type=int, default=-1, help="CILQR_OPT_SEQ_ROUNDS value (tuning experiments)")
     ap.add_argument("--team-threshold", type=int, default=-1, help="CILQR_OPT_TEAM_THRESHOLD value (tuning experiments)")
+    ap.add_argument("--tail-threshold", type=int, default=-1, help="CILQR_OPT_TAIL_THRESHOLD value (tuning experiments; 0 = lockstep to the end)")
     ap.add_argument("--pipeline", type=int, default=3,
                     help="batches in flight during the timed region (handles, each with its own stream and host thread); 1 = sequential")
     ap.add_argument("--coarse", default="generator", choices=["generator", "dp"],
@@ -153,6 +154,8 @@ def main():
                 o.set_option(api.OPT_SPEC_THRESHOLD, args.spec_threshold)
             if args.team_threshold >= 0:
                 o.set_option(api.OPT_TEAM_THRESHOLD, args.team_threshold)
+            if args.tail_threshold >= 0:
+                o.set_option(api.OPT_TAIL_THRESHOLD, args.tail_threshold)
             self.traj = torch.zeros((B, K, 10), dtype=torch.float64, device=dev)
             self.hist = torch.zeros((B, M + 1, 5), dtype=torch.float64, device=dev)
             self.nc = torch.zeros(B, dtype=torch.int32, device=dev)
@@ -218,6 +221,7 @@ def main():
             raise api.CilqrError(rc, "in calibration step")
         pc = opt.profile()
         single = dict(quad_ms=pc.quadratize_ms, bwd_ms=pc.backward_ms, ls_ms=pc.linesearch_ms, other_ms=pc.other_ms,
+                      tail_ms=pc.tail_ms, tail_problems=pc.tail_problems, lockstep_launches=pc.backward_launches,
                       total_ms=pc.total_ms, iterations=pc.iterations,
                       bwd_full_ms=(pc.backward_full_ms / pc.backward_full_launches) if pc.backward_full_launches else None)
         for c in ctx:
@@ -476,9 +480,12 @@ def main():
             "c_abi_gather": cabi,
             "end_to_end": end_to_end,
             # per-phase HIP-event times of the calibration step (one batch alone, events around every phase)
-            "breakdown_ms_per_step": ({k: round(single[k], 3) for k in ("quad_ms", "bwd_ms", "ls_ms", "other_ms", "total_ms")}
+            # quad / bwd / ls / other: the lockstep iterations; tail: the per-problem kernel that finishes the
+            # last `tail_problems` problems in one launch (CILQR_OPT_TAIL_THRESHOLD)
+            "breakdown_ms_per_step": ({**{k: round(single[k], 3) for k in ("quad_ms", "bwd_ms", "ls_ms", "other_ms", "tail_ms", "total_ms")},
+                                       "tail_problems": single["tail_problems"], "lockstep_iterations": single["lockstep_launches"]}
                                       if single else None),
-            "lockstep_iterations_per_step": prof_acc["iters"] / args.steps if prof_acc["iters"] else (single or {}).get("iterations"),
+            "iterations_per_step": prof_acc["iters"] / args.steps if prof_acc["iters"] else (single or {}).get("iterations"),
             "mean_cost_rows": float(nc.mean()),
             "status_histogram": np.bincount(st, minlength=7).tolist(),
             "scene_generation_s": round(t_gen, 1),

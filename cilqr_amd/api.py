@@ -22,8 +22,9 @@ OPT_SPEC_THRESHOLD = 1
 OPT_COMPACTION = 2
 OPT_SEQ_ROUNDS = 3
 OPT_TEAM_THRESHOLD = 4
+OPT_TAIL_THRESHOLD = 5
 ST_RUNNING, ST_CONVERGED_ABS, ST_CONVERGED_REL, ST_GNORM, ST_UNSOLVED, ST_MAX_ITER, ST_NO_CORRIDOR = range(7)
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 T_GOALS, T_CORRIDOR, T_LANES, T_X, T_U, T_XCAND, T_UCAND, T_A, T_B, T_LX, T_LU, T_LXX, T_LUU, \
     T_KFB, T_KFF, T_DV, T_GNORM = range(17)
@@ -108,7 +109,8 @@ class Profile(C.Structure):
         ("iterations", C.c_int32), ("backward_launches", C.c_int32), ("backward_ms", C.c_double),
         ("quadratize_ms", C.c_double), ("linesearch_ms", C.c_double), ("other_ms", C.c_double),
         ("total_ms", C.c_double), ("backward_problem_steps", C.c_int64),
-        ("backward_full_launches", C.c_int32), ("reserved1", C.c_int32), ("backward_full_ms", C.c_double),
+        ("backward_full_launches", C.c_int32), ("tail_problems", C.c_int32), ("backward_full_ms", C.c_double),
+        ("tail_ms", C.c_double),
     ]
 
 

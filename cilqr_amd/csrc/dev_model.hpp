@@ -389,6 +389,17 @@ CILQR_DEV void store_u(const DeviceState& s, int buf, int i, int slot, const dou
   s.U[((size_t)buf * s.p.N + i) * s.Bcap + slot] = make_double2(u[0], u[1]);
 }
 
+// one point of TransformToTrajectory (cc:771-791): t x y theta v a delta kappa jerk delta_rate
+CILQR_DEV void write_traj_point(const DeviceState& s, int buf, int i, int slot, double* __restrict__ o) {
+  double x[6], u[2] = {0.0, 0.0};
+  load_x(s, buf, i, slot, x);
+  if (i < s.p.N) load_u(s, buf, i, slot, u);
+  o[0] = i * s.p.dt;
+  o[1] = x[0]; o[2] = x[1]; o[3] = x[2]; o[4] = x[3]; o[5] = x[4]; o[6] = x[5];
+  o[7] = tan(x[5]) / s.p.wheel_base;
+  o[8] = u[0]; o[9] = u[1];
+}
+
 // sum of the knot partials in index order -> c5 (total, J, dynamics, corridor, lane).  `cand`: which buffer of the
 // slot the partials were computed on (0 = the iterate, 1 = the candidate) -- only the test-only reference-order build
 // needs it, which re-evaluates the whole cost from that trajectory instead of summing partials.

@@ -13,257 +13,15 @@
 // wave-step, every access 16 B/lane and 1 KiB contiguous per wave.  Structural zeros/ones of A and
 // B are skipped at compile time; adding an exact zero never changes an IEEE sum, so the results
 // are those of the dense recursion.
-#include "dev_model.hpp"
+#include "backward_core.hpp"
 
 namespace cilqr {
-
-// structure of A (6x6) and B (6x2): 0 = exact zero, 1 = exact one, 2 = value
-__host__ __device__ constexpr int a_kind(int r, int c) {
-  return (r == c) ? 1
-         : ((r == 0 || r == 1) && c >= 2) ? 2
-         : (r == 2 && c >= 3) ? 2
-         : (r == 3 && c == 4) ? 2
-         : 0;
-}
-__host__ __device__ constexpr int b_kind(int r, int c) {
-  return ((r == 2 && c == 1) || (r == 3 && c == 0) || (r == 4 && c == 0) || (r == 5 && c == 1)) ? 2 : 0;
-}
-// structure of lxx: dense 3x3 block + diagonal
-__host__ __device__ constexpr int h_kind(int r, int c) {
-  return (r < 3 && c < 3) ? 2 : (r == c) ? 2 : 0;
-}
-
-struct Acc {
-  double v;
-  bool any;
-};
-#define ACC_TERM(acc, t)            \
-  do {                              \
-    if ((acc).any) (acc).v += (t);  \
-    else { (acc).v = (t); (acc).any = true; } \
-  } while (0)
-
-// out[R][6] = M^T X with M = A (6x6) or B (6x2): out(r,c) = sum_k M(k,r) X(k,c)
-template <int R, int xcols, bool IsA>
-CILQR_DEV void mt_x(const double* __restrict__ M, const double* __restrict__ X, double* out) {
-#pragma unroll
-  for (int r = 0; r < R; ++r)
-#pragma unroll
-    for (int c = 0; c < xcols; ++c) {
-      Acc a{0.0, false};
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        const int kind = IsA ? a_kind(k, r) : b_kind(k, r);
-        if (kind == 0) continue;
-        const double x = X[k * xcols + c];
-        const double t = (kind == 1) ? x : M[k * R + r] * x;
-        ACC_TERM(a, t);
-      }
-      out[r * xcols + c] = a.any ? a.v : 0.0;
-    }
-}
-// out[rows][C] = X M with M = A (6x6) or B (6x2): out(r,c) = sum_k X(r,k) M(k,c)
-template <int C, int rows, bool IsA>
-CILQR_DEV void x_m(const double* __restrict__ X, const double* __restrict__ M, double* out) {
-#pragma unroll
-  for (int r = 0; r < rows; ++r)
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      Acc a{0.0, false};
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        const int kind = IsA ? a_kind(k, c) : b_kind(k, c);
-        if (kind == 0) continue;
-        const double x = X[r * 6 + k];
-        const double t = (kind == 1) ? x : x * M[k * C + c];
-        ACC_TERM(a, t);
-      }
-      out[r * C + c] = a.any ? a.v : 0.0;
-    }
-}
-
-template <bool kStore>
-CILQR_DEV void backward_problem(const DeviceState& s, int slot, double lambda) {
-  const Params& p = s.p;
-  const int Bc = s.Bcap, N = p.N;
-  const double dt = p.dt;
-  double Vx[6], Vxx[36];
-  {
-    const double2* t = s.term + slot;
-    const double2 t0 = t[0], t1 = t[(size_t)Bc], t2 = t[(size_t)2 * Bc], t3 = t[(size_t)3 * Bc],
-                  t4 = t[(size_t)4 * Bc], t5 = t[(size_t)5 * Bc], t6 = t[(size_t)6 * Bc],
-                  t7 = t[(size_t)7 * Bc], t8 = t[(size_t)8 * Bc];
-    Vx[0] = t0.x; Vx[1] = t0.y; Vx[2] = t1.x; Vx[3] = t1.y; Vx[4] = t2.x; Vx[5] = t2.y;
-#pragma unroll
-    for (int e = 0; e < 36; ++e) Vxx[e] = 0.0;
-    Vxx[0] = t3.x; Vxx[1] = t3.y; Vxx[2] = t4.x;
-    Vxx[6] = t4.y; Vxx[7] = t5.x; Vxx[8] = t5.y;
-    Vxx[12] = t6.x; Vxx[13] = t6.y; Vxx[14] = t7.x;
-    Vxx[21] = t7.y; Vxx[28] = t8.x; Vxx[35] = t8.y;
-  }
-  const int buf = s.cur[slot];
-  double dV0 = 0.0, dV1 = 0.0, gsum = 0.0;
-  // software pipeline: the operands of step i-1 are requested before step i is computed, so a
-  // wave (one per SIMD at B = 65536) always has 18 KiB of loads in flight behind its arithmetic
-  double2 w[kLinPairs], wn[kLinPairs];
-  double2 uu, uun;
-  {
-    const double2* q = s.lin + (size_t)(N - 1) * kLinPairs * Bc + slot;
-#pragma unroll
-    for (int r = 0; r < kLinPairs; ++r) w[r] = q[(size_t)r * Bc];
-    uu = s.U[((size_t)buf * N + (N - 1)) * Bc + slot];
-  }
-  for (int i = N - 1; i >= 0; --i) {
-    {
-      const int ip = (i > 0) ? i - 1 : 0;
-      const double2* q = s.lin + (size_t)ip * kLinPairs * Bc + slot;
-#pragma unroll
-      for (int r = 0; r < kLinPairs; ++r) wn[r] = q[(size_t)r * Bc];
-      uun = s.U[((size_t)buf * N + ip) * Bc + slot];
-    }
-    // A and B as dense register arrays; entries of kind 0/1 are never read
-    double A[36], B[12];
-    A[2] = w[0].x; A[3] = w[0].y; A[4] = w[1].x; A[5] = w[1].y;
-    A[8] = w[2].x; A[9] = w[2].y; A[10] = w[3].x; A[11] = w[3].y;
-    A[15] = w[4].x; A[16] = w[4].y; A[17] = w[5].x;
-    A[22] = dt;
-    B[5] = w[5].y; B[6] = 0.5 * dt * dt; B[8] = dt; B[11] = dt;
-    const double lx[6] = {w[6].x, w[6].y, w[7].x, w[7].y, w[8].x, w[8].y};
-    const double lu[2] = {w[9].x, w[9].y};
-    // lxx (kind 2 entries only)
-    double H[36];
-    H[0] = w[10].x; H[1] = w[10].y; H[2] = w[11].x;
-    H[6] = w[11].y; H[7] = w[12].x; H[8] = w[12].y;
-    H[12] = w[13].x; H[13] = w[13].y; H[14] = w[14].x;
-    H[21] = w[14].y; H[28] = w[15].x; H[35] = w[15].y;
-    const double luu0 = w[16].x, luu1 = w[16].y;
-
-    // ---- quantities from the OLD Vx / Vxx ----
-    double BtV[12], Qux[12], BtVB[4], BtVx[2];
-    mt_x<2, 6, false>(B, Vxx, BtV);          // B^T Vxx
-    x_m<6, 2, true>(BtV, A, Qux);            // (B^T Vxx) A                    cc:353
-    x_m<2, 2, false>(BtV, B, BtVB);          // (B^T Vxx) B
-    mt_x<2, 1, false>(B, Vx, BtVx);
-    const double Quu[4] = {luu0 + BtVB[0], BtVB[1], BtVB[2], luu1 + BtVB[3]};      // cc:352
-    const double Qu[2] = {lu[0] + BtVx[0], lu[1] + BtVx[1]};                       // cc:349
-    // (Quu + lambda I)^-1, closed form                                             cc:361-363
-    const double m00 = Quu[0] + lambda, m01 = Quu[1], m10 = Quu[2], m11 = Quu[3] + lambda;
-    const double invdet = 1.0 / (m00 * m11 - m10 * m01);
-    const double n00 = -(m11 * invdet), n01 = -(-m01 * invdet), n10 = -(-m10 * invdet),
-                 n11 = -(m00 * invdet);
-    double Kc[12], kc[2];
-#pragma unroll
-    for (int c = 0; c < 6; ++c) {                                                   // cc:365
-      Kc[c] = n00 * Qux[c] + n01 * Qux[6 + c];
-      Kc[6 + c] = n10 * Qux[c] + n11 * Qux[6 + c];
-    }
-    kc[0] = n00 * Qu[0] + n01 * Qu[1];                                              // cc:366
-    kc[1] = n10 * Qu[0] + n11 * Qu[1];
-    if (kStore) {
-      double2* g = s.gains + (size_t)i * kGainPairs * Bc + slot;
-#pragma unroll
-      for (int r = 0; r < 6; ++r) g[(size_t)r * Bc] = make_double2(Kc[2 * r], Kc[2 * r + 1]);
-      g[(size_t)6 * Bc] = make_double2(kc[0], kc[1]);
-    }
-    {  // CalGradientNorm term, cc:328-329
-      const double v0 = fabs(kc[0]) / (fabs(uu.x) + 1), v1 = fabs(kc[1]) / (fabs(uu.y) + 1);
-      gsum += (v0 > v1 ? v0 : v1);
-    }
-    double AtVx[6], AtV[36], AtVA[36];
-    mt_x<6, 1, true>(A, Vx, AtVx);
-    mt_x<6, 6, true>(A, Vxx, AtV);
-    x_m<6, 6, true>(AtV, A, AtVA);
-    // K^T Quu (6x2), then the three correction terms of each update              cc:379-380
-    double KtQ[12];
-#pragma unroll
-    for (int r = 0; r < 6; ++r) {
-      KtQ[r * 2 + 0] = Kc[r] * Quu[0] + Kc[6 + r] * Quu[2];
-      KtQ[r * 2 + 1] = Kc[r] * Quu[1] + Kc[6 + r] * Quu[3];
-    }
-    double nVx[6];
-#pragma unroll
-    for (int r = 0; r < 6; ++r) {
-      const double t1 = KtQ[r * 2] * kc[0] + KtQ[r * 2 + 1] * kc[1];
-      const double t2 = Kc[r] * Qu[0] + Kc[6 + r] * Qu[1];
-      const double t3 = Qux[r] * kc[0] + Qux[6 + r] * kc[1];
-      nVx[r] = (((lx[r] + AtVx[r]) + t1) + t2) + t3;
-    }
-#pragma unroll
-    for (int r = 0; r < 6; ++r)
-#pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        const double m1 = KtQ[r * 2] * Kc[c] + KtQ[r * 2 + 1] * Kc[6 + c];
-        const double m2 = Kc[r] * Qux[c] + Kc[6 + r] * Qux[6 + c];
-        const double m3 = Qux[r] * Kc[c] + Qux[6 + r] * Kc[6 + c];
-        const double qxx = (h_kind(r, c) == 2) ? (H[r * 6 + c] + AtVA[r * 6 + c]) : AtVA[r * 6 + c];
-        Vxx[r * 6 + c] = ((qxx + m1) + m2) + m3;
-      }
-#pragma unroll
-    for (int r = 0; r < 6; ++r) Vx[r] = nVx[r];
-    // in-place symmetrisation, column-major order                                 cc:381
-#pragma unroll
-    for (int c = 0; c < 6; ++c)
-#pragma unroll
-      for (int r = 0; r < 6; ++r) Vxx[r * 6 + c] = 0.5 * (Vxx[r * 6 + c] + Vxx[c * 6 + r]);
-    // ---- delta_V_ with Qu / Quu re-evaluated on the NEW Vx / Vxx ----            cc:383-384
-    double BtV2[12], BtVB2[4], BtVx2[2];
-    mt_x<2, 1, false>(B, Vx, BtVx2);
-    const double Qu0 = lu[0] + BtVx2[0], Qu1 = lu[1] + BtVx2[1];
-    dV0 += kc[0] * Qu0 + kc[1] * Qu1;
-    mt_x<2, 6, false>(B, Vxx, BtV2);
-    x_m<2, 2, false>(BtV2, B, BtVB2);
-    const double q00 = luu0 + BtVB2[0], q01 = BtVB2[1], q10 = BtVB2[2], q11 = luu1 + BtVB2[3];
-    const double hk0 = 0.5 * kc[0], hk1 = 0.5 * kc[1];
-    const double r0 = hk0 * q00 + hk1 * q10, r1 = hk0 * q01 + hk1 * q11;
-    dV1 += r0 * kc[0] + r1 * kc[1];
-#pragma unroll
-    for (int r = 0; r < kLinPairs; ++r) w[r] = wn[r];
-    uu = uun;
-  }
-  s.dV[slot] = dV0;
-  s.dV[(size_t)Bc + slot] = dV1;
-  s.gnorm[slot] = gsum / N;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Team variant for small active sets.  With a few hundred problems left, one lane per problem
-// leaves the chip idle and every launch takes N dependent steps of ~1100 dependent fp64
-// instructions each.  Here eight lanes share a problem: lane c (c < 6) owns column c of Vxx and of
-// every 6-column intermediate (B^T Vxx, Qux, K, A^T Vxx, A^T Vxx A, the new Vxx) and entry c of
-// Vx; the 2x2 / 2-vector quantities (Quu, Qu, the inverse, k, delta_V, the gradient norm) are
-// evaluated redundantly by every lane.  Three exchanges per step go through LDS (the block is one
-// wave, so a barrier is a wait on the LDS counter).
-//
-// Every number is produced by the same operations on the same operands in the same order as in
-// backward_problem, so the results are bit-identical (tested): columns are independent in the
-// reference's products, and where the sparsity of a product depends on the column (A's column c in
-// X A, A^T x) the lanes use the dense form with A's exact zeros and ones -- x * 1.0 = x and
-// s + x * 0.0 = s are exact (up to the sign of a zero).
-// ---------------------------------------------------------------------------------------------
-namespace team {
-constexpr int kLanes = 8;          // lanes per problem
-constexpr int kStride = 132;       // doubles per team in LDS; 132 * 8 B = 8 banks (mod 64): no conflicts between teams
-constexpr int oAtV = 0;            // [6][4]  columns 0..3 of A^T Vxx
-constexpr int oKc = 24;            // [2][6]
-constexpr int oQux = 36;           // [2][6]
-constexpr int oVn = 48;            // [6 columns][6 rows] new Vxx before symmetrisation
-constexpr int oB0 = 84;            // (B^T Vxx)(0, .) of the updated Vxx
-constexpr int oB1 = 90;            // (B^T Vxx)(1, .) with this step's B(2,1)
-constexpr int oBn = 96;            // (B^T Vxx)(1, .) with the next step's B(2,1)
-constexpr int oVx = 102;           // Vx
-}  // namespace team
 
 __global__ __launch_bounds__(64) void k_backward_team(DeviceState s, const int* __restrict__ list, int n,
                                                       const double* __restrict__ lambda_override) {
   using namespace team;
   __shared__ double lds[(64 / kLanes) * kStride];
-  const Params& p = s.p;
-  const int Bc = s.Bcap, N = p.N;
-  const double dt = p.dt;
   const int lane = threadIdx.x;
-  const int cl = lane & (kLanes - 1);          // lane within the team
-  const int c = cl < 6 ? cl : 5;               // column this lane computes (lanes 6, 7 shadow column 5)
-  const bool owner = cl < 6;
   const int n_act = active_count(s, n);
   const int jraw = blockIdx.x * (64 / kLanes) + lane / kLanes;
   if ((int)(blockIdx.x * (64 / kLanes)) >= n_act) return;   // whole block idle (uniform)
@@ -271,245 +29,7 @@ __global__ __launch_bounds__(64) void k_backward_team(DeviceState s, const int* 
   const int j = live ? jraw : n_act - 1;       // idle teams shadow the last problem, stores masked
   const int slot = list ? list[j] : j;
   const double lambda = lambda_override ? lambda_override[slot] : s.lambda[slot];
-  double* T = lds + (lane / kLanes) * kStride;
-  // column selectors
-  const bool c0 = c == 0, c1 = c == 1, c2 = c == 2, c3 = c == 3, c4 = c == 4;
-  auto sel6 = [&](double v0, double v1, double v2, double v3, double v4, double v5) {
-    return c0 ? v0 : c1 ? v1 : c2 ? v2 : c3 ? v3 : c4 ? v4 : v5;
-  };
-  // terminal value function: column c of Vxx, entry c of Vx
-  double V[6], vx;
-  {
-    const double2* t = s.term + slot;
-    const double2 t0 = t[0], t1 = t[(size_t)Bc], t2 = t[(size_t)2 * Bc], t3 = t[(size_t)3 * Bc],
-                  t4 = t[(size_t)4 * Bc], t5 = t[(size_t)5 * Bc], t6 = t[(size_t)6 * Bc],
-                  t7 = t[(size_t)7 * Bc], t8 = t[(size_t)8 * Bc];
-    vx = sel6(t0.x, t0.y, t1.x, t1.y, t2.x, t2.y);
-    V[0] = sel6(t3.x, t3.y, t4.x, 0.0, 0.0, 0.0);
-    V[1] = sel6(t4.y, t5.x, t5.y, 0.0, 0.0, 0.0);
-    V[2] = sel6(t6.x, t6.y, t7.x, 0.0, 0.0, 0.0);
-    V[3] = sel6(0.0, 0.0, 0.0, t7.y, 0.0, 0.0);
-    V[4] = sel6(0.0, 0.0, 0.0, 0.0, t8.x, 0.0);
-    V[5] = sel6(0.0, 0.0, 0.0, 0.0, 0.0, t8.y);
-  }
-  const int buf = s.cur[slot];
-  const double B30 = 0.5 * dt * dt, B40 = dt, B51 = dt;
-  double dV0 = 0.0, dV1 = 0.0, gsum = 0.0;
-  // What a lane needs from the linearisation of a step is a handful of scalars that depend on its
-  // column: rows 0..3 of A's column c, lx(c), column c of lxx -- plus the pairs every lane needs
-  // (B(2,1), lu, luu).  Each is fetched straight from its place in the [17 pairs][Bcap] record
-  // (offsets in doubles from the step's first pair, fixed per lane), instead of loading all 17
-  // pairs and selecting by column.  Structural zeros / ones never touch memory: `k` = kind.
-  const size_t row = (size_t)Bc * 2;                       // doubles per pair row
-  auto at = [&](int pair, int half) { return (size_t)pair * row + (size_t)half; };
-  // A(0,c): pairs 0,1 = (A02,A03),(A04,A05); A(1,c): pairs 2,3; A(2,c): pair 4 = (A23,A24), 5.x = A25
-  const size_t o_a0 = c >= 2 ? at((c - 2) >> 1, (c - 2) & 1) : 0;
-  const size_t o_a1 = c >= 2 ? at(2 + ((c - 2) >> 1), (c - 2) & 1) : 0;
-  const size_t o_a2 = c >= 3 ? at(4 + ((c - 3) >> 1), (c - 3) & 1) : 0;
-  const size_t o_lx = at(6 + (c >> 1), c & 1);
-  // lxx: pairs 10..15 = (H00,H01),(H02,H10),(H11,H12),(H20,H21),(H22,H33),(H44,H55)
-  //   column c < 3: rows 0..2 -> H(r,c) is scalar number 3 r + c of the first nine
-  //   column c >= 3: the diagonal entry, scalar number 6 + c
-  auto hs = [&](int sidx) { return at(10 + (sidx >> 1), sidx & 1); };
-  const size_t o_h0 = hs(c < 3 ? c : 6 + c), o_h1 = hs(c < 3 ? 3 + c : 6 + c), o_h2 = hs(c < 3 ? 6 + c : 6 + c);
-  const double ka0 = c0 ? 1.0 : 0.0, ka1 = c1 ? 1.0 : 0.0, ka2 = c2 ? 1.0 : 0.0;   // value when not loaded
-  struct StepIn {
-    double a0, a1, a2, lx, h0, h1, h2;
-    double2 wa[6], lu, luu, u;     // wa: the pairs that hold A (and B(2,1)): A^T x needs all of A
-  };
-  auto load_step = [&](int i, StepIn& o) {
-    const double* q = reinterpret_cast<const double*>(s.lin + (size_t)i * kLinPairs * Bc + slot);
-    o.a0 = q[o_a0]; o.a1 = q[o_a1]; o.a2 = q[o_a2]; o.lx = q[o_lx];
-    o.h0 = q[o_h0]; o.h1 = q[o_h1]; o.h2 = q[o_h2];
-    const double2* q2 = s.lin + (size_t)i * kLinPairs * Bc + slot;
-#pragma unroll
-    for (int r = 0; r < 6; ++r) o.wa[r] = q2[(size_t)r * Bc];
-    o.lu = q2[(size_t)9 * Bc]; o.luu = q2[(size_t)16 * Bc];
-    o.u = s.U[((size_t)buf * N + i) * Bc + slot];
-  };
-  StepIn w, wn;
-  load_step(N - 1, w);
-  // B^T Vxx and Vx of the terminal value function, for the first step
-  if (owner) {
-    T[oB0 + c] = B30 * V[3] + B40 * V[4];
-    T[oBn + c] = w.wa[5].y * V[2] + B51 * V[5];
-    T[oVx + c] = vx;
-  }
-  __syncthreads();
-  double BtV0[6], BtV1[6], Vxa[6];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    BtV0[k] = T[oB0 + k];
-    BtV1[k] = T[oBn + k];
-    Vxa[k] = T[oVx + k];
-  }
-  for (int i = N - 1; i >= 0; --i) {
-    load_step((i > 0) ? i - 1 : 0, wn);
-    // A (the entries the column-independent product A^T x reads) and B
-    double A[36], B[12];
-    A[2] = w.wa[0].x; A[3] = w.wa[0].y; A[4] = w.wa[1].x; A[5] = w.wa[1].y;
-    A[8] = w.wa[2].x; A[9] = w.wa[2].y; A[10] = w.wa[3].x; A[11] = w.wa[3].y;
-    A[15] = w.wa[4].x; A[16] = w.wa[4].y; A[17] = w.wa[5].x;
-    A[22] = dt;
-    B[5] = w.wa[5].y; B[6] = B30; B[8] = B40; B[11] = B51;
-    // rows 0..3 of A's column c, exact zeros and ones included; rows 4, 5 of a column hold only
-    // its diagonal one
-    const double a0 = c >= 2 ? w.a0 : ka0;
-    const double a1 = c >= 2 ? w.a1 : ka1;
-    const double a2 = c >= 3 ? w.a2 : ka2;
-    const double a3 = c3 ? 1.0 : c4 ? dt : 0.0;
-    const bool late = c >= 4;   // diagonal entry below row 3: one more term, the own column
-    const double lxc = w.lx;
-    const double lu[2] = {w.lu.x, w.lu.y};
-    // column c of lxx (zeros where the reference's lxx has none)
-    const bool blk = c < 3;
-    const double hc[6] = {blk ? w.h0 : 0.0, blk ? w.h1 : 0.0, blk ? w.h2 : 0.0,
-                          c3 ? w.h0 : 0.0, c4 ? w.h0 : 0.0, (c == 5) ? w.h0 : 0.0};
-    const double luu0 = w.luu.x, luu1 = w.luu.y;
-    const double2 uu = w.u;
-
-    // ---- quantities from the OLD Vx / Vxx ----
-    // column c of Qux = (B^T Vxx) A                                               cc:353
-    double Qux0, Qux1;
-    {
-      double q0 = BtV0[0] * a0; q0 += BtV0[1] * a1; q0 += BtV0[2] * a2; q0 += BtV0[3] * a3;
-      double q1 = BtV1[0] * a0; q1 += BtV1[1] * a1; q1 += BtV1[2] * a2; q1 += BtV1[3] * a3;
-      const double own0 = c4 ? BtV0[4] : BtV0[5], own1 = c4 ? BtV1[4] : BtV1[5];
-      Qux0 = late ? q0 + own0 : q0;
-      Qux1 = late ? q1 + own1 : q1;
-    }
-    const double BtVB[4] = {BtV0[3] * B[6] + BtV0[4] * B[8], BtV0[2] * B[5] + BtV0[5] * B[11],
-                            BtV1[3] * B[6] + BtV1[4] * B[8], BtV1[2] * B[5] + BtV1[5] * B[11]};
-    const double BtVx[2] = {B[6] * Vxa[3] + B[8] * Vxa[4], B[5] * Vxa[2] + B[11] * Vxa[5]};
-    const double Quu[4] = {luu0 + BtVB[0], BtVB[1], BtVB[2], luu1 + BtVB[3]};      // cc:352
-    const double Qu[2] = {lu[0] + BtVx[0], lu[1] + BtVx[1]};                       // cc:349
-    const double m00 = Quu[0] + lambda, m01 = Quu[1], m10 = Quu[2], m11 = Quu[3] + lambda;
-    const double invdet = 1.0 / (m00 * m11 - m10 * m01);                            // cc:361-363
-    const double n00 = -(m11 * invdet), n01 = -(-m01 * invdet), n10 = -(-m10 * invdet),
-                 n11 = -(m00 * invdet);
-    const double Kc0 = n00 * Qux0 + n01 * Qux1;                                     // cc:365
-    const double Kc1 = n10 * Qux0 + n11 * Qux1;
-    const double kc[2] = {n00 * Qu[0] + n01 * Qu[1], n10 * Qu[0] + n11 * Qu[1]};    // cc:366
-    {  // CalGradientNorm term, cc:328-329
-      const double v0 = fabs(kc[0]) / (fabs(uu.x) + 1), v1 = fabs(kc[1]) / (fabs(uu.y) + 1);
-      gsum += (v0 > v1 ? v0 : v1);
-    }
-    // entry c of A^T Vx, column c of A^T Vxx
-    double AtVxc;
-    {
-      double q = a0 * Vxa[0]; q += a1 * Vxa[1]; q += a2 * Vxa[2]; q += a3 * Vxa[3];
-      AtVxc = late ? q + (c4 ? Vxa[4] : Vxa[5]) : q;
-    }
-    double AtVc[6];
-    mt_x<6, 1, true>(A, V, AtVc);
-    if (owner) {
-      if (c < 4) {
-#pragma unroll
-        for (int r = 0; r < 6; ++r) T[oAtV + r * 4 + c] = AtVc[r];
-      }
-      T[oKc + c] = Kc0;
-      T[oKc + 6 + c] = Kc1;
-      T[oQux + c] = Qux0;
-      T[oQux + 6 + c] = Qux1;
-    }
-    __syncthreads();
-    double Ka[12], Qa[12];
-#pragma unroll
-    for (int e = 0; e < 12; ++e) {
-      Ka[e] = T[oKc + e];
-      Qa[e] = T[oQux + e];
-    }
-    if (live) {   // gains: lane r < 6 stores pair r of (K row 0 | K row 1), lane 6 stores k
-      double2* g = s.gains + (size_t)i * kGainPairs * Bc + slot;
-      if (cl < 6) g[(size_t)cl * Bc] = make_double2(Ka[2 * cl], Ka[2 * cl + 1]);
-      else if (cl == 6) g[(size_t)6 * Bc] = make_double2(kc[0], kc[1]);
-    }
-    // column c of (A^T Vxx) A
-    double AtVAc[6];
-#pragma unroll
-    for (int r = 0; r < 6; ++r) {
-      double q = T[oAtV + r * 4 + 0] * a0;
-      q += T[oAtV + r * 4 + 1] * a1;
-      q += T[oAtV + r * 4 + 2] * a2;
-      q += T[oAtV + r * 4 + 3] * a3;
-      AtVAc[r] = late ? q + AtVc[r] : q;
-    }
-    // K^T Quu, all rows                                                          cc:379-380
-    double KtQ[12];
-#pragma unroll
-    for (int r = 0; r < 6; ++r) {
-      KtQ[r * 2 + 0] = Ka[r] * Quu[0] + Ka[6 + r] * Quu[2];
-      KtQ[r * 2 + 1] = Ka[r] * Quu[1] + Ka[6 + r] * Quu[3];
-    }
-    double nvx;
-    {
-      const double kq0 = sel6(KtQ[0], KtQ[2], KtQ[4], KtQ[6], KtQ[8], KtQ[10]);
-      const double kq1 = sel6(KtQ[1], KtQ[3], KtQ[5], KtQ[7], KtQ[9], KtQ[11]);
-      const double t1 = kq0 * kc[0] + kq1 * kc[1];
-      const double t2 = Kc0 * Qu[0] + Kc1 * Qu[1];
-      const double t3 = Qux0 * kc[0] + Qux1 * kc[1];
-      nvx = (((lxc + AtVxc) + t1) + t2) + t3;
-    }
-    double Vn[6];
-#pragma unroll
-    for (int r = 0; r < 6; ++r) {
-      const double m1 = KtQ[r * 2] * Kc0 + KtQ[r * 2 + 1] * Kc1;
-      const double m2 = Ka[r] * Qux0 + Ka[6 + r] * Qux1;
-      const double m3 = Qa[r] * Kc0 + Qa[6 + r] * Kc1;
-      const double qxx = hc[r] + AtVAc[r];
-      Vn[r] = ((qxx + m1) + m2) + m3;
-    }
-    if (owner) {
-#pragma unroll
-      for (int r = 0; r < 6; ++r) T[oVn + c * 6 + r] = Vn[r];
-    }
-    __syncthreads();
-    // in-place symmetrisation, column-major order (cc:381): entries below the diagonal average
-    // the two old values; entries above it average the old value with the already averaged one
-#pragma unroll
-    for (int r = 0; r < 6; ++r) {
-      const double o_cr = T[oVn + r * 6 + c];   // old (c, r): row c of column r
-      const double lower = 0.5 * (Vn[r] + o_cr);
-      const double upper = 0.5 * (Vn[r] + 0.5 * (o_cr + Vn[r]));
-      V[r] = (r < c) ? upper : lower;
-    }
-    vx = nvx;
-    // B^T Vxx of the updated Vxx: with this step's B for delta_V, with the next step's for the
-    // next step's gains
-    if (owner) {
-      T[oB0 + c] = B30 * V[3] + B40 * V[4];
-      T[oB1 + c] = B[5] * V[2] + B51 * V[5];
-      T[oBn + c] = wn.wa[5].y * V[2] + B51 * V[5];
-      T[oVx + c] = vx;
-    }
-    __syncthreads();
-    double Bt2_1[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      BtV0[k] = T[oB0 + k];
-      Bt2_1[k] = T[oB1 + k];
-      BtV1[k] = T[oBn + k];
-      Vxa[k] = T[oVx + k];
-    }
-    // ---- delta_V_ with Qu / Quu re-evaluated on the NEW Vx / Vxx ----            cc:383-384
-    {
-      const double BtVx2[2] = {B[6] * Vxa[3] + B[8] * Vxa[4], B[5] * Vxa[2] + B[11] * Vxa[5]};
-      const double Qu0 = lu[0] + BtVx2[0], Qu1 = lu[1] + BtVx2[1];
-      dV0 += kc[0] * Qu0 + kc[1] * Qu1;
-      const double BtVB2[4] = {BtV0[3] * B[6] + BtV0[4] * B[8], BtV0[2] * B[5] + BtV0[5] * B[11],
-                               Bt2_1[3] * B[6] + Bt2_1[4] * B[8], Bt2_1[2] * B[5] + Bt2_1[5] * B[11]};
-      const double q00 = luu0 + BtVB2[0], q01 = BtVB2[1], q10 = BtVB2[2], q11 = luu1 + BtVB2[3];
-      const double hk0 = 0.5 * kc[0], hk1 = 0.5 * kc[1];
-      const double r0 = hk0 * q00 + hk1 * q10, r1 = hk0 * q01 + hk1 * q11;
-      dV1 += r0 * kc[0] + r1 * kc[1];
-    }
-    w = wn;
-  }
-  if (live && cl == 0) {
-    s.dV[slot] = dV0;
-    s.dV[(size_t)Bc + slot] = dV1;
-    s.gnorm[slot] = gsum / N;
-  }
+  backward_team_problem(s, slot, lambda, live, lane & (kLanes - 1), lds + (lane / kLanes) * kStride, BlockSync{});
 }
 
 __global__ __launch_bounds__(64, 1) void k_backward(DeviceState s, const int* __restrict__ list, int n,

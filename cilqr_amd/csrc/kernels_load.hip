@@ -471,15 +471,6 @@ void launch_gather_scalar(const double* src, int rows, int Bcap, int B, double* 
 // ---------------------------------------------------------------------------------------------
 // Export: TransformToTrajectory (cc:771-791) into problem-major [B][K][10]
 // ---------------------------------------------------------------------------------------------
-CILQR_DEV void write_traj_point(const DeviceState& s, int buf, int i, int slot, double* __restrict__ o) {
-  double x[6], u[2] = {0.0, 0.0};
-  load_x(s, buf, i, slot, x);
-  if (i < s.p.N) load_u(s, buf, i, slot, u);
-  o[0] = i * s.p.dt;
-  o[1] = x[0]; o[2] = x[1]; o[3] = x[2]; o[4] = x[3]; o[5] = x[4]; o[6] = x[5];
-  o[7] = tan(x[5]) / s.p.wheel_base;
-  o[8] = u[0]; o[9] = u[1];
-}
 // final trajectory (cc:238,285,303,319) of every slot that terminated in the last k_update
 __global__ void k_export_done(DeviceState s, int n, double* __restrict__ traj) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;

@@ -16,198 +16,18 @@
 // Per-knot cost partials go to `part`; a per-problem pass sums them over knots in index order.
 // Sums over (disc, plane) are therefore re-associated with respect to the reference's running
 // sums; every individual term is computed with the reference's expression.
-#include "cost_reduce.hpp"
+#include "quad_core.hpp"
 
 namespace cilqr {
 
-constexpr int kPlaneChunk = 4;
-
-// lane tables -> LDS (call from every thread of the block, before any early exit)
-CILQR_DEV const double* stage_lanes(const DeviceState& s, double* lds) {
-  const int n = (s.nl + s.nr) * kLaneFields;
-  for (int e = threadIdx.x; e < n; e += blockDim.x) lds[e] = s.lanes[e];
-  __syncthreads();
-  return lds;
-}
-static inline size_t lane_lds_bytes(const DeviceState& s) {
-  return (size_t)(s.nl + s.nr) * kLaneFields * sizeof(double);
-}
-
-// one chunk of up to four corridor planes; missing planes are (0, 0, 1): g = -1, which multiplies
-// the barrier product by exactly 1 and adds exact zeros to every gradient / Hessian entry
-struct PlaneChunk {
-  double a[kPlaneChunk], b[kPlaneChunk], c[kPlaneChunk];
-};
-CILQR_DEV void load_chunk(const double* __restrict__ cor, int Bc, int c0, int cnt, PlaneChunk& pc) {
-#pragma unroll
-  for (int k = 0; k < kPlaneChunk; ++k) {
-    const bool live = (c0 + k) < cnt;
-    const double* q = cor + (size_t)(live ? (c0 + k) : 0) * 3 * Bc;
-    const double a = q[0], b = q[(size_t)Bc], c = q[(size_t)2 * Bc];
-    pc.a[k] = live ? a : 0.0;
-    pc.b[k] = live ? b : 0.0;
-    pc.c[k] = live ? c : 1.0;
-  }
-}
-
-// first chunk of a knot: requested before the plane count is known (its addresses do not depend on
-// it), masked once the count has arrived -- one dependent memory round trip less per knot
-CILQR_DEV void load_first_chunk(const double* __restrict__ cor, int Bc, int cmax, PlaneChunk& pc) {
-#pragma unroll
-  for (int k = 0; k < kPlaneChunk; ++k) {
-    const double* q = cor + (size_t)min(k, cmax - 1) * 3 * Bc;
-    pc.a[k] = q[0];
-    pc.b[k] = q[(size_t)Bc];
-    pc.c[k] = q[(size_t)2 * Bc];
-  }
-}
-CILQR_DEV void mask_first_chunk(int cnt, PlaneChunk& pc) {
-#pragma unroll
-  for (int k = 0; k < kPlaneChunk; ++k) {
-    const bool live = k < cnt;
-    pc.a[k] = live ? pc.a[k] : 0.0;
-    pc.b[k] = live ? pc.b[k] : 0.0;
-    pc.c[k] = live ? pc.c[k] : 1.0;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// cost partials of one knot.  x, u: the knot's state / control; out[0], out[stride], out[2*stride]
-// ---------------------------------------------------------------------------------------------
-// bound barriers of one knot (DynamicsCost cc:518-551); returns {state part, control part}
-CILQR_DEV double2 knot_bound_cost(const Params& p, int i, const double* x, const double* u) {
-  double du = 0.0;
-  if (i < p.N) {
-    BarGroup g;
-    const double gu[4] = {u[0] - p.jerk_max, p.jerk_min - u[0],                    // cc:543-546
-                          u[1] - p.delta_rate_max, p.delta_rate_min - u[1]};
-    bar_accumulate(p, gu, g);
-    du = bar_group_value(p, g);
-  }
-  BarGroup g;
-  const double gx[6] = {-x[3], x[3] - p.max_velocity, x[4] - p.max_acc,            // cc:523-528
-                        p.min_acc - x[4], x[5] - p.delta_max, p.delta_min - x[5]};
-  bar_accumulate(p, gx, g);
-  return make_double2(bar_group_value(p, g), du);
-}
-
-template <int D>
-CILQR_DEV void knot_cost_core(const DeviceState& s, const double* __restrict__ lanes, int i, int slot,
-                              const double* x, const double* u, double2* __restrict__ out, size_t stride) {
-  const Params& p = s.p;
-  const int Bc = s.Bcap;
-  const double2* gp = s.goals + (size_t)i * 3 * Bc + slot;
-  const double2 g0 = gp[0];
-  const double gth = gp[(size_t)Bc].x;
-  const double* __restrict__ cor = s.cor + (size_t)i * s.cmax * 3 * Bc + slot;
-  PlaneChunk pc;
-  load_first_chunk(cor, Bc, s.cmax, pc);
-  const int cnt = s.ccnt[(size_t)i * Bc + slot];
-  mask_first_chunk(cnt, pc);
-  // JCost cc:501-513
-  const double ex = x[0] - g0.x, ey = x[1] - g0.y, eth = x[2] - gth;
-  const double jx = p.w_x * (ex * ex) + p.w_y * (ey * ey) + p.w_theta * (eth * eth);
-  const double ju = (i < p.N) ? p.w_jerk * (u[0] * u[0]) + p.w_delta_rate * (u[1] * u[1]) : 0.0;
-  const double2 dyn = knot_bound_cost(p, i, x, u);
-  double sn, cs;
-  lean_sincos(x[2], &sn, &cs);
-  double px[D], py[D];
-  BarGroup grp[D];
-#pragma unroll
-  for (int j = 0; j < D; ++j) {
-    px[j] = x[0] + p.disc_off[j] * cs;                     // cc:564-565
-    py[j] = x[1] + p.disc_off[j] * sn;
-  }
-  // CorridorCost cc:553-581: planes outer (each read once), discs inner; one log for the knot
-  for (int c0 = 0; c0 < cnt; c0 += kPlaneChunk) {
-    PlaneChunk nx;
-    if (c0 + kPlaneChunk < cnt) load_chunk(cor, Bc, c0 + kPlaneChunk, cnt, nx);
-#pragma unroll
-    for (int j = 0; j < D; ++j) {
-      double g[kPlaneChunk];
-#pragma unroll
-      for (int k = 0; k < kPlaneChunk; ++k) g[k] = pc.a[k] * px[j] + pc.b[k] * py[j] - pc.c[k];
-      bar_accumulate(p, g, grp[j]);
-    }
-    if ((c0 & (16 * kPlaneChunk - 1)) == 15 * kPlaneChunk) {   // every 64 planes: keep the products in range
-#pragma unroll
-      for (int j = 0; j < D; ++j) bar_renormalize(grp[j]);
-    }
-    pc = nx;
-  }
-  BarGroup call;
-#pragma unroll
-  for (int j = 0; j < D; ++j) {
-    bar_renormalize(grp[j]);
-    bar_merge(call, grp[j]);
-  }
-  const double ccost = bar_group_value(p, call);
-  // LaneBoundaryCost cc:583-603: the ten candidate-list loads go out together, then the searches
-  uint4 cl[D], cr[D];
-#pragma unroll
-  for (int j = 0; j < D; ++j) {
-    cl[j] = lane_cell_fetch(s, 0, px[j], py[j]);
-    cr[j] = lane_cell_fetch(s, 1, px[j], py[j]);
-  }
-  BarGroup lall;
-#pragma unroll
-  for (int j = 0; j < D; ++j) {
-    const double* L = lanes + nearest_from_cell(s, lanes, 0, cl[j], px[j], py[j]) * kLaneFields;
-    const double* Rr = lanes + (s.nl + nearest_from_cell(s, lanes, 1, cr[j], px[j], py[j])) * kLaneFields;
-    const double g[2] = {L[0] * px[j] + L[1] * py[j] - L[2], Rr[0] * px[j] + Rr[1] * py[j] - Rr[2]};
-    bar_accumulate(p, g, lall);
-  }
-  const double lcost = bar_group_value(p, lall);
-  out[0] = make_double2(jx, ju);
-  out[stride] = dyn;
-  out[2 * stride] = make_double2(ccost, lcost);
-}
-
-// discs as a run-time count (any num_of_disc != 5): same arithmetic, disc-major loops
-CILQR_DEV void knot_cost_generic(const DeviceState& s, const double* __restrict__ lanes, int i, int slot,
-                                 const double* x, const double* u, double2* __restrict__ out, size_t stride) {
-  const Params& p = s.p;
-  const int Bc = s.Bcap;
-  const double2* gp = s.goals + (size_t)i * 3 * Bc + slot;
-  const double2 g0 = gp[0];
-  const double gth = gp[(size_t)Bc].x;
-  const double ex = x[0] - g0.x, ey = x[1] - g0.y, eth = x[2] - gth;
-  const double jx = p.w_x * (ex * ex) + p.w_y * (ey * ey) + p.w_theta * (eth * eth);
-  const double ju = (i < p.N) ? p.w_jerk * (u[0] * u[0]) + p.w_delta_rate * (u[1] * u[1]) : 0.0;
-  const double2 dyn = knot_bound_cost(p, i, x, u);
-  double sn, cs;
-  lean_sincos(x[2], &sn, &cs);
-  const int cnt = s.ccnt[(size_t)i * Bc + slot];
-  const double* __restrict__ cor = s.cor + (size_t)i * s.cmax * 3 * Bc + slot;
-  BarGroup call, lall;
-  for (int j = 0; j < p.num_of_disc; ++j) {
-    const double px = x[0] + p.disc_off[j] * cs, py = x[1] + p.disc_off[j] * sn;
-    for (int c = 0; c < cnt; ++c) {
-      const double* q = cor + (size_t)c * 3 * Bc;
-      const double g[1] = {q[0] * px + q[(size_t)Bc] * py - q[(size_t)2 * Bc]};
-      bar_accumulate(p, g, call);
-      if ((c & 63) == 63) bar_renormalize(call);
-    }
-    bar_renormalize(call);
-    const double* L = lanes + nearest_segment(s, lanes, 0, px, py) * kLaneFields;
-    const double* Rr = lanes + (s.nl + nearest_segment(s, lanes, 1, px, py)) * kLaneFields;
-    const double g[2] = {L[0] * px + L[1] * py - L[2], Rr[0] * px + Rr[1] * py - Rr[2]};
-    bar_accumulate(p, g, lall);
-    bar_renormalize(lall);
-  }
-  out[0] = make_double2(jx, ju);
-  out[stride] = dyn;
-  out[2 * stride] = make_double2(bar_group_value(p, call), bar_group_value(p, lall));
-}
-
-CILQR_DEV void knot_cost_any(const DeviceState& s, const double* __restrict__ lanes, int i, int slot,
-                             const double* x, const double* u, double2* __restrict__ out, size_t stride) {
-  if (s.p.num_of_disc == 5) knot_cost_core<5>(s, lanes, i, slot, x, u, out, stride);
-  else knot_cost_generic(s, lanes, i, slot, x, u, out, stride);
-}
+#ifdef CILQR_COST_OCC
+#define CILQR_COST_ATTR __attribute__((amdgpu_waves_per_eu(CILQR_COST_OCC, CILQR_COST_OCC)))
+#else
+#define CILQR_COST_ATTR
+#endif
 
 // list == nullptr: slots 0..n-1.  skip_done: ignore slots that already left the iteration.
-__global__ __launch_bounds__(256) void k_cost_knots(DeviceState s, const int* __restrict__ list,
+__global__ __launch_bounds__(256) CILQR_COST_ATTR void k_cost_knots(DeviceState s, const int* __restrict__ list,
                                                     const int* __restrict__ n_ptr, int n_max, int cand,
                                                     int skip_done) {
   extern __shared__ double lds[];
@@ -227,7 +47,7 @@ __global__ __launch_bounds__(256) void k_cost_knots(DeviceState s, const int* __
 }
 
 // speculative line search: knot i of candidate alpha_{r0 + blockIdx.z} of list entry j
-__global__ __launch_bounds__(256) void k_spec_cost(DeviceState s, const int* __restrict__ list,
+__global__ __launch_bounds__(256) CILQR_COST_ATTR void k_spec_cost(DeviceState s, const int* __restrict__ list,
                                                    const int* __restrict__ n_ptr, int n_max, int r0) {
   extern __shared__ double lds[];
   const int n = n_ptr ? min(*n_ptr, n_max) : active_count(s, n_max);
@@ -249,14 +69,53 @@ __global__ __launch_bounds__(256) void k_spec_cost(DeviceState s, const int* __r
     knot_cost_any(s, lanes, i, slot, x, u, s.parts + ((size_t)r * s.p.K + i) * kPartPairs * cap + j, cap);
   }
 }
+// The same for a SPARSE list (the problems that rejected every sequential round: a few percent of the slots, in
+// no particular order).  With one lane per problem every load of a corridor plane, a goal or a grid cell then
+// touches a cache line of its own -- 64 lines per instruction where the dense kernels touch 8.  Here eight
+// consecutive lanes hold the (up to eight) remaining step sizes of ONE problem: what depends on the problem and the
+// knot only is read once per eight lanes (same address: one line), and only the candidate itself (3 + 1 pairs)
+// is read per lane.  Same arithmetic per (problem, step size, knot); measured 4.6x faster per knot cost.
+constexpr int kPackLanes = 8;
+__global__ __launch_bounds__(256) CILQR_COST_ATTR void k_spec_cost_packed(DeviceState s, const int* __restrict__ list,
+                                                                          const int* __restrict__ n_ptr, int n_max, int r0) {
+  extern __shared__ double lds[];
+  const int n = n_ptr ? min(*n_ptr, n_max) : active_count(s, n_max);
+  constexpr int per_block = 256 / kPackLanes;
+  if ((int)(blockIdx.x * per_block) >= n) return;
+  const double* lanes = stage_lanes(s, lds);
+  const int i = blockIdx.y, r = r0 + (threadIdx.x & (kPackLanes - 1));
+  const size_t cap = (size_t)s.spec_cap;
+  if (r >= kNumAlpha) return;
+  for (int j = blockIdx.x * per_block + threadIdx.x / kPackLanes; j < n; j += gridDim.x * per_block) {
+    const int slot = list[j];
+    if (s.acc_idx[slot] != -1) continue;   // left at the gradient-norm exit
+    const double2* xb = s.Xs + ((size_t)r * s.p.K + i) * 3 * cap + j;
+    const double2 p0 = xb[0], p1 = xb[cap], p2 = xb[2 * cap];
+    const double x[6] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y};
+    double u[2] = {0.0, 0.0};
+    if (i < s.p.N) {
+      const double2 q = s.Us[((size_t)r * s.p.N + i) * cap + j];
+      u[0] = q.x; u[1] = q.y;
+    }
+    knot_cost_any(s, lanes, i, slot, x, u, s.parts + ((size_t)r * s.p.K + i) * kPartPairs * cap + j, cap);
+  }
+}
+
+// sparse: the list is a small, unordered subset of the slots (see k_spec_cost_packed)
 void launch_spec_cost(const DeviceState& s, const int* list, const int* n_ptr, int n_max, int n_grid, int r0,
-                      hipStream_t st) {
+                      int sparse, hipStream_t st) {
+  if (sparse && kNumAlpha - r0 <= kPackLanes) {
+    constexpr int per_block = 256 / kPackLanes;
+    dim3 g((n_grid + per_block - 1) / per_block, s.p.K);
+    hipLaunchKernelGGL(k_spec_cost_packed, g, dim3(256), lane_lds_bytes(s), st, s, list, n_ptr, n_max, r0);
+    return;
+  }
   dim3 g((n_grid + 255) / 256, s.p.K, kNumAlpha - r0);
   hipLaunchKernelGGL(k_spec_cost, g, dim3(256), lane_lds_bytes(s), st, s, list, n_ptr, n_max, r0);
 }
 
 // knot i of candidate alpha_r of the problems pending in round r
-__global__ __launch_bounds__(256) void k_round_cost(DeviceState s, int r, int n_max) {
+__global__ __launch_bounds__(256) CILQR_COST_ATTR void k_round_cost(DeviceState s, int r, int n_max) {
   extern __shared__ double lds[];
   const int* __restrict__ list = s.pend + (size_t)r * s.Bcap;
   const int n = (r == 0) ? active_count(s, n_max) : min(s.counters[r], n_max);
@@ -324,231 +183,6 @@ __global__ void k_init_cost_commit(DeviceState s, int n) {
 void launch_init_cost_commit(const DeviceState& s, int n, hipStream_t st) {
   hipLaunchKernelGGL(k_init_cost_commit, dim3((n + 255) / 256), dim3(256), 0, st, s, n);
 }
-
-// ---------------------------------------------------------------------------------------------
-// quadratisation of knot i: A, B, lx, lu, lxx, luu (terminal knot: lx, lxx with u = 0)
-// ---------------------------------------------------------------------------------------------
-struct Quad {
-  double lx[6];
-  double lu[2];
-  double h[9];     // lxx rows/cols 0..2 (full 3x3; the reference block is not bitwise symmetric)
-  double hd[3];    // lxx(3,3), (4,4), (5,5)
-  double huu[2];   // luu(0,0), (1,1)
-};
-
-// One half-plane g = a x + b y - c seen from the discs of a knot, disc point (px, py) =
-// (x, y) + (lc, ls).  dg = (a, b, d2) with d2 = -a ls + b lc (cc:703), ddg(2,2) = -a lc - b ls
-// (cc:723-724).  a and b are the same for every disc, so the sums over the discs of
-//   jc dg            = (a T0, b T0, T1)
-//   c1 dg dg^T       = [a a S0, a b S0, a S1; . , b b S0, b S1; . , . , S2]
-//   c2 ddg           = W   (entry (2,2) only; c2 = 0 on the relaxed branch)
-// need five running sums per plane instead of a 3-vector and a 3x3 update per (plane, disc).
-// This re-associates the reference's accumulation (and makes the 3x3 block exactly symmetric,
-// which the reference's is only to rounding).
-struct PlaneSums {
-  double T0 = 0.0, T1 = 0.0, S0 = 0.0, S1 = 0.0, S2 = 0.0, W = 0.0;
-};
-CILQR_DEV void plane_disc(const Params& p, double a, double b, double c, double px, double py, double lc,
-                          double ls, PlaneSums& m) {
-  const double g = a * px + b * py - c;
-  const double d2 = -a * ls + b * lc;
-  const double dd22 = -a * lc - b * ls;
-  double jc, c1, c2;
-  bool lg;
-  bar_coefs(p, g, jc, c1, c2, lg);
-  m.T0 += jc;
-  m.T1 += jc * d2;
-  m.S0 += c1;
-  const double t = c1 * d2;
-  m.S1 += t;
-  m.S2 += t * d2;
-  m.W += c2 * dd22;
-}
-CILQR_DEV void plane_commit(Quad& q, double a, double b, const PlaneSums& m) {
-  q.lx[0] += a * m.T0;
-  q.lx[1] += b * m.T0;
-  q.lx[2] += m.T1;
-  const double aS = a * m.S0, bS = b * m.S0;
-  const double h01 = aS * b, h02 = a * m.S1, h12 = b * m.S1;
-  q.h[0] += aS * a; q.h[1] += h01; q.h[2] += h02;
-  q.h[3] += h01; q.h[4] += bS * b; q.h[5] += h12;
-  q.h[6] += h02; q.h[7] += h12; q.h[8] += m.S2 - m.W;
-}
-
-template <int D>
-CILQR_DEV void knot_quadratize(const DeviceState& s, const double* __restrict__ lanes, int buf, int i, int slot) {
-  const Params& p = s.p;
-  const int Bc = s.Bcap;
-  const bool term = (i == p.N);
-  const int nd = (D > 0) ? D : p.num_of_disc;
-  double x[6], u[2] = {0.0, 0.0};
-  load_x(s, buf, i, slot, x);
-  if (!term) load_u(s, buf, i, slot, u);
-  const double2* gp = s.goals + (size_t)i * 3 * Bc + slot;
-  const double2 g0 = gp[0];
-  const double gth = gp[(size_t)Bc].x;
-  const double* __restrict__ cor = s.cor + (size_t)i * s.cmax * 3 * Bc + slot;
-  PlaneChunk pc;
-  load_first_chunk(cor, Bc, s.cmax, pc);
-  const int cnt = s.ccnt[(size_t)i * Bc + slot];
-  mask_first_chunk(cnt, pc);
-  Quad q;
-  q.lx[0] = 2.0 * p.w_x * (x[0] - g0.x);           // cc:623-628
-  q.lx[1] = 2.0 * p.w_y * (x[1] - g0.y);
-  q.lx[2] = 2.0 * p.w_theta * (x[2] - gth);
-  q.lx[3] = 0.0; q.lx[4] = 0.0; q.lx[5] = 0.0;
-  q.lu[0] = 2.0 * p.w_jerk * u[0];                 // cc:630-631
-  q.lu[1] = 2.0 * p.w_delta_rate * u[1];
-#pragma unroll
-  for (int e = 0; e < 9; ++e) q.h[e] = 0.0;
-  q.h[0] = 2.0 * p.w_x; q.h[4] = 2.0 * p.w_y; q.h[8] = 2.0 * p.w_theta;   // cc:642-647
-  q.hd[0] = 2.0 * p.w_v; q.hd[1] = 2.0 * p.w_a; q.hd[2] = 2.0 * p.w_delta;
-  q.huu[0] = 2.0 * p.w_jerk; q.huu[1] = 2.0 * p.w_delta_rate;             // cc:649-650
-  // state / control bounds (cc:657-688): lower bound first, the pair is summed, then added
-  {
-    const double gl[3] = {0.0 - x[3], p.min_acc - x[4], p.delta_min - x[5]};
-    const double gh[3] = {x[3] - p.max_velocity, x[4] - p.max_acc, x[5] - p.delta_max};
-#pragma unroll
-    for (int e = 0; e < 3; ++e) {
-      double jl, jh, c1l, c1h, c2;
-      bool lg;
-      bar_coefs(p, gl[e], jl, c1l, c2, lg);
-      bar_coefs(p, gh[e], jh, c1h, c2, lg);
-      q.lx[3 + e] += jl * -1.0 + jh * 1.0;
-      q.hd[e] += c1l + c1h;
-    }
-    const double ul[2] = {p.jerk_min - u[0], p.delta_rate_min - u[1]};
-    const double uh[2] = {u[0] - p.jerk_max, u[1] - p.delta_rate_max};
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      double jl, jh, c1l, c1h, c2;
-      bool lg;
-      bar_coefs(p, ul[e], jl, c1l, c2, lg);
-      bar_coefs(p, uh[e], jh, c1h, c2, lg);
-      q.lu[e] += jl * -1.0 + jh * 1.0;
-      q.huu[e] += c1l + c1h;
-    }
-  }
-  double sn, cs;
-  lean_sincos(x[2], &sn, &cs);
-  // corridor planes x discs (cc:690-727); planes outer (each read once), discs inner
-  for (int c0 = 0; c0 < cnt; c0 += kPlaneChunk) {
-    PlaneChunk nx;
-    if (c0 + kPlaneChunk < cnt) load_chunk(cor, Bc, c0 + kPlaneChunk, cnt, nx);
-#pragma unroll
-    for (int k = 0; k < kPlaneChunk; ++k) {
-      PlaneSums m;
-      if constexpr (D > 0) {
-#pragma unroll
-        for (int j = 0; j < D; ++j) {
-          const double lc = p.disc_off[j] * cs, ls = p.disc_off[j] * sn;
-          plane_disc(p, pc.a[k], pc.b[k], pc.c[k], x[0] + lc, x[1] + ls, lc, ls, m);
-        }
-      } else {
-#pragma unroll 1
-        for (int j = 0; j < nd; ++j) {
-          const double lc = p.disc_off[j] * cs, ls = p.disc_off[j] * sn;
-          plane_disc(p, pc.a[k], pc.b[k], pc.c[k], x[0] + lc, x[1] + ls, lc, ls, m);
-        }
-      }
-      plane_commit(q, pc.a[k], pc.b[k], m);
-    }
-    pc = nx;
-  }
-  // nearest left / right lane plane, all discs (cc:729-769)
-#pragma unroll 1
-  for (int j = 0; j < nd; ++j) {
-    const double lcj = p.disc_off[j] * cs, lsj = p.disc_off[j] * sn;
-    const double px = x[0] + lcj, py = x[1] + lsj;
-    const double* L = lanes + nearest_segment(s, lanes, 0, px, py) * kLaneFields;
-    PlaneSums ml, mr;
-    plane_disc(p, L[0], L[1], L[2], px, py, lcj, lsj, ml);
-    plane_commit(q, L[0], L[1], ml);
-    const double* Rr = lanes + (s.nl + nearest_segment(s, lanes, 1, px, py)) * kLaneFields;
-    plane_disc(p, Rr[0], Rr[1], Rr[2], px, py, lcj, lsj, mr);
-    plane_commit(q, Rr[0], Rr[1], mr);
-  }
-  if (term) {
-    double2* o = s.term + slot;
-    o[0] = make_double2(q.lx[0], q.lx[1]);
-    o[(size_t)Bc] = make_double2(q.lx[2], q.lx[3]);
-    o[(size_t)2 * Bc] = make_double2(q.lx[4], q.lx[5]);
-    o[(size_t)3 * Bc] = make_double2(q.h[0], q.h[1]);
-    o[(size_t)4 * Bc] = make_double2(q.h[2], q.h[3]);
-    o[(size_t)5 * Bc] = make_double2(q.h[4], q.h[5]);
-    o[(size_t)6 * Bc] = make_double2(q.h[6], q.h[7]);
-    o[(size_t)7 * Bc] = make_double2(q.h[8], q.hd[0]);
-    o[(size_t)8 * Bc] = make_double2(q.hd[1], q.hd[2]);
-    return;
-  }
-  DynJac J;
-  dynamics_jacobian(p, x, u, J);
-  double2* o = s.lin + (size_t)i * kLinPairs * Bc + slot;
-  o[(size_t)0 * Bc] = make_double2(J.a02, J.a03);
-  o[(size_t)1 * Bc] = make_double2(J.a04, J.a05);
-  o[(size_t)2 * Bc] = make_double2(J.a12, J.a13);
-  o[(size_t)3 * Bc] = make_double2(J.a14, J.a15);
-  o[(size_t)4 * Bc] = make_double2(J.a23, J.a24);
-  o[(size_t)5 * Bc] = make_double2(J.a25, J.b21);
-  o[(size_t)6 * Bc] = make_double2(q.lx[0], q.lx[1]);
-  o[(size_t)7 * Bc] = make_double2(q.lx[2], q.lx[3]);
-  o[(size_t)8 * Bc] = make_double2(q.lx[4], q.lx[5]);
-  o[(size_t)9 * Bc] = make_double2(q.lu[0], q.lu[1]);
-  o[(size_t)10 * Bc] = make_double2(q.h[0], q.h[1]);
-  o[(size_t)11 * Bc] = make_double2(q.h[2], q.h[3]);
-  o[(size_t)12 * Bc] = make_double2(q.h[4], q.h[5]);
-  o[(size_t)13 * Bc] = make_double2(q.h[6], q.h[7]);
-  o[(size_t)14 * Bc] = make_double2(q.h[8], q.hd[0]);
-  o[(size_t)15 * Bc] = make_double2(q.hd[1], q.hd[2]);
-  o[(size_t)16 * Bc] = make_double2(q.huu[0], q.huu[1]);
-}
-
-#ifdef CILQR_REF_ORDER
-// test-only: the knot's quadratisation in the reference's operation order (ref_order.hpp), same storage layout
-CILQR_DEV void knot_quadratize_ref(const DeviceState& s, int buf, int i, int slot) {
-  const Params& p = s.p;
-  const int Bc = s.Bcap;
-  const bool term = (i == p.N);
-  double x[6], u[2] = {0.0, 0.0};
-  load_x(s, buf, i, slot, x);
-  if (!term) load_u(s, buf, i, slot, u);
-  Quad q;
-  reforder::knot_quadratize(s, i, slot, x, u, q.lx, q.lu, q.h, q.hd, q.huu);
-  if (term) {
-    double2* o = s.term + slot;
-    o[0] = make_double2(q.lx[0], q.lx[1]);
-    o[(size_t)Bc] = make_double2(q.lx[2], q.lx[3]);
-    o[(size_t)2 * Bc] = make_double2(q.lx[4], q.lx[5]);
-    o[(size_t)3 * Bc] = make_double2(q.h[0], q.h[1]);
-    o[(size_t)4 * Bc] = make_double2(q.h[2], q.h[3]);
-    o[(size_t)5 * Bc] = make_double2(q.h[4], q.h[5]);
-    o[(size_t)6 * Bc] = make_double2(q.h[6], q.h[7]);
-    o[(size_t)7 * Bc] = make_double2(q.h[8], q.hd[0]);
-    o[(size_t)8 * Bc] = make_double2(q.hd[1], q.hd[2]);
-    return;
-  }
-  DynJac J;
-  dynamics_jacobian(p, x, u, J);
-  double2* o = s.lin + (size_t)i * kLinPairs * Bc + slot;
-  o[(size_t)0 * Bc] = make_double2(J.a02, J.a03);
-  o[(size_t)1 * Bc] = make_double2(J.a04, J.a05);
-  o[(size_t)2 * Bc] = make_double2(J.a12, J.a13);
-  o[(size_t)3 * Bc] = make_double2(J.a14, J.a15);
-  o[(size_t)4 * Bc] = make_double2(J.a23, J.a24);
-  o[(size_t)5 * Bc] = make_double2(J.a25, J.b21);
-  o[(size_t)6 * Bc] = make_double2(q.lx[0], q.lx[1]);
-  o[(size_t)7 * Bc] = make_double2(q.lx[2], q.lx[3]);
-  o[(size_t)8 * Bc] = make_double2(q.lx[4], q.lx[5]);
-  o[(size_t)9 * Bc] = make_double2(q.lu[0], q.lu[1]);
-  o[(size_t)10 * Bc] = make_double2(q.h[0], q.h[1]);
-  o[(size_t)11 * Bc] = make_double2(q.h[2], q.h[3]);
-  o[(size_t)12 * Bc] = make_double2(q.h[4], q.h[5]);
-  o[(size_t)13 * Bc] = make_double2(q.h[6], q.h[7]);
-  o[(size_t)14 * Bc] = make_double2(q.h[8], q.hd[0]);
-  o[(size_t)15 * Bc] = make_double2(q.hd[1], q.hd[2]);
-  o[(size_t)16 * Bc] = make_double2(q.huu[0], q.huu[1]);
-}
-#endif
 
 __global__ __launch_bounds__(256) void k_quadratize(DeviceState s, const int* __restrict__ list, int n,
                                                     int only_upd) {

@@ -11,179 +11,9 @@
 //   [reduce + accept test, or roll out alpha_{r+1} and join pending list r+1] -> cost -> ...
 // The first passing list index wins, as in the sequential loop.  Pending lists are compacted
 // with wave-aggregated atomics; their order only affects coalescing, never results.
-#include "cost_reduce.hpp"
+#include "search_core.hpp"
 
 namespace cilqr {
-
-__device__ const double kAlpha[kNumAlpha] = {1.0000, 0.5012, 0.2512, 0.1259, 0.0631, 0.0316,
-                                             0.0158, 0.0079, 0.0040, 0.0020, 0.0010};
-
-
-// where a rollout is written: the slot's candidate buffer, or the speculative arena
-struct OutSlot {
-  const DeviceState& s;
-  int nb, slot;
-  CILQR_DEV void x(int i, const double* v) const { store_x(s, nb, i, slot, v); }
-  CILQR_DEV void u(int i, const double* v) const { store_u(s, nb, i, slot, v); }
-};
-struct OutSpec {
-  const DeviceState& s;
-  int r, j;
-  CILQR_DEV void x(int i, const double* v) const {
-    const size_t cap = (size_t)s.spec_cap;
-    double2* b = s.Xs + ((size_t)r * s.p.K + i) * 3 * cap + j;
-    b[0] = make_double2(v[0], v[1]);
-    b[cap] = make_double2(v[2], v[3]);
-    b[2 * cap] = make_double2(v[4], v[5]);
-  }
-  CILQR_DEV void u(int i, const double* v) const {
-    s.Us[((size_t)r * s.p.N + i) * (size_t)s.spec_cap + j] = make_double2(v[0], v[1]);
-  }
-};
-
-// what step i of a rollout reads: nominal state / control and the gains K_i, k_i
-constexpr int kFwdAhead = 4;
-struct FwdStep {
-  double2 x0, x1, x2, u, kk[kGainPairs];
-};
-CILQR_DEV void load_fwd_step(const DeviceState& s, int buf, int i, int slot, FwdStep& f) {
-  const int Bc = s.Bcap;
-  const double2* b = s.X + ((size_t)buf * s.p.K + i) * 3 * Bc + slot;
-  f.x0 = b[0]; f.x1 = b[(size_t)Bc]; f.x2 = b[(size_t)2 * Bc];
-  f.u = s.U[((size_t)buf * s.p.N + i) * Bc + slot];
-  const double2* g = s.gains + (size_t)i * kGainPairs * Bc + slot;
-#pragma unroll
-  for (int r = 0; r < kGainPairs; ++r) f.kk[r] = g[(size_t)r * Bc];
-}
-
-// roll the closed-loop policy out from goals_[0] (cc:392-415)
-template <class Out>
-CILQR_DEV void forward_core(const DeviceState& s, int slot, double alpha, const Out& out) {
-  const Params& p = s.p;
-  const int Bc = s.Bcap, N = p.N;
-  const int buf = s.cur[slot];
-  double x[6];
-  {
-    const double2* gp = s.goals + slot;
-    const double2 g0 = gp[0], g1 = gp[(size_t)Bc], g2 = gp[(size_t)2 * Bc];
-    x[0] = g0.x; x[1] = g0.y; x[2] = g1.x; x[3] = g1.y; x[4] = g2.x; x[5] = g2.y;
-  }
-  out.x(0, x);
-  // The nominal (xs, us) and the gains of a step do not depend on the rollout, and one lane's step
-  // is short (~0.5 us of arithmetic) against the latency of a load that misses L2 (the gains were
-  // just written by another kernel): keep the loads of the next kFwdAhead steps in flight.
-  FwdStep pf[kFwdAhead];
-#pragma unroll
-  for (int d = 0; d < kFwdAhead; ++d)
-    if (d < N) load_fwd_step(s, buf, d, slot, pf[d]);
-  for (int i0 = 0; i0 < N; i0 += kFwdAhead) {
-#pragma unroll
-    for (int d = 0; d < kFwdAhead; ++d) {
-      const int i = i0 + d;
-      if (i < N) {
-        const FwdStep c = pf[d];
-        if (i + kFwdAhead < N) load_fwd_step(s, buf, i + kFwdAhead, slot, pf[d]);
-        const double xs[6] = {c.x0.x, c.x0.y, c.x1.x, c.x1.y, c.x2.x, c.x2.y};
-        const double us[2] = {c.u.x, c.u.y};
-        double dx[6];
-#pragma unroll
-        for (int e = 0; e < 6; ++e) dx[e] = x[e] - xs[e];
-        double u[2];
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-          double acc = c.kk[r * 3].x * dx[0];
-          acc += c.kk[r * 3].y * dx[1];
-          acc += c.kk[r * 3 + 1].x * dx[2];
-          acc += c.kk[r * 3 + 1].y * dx[3];
-          acc += c.kk[r * 3 + 2].x * dx[4];
-          acc += c.kk[r * 3 + 2].y * dx[5];
-          const double kff = (r == 0) ? c.kk[6].x : c.kk[6].y;
-          u[r] = (us[r] + acc) + alpha * kff;                           // cc:407
-        }
-        u[1] = normalize_angle(u[1]);                                     // cc:408
-        out.u(i, u);
-        dynamics(p, x, u, x);
-        out.x(i + 1, x);
-      }
-    }
-  }
-}
-CILQR_DEV void forward_problem(const DeviceState& s, int slot, double alpha) {
-  forward_core(s, slot, alpha, OutSlot{s, s.cur[slot] ^ 1, slot});
-}
-
-// G rollouts of one problem at once (alpha_0 .. alpha_{G-1}) into the speculative arena at list
-// position j: the nominal trajectory and the gains of a step are loaded once for all of them, and
-// the G dynamics chains are independent, which fills the latency of each other.  Same arithmetic
-// per rollout as forward_core.
-template <int G>
-CILQR_DEV void forward_multi(const DeviceState& s, int slot, int j) {
-  const Params& p = s.p;
-  const int Bc = s.Bcap, N = p.N;
-  const int buf = s.cur[slot];
-  double x[G][6];
-  {
-    const double2* gp = s.goals + slot;
-    const double2 g0 = gp[0], g1 = gp[(size_t)Bc], g2 = gp[(size_t)2 * Bc];
-#pragma unroll
-    for (int r = 0; r < G; ++r) {
-      x[r][0] = g0.x; x[r][1] = g0.y; x[r][2] = g1.x; x[r][3] = g1.y; x[r][4] = g2.x; x[r][5] = g2.y;
-      OutSpec{s, r, j}.x(0, x[r]);
-    }
-  }
-  FwdStep pf[kFwdAhead];
-#pragma unroll
-  for (int d = 0; d < kFwdAhead; ++d)
-    if (d < N) load_fwd_step(s, buf, d, slot, pf[d]);
-  for (int i0 = 0; i0 < N; i0 += kFwdAhead) {
-#pragma unroll
-    for (int d = 0; d < kFwdAhead; ++d) {
-      const int i = i0 + d;
-      if (i < N) {
-        const FwdStep c = pf[d];
-        if (i + kFwdAhead < N) load_fwd_step(s, buf, i + kFwdAhead, slot, pf[d]);
-        const double xs[6] = {c.x0.x, c.x0.y, c.x1.x, c.x1.y, c.x2.x, c.x2.y};
-        const double us[2] = {c.u.x, c.u.y};
-#pragma unroll
-        for (int r = 0; r < G; ++r) {
-          double dx[6];
-#pragma unroll
-          for (int e = 0; e < 6; ++e) dx[e] = x[r][e] - xs[e];
-          double u[2];
-#pragma unroll
-          for (int q = 0; q < 2; ++q) {
-            double acc = c.kk[q * 3].x * dx[0];
-            acc += c.kk[q * 3].y * dx[1];
-            acc += c.kk[q * 3 + 1].x * dx[2];
-            acc += c.kk[q * 3 + 1].y * dx[3];
-            acc += c.kk[q * 3 + 2].x * dx[4];
-            acc += c.kk[q * 3 + 2].y * dx[5];
-            const double kff = (q == 0) ? c.kk[6].x : c.kk[6].y;
-            u[q] = (us[q] + acc) + kAlpha[r] * kff;                         // cc:407
-          }
-          u[1] = normalize_angle(u[1]);                                     // cc:408
-          const OutSpec out{s, r, j};
-          out.u(i, u);
-          dynamics(p, x[r], u, x[r]);
-          out.x(i + 1, x[r]);
-        }
-      }
-    }
-  }
-}
-
-// Leaves the iteration before the line search (acc_idx = -2 must then be set by ONE lane of the
-// problem): gradient-norm exit (cc:235-241), or a problem that was never admissible (a knot without
-// corridor, status 6 -- the reference aborts such a Plan before Optimize, corridor.cc:78-81).
-CILQR_DEV bool leaves_before_search(const DeviceState& s, int slot, bool write) {
-  const int pb = s.pid[slot];
-  if (s.status[pb] == 6) return true;
-  if (s.gnorm[slot] < 1e-6 && s.lambda[slot] < 1e-5) {   // cc:235-241
-    if (write) s.status[pb] = 3;   // CILQR_ST_GNORM
-    return true;
-  }
-  return false;
-}
 
 // stage API: plain rollout of the listed slots with one alpha
 __global__ __launch_bounds__(64) void k_forward(DeviceState s, const int* __restrict__ list, int n,
@@ -245,6 +75,21 @@ __global__ __launch_bounds__(64) void k_search_round(DeviceState s, int r, int n
 // Used for the whole line search of small active sets (r0 = 0, list = active list, `open` = also
 // take the gradient-norm exit) and for the tail of the round-by-round search (r0 = number of
 // sequential rounds done, list = the problems that rejected all of them).
+// rollouts of a SPARSE list: eight consecutive lanes hold the remaining step sizes of one problem, so the nominal
+// trajectory and the gains of a step (11 pairs, the same for every step size) are read once per eight lanes
+// (see k_spec_cost_packed in kernels_quad.hip)
+__global__ __launch_bounds__(64) void k_spec_forward_packed(DeviceState s, const int* __restrict__ list,
+                                                            const int* __restrict__ n_ptr, int n_max, int r0) {
+  const int n = n_ptr ? min(*n_ptr, n_max) : active_count(s, n_max);
+  constexpr int per_block = 64 / 8;
+  const int r = r0 + (threadIdx.x & 7);
+  if (r >= kNumAlpha) return;
+  for (int j = blockIdx.x * per_block + threadIdx.x / 8; j < n; j += gridDim.x * per_block) {
+    const int slot = list[j];
+    forward_core(s, slot, kAlpha[r], OutSpec{s, r, j});
+  }
+}
+
 __global__ __launch_bounds__(64) void k_spec_forward(DeviceState s, const int* __restrict__ list,
                                                      const int* __restrict__ n_ptr, int n_max, int r0, int open) {
   const int n = n_ptr ? min(*n_ptr, n_max) : active_count(s, n_max);
@@ -464,8 +309,13 @@ __global__ __launch_bounds__(256) void k_multi_copy(DeviceState s, int n_max, in
 static void launch_spec(const DeviceState& s, const int* list, const int* n_ptr, int n_max, int n_grid, int r0,
                         int open, hipStream_t st) {
   const int na = kNumAlpha - r0;
-  hipLaunchKernelGGL(k_spec_forward, dim3((n_grid + 63) / 64, na), dim3(64), 0, st, s, list, n_ptr, n_max, r0, open);
-  launch_spec_cost(s, list, n_ptr, n_max, n_grid, r0, st);
+  // the pending list of the hybrid schedule is sparse and unordered: packed kernels (eight lanes per problem)
+  const int sparse = (!open && na <= 8) ? 1 : 0;
+  if (sparse)
+    hipLaunchKernelGGL(k_spec_forward_packed, dim3((n_grid + 7) / 8), dim3(64), 0, st, s, list, n_ptr, n_max, r0);
+  else
+    hipLaunchKernelGGL(k_spec_forward, dim3((n_grid + 63) / 64, na), dim3(64), 0, st, s, list, n_ptr, n_max, r0, open);
+  launch_spec_cost(s, list, n_ptr, n_max, n_grid, r0, sparse, st);
   hipLaunchKernelGGL(k_spec_reduce, dim3((n_grid + 63) / 64, na), dim3(64), 0, st, s, list, n_ptr, n_max, r0, open);
   hipLaunchKernelGGL(k_spec_pick, dim3((n_grid + 63) / 64), dim3(64), 0, st, s, list, n_ptr, n_max, r0);
   hipLaunchKernelGGL(k_spec_copy, dim3((n_grid + 255) / 256, s.p.K), dim3(256), 0, st, s, list, n_ptr, n_max, r0);
@@ -555,60 +405,7 @@ CILQR_DEV void update_epilogue(const DeviceState& s) {
 
 CILQR_DEV void update_problem(const DeviceState& s, int j) {
   const int slot = s.act[j];
-  const int pb = s.pid[slot];
-  const Params& p = s.p;
-  bool done = false;
-  int st = s.status[pb];
-  s.emit[slot] = 0;
-  const int it0 = s.iter[pb];
-  if (st == 3 || st == 6) {
-    done = true;
-    s.atrace[(size_t)it0 * s.Bcap + pb] = (signed char)-2;
-  } else {
-    const int a = s.acc_idx[slot];
-    s.atrace[(size_t)it0 * s.Bcap + pb] = (signed char)a;
-    const double lam = s.lambda[slot], dl = s.dlambda[slot];
-    if (a >= 0) {
-      const double ndl = fmin(dl / 1.6, 1.0 / 1.6);                                // cc:273
-      s.dlambda[slot] = ndl;
-      s.lambda[slot] = lam * ndl * ((lam > 1e-8) ? 1.0 : 0.0);                     // cc:275
-      s.upd[slot] = 1;
-      const double dc = s.dcost[slot], co = s.cost_old[slot];
-      const int nc = s.n_cost[pb];
-#pragma unroll
-      for (int c = 0; c < 5; ++c)
-        s.hist[((size_t)nc * 5 + c) * s.Bcap + pb] = s.trial[(size_t)c * s.Bcap + slot];
-      s.n_cost[pb] = nc + 1;
-      if (dc < p.abs_tol || dc / co < p.rel_tol) {                                 // cc:281-293
-        st = (dc < p.abs_tol) ? 1 : 2;
-        done = true;
-      } else {
-        s.n_iter_trajs[pb] += 1;                                                   // cc:294
-        s.emit[slot] = 1;
-        s.cost_old[slot] = s.trial[slot];                                          // cc:295
-      }
-    } else {
-      const double ndl = fmax(dl * 1.6, 1.6);                                      // cc:298
-      const double nl = fmax(lam * ndl, 1e-8);                                     // cc:299
-      s.dlambda[slot] = ndl;
-      s.lambda[slot] = nl;
-      s.upd[slot] = 0;
-      if (nl > 1e11) {                                                             // cc:302
-        st = 4;
-        done = true;
-      }
-    }
-  }
-  const int it = it0 + 1;
-  s.iter[pb] = it;
-  if (!done && it >= p.max_iter) {                                                 // cc:312
-    st = 5;
-    done = true;
-  }
-  s.status[pb] = st;
-  s.acc_idx[slot] = -1;
-  s.done_now[slot] = done ? 1 : 0;
-  if (!done) {
+  if (!update_state(s, s, slot)) {
     const int pos = atomicAdd(s.n_next, 1);
     s.act_next[pos] = slot;
   }

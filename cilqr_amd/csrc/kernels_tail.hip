@@ -1,0 +1,301 @@
+// Tail of a batch: one workgroup per problem runs ALL remaining iterations of Optimize() in one launch.
+//
+// Reference behaviour: the body of the loop of IlqrOptimizer::Optimize (algorithm/ilqr/ilqr_optimizer.cc:201-319):
+// quadratisation cc:203-214, Backward cc:218, gradient-norm exit cc:235-241, the 11-step line search cc:243-270,
+// regularisation schedule and exits cc:272-308, iteration cap cc:312-319.
+//
+// Why.  After ~30 lockstep iterations under 2 % of a batch is still iterating and stays so for up to 70 more
+// iterations (the stragglers are the problems whose iteration is chaotic).  A lockstep iteration over a few hundred
+// problems is nine launches that each sit on a chain of dependent work (50 backward steps, 50 rollout steps) with
+// the GPU otherwise idle: ~255 us per iteration, a quarter of a solve.  Here a problem's iterations follow each
+// other inside one kernel: no launches, no bookkeeping kernels between the phases, and a problem that converges
+// leaves at once instead of waiting for the slowest one of its iteration.
+//
+// Same arithmetic.  Every phase calls the device function the lockstep kernels call (knot_quadratize,
+// backward_team_problem, forward_core, knot_cost_any, update_state) on a view of the state in which the problem is
+// the only one: the block copies its problem's working set into a private, contiguous arena and runs the functions
+// with Bcap = 1, slot = 0.  Results are bit-identical to the lockstep path (tested with the tail switched off).
+//
+// Phases of one iteration (256 threads; `|` = __syncthreads):
+//   quadratize, one knot per thread | backward, 8 lanes of wave 0 | exit test | rollouts of all 11 step sizes,
+//   11 lanes | knot costs of alpha_0..4 (5 K items over the block) | totals, 5 lanes | first passing index;
+//   only if none: alpha_5..9, then alpha_10 | the winner becomes the iterate | update_state | exports.
+// The first passing list index wins whatever the evaluation order (cc:246-265), so evaluating the candidates in
+// chunks of five and stopping at the first chunk with a winner gives the sequential loop's answer.
+#include "backward_core.hpp"
+#include "quad_core.hpp"
+#include "search_core.hpp"
+
+namespace cilqr {
+
+constexpr int kTailThreads = 256;
+constexpr int kTailChunk = 5;   // step sizes costed together: 5 x 51 knots = 255 items for 256 threads
+
+// byte offsets of the tensors inside one block's private arena
+struct TailLayout {
+  size_t X, U, goals, cor, ccnt, lin, term, gains, Xs, Us, parts, spec_tot, dbl, ints, stride;
+};
+struct TailArgs {
+  char* ws;
+  TailLayout L;
+  double* traj;
+  double* iter_trajs;
+  int it_cap;
+  int* max_iter;   // host-visible: largest iteration count a problem of the tail reached
+};
+
+static TailLayout tail_layout(const DeviceState& s) {
+  const size_t K = s.p.K, N = s.p.N;
+  TailLayout L;
+  size_t o = 0;
+  auto take = [&](size_t bytes) {
+    const size_t at = o;
+    o += (bytes + 15) / 16 * 16;
+    return at;
+  };
+  L.X = take(2 * K * 3 * sizeof(double2));
+  L.U = take(2 * N * sizeof(double2));
+  L.goals = take(K * 3 * sizeof(double2));
+  L.cor = take(K * s.cmax * 3 * sizeof(double));
+  L.ccnt = take(K * sizeof(int));
+  L.lin = take(N * kLinPairs * sizeof(double2));
+  L.term = take(kTermPairs * sizeof(double2));
+  L.gains = take(N * kGainPairs * sizeof(double2));
+  L.Xs = take((size_t)kNumAlpha * K * 3 * sizeof(double2));
+  L.Us = take((size_t)kNumAlpha * N * sizeof(double2));
+  L.parts = take((size_t)kNumAlpha * K * kPartPairs * sizeof(double2));
+  L.spec_tot = take((size_t)kNumAlpha * 5 * sizeof(double));
+  L.dbl = take(16 * sizeof(double));   // dV[2] gnorm trial[5] lambda dlambda cost_old dcost
+  L.ints = take(8 * sizeof(int));      // cur pid done_now upd acc_idx emit
+  L.stride = (o + 255) / 256 * 256;
+  return L;
+}
+size_t tail_workspace_bytes(const DeviceState& s) { return tail_layout(s).stride; }
+
+// the state as the problem of block `blk` sees it: itself in slot 0 of an arena of capacity 1
+CILQR_DEV DeviceState tail_view(const DeviceState& g, const TailArgs& a, int blk) {
+  DeviceState t = g;
+  char* p = a.ws + (size_t)blk * a.L.stride;
+  t.Bcap = 1;
+  t.spec_cap = 1;
+  t.X = reinterpret_cast<double2*>(p + a.L.X);
+  t.U = reinterpret_cast<double2*>(p + a.L.U);
+  t.goals = reinterpret_cast<double2*>(p + a.L.goals);
+  t.cor = reinterpret_cast<double*>(p + a.L.cor);
+  t.ccnt = reinterpret_cast<int*>(p + a.L.ccnt);
+  t.lin = reinterpret_cast<double2*>(p + a.L.lin);
+  t.term = reinterpret_cast<double2*>(p + a.L.term);
+  t.gains = reinterpret_cast<double2*>(p + a.L.gains);
+  t.Xs = reinterpret_cast<double2*>(p + a.L.Xs);
+  t.Us = reinterpret_cast<double2*>(p + a.L.Us);
+  t.parts = reinterpret_cast<double2*>(p + a.L.parts);
+  t.spec_tot = reinterpret_cast<double*>(p + a.L.spec_tot);
+  double* d = reinterpret_cast<double*>(p + a.L.dbl);
+  t.dV = d;            // [2]
+  t.gnorm = d + 2;
+  t.trial = d + 3;     // [5]
+  t.lambda = d + 8;
+  t.dlambda = d + 9;
+  t.cost_old = d + 10;
+  t.dcost = d + 11;
+  int* q = reinterpret_cast<int*>(p + a.L.ints);
+  t.cur = q;
+  t.pid = q + 1;
+  t.done_now = q + 2;
+  t.upd = q + 3;
+  t.acc_idx = q + 4;
+  t.emit = q + 5;
+  t.part = nullptr;    // the tail costs candidates only (parts)
+  t.n_dev = nullptr;
+  return t;
+}
+
+template <int D>
+__global__ __launch_bounds__(kTailThreads) void k_tail(DeviceState g, TailArgs a, int n_max) {
+  extern __shared__ double lds[];
+  const int n = active_count(g, n_max);
+  const int blk = blockIdx.x;
+  if (blk >= n) return;
+  const int tid = threadIdx.x;
+  const double* lanes = stage_lanes(g, lds);
+  double* T = lds + ((g.nl + g.nr) * kLaneFields + 1) / 2 * 2;   // team scratch of the backward pass
+  double* tot = T + team::kStride;                               // [11][5] candidate totals
+  int* flag = reinterpret_cast<int*>(tot + kNumAlpha * 5);       // [0] leaves before the search [1] accepted index [2] done
+  const DeviceState t = tail_view(g, a, blk);
+  const int K = g.p.K, N = g.p.N;
+  const size_t Bc = (size_t)g.Bcap;
+
+  {  // working set of the problem -> private arena (what k_compact moves, same rules: iterate into buffer 0, upd = 1)
+    const int src = g.act[blk];
+    const int buf = g.cur[src];
+    for (int i = tid; i < K; i += kTailThreads) {
+      const double2* x = g.X + ((size_t)buf * K + i) * 3 * Bc + src;
+      t.X[i * 3 + 0] = x[0];
+      t.X[i * 3 + 1] = x[Bc];
+      t.X[i * 3 + 2] = x[2 * Bc];
+      if (i < N) t.U[i] = g.U[((size_t)buf * N + i) * Bc + src];
+      const double2* gg = g.goals + (size_t)i * 3 * Bc + src;
+      t.goals[i * 3 + 0] = gg[0];
+      t.goals[i * 3 + 1] = gg[Bc];
+      t.goals[i * 3 + 2] = gg[2 * Bc];
+      t.ccnt[i] = g.ccnt[(size_t)i * Bc + src];
+    }
+    const int rows = g.cmax * 3;
+    for (int e = tid; e < K * rows; e += kTailThreads) {
+      const int i = e / rows, r = e - i * rows;
+      if (r < g.ccnt[(size_t)i * Bc + src] * 3) t.cor[e] = g.cor[((size_t)i * rows + r) * Bc + src];
+    }
+    if (tid == 0) {
+      t.cur[0] = 0;
+      t.pid[0] = g.pid[src];
+      t.lambda[0] = g.lambda[src];
+      t.dlambda[0] = g.dlambda[src];
+      t.cost_old[0] = g.cost_old[src];
+      t.dcost[0] = g.dcost[src];
+      t.upd[0] = 1;
+      t.acc_idx[0] = -1;
+      t.emit[0] = 0;
+      t.done_now[0] = 0;
+    }
+  }
+  __syncthreads();
+  const int pb = t.pid[0];
+
+  for (;;) {
+    if (t.upd[0]) {                                                        // cc:203-214
+      for (int i = tid; i < K; i += kTailThreads) knot_quadratize<D>(t, lanes, t.cur[0], i, 0);
+    }
+    __syncthreads();
+    if (tid < team::kLanes) backward_team_problem(t, 0, t.lambda[0], true, tid, T, WaveSync{});   // cc:218
+    __syncthreads();
+    if (tid == 0) {                                                        // cc:235-241
+      const bool leave = leaves_before_search(t, 0, true);
+      t.acc_idx[0] = leave ? -2 : -1;
+      flag[0] = leave ? 1 : 0;
+      flag[1] = -1;
+    }
+    __syncthreads();
+    if (!flag[0]) {
+      if (tid < kNumAlpha) forward_core(t, 0, kAlpha[tid], OutSpec{t, tid, 0});   // cc:246-250, all step sizes
+      __syncthreads();
+      int acc = -1;
+      for (int r0 = 0; r0 < kNumAlpha && acc < 0; r0 += kTailChunk) {
+        const int nr = min(kTailChunk, kNumAlpha - r0);
+        for (int e = tid; e < nr * K; e += kTailThreads) {
+          const int rr = e / K, i = e - rr * K, r = r0 + rr;
+          const double2* xb = t.Xs + ((size_t)r * K + i) * 3;
+          const double2 p0 = xb[0], p1 = xb[1], p2 = xb[2];
+          const double x[6] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y};
+          double u[2] = {0.0, 0.0};
+          if (i < N) {
+            const double2 q = t.Us[(size_t)r * N + i];
+            u[0] = q.x; u[1] = q.y;
+          }
+          if (D == 5) knot_cost_core<5>(t, lanes, i, 0, x, u, t.parts + ((size_t)r * K + i) * kPartPairs, 1);
+          else knot_cost_generic(t, lanes, i, 0, x, u, t.parts + ((size_t)r * K + i) * kPartPairs, 1);
+        }
+        __syncthreads();
+        if (tid < nr) {   // total of candidate r: knot partials in index order (k_spec_reduce)
+          const int r = r0 + tid;
+          double jj = 0.0, dx = 0.0, du = 0.0, cc = 0.0, lc = 0.0;
+          const double2* pp = t.parts + (size_t)r * K * kPartPairs;
+#pragma unroll 8
+          for (int i = 0; i < K; ++i) {
+            const double2* o = pp + (size_t)i * kPartPairs;
+            const double2 aa = o[0], bb = o[1], c2 = o[2];
+            jj += aa.x;
+            dx += bb.x;
+            cc += c2.x;
+            lc += c2.y;
+          }
+#pragma unroll 8
+          for (int i = 0; i < N; ++i) {
+            const double2* o = pp + (size_t)i * kPartPairs;
+            jj += o[0].y;
+            du += o[1].y;
+          }
+          const double dyn = dx + du;
+          double* tr = tot + r * 5;
+          tr[0] = jj + dyn + cc + lc;
+          tr[1] = jj; tr[2] = dyn; tr[3] = cc; tr[4] = lc;
+        }
+        __syncthreads();
+        if (tid == 0) {   // first passing step size of the chunk (cc:252-261, k_spec_pick)
+          const double cost_old = t.cost_old[0], dV0 = t.dV[0], dV1 = t.dV[1];
+          int won = -1;
+          double dcost = 0.0;
+          for (int r = r0; r < r0 + nr; ++r) {
+            const double alpha = kAlpha[r];
+            dcost = cost_old - tot[r * 5];
+            const double expected = -alpha * (dV0 + alpha * dV1);
+            const double z = dcost / expected;
+            if ((z > 1e-4 && z < 10.0) && dcost > 0.0) {
+              won = r;
+              break;
+            }
+          }
+          const bool all_tried = (r0 + nr == kNumAlpha);
+          if (won >= 0 || all_tried) {
+            const int last = (won >= 0) ? won : kNumAlpha - 1;
+#pragma unroll
+            for (int c = 0; c < 5; ++c) t.trial[c] = tot[last * 5 + c];
+          }
+          if (won >= 0) {
+            t.acc_idx[0] = won;
+            t.dcost[0] = dcost;
+            t.cur[0] ^= 1;
+          }
+          flag[1] = won;
+        }
+        __syncthreads();
+        acc = flag[1];
+      }
+      if (acc >= 0) {   // the accepted candidate becomes the iterate
+        const int nb = t.cur[0];
+        for (int i = tid; i < K; i += kTailThreads) {
+          const double2* xb = t.Xs + ((size_t)acc * K + i) * 3;
+          double2* o = t.X + ((size_t)nb * K + i) * 3;
+          o[0] = xb[0];
+          o[1] = xb[1];
+          o[2] = xb[2];
+          if (i < N) t.U[(size_t)nb * N + i] = t.Us[(size_t)acc * N + i];
+        }
+      }
+    }
+    __syncthreads();
+    if (tid == 0) flag[2] = update_state(t, g, 0) ? 1 : 0;                // cc:272-319
+    __syncthreads();
+    const bool done = flag[2] != 0;
+    if (a.iter_trajs && t.emit[0]) {
+      const int idx = g.n_iter_trajs[pb] - 1;
+      if (idx < a.it_cap)
+        for (int i = tid; i < K; i += kTailThreads)
+          write_traj_point(t, t.cur[0], i, 0, a.iter_trajs + (((size_t)pb * a.it_cap + idx) * K + i) * 10);
+    }
+    if (done) {
+      for (int i = tid; i < K; i += kTailThreads)
+        write_traj_point(t, t.cur[0], i, 0, a.traj + ((size_t)pb * K + i) * 10);
+      if (tid == 0) atomicMax(a.max_iter, g.iter[pb]);
+      break;
+    }
+  }
+}
+
+// g.act / g.n_dev: the active list the tail takes over (n_max bounds its length and sizes the grid)
+void launch_tail(const DeviceState& g, void* workspace, int n_max, double* traj, double* iter_trajs,
+                 int max_iter_trajs, int* max_iter_dev, hipStream_t st) {
+  if (n_max <= 0) return;
+  TailArgs a;
+  a.ws = static_cast<char*>(workspace);
+  a.L = tail_layout(g);
+  a.traj = traj;
+  a.iter_trajs = iter_trajs;
+  a.it_cap = max_iter_trajs;
+  a.max_iter = max_iter_dev;
+  const size_t lane_d = (size_t)((g.nl + g.nr) * kLaneFields + 1) / 2 * 2;
+  const size_t lds = (lane_d + team::kStride + kNumAlpha * 5) * sizeof(double) + 16 * sizeof(int);
+  if (g.p.num_of_disc == 5) hipLaunchKernelGGL(k_tail<5>, dim3(n_max), dim3(kTailThreads), lds, st, g, a, n_max);
+  else hipLaunchKernelGGL(k_tail<0>, dim3(n_max), dim3(kTailThreads), lds, st, g, a, n_max);
+}
+
+}  // namespace cilqr

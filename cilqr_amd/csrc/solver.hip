@@ -35,6 +35,8 @@ int dev_alloc(cilqr_solver* h, T** p, size_t count) {
   return CILQR_OK;
 }
 
+constexpr int64_t kTailMaxProblems = 8192;   // CILQR_OPT_TAIL_THRESHOLD is clamped to this
+
 int grow(void** p, size_t* have, size_t need) {
   if (need <= *have) return CILQR_OK;
   if (*p) HIP_TRY(hipFree(*p));
@@ -167,7 +169,7 @@ int do_load(cilqr_solver* h, const cilqr_problem_batch* in) {
 struct Timer {  // event pairs, resolved after the final sync
   cilqr_solver* h;
   size_t next = 0;
-  std::vector<int> kind;  // 0 quad, 1 backward, 2 linesearch, 3 other
+  std::vector<int> kind;  // 0 quad, 1 backward, 2 linesearch, 3 other, 4 tail
   std::vector<char> full_flags, live_flags;  // per backward launch: covered the whole batch / had work
   bool open = false;   // the last begin() recorded an event, so the matching end() must too
   int begin(int k) {
@@ -202,6 +204,7 @@ struct Timer {  // event pairs, resolved after the final sync
           ++nb;
           break;
         case 2: p->linesearch_ms += ms; break;
+        case 4: p->tail_ms += ms; break;
         default: p->other_ms += ms; break;
       }
     }
@@ -347,6 +350,7 @@ int cilqr_create(const cilqr_config* cfg, int32_t device, int32_t batch_capacity
 #undef ALLOC2
   if (rc == CILQR_OK) rc = dev_alloc(h, &h->lanes_raw, (size_t)2 * max_lane_segments * 7);
   if (rc == CILQR_OK) rc = dev_alloc(h, &h->lambda_stage, B);
+  if (rc == CILQR_OK) rc = dev_alloc(h, &h->tail_iter_dev, 4);
   if (rc == CILQR_OK && hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess)
     rc = CILQR_ERR_DEVICE;
   if (rc == CILQR_OK && hipHostMalloc(reinterpret_cast<void**>(&h->h_count), (size_t)(cfg->max_iter + 64) * sizeof(int),
@@ -379,6 +383,7 @@ int cilqr_destroy(cilqr_handle h) {
   for (void* p : h->allocs) (void)hipFree(p);
   if (h->in_stage) (void)hipFree(h->in_stage);
   if (h->out_stage) (void)hipFree(h->out_stage);
+  if (h->tail_ws) (void)hipFree(h->tail_ws);
   if (h->h_count) (void)hipHostFree(h->h_count);
   for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->iter_ev) (void)hipEventDestroy(e);
@@ -412,6 +417,10 @@ int cilqr_set_option(cilqr_handle h, int32_t option, int64_t value) {
     case CILQR_OPT_TEAM_THRESHOLD:
       if (value < 0) return CILQR_ERR_ARG;
       h->team_threshold = (int)(value > 0x7fffffff ? 0x7fffffff : value);
+      return CILQR_OK;
+    case CILQR_OPT_TAIL_THRESHOLD:
+      if (value < 0) return CILQR_ERR_ARG;
+      h->tail_threshold = (int)(value > kTailMaxProblems ? kTailMaxProblems : value);
       return CILQR_OK;
     default:
       return CILQR_ERR_ARG;
@@ -577,6 +586,19 @@ static int solve_core(cilqr_handle h, const cilqr_problem_batch* in, cilqr_solut
     for (size_t i = old; i < h->iter_ev.size(); ++i)
       HIP_TRY(hipEventCreateWithFlags(&h->iter_ev[i], hipEventDisableTiming));
   }
+  // The tail of the batch (kernels_tail.hip) needs a private arena per problem; sized before the first kernel so
+  // that no allocation falls into the solve.
+#ifdef CILQR_REF_ORDER
+  const int tail_threshold = 0;   // the test-only build re-evaluates whole trajectories in the reference's order
+#else
+  const int tail_threshold = h->tail_threshold;
+#endif
+  if (tail_threshold > 0) {
+    rc = grow(&h->tail_ws, &h->tail_ws_bytes, (size_t)std::min(B, tail_threshold) * tail_workspace_bytes(d));
+    if (rc != CILQR_OK) return rc;
+  }
+  bool tail_used = false;
+  int tail_n = 0;
   launch_init_counters(d, B, st);
   int n_hint = B;   // upper bound of the active count of the iteration being enqueued
   int span = B;     // slots occupied in the current arena (upper bound)
@@ -595,6 +617,17 @@ static int solve_core(cilqr_handle h, const cilqr_problem_batch* in, cilqr_solut
     d.n_clear = d.counters + kCntActive + (it + 2) % 3;
     d.h_count_dev = h->h_count_dev + it;
     o.n_dev = d.n_dev; o.n_next = d.n_next; o.n_clear = d.n_clear; o.h_count_dev = d.h_count_dev;
+    if (n_hint <= tail_threshold) {
+      // few problems left: each gets a workgroup that runs all its remaining iterations (cc:201-319) in one launch
+      if (tm.begin(4)) return CILQR_ERR_DEVICE;
+      HIP_TRY(hipMemsetAsync(h->tail_iter_dev, 0, sizeof(int), st));
+      launch_tail(d, h->tail_ws, n_hint, o_traj, o_it, out->max_iter_trajs, h->tail_iter_dev, st);
+      HIP_TRY(hipMemcpyAsync(h->h_count + M + 32, h->tail_iter_dev, sizeof(int), hipMemcpyDeviceToHost, st));
+      if (tm.end()) return CILQR_ERR_DEVICE;
+      tail_used = true;
+      tail_n = n_hint;
+      break;
+    }
     if (tm.begin(0)) return CILQR_ERR_DEVICE;
     launch_quadratize(d, d.act, n_hint, 1, st);        // cc:203-214
     if (tm.end() || tm.begin(1)) return CILQR_ERR_DEVICE;
@@ -639,6 +672,10 @@ static int solve_core(cilqr_handle h, const cilqr_problem_batch* in, cilqr_solut
       tm.live_flags[k] = (n_in > 0);
     }
     it = used;
+    if (tail_used) {
+      it = std::max(it, h->h_count[M + 32]);
+      h->prof.tail_problems = tail_n;   // upper bound (the count the host knew when it enqueued the tail)
+    }
   }
   h->prof.iterations = it;
   if (tm.begin(3)) return CILQR_ERR_DEVICE;

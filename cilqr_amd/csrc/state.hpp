@@ -184,7 +184,7 @@ void launch_cost_only(const DeviceState& s, const int* list, int n, int cand, hi
 void launch_cost_knots(const DeviceState& s, const int* list, const int* n_ptr, int n_max, int n_grid,
                        int cand, int skip_done, hipStream_t st);
 void launch_spec_cost(const DeviceState& s, const int* list, const int* n_ptr, int n_max, int n_grid, int r0,
-                      hipStream_t st);
+                      int sparse, hipStream_t st);
 void launch_round_cost(const DeviceState& s, int r, int n_max, int n_grid, hipStream_t st);
 void launch_init_cost_commit(const DeviceState& s, int n, hipStream_t st);
 void launch_quadratize(const DeviceState& s, const int* list, int n, int only_upd, hipStream_t st);
@@ -196,6 +196,10 @@ void launch_forward(const DeviceState& s, const int* list, int n, double alpha, 
 // the 11-round line search of one lockstep iteration (forward/cost/accept with compaction)
 void launch_linesearch(const DeviceState& s, int n_act, int spec_threshold, int seq_rounds, hipStream_t st);
 void launch_init_counters(const DeviceState& s, int first_n, hipStream_t st);
+// kernels_tail.hip: one workgroup per problem finishes every problem of the active list (all remaining iterations)
+size_t tail_workspace_bytes(const DeviceState& s);   // private arena of one problem
+void launch_tail(const DeviceState& s, void* workspace, int n_max, double* traj, double* iter_trajs,
+                 int max_iter_trajs, int* max_iter_dev, hipStream_t st);
 void launch_update(const DeviceState& s, int n_act, hipStream_t st);
 // trajectories of the slots that finished in the last update -> traj[pid]
 void launch_export_done(const DeviceState& s, int n_act, double* traj, hipStream_t st);

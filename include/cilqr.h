@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define CILQR_ABI_VERSION 2
+#define CILQR_ABI_VERSION 3
 
 #define CILQR_NX 6  /* state  (x, y, theta, v, a, delta)   vehicle_model.h:11 */
 #define CILQR_NU 2  /* control (jerk, delta_rate)           vehicle_model.h:12 */
@@ -146,7 +146,7 @@ typedef struct cilqr_solution_batch {
 
 /* Per-solve kernel timing, filled when profiling is on (cilqr_set_profiling). */
 typedef struct cilqr_profile {
-  int32_t iterations;            /* lockstep outer iterations of the last solve */
+  int32_t iterations;            /* outer iterations of the last solve (the slowest problem's count) */
   int32_t backward_launches;
   double backward_ms;            /* sum of HIP-event durations of the backward kernel */
   double quadratize_ms;
@@ -155,8 +155,9 @@ typedef struct cilqr_profile {
   double total_ms;               /* first kernel start -> last kernel end */
   int64_t backward_problem_steps;/* sum over launches of (active problems x N) */
   int32_t backward_full_launches;/* launches whose active set was the whole batch */
-  int32_t reserved1;
+  int32_t tail_problems;         /* problems handed to the per-problem tail kernel (upper bound), 0 = not used */
   double backward_full_ms;       /* their summed duration */
+  double tail_ms;                /* duration of the tail kernel (not part of the four phase sums above) */
 } cilqr_profile;
 
 int cilqr_abi_version(void);
@@ -184,6 +185,11 @@ int cilqr_set_stream(cilqr_handle h, void* hip_stream);
  * problem over eight lanes (column-wise) instead of one, which shortens the chain of dependent
  * steps a small launch waits on; 0 = always one lane per problem.  Bit-identical results. */
 #define CILQR_OPT_TEAM_THRESHOLD 4
+/* CILQR_OPT_TAIL_THRESHOLD (default 1024, at most 8192): once at most this many problems are still iterating they
+ * leave the lockstep loop; one workgroup per problem runs all its remaining iterations in a single launch
+ * (kernels_tail.hip), so the stragglers of a batch no longer cost nine launches per iteration.  0 = lockstep to
+ * the end.  Bit-identical results. */
+#define CILQR_OPT_TAIL_THRESHOLD 5
 int cilqr_set_option(cilqr_handle h, int32_t option, int64_t value);
 /* enable = 1: HIP events around every phase of every lockstep iteration (cilqr_profile complete; about 4 %
  * slower: ~800 event records per solve); enable = 2: around the backward launches only (backward_* fields;

@@ -27,9 +27,34 @@ def _plan(opt, sc, **kw):
     return opt.plan(sc, max_iter_trajs=ITER_CAP, alpha_trace=True, **kw)
 
 
+# Which solve loop the optimisers of a test run.  None = the product default (CILQR_OPT_TAIL_THRESHOLD 1024: batches
+# of the sizes used here run entirely in the per-problem tail kernel, kernels_tail.hip); 0 = lockstep kernels to the
+# end.  The `both_paths` fixture runs a test once with each.
+_TAIL = [None]
+
+
 def _opt(sc, B=None, **cfg_over):
     cfg = api.default_config(sc["n_steps"], **cfg_over)
-    return api.BatchIlqrOptimizer(cfg, batch_capacity=B or sc["coarse"].shape[0], cmax=sc["cmax"])
+    opt = api.BatchIlqrOptimizer(cfg, batch_capacity=B or sc["coarse"].shape[0], cmax=sc["cmax"])
+    if _TAIL[0] is not None:
+        opt.set_option(api.OPT_TAIL_THRESHOLD, _TAIL[0])
+    return opt
+
+
+@pytest.fixture(params=["tail", "lockstep"])
+def both_paths(request):
+    _TAIL[0] = None if request.param == "tail" else 0
+    yield request.param
+    _TAIL[0] = None
+
+
+@pytest.fixture
+def lockstep_only():
+    """Tests of the lockstep kernels' schedules (team backward, speculative rounds, re-packing): the tail kernel
+    would take these small batches over from the first iteration."""
+    _TAIL[0] = 0
+    yield
+    _TAIL[0] = None
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -106,7 +131,7 @@ def test_open_loop_rollout():
 # full solves
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("family,B,seed", [("ped6", 200, 41), ("mix11", 333, 42), ("dyn20", 96, 43), ("demo80", 64, 44)])
-def test_full_solve_parity(family, B, seed):
+def test_full_solve_parity(family, B, seed, both_paths):
     """Whole solves vs the oracle (status, iteration count, accepted step size of every iteration, every
     Cost row, final trajectory: 1e-4 on every oracle-stable problem; stability = 8 oracle re-runs at a
     4e-16 input perturbation) AND every single step of every problem, stable or not, replayed in the
@@ -266,7 +291,7 @@ def test_golden_fixtures_through_the_c_abi():
     (dict(rel_cost_tol=0.0, abs_cost_tol=5.0), api.ST_CONVERGED_ABS),
     (dict(rel_cost_tol=0.0, abs_cost_tol=0.0, max_iter=60), None),
 ])
-def test_exit_paths(over, expect):
+def test_exit_paths(over, expect, both_paths):
     """Every exit of Optimize() (max-iter, abs tol, lambda > 1e11 / gnorm) agrees with the oracle."""
     sc = scenario.generate("ped6", 48, seed=51)
     opt = _opt(sc, **over)
@@ -294,7 +319,7 @@ def test_exit_paths(over, expect):
     opt.close()
 
 
-def test_ragged_counts_single_problem_and_odd_batches():
+def test_ragged_counts_single_problem_and_odd_batches(both_paths):
     sc = scenario.generate("mix11", 130, seed=61)
     # ragged corridor: drop to the 4 box planes on some knots, keep everything on others
     sc["ccount"][::3, ::2] = 4
@@ -625,7 +650,7 @@ def test_lean_sin_cos_tan_are_accurate_to_a_few_ulp():
     opt.close()
 
 
-def test_team_backward_is_bit_identical_to_one_lane_per_problem():
+def test_team_backward_is_bit_identical_to_one_lane_per_problem(lockstep_only):
     """CILQR_OPT_TEAM_THRESHOLD: small backward launches spread a problem over eight lanes
     (k_backward_team).  Stage outputs (gains, delta_V, gradient norm) and whole solves must not
     change by a bit, for batch sizes that leave teams idle, fill them exactly, or cross blocks."""
@@ -656,7 +681,7 @@ def test_team_backward_is_bit_identical_to_one_lane_per_problem():
 
 
 @pytest.mark.parametrize("N", [1, 2, 3, 5, 7])
-def test_short_horizons_empty_knots_and_single_segment_lanes(N):
+def test_short_horizons_empty_knots_and_single_segment_lanes(N, both_paths):
     """Horizons shorter than the rollout's prefetch depth (4 steps) and than a backward team's
     pipeline, knots without any corridor plane, lane tables of one segment, batches of 1 / 3 / 65."""
     import dataclasses
@@ -761,7 +786,7 @@ def test_nearest_lane_grid_equals_linear_scan():
     opt.close()
 
 
-def test_speculative_line_search_is_bit_identical_to_round_by_round():
+def test_speculative_line_search_is_bit_identical_to_round_by_round(lockstep_only):
     """Small active sets evaluate all 11 step sizes at once; the first passing index must win exactly
     as in the sequential loop (ilqr_optimizer.cc:246-265), so both modes give the same bits."""
     sc = scenario.generate("mix11", 300, seed=95)
@@ -786,6 +811,33 @@ def test_speculative_line_search_is_bit_identical_to_round_by_round():
     for k in ("traj", "cost_hist", "n_cost", "status", "n_iter", "iter_trajs", "n_iter_trajs"):
         for other in outs:
             assert np.array_equal(a[k], other[k]), k
+    opt.close()
+
+
+@pytest.mark.parametrize("family,B,seed", [("mix11", 700, 96), ("ped6", 150, 97), ("dyn20x", 130, 98), ("demo80", 40, 99)])
+def test_tail_kernel_is_bit_identical_to_the_lockstep_loop(family, B, seed):
+    """CILQR_OPT_TAIL_THRESHOLD: once few problems are left, one workgroup per problem runs all remaining
+    iterations (kernels_tail.hip) with the device functions of the lockstep kernels on a private copy of the
+    problem.  Every output must be the lockstep loop's, bit for bit, whether the tail takes the batch over from
+    the first iteration, in the middle of the solve (after re-packing, or without it), or only for the last
+    stragglers -- including the per-iteration records (cost rows, accepted step sizes, iterates)."""
+    sc = scenario.generate(family, B, seed=seed)
+    opt = _opt(sc)
+    opt.set_option(api.OPT_TAIL_THRESHOLD, 0)
+    ref = _plan(opt, sc)
+    assert ref["n_iter"].max() > 12, "scene set too easy to say anything about a tail"
+    keys = ("traj", "cost_hist", "n_cost", "status", "n_iter", "iter_trajs", "n_iter_trajs", "alpha_trace")
+    for thr, compaction in ((8192, 1), (B // 3, 1), (B // 3, 0), (16, 1), (1, 1)):
+        opt.set_option(api.OPT_TAIL_THRESHOLD, thr)
+        opt.set_option(api.OPT_COMPACTION, compaction)
+        got = _plan(opt, sc)
+        for k in keys:
+            assert np.array_equal(ref[k], got[k], equal_nan=True), (family, thr, compaction, k)
+    # and without the optional outputs
+    opt.set_option(api.OPT_TAIL_THRESHOLD, 1024)
+    plain = opt.plan(sc)
+    for k in ("traj", "cost_hist", "n_cost", "status", "n_iter"):
+        assert np.array_equal(ref[k], plain[k], equal_nan=True), k
     opt.close()
 
 
@@ -831,7 +883,7 @@ def test_cpp_adapter_plan_matches_oracle(tmp_path):
     dict(barrier_t=10.0, barrier_eps=0.05),
     dict(dt=0.08, max_velocity=15.0, jerk_max=6.0, jerk_min=-6.0, width=1.6, wheel_base=1.4),
 ])
-def test_nondefault_configuration_parity(over):
+def test_nondefault_configuration_parity(over, both_paths):
     """Every live field of IlqrConfig / VehicleParam reaches the kernels (nothing is hard-wired to
     the reference defaults)."""
     sc = scenario.generate("mix11", 72, seed=97)

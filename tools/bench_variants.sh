@@ -2,6 +2,7 @@
 # Runs bench.py for a list of "name|CILQR_LIB path or -|extra bench args" variants (tuning experiments on the GPU box).
 # usage: tools/bench_variants.sh <out-prefix> "name|lib|args" ...
 out=$1; shift
+mkdir -p "$(dirname "$out")"
 for v in "$@"; do
   IFS='|' read -r name lib args <<< "$v"
   if [ "$lib" = "-" ]; then unset CILQR_LIB; else export CILQR_LIB="$lib"; fi
