@@ -20,13 +20,18 @@
 
 namespace cilqr {
 
-#ifdef CILQR_COST_OCC
-#define CILQR_COST_ATTR __attribute__((amdgpu_waves_per_eu(CILQR_COST_OCC, CILQR_COST_OCC)))
-#else
-#define CILQR_COST_ATTR
-#endif
+// The cost kernels exist per disc count: D = 5 (the reference's; unrolled) and D = 0 (any other count), so that the
+// generic path does not set the register budget of the common one.  Three waves per SIMD: the 5-disc cost function
+// fits 168 VGPRs (quad_core.hpp), and the attribute keeps the allocator from trading that for a shorter schedule.
+#define CILQR_COST_ATTR __attribute__((amdgpu_waves_per_eu(3, 3)))
+#define CILQR_LAUNCH_BY_DISCS(kernel, grid, block, lds, st, ...)                                   \
+  do {                                                                                            \
+    if (s.p.num_of_disc == 5) hipLaunchKernelGGL(kernel<5>, grid, block, lds, st, __VA_ARGS__);   \
+    else hipLaunchKernelGGL(kernel<0>, grid, block, lds, st, __VA_ARGS__);                        \
+  } while (0)
 
 // list == nullptr: slots 0..n-1.  skip_done: ignore slots that already left the iteration.
+template <int D>
 __global__ __launch_bounds__(256) CILQR_COST_ATTR void k_cost_knots(DeviceState s, const int* __restrict__ list,
                                                     const int* __restrict__ n_ptr, int n_max, int cand,
                                                     int skip_done) {
@@ -42,11 +47,12 @@ __global__ __launch_bounds__(256) CILQR_COST_ATTR void k_cost_knots(DeviceState 
     double x[6], u[2] = {0.0, 0.0};
     load_x(s, buf, i, slot, x);
     if (i < s.p.N) load_u(s, buf, i, slot, u);
-    knot_cost_any(s, lanes, i, slot, x, u, s.part + (size_t)i * kPartPairs * s.Bcap + slot, (size_t)s.Bcap);
+    knot_cost<D>(s, lanes, i, slot, x, u, s.part + (size_t)i * kPartPairs * s.Bcap + slot, (size_t)s.Bcap);
   }
 }
 
 // speculative line search: knot i of candidate alpha_{r0 + blockIdx.z} of list entry j
+template <int D>
 __global__ __launch_bounds__(256) CILQR_COST_ATTR void k_spec_cost(DeviceState s, const int* __restrict__ list,
                                                    const int* __restrict__ n_ptr, int n_max, int r0) {
   extern __shared__ double lds[];
@@ -66,7 +72,7 @@ __global__ __launch_bounds__(256) CILQR_COST_ATTR void k_spec_cost(DeviceState s
       const double2 q = s.Us[((size_t)r * s.p.N + i) * cap + j];
       u[0] = q.x; u[1] = q.y;
     }
-    knot_cost_any(s, lanes, i, slot, x, u, s.parts + ((size_t)r * s.p.K + i) * kPartPairs * cap + j, cap);
+    knot_cost<D>(s, lanes, i, slot, x, u, s.parts + ((size_t)r * s.p.K + i) * kPartPairs * cap + j, cap);
   }
 }
 // The same for a SPARSE list (the problems that rejected every sequential round: a few percent of the slots, in
@@ -76,6 +82,7 @@ __global__ __launch_bounds__(256) CILQR_COST_ATTR void k_spec_cost(DeviceState s
 // knot only is read once per eight lanes (same address: one line), and only the candidate itself (3 + 1 pairs)
 // is read per lane.  Same arithmetic per (problem, step size, knot); measured 4.6x faster per knot cost.
 constexpr int kPackLanes = 8;
+template <int D>
 __global__ __launch_bounds__(256) CILQR_COST_ATTR void k_spec_cost_packed(DeviceState s, const int* __restrict__ list,
                                                                           const int* __restrict__ n_ptr, int n_max, int r0) {
   extern __shared__ double lds[];
@@ -97,7 +104,7 @@ __global__ __launch_bounds__(256) CILQR_COST_ATTR void k_spec_cost_packed(Device
       const double2 q = s.Us[((size_t)r * s.p.N + i) * cap + j];
       u[0] = q.x; u[1] = q.y;
     }
-    knot_cost_any(s, lanes, i, slot, x, u, s.parts + ((size_t)r * s.p.K + i) * kPartPairs * cap + j, cap);
+    knot_cost<D>(s, lanes, i, slot, x, u, s.parts + ((size_t)r * s.p.K + i) * kPartPairs * cap + j, cap);
   }
 }
 
@@ -107,14 +114,15 @@ void launch_spec_cost(const DeviceState& s, const int* list, const int* n_ptr, i
   if (sparse && kNumAlpha - r0 <= kPackLanes) {
     constexpr int per_block = 256 / kPackLanes;
     dim3 g((n_grid + per_block - 1) / per_block, s.p.K);
-    hipLaunchKernelGGL(k_spec_cost_packed, g, dim3(256), lane_lds_bytes(s), st, s, list, n_ptr, n_max, r0);
+    CILQR_LAUNCH_BY_DISCS(k_spec_cost_packed, g, dim3(256), lane_lds_bytes(s), st, s, list, n_ptr, n_max, r0);
     return;
   }
   dim3 g((n_grid + 255) / 256, s.p.K, kNumAlpha - r0);
-  hipLaunchKernelGGL(k_spec_cost, g, dim3(256), lane_lds_bytes(s), st, s, list, n_ptr, n_max, r0);
+  CILQR_LAUNCH_BY_DISCS(k_spec_cost, g, dim3(256), lane_lds_bytes(s), st, s, list, n_ptr, n_max, r0);
 }
 
 // knot i of candidate alpha_r of the problems pending in round r
+template <int D>
 __global__ __launch_bounds__(256) CILQR_COST_ATTR void k_round_cost(DeviceState s, int r, int n_max) {
   extern __shared__ double lds[];
   const int* __restrict__ list = s.pend + (size_t)r * s.Bcap;
@@ -135,13 +143,13 @@ __global__ __launch_bounds__(256) CILQR_COST_ATTR void k_round_cost(DeviceState 
       const double2 q = s.Us[((size_t)r * s.p.N + i) * cap + j];
       u[0] = q.x; u[1] = q.y;
     }
-    knot_cost_any(s, lanes, i, slot, x, u, s.parts + ((size_t)r * s.p.K + i) * kPartPairs * cap + j, cap);
+    knot_cost<D>(s, lanes, i, slot, x, u, s.parts + ((size_t)r * s.p.K + i) * kPartPairs * cap + j, cap);
   }
 }
 
 void launch_round_cost(const DeviceState& s, int r, int n_max, int n_grid, hipStream_t st) {
   dim3 g((n_grid + 255) / 256, s.p.K);
-  hipLaunchKernelGGL(k_round_cost, g, dim3(256), lane_lds_bytes(s), st, s, r, n_max);
+  CILQR_LAUNCH_BY_DISCS(k_round_cost, g, dim3(256), lane_lds_bytes(s), st, s, r, n_max);
 }
 
 __global__ __launch_bounds__(64) void k_reduce_only(DeviceState s, const int* __restrict__ list, int n) {
@@ -159,7 +167,7 @@ void launch_cost_knots(const DeviceState& s, const int* list, const int* n_ptr, 
                        int cand, int skip_done, hipStream_t st) {
   if (n_grid <= 0) return;
   dim3 g((n_grid + 255) / 256, s.p.K);
-  hipLaunchKernelGGL(k_cost_knots, g, dim3(256), lane_lds_bytes(s), st, s, list, n_ptr, n_max, cand, skip_done);
+  CILQR_LAUNCH_BY_DISCS(k_cost_knots, g, dim3(256), lane_lds_bytes(s), st, s, list, n_ptr, n_max, cand, skip_done);
 }
 
 void launch_cost_only(const DeviceState& s, const int* list, int n, int cand, hipStream_t st) {

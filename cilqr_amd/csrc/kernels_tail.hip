@@ -12,7 +12,7 @@
 // leaves at once instead of waiting for the slowest one of its iteration.
 //
 // Same arithmetic.  Every phase calls the device function the lockstep kernels call (knot_quadratize,
-// backward_team_problem, forward_core, knot_cost_any, update_state) on a view of the state in which the problem is
+// backward_team_problem, forward_core, knot_cost, update_state) on a view of the state in which the problem is
 // the only one: the block copies its problem's working set into a private, contiguous arena and runs the functions
 // with Bcap = 1, slot = 0.  Results are bit-identical to the lockstep path (tested with the tail switched off).
 //
@@ -191,8 +191,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(DeviceState g, TailArgs a
             const double2 q = t.Us[(size_t)r * N + i];
             u[0] = q.x; u[1] = q.y;
           }
-          if (D == 5) knot_cost_core<5>(t, lanes, i, 0, x, u, t.parts + ((size_t)r * K + i) * kPartPairs, 1);
-          else knot_cost_generic(t, lanes, i, 0, x, u, t.parts + ((size_t)r * K + i) * kPartPairs, 1);
+          knot_cost<D>(t, lanes, i, 0, x, u, t.parts + ((size_t)r * K + i) * kPartPairs, 1);
         }
         __syncthreads();
         if (tid < nr) {   // total of candidate r: knot partials in index order (k_spec_reduce)

@@ -10,11 +10,11 @@
 
 namespace cilqr {
 
-
-#ifndef CILQR_PLANE_CHUNK
-#define CILQR_PLANE_CHUNK 4
-#endif
-constexpr int kPlaneChunk = CILQR_PLANE_CHUNK;
+// corridor planes are read in chunks (all loads of a chunk in flight at once).  The cost function keeps its
+// chunks small: with two planes per chunk and the lane-grid cells fetched disc by disc it fits 168 VGPRs, i.e.
+// three waves per SIMD instead of two (+2 % solve throughput, measured); the quadratisation has the room for four.
+constexpr int kCostChunk = 2;
+constexpr int kQuadChunk = 4;
 
 // lane tables -> LDS (call from every thread of the block, before any early exit)
 CILQR_DEV const double* stage_lanes(const DeviceState& s, double* lds) {
@@ -27,14 +27,16 @@ static inline size_t lane_lds_bytes(const DeviceState& s) {
   return (size_t)(s.nl + s.nr) * kLaneFields * sizeof(double);
 }
 
-// one chunk of up to four corridor planes; missing planes are (0, 0, 1): g = -1, which multiplies
+// one chunk of up to C corridor planes; missing planes are (0, 0, 1): g = -1, which multiplies
 // the barrier product by exactly 1 and adds exact zeros to every gradient / Hessian entry
+template <int C>
 struct PlaneChunk {
-  double a[kPlaneChunk], b[kPlaneChunk], c[kPlaneChunk];
+  double a[C], b[C], c[C];
 };
-CILQR_DEV void load_chunk(const double* __restrict__ cor, int Bc, int c0, int cnt, PlaneChunk& pc) {
+template <int C>
+CILQR_DEV void load_chunk(const double* __restrict__ cor, int Bc, int c0, int cnt, PlaneChunk<C>& pc) {
 #pragma unroll
-  for (int k = 0; k < kPlaneChunk; ++k) {
+  for (int k = 0; k < C; ++k) {
     const bool live = (c0 + k) < cnt;
     const double* q = cor + (size_t)(live ? (c0 + k) : 0) * 3 * Bc;
     const double a = q[0], b = q[(size_t)Bc], c = q[(size_t)2 * Bc];
@@ -46,18 +48,20 @@ CILQR_DEV void load_chunk(const double* __restrict__ cor, int Bc, int c0, int cn
 
 // first chunk of a knot: requested before the plane count is known (its addresses do not depend on
 // it), masked once the count has arrived -- one dependent memory round trip less per knot
-CILQR_DEV void load_first_chunk(const double* __restrict__ cor, int Bc, int cmax, PlaneChunk& pc) {
+template <int C>
+CILQR_DEV void load_first_chunk(const double* __restrict__ cor, int Bc, int cmax, PlaneChunk<C>& pc) {
 #pragma unroll
-  for (int k = 0; k < kPlaneChunk; ++k) {
+  for (int k = 0; k < C; ++k) {
     const double* q = cor + (size_t)min(k, cmax - 1) * 3 * Bc;
     pc.a[k] = q[0];
     pc.b[k] = q[(size_t)Bc];
     pc.c[k] = q[(size_t)2 * Bc];
   }
 }
-CILQR_DEV void mask_first_chunk(int cnt, PlaneChunk& pc) {
+template <int C>
+CILQR_DEV void mask_first_chunk(int cnt, PlaneChunk<C>& pc) {
 #pragma unroll
-  for (int k = 0; k < kPlaneChunk; ++k) {
+  for (int k = 0; k < C; ++k) {
     const bool live = k < cnt;
     pc.a[k] = live ? pc.a[k] : 0.0;
     pc.b[k] = live ? pc.b[k] : 0.0;
@@ -88,13 +92,14 @@ CILQR_DEV double2 knot_bound_cost(const Params& p, int i, const double* x, const
 template <int D>
 CILQR_DEV void knot_cost_core(const DeviceState& s, const double* __restrict__ lanes, int i, int slot,
                               const double* x, const double* u, double2* __restrict__ out, size_t stride) {
+  constexpr int C = kCostChunk;
   const Params& p = s.p;
   const int Bc = s.Bcap;
   const double2* gp = s.goals + (size_t)i * 3 * Bc + slot;
   const double2 g0 = gp[0];
   const double gth = gp[(size_t)Bc].x;
   const double* __restrict__ cor = s.cor + (size_t)i * s.cmax * 3 * Bc + slot;
-  PlaneChunk pc;
+  PlaneChunk<C> pc;
   load_first_chunk(cor, Bc, s.cmax, pc);
   const int cnt = s.ccnt[(size_t)i * Bc + slot];
   mask_first_chunk(cnt, pc);
@@ -113,17 +118,17 @@ CILQR_DEV void knot_cost_core(const DeviceState& s, const double* __restrict__ l
     py[j] = x[1] + p.disc_off[j] * sn;
   }
   // CorridorCost cc:553-581: planes outer (each read once), discs inner; one log for the knot
-  for (int c0 = 0; c0 < cnt; c0 += kPlaneChunk) {
-    PlaneChunk nx;
-    if (c0 + kPlaneChunk < cnt) load_chunk(cor, Bc, c0 + kPlaneChunk, cnt, nx);
+  for (int c0 = 0; c0 < cnt; c0 += C) {
+    PlaneChunk<C> nx;
+    if (c0 + C < cnt) load_chunk(cor, Bc, c0 + C, cnt, nx);
 #pragma unroll
     for (int j = 0; j < D; ++j) {
-      double g[kPlaneChunk];
+      double g[C];
 #pragma unroll
-      for (int k = 0; k < kPlaneChunk; ++k) g[k] = pc.a[k] * px[j] + pc.b[k] * py[j] - pc.c[k];
+      for (int k = 0; k < C; ++k) g[k] = pc.a[k] * px[j] + pc.b[k] * py[j] - pc.c[k];
       bar_accumulate(p, g, grp[j]);
     }
-    if ((c0 & (16 * kPlaneChunk - 1)) == 15 * kPlaneChunk) {   // every 64 planes: keep the products in range
+    if ((c0 & 63) == 64 - C) {   // every 64 planes: keep the products in range
 #pragma unroll
       for (int j = 0; j < D; ++j) bar_renormalize(grp[j]);
     }
@@ -136,28 +141,15 @@ CILQR_DEV void knot_cost_core(const DeviceState& s, const double* __restrict__ l
     bar_merge(call, grp[j]);
   }
   const double ccost = bar_group_value(p, call);
-  // LaneBoundaryCost cc:583-603: the ten candidate-list loads go out together, then the searches
-#ifdef CILQR_LANE_LATE_FETCH
+  // LaneBoundaryCost cc:583-603, disc by disc (a rolled loop: fetching the ten candidate lists up front hides
+  // their latency but holds 40 registers through the searches, which costs the third wave per SIMD)
   BarGroup lall;
 #pragma unroll 1
   for (int j = 0; j < D; ++j) {
-    const uint4 clj = lane_cell_fetch(s, 0, px[j], py[j]);
-    const uint4 crj = lane_cell_fetch(s, 1, px[j], py[j]);
-    const double* L = lanes + nearest_from_cell(s, lanes, 0, clj, px[j], py[j]) * kLaneFields;
-    const double* Rr = lanes + (s.nl + nearest_from_cell(s, lanes, 1, crj, px[j], py[j])) * kLaneFields;
-#else
-  uint4 cl[D], cr[D];
-#pragma unroll
-  for (int j = 0; j < D; ++j) {
-    cl[j] = lane_cell_fetch(s, 0, px[j], py[j]);
-    cr[j] = lane_cell_fetch(s, 1, px[j], py[j]);
-  }
-  BarGroup lall;
-#pragma unroll
-  for (int j = 0; j < D; ++j) {
-    const double* L = lanes + nearest_from_cell(s, lanes, 0, cl[j], px[j], py[j]) * kLaneFields;
-    const double* Rr = lanes + (s.nl + nearest_from_cell(s, lanes, 1, cr[j], px[j], py[j])) * kLaneFields;
-#endif
+    const uint4 cl = lane_cell_fetch(s, 0, px[j], py[j]);
+    const uint4 cr = lane_cell_fetch(s, 1, px[j], py[j]);
+    const double* L = lanes + nearest_from_cell(s, lanes, 0, cl, px[j], py[j]) * kLaneFields;
+    const double* Rr = lanes + (s.nl + nearest_from_cell(s, lanes, 1, cr, px[j], py[j])) * kLaneFields;
     const double g[2] = {L[0] * px[j] + L[1] * py[j] - L[2], Rr[0] * px[j] + Rr[1] * py[j] - Rr[2]};
     bar_accumulate(p, g, lall);
   }
@@ -204,14 +196,12 @@ CILQR_DEV void knot_cost_generic(const DeviceState& s, const double* __restrict_
   out[2 * stride] = make_double2(bar_group_value(p, call), bar_group_value(p, lall));
 }
 
-CILQR_DEV void knot_cost_any(const DeviceState& s, const double* __restrict__ lanes, int i, int slot,
-                             const double* x, const double* u, double2* __restrict__ out, size_t stride) {
-#ifdef CILQR_ONLY5
-  knot_cost_core<5>(s, lanes, i, slot, x, u, out, stride);
-#else
-  if (s.p.num_of_disc == 5) knot_cost_core<5>(s, lanes, i, slot, x, u, out, stride);
+// D = 5: the reference's disc count, unrolled (knot_cost_core); D = 0: any other count
+template <int D>
+CILQR_DEV void knot_cost(const DeviceState& s, const double* __restrict__ lanes, int i, int slot,
+                         const double* x, const double* u, double2* __restrict__ out, size_t stride) {
+  if constexpr (D == 5) knot_cost_core<5>(s, lanes, i, slot, x, u, out, stride);
   else knot_cost_generic(s, lanes, i, slot, x, u, out, stride);
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -277,7 +267,8 @@ CILQR_DEV void knot_quadratize(const DeviceState& s, const double* __restrict__ 
   const double2 g0 = gp[0];
   const double gth = gp[(size_t)Bc].x;
   const double* __restrict__ cor = s.cor + (size_t)i * s.cmax * 3 * Bc + slot;
-  PlaneChunk pc;
+  constexpr int C = kQuadChunk;
+  PlaneChunk<C> pc;
   load_first_chunk(cor, Bc, s.cmax, pc);
   const int cnt = s.ccnt[(size_t)i * Bc + slot];
   mask_first_chunk(cnt, pc);
@@ -321,11 +312,11 @@ CILQR_DEV void knot_quadratize(const DeviceState& s, const double* __restrict__ 
   double sn, cs;
   lean_sincos(x[2], &sn, &cs);
   // corridor planes x discs (cc:690-727); planes outer (each read once), discs inner
-  for (int c0 = 0; c0 < cnt; c0 += kPlaneChunk) {
-    PlaneChunk nx;
-    if (c0 + kPlaneChunk < cnt) load_chunk(cor, Bc, c0 + kPlaneChunk, cnt, nx);
+  for (int c0 = 0; c0 < cnt; c0 += C) {
+    PlaneChunk<C> nx;
+    if (c0 + C < cnt) load_chunk(cor, Bc, c0 + C, cnt, nx);
 #pragma unroll
-    for (int k = 0; k < kPlaneChunk; ++k) {
+    for (int k = 0; k < C; ++k) {
       PlaneSums m;
       if constexpr (D > 0) {
 #pragma unroll

@@ -185,7 +185,7 @@ int cilqr_set_stream(cilqr_handle h, void* hip_stream);
  * problem over eight lanes (column-wise) instead of one, which shortens the chain of dependent
  * steps a small launch waits on; 0 = always one lane per problem.  Bit-identical results. */
 #define CILQR_OPT_TEAM_THRESHOLD 4
-/* CILQR_OPT_TAIL_THRESHOLD (default 1024, at most 8192): once at most this many problems are still iterating they
+/* CILQR_OPT_TAIL_THRESHOLD (default 256, at most 8192): once at most this many problems are still iterating they
  * leave the lockstep loop; one workgroup per problem runs all its remaining iterations in a single launch
  * (kernels_tail.hip), so the stragglers of a batch no longer cost nine launches per iteration.  0 = lockstep to
  * the end.  Bit-identical results. */

@@ -27,7 +27,7 @@ def _plan(opt, sc, **kw):
     return opt.plan(sc, max_iter_trajs=ITER_CAP, alpha_trace=True, **kw)
 
 
-# Which solve loop the optimisers of a test run.  None = the product default (CILQR_OPT_TAIL_THRESHOLD 1024: batches
+# Which solve loop the optimisers of a test run.  None = the product default (CILQR_OPT_TAIL_THRESHOLD 256: batches
 # of the sizes used here run entirely in the per-problem tail kernel, kernels_tail.hip); 0 = lockstep kernels to the
 # end.  The `both_paths` fixture runs a test once with each.
 _TAIL = [None]
