@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--spec-threshold", type=int, default=-1, help="CILQR_OPT_SPEC_THRESHOLD value (tuning experiments)")
     ap.add_argument("--seq-rounds", type=int, default=-1, help="CILQR_OPT_SEQ_ROUNDS value (tuning experiments)")
     ap.add_argument("--team-threshold", type=int, default=-1, help="CILQR_OPT_TEAM_THRESHOLD value (tuning experiments)")
+    ap.add_argument("--wave-threshold", type=int, default=-1, help="CILQR_OPT_WAVE_THRESHOLD value (tuning experiments)")
     ap.add_argument("--tail-threshold", type=int, default=-1, help="CILQR_OPT_TAIL_THRESHOLD value (tuning experiments; 0 = lockstep to the end)")
     ap.add_argument("--pipeline", type=int, default=3,
                     help="batches in flight during the timed region (handles, each with its own stream and host thread); 1 = sequential")
@@ -156,6 +157,8 @@ def main():
                 o.set_option(api.OPT_TEAM_THRESHOLD, args.team_threshold)
             if args.tail_threshold >= 0:
                 o.set_option(api.OPT_TAIL_THRESHOLD, args.tail_threshold)
+            if args.wave_threshold >= 0:
+                o.set_option(api.OPT_WAVE_THRESHOLD, args.wave_threshold)
             self.traj = torch.zeros((B, K, 10), dtype=torch.float64, device=dev)
             self.hist = torch.zeros((B, M + 1, 5), dtype=torch.float64, device=dev)
             self.nc = torch.zeros(B, dtype=torch.int32, device=dev)
@@ -215,6 +218,9 @@ def main():
     # the full-batch backward launch.  Untimed (part of the warm-up).
     single = None
     if not args.no_profile:
+        rc = opt.solve_raw(prob, ctx[0].sol)   # first solve of the process: code objects, scratch and staging get allocated
+        if rc != api.OK:
+            raise api.CilqrError(rc, "in the first solve")
         opt.set_profiling(1)
         rc = opt.solve_raw(prob, ctx[0].sol)
         if rc != api.OK:

@@ -508,4 +508,206 @@ CILQR_DEV void backward_team_problem(const DeviceState& s, int slot, double lamb
 }
 
 
+// ---------------------------------------------------------------------------------------------
+// Wave variant: one wavefront per problem, operands staged in LDS.
+//
+// The chain of dependent work of a backward step is short (the 2x2 inverse and a few 6-term dot products); what
+// makes a step slow with one or eight lanes per problem is the NUMBER of instructions every lane issues.  Here the
+// 64 lanes of a wave each own one output element of every stage, all stages are written as one generic 6-term dot
+// product whose operand addresses are per-lane constants, and every lane issues ~200 instructions per step instead
+// of ~500 (team) or ~1100 (lane).  Lane roles:
+//   0..35   (r, c)  element of A^T Vxx, (A^T Vxx) A, the new Vxx
+//   36..47  (q, c)  element of B^T Vxx, Qux, K
+//   48..53  r       entry of A^T Vx, of the new Vx
+//   54..57          B^T Vx with this step's B (gains) / with the previous step's B (its delta_V, see below)
+//   58..63  c       (B^T Vxx)(1, c) with the previous step's B
+// The 2x2 / 2-vector quantities (Quu, Qu, the inverse, k) are evaluated by every lane.  delta_V of a step needs
+// Qu / Quu on the UPDATED Vx / Vxx (cc:383-384), which are the next step's inputs: the spare lanes evaluate them
+// during the next step's first two stages, and the sums are taken one step late, in the same order.
+// Dense products with A's and B's exact zeros and ones stand for the sparse ones of backward_problem (x * 1 = x,
+// s + x * 0 = s), sums run k = 0..5 in order: bit-identical results (tested against both other kernels).
+// ---------------------------------------------------------------------------------------------
+namespace wave {
+constexpr int oA = 0, oB = 36, oBo = 48, oV = 60, oVx = 96, oAtV = 102, oBtV = 138, oBtV2 = 150, oAtVx = 162,
+              oBtVx = 168, oBtVx2 = 170, oQux = 172, oBtVB = 188, oBtVB2 = 192, oK = 196, oVn = 212, oLx = 248,
+              oLu = 254, oLuu = 256, oU = 258, oH = 260, oDummy = 296, kDoubles = 304;
+// Qux and K are [2][8]: columns 0..5, column 6 = (Qu | k) so that the new Vx is the "seventh column" of the Vxx update
+}  // namespace wave
+
+template <class Sync>
+CILQR_DEV void backward_wave_problem(const DeviceState& s, int slot, double lambda, int lane,
+                                     double* __restrict__ L, const Sync& sync) {
+  using namespace wave;
+  const Params& p = s.p;
+  const int Bc = s.Bcap, N = p.N;
+  const double dt = p.dt;
+  const int buf = s.cur[slot];
+  // ---- per-lane roles ----
+  const bool mat = lane < 36, row2 = lane >= 36 && lane < 48, vec = lane >= 48 && lane < 54;
+  const int r = mat ? lane / 6 : (vec ? lane - 48 : 0);
+  const int c = mat ? lane % 6 : (row2 ? (lane - 36) % 6 : (lane >= 58 ? lane - 58 : 0));
+  const int q = row2 ? (lane - 36) / 6 : ((lane >= 54 && lane < 58) ? (lane & 1) : 0);
+  // stage 1: sum_k M[pm1 + k sm1] * X[px1 + k sx1] -> L[po1]
+  int pm1, sm1, px1, sx1, po1;
+  if (mat)            { pm1 = oA + r;  sm1 = 6; px1 = oV + c; sx1 = 6; po1 = oAtV + r * 6 + c; }
+  else if (row2)      { pm1 = oB + q;  sm1 = 2; px1 = oV + c; sx1 = 6; po1 = oBtV + q * 6 + c; }
+  else if (vec)       { pm1 = oA + r;  sm1 = 6; px1 = oVx;    sx1 = 1; po1 = oAtVx + r; }
+  else if (lane < 56) { pm1 = oB + q;  sm1 = 2; px1 = oVx;    sx1 = 1; po1 = oBtVx + q; }
+  else if (lane < 58) { pm1 = oBo + q; sm1 = 2; px1 = oVx;    sx1 = 1; po1 = oBtVx2 + q; }
+  else                { pm1 = oBo + 1; sm1 = 2; px1 = oV + c; sx1 = 6; po1 = oBtV2 + 6 + c; }
+  // stage 2: sum_k X[px2 + k] * M[pm2 + k sm2] -> L[po2] (matrix lanes keep the result)
+  int px2, pm2, sm2, po2;
+  if (mat)            { px2 = oAtV + r * 6; pm2 = oA + c; sm2 = 6; po2 = oDummy; }
+  else if (row2)      { px2 = oBtV + q * 6; pm2 = oA + c; sm2 = 6; po2 = oQux + q * 8 + c; }
+  else if (lane < 52) { const int a = (lane - 48) >> 1, b = (lane - 48) & 1;
+                        px2 = oBtV + a * 6; pm2 = oB + b; sm2 = 2; po2 = oBtVB + a * 2 + b; }
+  else if (lane < 56) { const int a = (lane - 52) >> 1, b = (lane - 52) & 1;
+                        px2 = (a == 0) ? oBtV : oBtV2 + 6; pm2 = oBo + b; sm2 = 2; po2 = oBtVB2 + a * 2 + b; }
+  else                { px2 = oBtV; pm2 = oB; sm2 = 2; po2 = oDummy + 1 + (lane & 3); }
+  // stage 3: K(q, c) (lanes 36..47), the others write to the dummy cell
+  const int pk3 = row2 ? oK + q * 8 + c : oDummy + 5;
+  const int pq3 = row2 ? oQux + c : oQux;          // Qux(0, c), Qux(1, c) = +8
+  // stage 4: column quantities (K(., c), Qux(., c)), c = 6 for the Vx lanes
+  const int c4 = mat ? c : 6;
+  const int pbase = mat ? oH + r * 6 + c : oLx + r;
+  const int po4 = mat ? oVn + r * 6 + c : (vec ? oVx + r : oDummy + 6);
+  // stage 5: symmetrisation partner
+  const int psym = mat ? oVn + c * 6 + r : oVn;
+  // ---- constants of A, B, H; terminal value function ----
+  if (lane < 36) {
+    L[oA + lane] = (lane / 6 == lane % 6) ? 1.0 : (lane == 3 * 6 + 4 ? dt : 0.0);
+    L[oH + lane] = 0.0;
+  }
+  if (lane < 12) {
+    const double b = (lane == 3 * 2 + 0) ? 0.5 * dt * dt : ((lane == 4 * 2 + 0 || lane == 5 * 2 + 1) ? dt : 0.0);
+    L[oB + lane] = b;
+    L[oBo + lane] = b;
+  }
+  if (lane < 36) L[oV + lane] = 0.0;
+  if (lane < 16) { L[oQux + lane] = 0.0; L[oK + lane] = 0.0; }
+  sync();
+  if (lane < 9) {
+    const double2 t = s.term[(size_t)lane * Bc + slot];
+    // pairs 0..2: Vx; 3..8: (h00,h01) (h02,h10) (h11,h12) (h20,h21) (h22,h33) (h44,h55) of Vxx
+    constexpr int px[9] = {oVx + 0, oVx + 2, oVx + 4, oV + 0, oV + 2, oV + 7, oV + 12, oV + 14, oV + 28};
+    constexpr int py[9] = {oVx + 1, oVx + 3, oVx + 5, oV + 1, oV + 6, oV + 8, oV + 13, oV + 21, oV + 35};
+    L[px[lane]] = t.x;
+    L[py[lane]] = t.y;
+  }
+  // where the pair a lane fetches (17 pairs of lin, then u) goes: two cells of A / B / lx / lu / H / luu / u
+  int in0 = oDummy + 2, in1 = oDummy + 3;
+  {
+    constexpr int t0[18] = {oA + 2, oA + 4, oA + 8, oA + 10, oA + 15, oA + 17, oLx + 0, oLx + 2, oLx + 4, oLu,
+                            oH + 0, oH + 2, oH + 7, oH + 12, oH + 14, oH + 28, oLuu, oU};
+    constexpr int t1[18] = {oA + 3, oA + 5, oA + 9, oA + 11, oA + 16, oB + 5, oLx + 1, oLx + 3, oLx + 5, oLu + 1,
+                            oH + 1, oH + 6, oH + 8, oH + 13, oH + 21, oH + 35, oLuu + 1, oU + 1};
+    if (lane < 18) { in0 = t0[lane]; in1 = t1[lane]; }
+  }
+  auto fetch = [&](int i) -> double2 {
+    if (lane < kLinPairs) return s.lin[((size_t)i * kLinPairs + lane) * Bc + slot];
+    if (lane == kLinPairs) return s.U[((size_t)buf * N + i) * Bc + slot];
+    return make_double2(0.0, 0.0);
+  };
+  double2 pre = fetch(N - 1);
+  double dV0 = 0.0, dV1 = 0.0, gsum = 0.0;
+  double kp0 = 0.0, kp1 = 0.0, lup0 = 0.0, lup1 = 0.0, luup0 = 0.0, luup1 = 0.0;   // previous step: k, lu, luu
+  // delta_V terms of the step whose B is in Bo, Qu / Quu on the current Vx / Vxx (cc:383-384)
+  auto delta_v = [&]() {
+    const double Qu0 = lup0 + L[oBtVx2], Qu1 = lup1 + L[oBtVx2 + 1];
+    dV0 += kp0 * Qu0 + kp1 * Qu1;
+    const double q00 = luup0 + L[oBtVB2], q01 = L[oBtVB2 + 1], q10 = L[oBtVB2 + 2], q11 = luup1 + L[oBtVB2 + 3];
+    const double hk0 = 0.5 * kp0, hk1 = 0.5 * kp1;
+    const double r0 = hk0 * q00 + hk1 * q10, r1 = hk0 * q01 + hk1 * q11;
+    dV1 += r0 * kp0 + r1 * kp1;
+  };
+  for (int i = N - 1; i >= -1; --i) {
+    // inputs of step i (previous B(2,1) moves to Bo first); step -1 only finishes delta_V of step 0
+    if (lane == 0) L[oBo + 5] = L[oB + 5];
+    sync();
+    if (i >= 0 && lane <= kLinPairs) { L[in0] = pre.x; L[in1] = pre.y; }
+    if (i > 0) pre = fetch(i - 1);
+    sync();
+    // ---- stage 1 ----
+    double res1;
+    {
+      double a = L[pm1] * L[px1];
+#pragma unroll
+      for (int k = 1; k < 6; ++k) a += L[pm1 + k * sm1] * L[px1 + k * sx1];
+      res1 = a;
+      L[po1] = a;
+    }
+    sync();
+    // ---- stage 2 ----
+    double res2;
+    {
+      double a = L[px2] * L[pm2];
+#pragma unroll
+      for (int k = 1; k < 6; ++k) a += L[px2 + k] * L[pm2 + k * sm2];
+      res2 = a;
+      if (!mat && lane < 56) L[po2] = a;
+    }
+    sync();
+    if (i < N - 1) delta_v();
+    if (i < 0) break;
+    // ---- stage 3: Quu, Qu, inverse, k (every lane), K (lanes 36..47) ----
+    const double lu0 = L[oLu], lu1 = L[oLu + 1], luu0 = L[oLuu], luu1 = L[oLuu + 1];
+    const double Quu[4] = {luu0 + L[oBtVB], L[oBtVB + 1], L[oBtVB + 2], luu1 + L[oBtVB + 3]};     // cc:352
+    const double Qu[2] = {lu0 + L[oBtVx], lu1 + L[oBtVx + 1]};                                     // cc:349
+    const double m00 = Quu[0] + lambda, m01 = Quu[1], m10 = Quu[2], m11 = Quu[3] + lambda;
+    const double invdet = 1.0 / (m00 * m11 - m10 * m01);                                           // cc:361-363
+    const double n00 = -(m11 * invdet), n01 = -(-m01 * invdet), n10 = -(-m10 * invdet), n11 = -(m00 * invdet);
+    const double kc0 = n00 * Qu[0] + n01 * Qu[1], kc1 = n10 * Qu[0] + n11 * Qu[1];                 // cc:366
+    {
+      const double x0 = L[pq3], x1 = L[pq3 + 8];
+      const double n0 = (q == 0) ? n00 : n10, n1 = (q == 0) ? n01 : n11;
+      const double kq = n0 * x0 + n1 * x1;                                                         // cc:365
+      if (row2) L[pk3] = kq;
+    }
+    if (lane == 0) { L[oK + 6] = kc0; L[oK + 14] = kc1; L[oQux + 6] = Qu[0]; L[oQux + 14] = Qu[1]; }
+    {  // CalGradientNorm term, cc:328-329
+      const double v0 = fabs(kc0) / (fabs(L[oU]) + 1), v1 = fabs(kc1) / (fabs(L[oU + 1]) + 1);
+      gsum += (v0 > v1 ? v0 : v1);
+    }
+    sync();
+    // gains: lanes 0..5 store pair r of (K row 0 | K row 1), lane 6 stores k
+    if (lane < 7) {
+      double2 g2;
+      if (lane < 6) {
+        const int e0 = 2 * lane, e1 = 2 * lane + 1;
+        g2 = make_double2(L[oK + (e0 / 6) * 8 + e0 % 6], L[oK + (e1 / 6) * 8 + e1 % 6]);
+      } else {
+        g2 = make_double2(kc0, kc1);
+      }
+      s.gains[((size_t)i * kGainPairs + lane) * Bc + slot] = g2;
+    }
+    // ---- stage 4: new Vxx (unsymmetrised) and new Vx ----
+    double own;
+    {
+      const double K0r = L[oK + r], K1r = L[oK + 8 + r], Q0r = L[oQux + r], Q1r = L[oQux + 8 + r];
+      const double a0 = L[oK + c4], a1 = L[oK + 8 + c4], b0 = L[oQux + c4], b1 = L[oQux + 8 + c4];
+      const double KtQ0 = K0r * Quu[0] + K1r * Quu[2], KtQ1 = K0r * Quu[1] + K1r * Quu[3];        // cc:379-380
+      const double m1 = KtQ0 * a0 + KtQ1 * a1;
+      const double m2 = K0r * b0 + K1r * b1;
+      const double m3 = Q0r * a0 + Q1r * a1;
+      const double base = L[pbase] + (mat ? res2 : res1);
+      own = ((base + m1) + m2) + m3;
+      if (mat || vec) L[po4] = own;
+    }
+    sync();
+    // ---- stage 5: in-place symmetrisation, column-major order (cc:381) ----
+    if (mat) {
+      const double o_cr = L[psym];
+      const double lower = 0.5 * (own + o_cr);
+      const double upper = 0.5 * (own + 0.5 * (o_cr + own));
+      L[oV + r * 6 + c] = (r < c) ? upper : lower;
+    }
+    kp0 = kc0; kp1 = kc1; lup0 = lu0; lup1 = lu1; luup0 = luu0; luup1 = luu1;
+  }
+  if (lane == 0) {
+    s.dV[slot] = dV0;
+    s.dV[(size_t)Bc + slot] = dV1;
+    s.gnorm[slot] = gsum / N;
+  }
+}
+
 }  // namespace cilqr

@@ -41,11 +41,25 @@ __global__ __launch_bounds__(64, 1) void k_backward(DeviceState s, const int* __
   backward_problem<true>(s, slot, lambda);
 }
 
-// team_threshold: active sets up to this size use eight lanes per problem
+// one wavefront per problem (backward_core.hpp: backward_wave_problem)
+__global__ __launch_bounds__(64) void k_backward_wave(DeviceState s, const int* __restrict__ list, int n,
+                                                      const double* __restrict__ lambda_override) {
+  __shared__ double lds[wave::kDoubles];
+  const int j = blockIdx.x;
+  if (j >= active_count(s, n)) return;
+  const int slot = list ? list[j] : j;
+  const double lambda = lambda_override ? lambda_override[slot] : s.lambda[slot];
+  backward_wave_problem(s, slot, lambda, (int)threadIdx.x, lds, WaveSync{});
+}
+
+// wave_threshold: active sets up to this size give every problem a wavefront; team_threshold: up to this size,
+// eight lanes; larger ones, one lane (the HBM-bound form)
 void launch_backward(const DeviceState& s, const int* list, int n, const double* lambda_override,
-                     int team_threshold, hipStream_t st) {
+                     int team_threshold, int wave_threshold, hipStream_t st) {
   if (n == 0) return;
-  if (n <= team_threshold)
+  if (n <= wave_threshold)
+    hipLaunchKernelGGL(k_backward_wave, dim3(n), dim3(64), 0, st, s, list, n, lambda_override);
+  else if (n <= team_threshold)
     hipLaunchKernelGGL(k_backward_team, dim3((n + 7) / 8), dim3(64), 0, st, s, list, n, lambda_override);
   else
     hipLaunchKernelGGL(k_backward, dim3((n + 63) / 64), dim3(64), 0, st, s, list, n, lambda_override);

@@ -12,12 +12,12 @@
 // leaves at once instead of waiting for the slowest one of its iteration.
 //
 // Same arithmetic.  Every phase calls the device function the lockstep kernels call (knot_quadratize,
-// backward_team_problem, forward_core, knot_cost, update_state) on a view of the state in which the problem is
+// backward_wave_problem, forward_core, knot_cost, update_state) on a view of the state in which the problem is
 // the only one: the block copies its problem's working set into a private, contiguous arena and runs the functions
 // with Bcap = 1, slot = 0.  Results are bit-identical to the lockstep path (tested with the tail switched off).
 //
 // Phases of one iteration (256 threads; `|` = __syncthreads):
-//   quadratize, one knot per thread | backward, 8 lanes of wave 0 | exit test | rollouts of all 11 step sizes,
+//   quadratize, one knot per thread | backward, wave 0 (one output element per lane) | exit test | rollouts of all 11 step sizes,
 //   11 lanes | knot costs of alpha_0..4 (5 K items over the block) | totals, 5 lanes | first passing index;
 //   only if none: alpha_5..9, then alpha_10 | the winner becomes the iterate | update_state | exports.
 // The first passing list index wins whatever the evaluation order (cc:246-265), so evaluating the candidates in
@@ -118,8 +118,8 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(DeviceState g, TailArgs a
   if (blk >= n) return;
   const int tid = threadIdx.x;
   const double* lanes = stage_lanes(g, lds);
-  double* T = lds + ((g.nl + g.nr) * kLaneFields + 1) / 2 * 2;   // team scratch of the backward pass
-  double* tot = T + team::kStride;                               // [11][5] candidate totals
+  double* T = lds + ((g.nl + g.nr) * kLaneFields + 1) / 2 * 2;   // operands of the backward pass
+  double* tot = T + wave::kDoubles;                              // [11][5] candidate totals
   int* flag = reinterpret_cast<int*>(tot + kNumAlpha * 5);       // [0] leaves before the search [1] accepted index [2] done
   const DeviceState t = tail_view(g, a, blk);
   const int K = g.p.K, N = g.p.N;
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(DeviceState g, TailArgs a
       for (int i = tid; i < K; i += kTailThreads) knot_quadratize<D>(t, lanes, t.cur[0], i, 0);
     }
     __syncthreads();
-    if (tid < team::kLanes) backward_team_problem(t, 0, t.lambda[0], true, tid, T, WaveSync{});   // cc:218
+    if (tid < 64) backward_wave_problem(t, 0, t.lambda[0], tid, T, WaveSync{});   // cc:218 (wave 0)
     __syncthreads();
     if (tid == 0) {                                                        // cc:235-241
       const bool leave = leaves_before_search(t, 0, true);
@@ -292,7 +292,7 @@ void launch_tail(const DeviceState& g, void* workspace, int n_max, double* traj,
   a.it_cap = max_iter_trajs;
   a.max_iter = max_iter_dev;
   const size_t lane_d = (size_t)((g.nl + g.nr) * kLaneFields + 1) / 2 * 2;
-  const size_t lds = (lane_d + team::kStride + kNumAlpha * 5) * sizeof(double) + 16 * sizeof(int);
+  const size_t lds = (lane_d + wave::kDoubles + kNumAlpha * 5) * sizeof(double) + 16 * sizeof(int);
   if (g.p.num_of_disc == 5) hipLaunchKernelGGL(k_tail<5>, dim3(n_max), dim3(kTailThreads), lds, st, g, a, n_max);
   else hipLaunchKernelGGL(k_tail<0>, dim3(n_max), dim3(kTailThreads), lds, st, g, a, n_max);
 }

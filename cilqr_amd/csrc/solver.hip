@@ -418,6 +418,10 @@ int cilqr_set_option(cilqr_handle h, int32_t option, int64_t value) {
       if (value < 0) return CILQR_ERR_ARG;
       h->team_threshold = (int)(value > 0x7fffffff ? 0x7fffffff : value);
       return CILQR_OK;
+    case CILQR_OPT_WAVE_THRESHOLD:
+      if (value < 0) return CILQR_ERR_ARG;
+      h->wave_threshold = (int)(value > 0x7fffffff ? 0x7fffffff : value);
+      return CILQR_OK;
     case CILQR_OPT_TAIL_THRESHOLD:
       if (value < 0) return CILQR_ERR_ARG;
       h->tail_threshold = (int)(value > kTailMaxProblems ? kTailMaxProblems : value);
@@ -631,7 +635,7 @@ static int solve_core(cilqr_handle h, const cilqr_problem_batch* in, cilqr_solut
     if (tm.begin(0)) return CILQR_ERR_DEVICE;
     launch_quadratize(d, d.act, n_hint, 1, st);        // cc:203-214
     if (tm.end() || tm.begin(1)) return CILQR_ERR_DEVICE;
-    launch_backward(d, d.act, n_hint, nullptr, h->team_threshold, st);    // cc:218
+    launch_backward(d, d.act, n_hint, nullptr, h->team_threshold, h->wave_threshold, st);    // cc:218
     if (tm.end() || tm.begin(2)) return CILQR_ERR_DEVICE;
     bwd_iter.push_back(it);
     launch_linesearch(d, n_hint, h->spec_threshold, h->seq_rounds, st);  // cc:235-270
@@ -855,7 +859,7 @@ int cilqr_stage_backward(cilqr_handle h, const double* lambda, int32_t memory) {
       dl = lambda;
     }
   }
-  launch_backward(h->ds, nullptr, h->B, dl, h->team_threshold, h->stream);
+  launch_backward(h->ds, nullptr, h->B, dl, h->team_threshold, h->wave_threshold, h->stream);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
   h->stage |= 8;

@@ -185,6 +185,10 @@ int cilqr_set_stream(cilqr_handle h, void* hip_stream);
  * problem over eight lanes (column-wise) instead of one, which shortens the chain of dependent
  * steps a small launch waits on; 0 = always one lane per problem.  Bit-identical results. */
 #define CILQR_OPT_TEAM_THRESHOLD 4
+/* CILQR_OPT_WAVE_THRESHOLD (default 1024): backward passes over at most this many problems give every problem a
+ * whole wavefront (operands in LDS, one output element per lane): the shortest chain of dependent work per step.
+ * 0 = never.  Bit-identical results. */
+#define CILQR_OPT_WAVE_THRESHOLD 6
 /* CILQR_OPT_TAIL_THRESHOLD (default 256, at most 8192): once at most this many problems are still iterating they
  * leave the lockstep loop; one workgroup per problem runs all its remaining iterations in a single launch
  * (kernels_tail.hip), so the stragglers of a batch no longer cost nine launches per iteration.  0 = lockstep to

@@ -651,33 +651,41 @@ def test_lean_sin_cos_tan_are_accurate_to_a_few_ulp():
 
 
 def test_team_backward_is_bit_identical_to_one_lane_per_problem(lockstep_only):
-    """CILQR_OPT_TEAM_THRESHOLD: small backward launches spread a problem over eight lanes
-    (k_backward_team).  Stage outputs (gains, delta_V, gradient norm) and whole solves must not
-    change by a bit, for batch sizes that leave teams idle, fill them exactly, or cross blocks."""
+    """CILQR_OPT_TEAM_THRESHOLD / CILQR_OPT_WAVE_THRESHOLD: small backward launches spread a problem over eight
+    lanes (k_backward_team) or over a whole wavefront (k_backward_wave).  Stage outputs (gains, delta_V, gradient
+    norm) and whole solves must not change by a bit, for batch sizes that leave teams idle, fill them exactly, or
+    cross blocks."""
     for B in (1, 7, 8, 9, 70):
         sc = scenario.generate("mix11", B, seed=140 + B)
         opt = _opt(sc)
         outs = []
-        for thr in (0, 4096):
-            opt.set_option(api.OPT_TEAM_THRESHOLD, thr)
+        for team, wave in ((0, 0), (4096, 0), (0, 4096)):
+            opt.set_option(api.OPT_TEAM_THRESHOLD, team)
+            opt.set_option(api.OPT_WAVE_THRESHOLD, wave)
             opt.stage_load(sc)
             opt.stage_init_guess()
             opt.stage_quadratize()
             opt.stage_backward(np.linspace(0.3, 2.0, B))
             outs.append([opt.read(t) for t in (api.T_KFB, api.T_KFF, api.T_DV, api.T_GNORM)])
-        for a, b in zip(*outs):
-            assert np.array_equal(a, b)
+        for other in outs[1:]:
+            for a, b in zip(outs[0], other):
+                assert np.array_equal(a, b)
         opt.close()
-    sc = scenario.generate("mix11", 300, seed=150)
-    opt = _opt(sc)
-    a = opt.plan(sc, max_iter_trajs=2)
-    opt.set_option(api.OPT_TEAM_THRESHOLD, 0)
-    b = opt.plan(sc, max_iter_trajs=2)
-    opt.set_option(api.OPT_TEAM_THRESHOLD, 64)       # switches kernels in the middle of the solve
-    c = opt.plan(sc, max_iter_trajs=2)
-    for k in ("traj", "cost_hist", "n_cost", "status", "n_iter", "iter_trajs"):
-        assert np.array_equal(a[k], b[k]) and np.array_equal(a[k], c[k]), k
-    opt.close()
+    for family, B, seed in (("mix11", 300, 150), ("dyn20x", 40, 151)):
+        sc = scenario.generate(family, B, seed=seed)
+        opt = _opt(sc)
+        opt.set_option(api.OPT_WAVE_THRESHOLD, 0)
+        opt.set_option(api.OPT_TEAM_THRESHOLD, 4096)
+        a = opt.plan(sc, max_iter_trajs=2)
+        outs = []
+        for team, wave in ((0, 0), (64, 0), (4096, 16), (0, 4096)):   # incl. switching kernels in the middle of a solve
+            opt.set_option(api.OPT_TEAM_THRESHOLD, team)
+            opt.set_option(api.OPT_WAVE_THRESHOLD, wave)
+            outs.append(opt.plan(sc, max_iter_trajs=2))
+        for k in ("traj", "cost_hist", "n_cost", "status", "n_iter", "iter_trajs"):
+            for o in outs:
+                assert np.array_equal(a[k], o[k]), (family, k)
+        opt.close()
 
 
 @pytest.mark.parametrize("N", [1, 2, 3, 5, 7])

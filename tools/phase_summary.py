@@ -14,7 +14,7 @@ def main():
         path = glob.glob(os.path.join(path, "**", "*.db"), recursive=True)[0]
     c = sqlite3.connect(path)
     rows = c.execute("select name, start, end, grid_x from kernels order by start").fetchall()
-    names = [r[0].split("(")[0].replace("cilqr::", "") for r in rows]
+    names = [r[0].split("(")[0].replace("void ", "").replace("cilqr::", "") for r in rows]
     starts = [i for i, n in enumerate(names) if n == "k_load_corridor"]
     lo = starts[solve]
     hi = starts[solve + 1] if solve + 1 < len(starts) else len(rows)

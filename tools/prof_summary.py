@@ -35,7 +35,7 @@ def load(path):
 
 
 def short(name):
-    return name.split("(")[0].replace("cilqr::", "")
+    return name.split("(")[0].replace("void ", "").replace("cilqr::", "")
 
 
 def main():
