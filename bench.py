@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--spec-threshold", type=int, default=-1, help="CILQR_OPT_SPEC_THRESHOLD value (tuning experiments)")
     ap.add_argument("--seq-rounds", type=int, default=-1, help="CILQR_OPT_SEQ_ROUNDS value (tuning experiments)")
     ap.add_argument("--team-threshold", type=int, default=-1, help="CILQR_OPT_TEAM_THRESHOLD value (tuning experiments)")
+    ap.add_argument("--round-group", type=int, default=-1, help="CILQR_OPT_ROUND_GROUP value (tuning experiments)")
     ap.add_argument("--wave-threshold", type=int, default=-1, help="CILQR_OPT_WAVE_THRESHOLD value (tuning experiments)")
     ap.add_argument("--tail-threshold", type=int, default=-1, help="CILQR_OPT_TAIL_THRESHOLD value (tuning experiments; 0 = lockstep to the end)")
     ap.add_argument("--pipeline", type=int, default=3,
@@ -157,6 +158,8 @@ def main():
                 o.set_option(api.OPT_TEAM_THRESHOLD, args.team_threshold)
             if args.tail_threshold >= 0:
                 o.set_option(api.OPT_TAIL_THRESHOLD, args.tail_threshold)
+            if args.round_group >= 1:
+                o.set_option(api.OPT_ROUND_GROUP, args.round_group)
             if args.wave_threshold >= 0:
                 o.set_option(api.OPT_WAVE_THRESHOLD, args.wave_threshold)
             self.traj = torch.zeros((B, K, 10), dtype=torch.float64, device=dev)

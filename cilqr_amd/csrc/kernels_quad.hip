@@ -75,25 +75,25 @@ __global__ __launch_bounds__(256) CILQR_COST_ATTR void k_spec_cost(DeviceState s
     knot_cost<D>(s, lanes, i, slot, x, u, s.parts + ((size_t)r * s.p.K + i) * kPartPairs * cap + j, cap);
   }
 }
-// The same for a SPARSE list (the problems that rejected every sequential round: a few percent of the slots, in
-// no particular order).  With one lane per problem every load of a corridor plane, a goal or a grid cell then
-// touches a cache line of its own -- 64 lines per instruction where the dense kernels touch 8.  Here eight
-// consecutive lanes hold the (up to eight) remaining step sizes of ONE problem: what depends on the problem and the
-// knot only is read once per eight lanes (same address: one line), and only the candidate itself (3 + 1 pairs)
-// is read per lane.  Same arithmetic per (problem, step size, knot); measured 4.6x faster per knot cost.
-constexpr int kPackLanes = 8;
-template <int D>
+// The same with P consecutive lanes per problem: knot i of candidates alpha_{r0} .. alpha_{r_end-1} of list entry j; the lanes
+// hold P step sizes of ONE problem.  What depends on the problem and the knot only (corridor planes, goal, plane
+// count) is then read once per P lanes (same address: one cache line), and only the candidate itself (3 + 1 pairs)
+// per lane.  For the SPARSE list of the hybrid schedule (the problems that rejected every sequential round: a few
+// percent of the slots, in no particular order) one lane per problem made every such load touch 64 different lines;
+// packed, the same knot costs are 4.6x faster (measured: 897 -> 155 us in the first iteration of the bench batch).
+template <int D, int P>
 __global__ __launch_bounds__(256) CILQR_COST_ATTR void k_spec_cost_packed(DeviceState s, const int* __restrict__ list,
-                                                                          const int* __restrict__ n_ptr, int n_max, int r0) {
+                                                                          const int* __restrict__ n_ptr, int n_max,
+                                                                          int r0, int r_end) {
   extern __shared__ double lds[];
   const int n = n_ptr ? min(*n_ptr, n_max) : active_count(s, n_max);
-  constexpr int per_block = 256 / kPackLanes;
+  constexpr int per_block = 256 / P;
   if ((int)(blockIdx.x * per_block) >= n) return;
   const double* lanes = stage_lanes(s, lds);
-  const int i = blockIdx.y, r = r0 + (threadIdx.x & (kPackLanes - 1));
+  const int i = blockIdx.y, r = r0 + (int)(threadIdx.x % P);
   const size_t cap = (size_t)s.spec_cap;
-  if (r >= kNumAlpha) return;
-  for (int j = blockIdx.x * per_block + threadIdx.x / kPackLanes; j < n; j += gridDim.x * per_block) {
+  if (r >= r_end) return;
+  for (int j = blockIdx.x * per_block + threadIdx.x / P; j < n; j += gridDim.x * per_block) {
     const int slot = list[j];
     if (s.acc_idx[slot] != -1) continue;   // left at the gradient-norm exit
     const double2* xb = s.Xs + ((size_t)r * s.p.K + i) * 3 * cap + j;
@@ -108,31 +108,52 @@ __global__ __launch_bounds__(256) CILQR_COST_ATTR void k_spec_cost_packed(Device
   }
 }
 
-// sparse: the list is a small, unordered subset of the slots (see k_spec_cost_packed)
+// Candidates alpha_{r0} .. alpha_10 of every listed problem.  The step sizes of a problem sit in neighbouring lanes
+// (eight, then four for what is left), so what depends on the problem and the knot only -- corridor planes, goal --
+// travels once per group instead of once per candidate; for the sparse pending list of the hybrid schedule this is
+// also what keeps a load instruction from touching 64 different cache lines.
 void launch_spec_cost(const DeviceState& s, const int* list, const int* n_ptr, int n_max, int n_grid, int r0,
                       int sparse, hipStream_t st) {
-  if (sparse && kNumAlpha - r0 <= kPackLanes) {
-    constexpr int per_block = 256 / kPackLanes;
-    dim3 g((n_grid + per_block - 1) / per_block, s.p.K);
-    CILQR_LAUNCH_BY_DISCS(k_spec_cost_packed, g, dim3(256), lane_lds_bytes(s), st, s, list, n_ptr, n_max, r0);
+  const size_t lds = lane_lds_bytes(s);
+  const bool five = s.p.num_of_disc == 5;
+  if (!sparse) {   // a dense list: one lane per problem is already coalesced, one grid layer per candidate (measured: 2 % faster)
+    dim3 g((n_grid + 255) / 256, s.p.K, kNumAlpha - r0);
+    CILQR_LAUNCH_BY_DISCS(k_spec_cost, g, dim3(256), lds, st, s, list, n_ptr, n_max, r0);
     return;
   }
-  dim3 g((n_grid + 255) / 256, s.p.K, kNumAlpha - r0);
-  CILQR_LAUNCH_BY_DISCS(k_spec_cost, g, dim3(256), lane_lds_bytes(s), st, s, list, n_ptr, n_max, r0);
+  for (int a = r0; a < kNumAlpha;) {
+    const int left = kNumAlpha - a;
+    const int P = left > 4 ? 8 : (left > 2 ? 4 : (left > 1 ? 2 : 1));
+    const int e = a + (P < left ? P : left);
+    const int per_block = 256 / P;
+    dim3 g((n_grid + per_block - 1) / per_block, s.p.K);
+#define CILQR_SC(DD, PP) hipLaunchKernelGGL((k_spec_cost_packed<DD, PP>), g, dim3(256), lds, st, s, list, n_ptr, n_max, a, e)
+    if (P == 8) { if (five) CILQR_SC(5, 8); else CILQR_SC(0, 8); }
+    else if (P == 4) { if (five) CILQR_SC(5, 4); else CILQR_SC(0, 4); }
+    else if (P == 2) { if (five) CILQR_SC(5, 2); else CILQR_SC(0, 2); }
+    else { if (five) CILQR_SC(5, 1); else CILQR_SC(0, 1); }
+#undef CILQR_SC
+    a = e;
+  }
 }
 
-// knot i of candidate alpha_r of the problems pending in round r
-template <int D>
-__global__ __launch_bounds__(256) CILQR_COST_ATTR void k_round_cost(DeviceState s, int r, int n_max) {
+// Sequential rounds, G step sizes per round: knot i of candidates alpha_{r0} .. alpha_{r0+G-1} of the problems that
+// rejected alpha_0 .. alpha_{r0-1} (pending list r0).  G consecutive lanes hold the G candidates of one problem, so
+// its corridor planes and goals travel once per G knot costs (see k_spec_cost_packed); with G = 2 a round costs
+// a candidate that the sequential loop might not have reached (alpha_1 for the 15 % that accept alpha_0), and saves
+// half of the plane traffic and half of the launches.  The first passing index still wins (k_round_pick).
+template <int D, int G>
+__global__ __launch_bounds__(256) CILQR_COST_ATTR void k_round_cost(DeviceState s, int r0, int n_max) {
   extern __shared__ double lds[];
-  const int* __restrict__ list = s.pend + (size_t)r * s.Bcap;
-  const int n = (r == 0) ? active_count(s, n_max) : min(s.counters[r], n_max);
-  if ((int)(blockIdx.x * blockDim.x) >= n) return;
+  const int* __restrict__ list = s.pend + (size_t)r0 * s.Bcap;
+  const int n = (r0 == 0) ? active_count(s, n_max) : min(s.counters[r0], n_max);
+  constexpr int per_block = 256 / G;
+  if ((int)(blockIdx.x * per_block) >= n) return;
   const double* lanes = stage_lanes(s, lds);
-  const int i = blockIdx.y;
+  const int i = blockIdx.y, r = r0 + (int)(threadIdx.x % G);
   const size_t cap = (size_t)s.spec_cap;
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
-    const int j = (r == 0) ? e : list[e];
+  for (int e = blockIdx.x * per_block + threadIdx.x / G; e < n; e += gridDim.x * per_block) {
+    const int j = (r0 == 0) ? e : list[e];
     const int slot = s.act[j];
     if (s.acc_idx[slot] != -1) continue;
     const double2* xb = s.Xs + ((size_t)r * s.p.K + i) * 3 * cap + j;
@@ -147,9 +168,17 @@ __global__ __launch_bounds__(256) CILQR_COST_ATTR void k_round_cost(DeviceState 
   }
 }
 
-void launch_round_cost(const DeviceState& s, int r, int n_max, int n_grid, hipStream_t st) {
-  dim3 g((n_grid + 255) / 256, s.p.K);
-  CILQR_LAUNCH_BY_DISCS(k_round_cost, g, dim3(256), lane_lds_bytes(s), st, s, r, n_max);
+// n_grid: problems the grid is sized for (threads stride over the rest); group: 1, 2 or 4 candidates per round
+void launch_round_cost(const DeviceState& s, int r0, int group, int n_max, int n_grid, hipStream_t st) {
+  const int per_block = 256 / group;
+  dim3 g((n_grid + per_block - 1) / per_block, s.p.K);
+  const size_t lds = lane_lds_bytes(s);
+  const bool five = s.p.num_of_disc == 5;
+#define CILQR_RC(DD, GG) hipLaunchKernelGGL((k_round_cost<DD, GG>), g, dim3(256), lds, st, s, r0, n_max)
+  if (group == 1) { if (five) CILQR_RC(5, 1); else CILQR_RC(0, 1); }
+  else if (group == 2) { if (five) CILQR_RC(5, 2); else CILQR_RC(0, 2); }
+  else { if (five) CILQR_RC(5, 4); else CILQR_RC(0, 4); }
+#undef CILQR_RC
 }
 
 __global__ __launch_bounds__(64) void k_reduce_only(DeviceState s, const int* __restrict__ list, int n) {

@@ -232,56 +232,63 @@ __global__ __launch_bounds__(64) void k_multi_forward(DeviceState s, int n) {
   forward_multi<G>(s, slot, j);
 }
 
-// round r: total cost of candidate alpha_r (knot partials summed in index order), acceptance test
-// (cc:252-261); rejected -> pending list r + 1 (positions, or slots when `last`)
-__global__ __launch_bounds__(64) void k_round_pick(DeviceState s, int r, int n_max, int last) {
-  const int* __restrict__ list = s.pend + (size_t)r * s.Bcap;
-  const int n = (r == 0) ? active_count(s, n_max) : min(s.counters[r], n_max);
+// round of G step sizes alpha_{r0} .. alpha_{r0+G-1}: total cost of each candidate (knot partials summed in index
+// order) and acceptance test (cc:252-261), IN LIST ORDER and stopping at the first that passes -- what the
+// sequential loop does; rejected all G -> pending list r0 + G (positions, or slots when `last`)
+__global__ __launch_bounds__(64) void k_round_pick(DeviceState s, int r0, int G, int n_max, int last) {
+  const int* __restrict__ list = s.pend + (size_t)r0 * s.Bcap;
+  const int n = (r0 == 0) ? active_count(s, n_max) : min(s.counters[r0], n_max);
   const size_t cap = (size_t)s.spec_cap;
   const int K = s.p.K, N = s.p.N;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
-    const int j = (r == 0) ? e : list[e];
+    const int j = (r0 == 0) ? e : list[e];
     const int slot = s.act[j];
     if (s.acc_idx[slot] != -1) continue;   // left at the gradient-norm exit
+    const double cost_old = s.cost_old[slot], dV0 = s.dV[slot], dV1 = s.dV[(size_t)s.Bcap + slot];
+    bool accepted = false;
+    for (int r = r0; r < r0 + G && !accepted; ++r) {
 #ifdef CILQR_REF_ORDER
-    double c5[5];
-    spec_total_cost(s, slot, r, j, c5);
-    (void)K; (void)N; (void)cap;
+      double c5[5];
+      spec_total_cost(s, slot, r, j, c5);
+      (void)K; (void)N; (void)cap;
 #else
-    double jj = 0.0, dx = 0.0, du = 0.0, cc = 0.0, lc = 0.0;
-    const double2* pb = s.parts + (size_t)r * K * kPartPairs * cap + j;
-    // loads of several knots in flight; the sums stay in knot order
+      double jj = 0.0, dx = 0.0, du = 0.0, cc = 0.0, lc = 0.0;
+      const double2* pb = s.parts + (size_t)r * K * kPartPairs * cap + j;
+      // loads of several knots in flight; the sums stay in knot order
 #pragma unroll 8
-    for (int i = 0; i < K; ++i) {
-      const double2* o = pb + (size_t)i * kPartPairs * cap;
-      const double2 a = o[0], b = o[cap], c = o[2 * cap];
-      jj += a.x;
-      dx += b.x;
-      cc += c.x;
-      lc += c.y;
-    }
+      for (int i = 0; i < K; ++i) {
+        const double2* o = pb + (size_t)i * kPartPairs * cap;
+        const double2 a = o[0], b = o[cap], c = o[2 * cap];
+        jj += a.x;
+        dx += b.x;
+        cc += c.x;
+        lc += c.y;
+      }
 #pragma unroll 8
-    for (int i = 0; i < N; ++i) {
-      const double2* o = pb + (size_t)i * kPartPairs * cap;
-      jj += o[0].y;
-      du += o[cap].y;
-    }
-    const double dyn = dx + du;
-    const double c5[5] = {jj + dyn + cc + lc, jj, dyn, cc, lc};
+      for (int i = 0; i < N; ++i) {
+        const double2* o = pb + (size_t)i * kPartPairs * cap;
+        jj += o[0].y;
+        du += o[cap].y;
+      }
+      const double dyn = dx + du;
+      const double c5[5] = {jj + dyn + cc + lc, jj, dyn, cc, lc};
 #endif
-    const double alpha = kAlpha[r];
-    const double dcost = s.cost_old[slot] - c5[0];                                  // cc:254
-    const double expected = -alpha * (s.dV[slot] + alpha * s.dV[(size_t)s.Bcap + slot]);  // cc:255
-    const double z = dcost / expected;                                              // cc:257
+      const double alpha = kAlpha[r];
+      const double dcost = cost_old - c5[0];                                          // cc:254
+      const double expected = -alpha * (dV0 + alpha * dV1);                           // cc:255
+      const double z = dcost / expected;                                              // cc:257
 #pragma unroll
-    for (int c = 0; c < 5; ++c) s.trial[(size_t)c * s.Bcap + slot] = c5[c];
-    if ((z > 1e-4 && z < 10.0) && dcost > 0.0) {                                    // cc:258
-      s.acc_idx[slot] = r;
-      s.dcost[slot] = dcost;
-      s.cur[slot] ^= 1;   // k_multi_copy fills the new current buffer
-    } else if (r + 1 < kNumAlpha) {
-      const int pos = atomicAdd(&s.counters[r + 1], 1);
-      s.pend[(size_t)(r + 1) * s.Bcap + pos] = last ? slot : j;
+      for (int c = 0; c < 5; ++c) s.trial[(size_t)c * s.Bcap + slot] = c5[c];
+      if ((z > 1e-4 && z < 10.0) && dcost > 0.0) {                                    // cc:258
+        s.acc_idx[slot] = r;
+        s.dcost[slot] = dcost;
+        s.cur[slot] ^= 1;   // k_multi_copy fills the new current buffer
+        accepted = true;
+      }
+    }
+    if (!accepted && r0 + G < kNumAlpha) {
+      const int pos = atomicAdd(&s.counters[r0 + G], 1);
+      s.pend[(size_t)(r0 + G) * s.Bcap + pos] = last ? slot : j;
     }
   }
 }
@@ -322,7 +329,8 @@ static void launch_spec(const DeviceState& s, const int* list, const int* n_ptr,
 }
 
 // seq_rounds: how many step sizes are tried round by round before the rest is evaluated at once
-void launch_linesearch(const DeviceState& s, int n_act, int spec_threshold, int seq_rounds, hipStream_t st) {
+void launch_linesearch(const DeviceState& s, int n_act, int spec_threshold, int seq_rounds, int round_group,
+                       hipStream_t st) {
   if (n_act == 0) return;
   if (n_act <= spec_threshold) {
     launch_spec(s, s.act, nullptr, n_act, n_act, 0, 1, st);
@@ -338,13 +346,16 @@ void launch_linesearch(const DeviceState& s, int n_act, int spec_threshold, int 
     else if (R == 4) hipLaunchKernelGGL(k_multi_forward<4>, gf, bf, 0, st, s, n_act);
     else if (R == 5) hipLaunchKernelGGL(k_multi_forward<5>, gf, bf, 0, st, s, n_act);
     else hipLaunchKernelGGL(k_multi_forward<6>, gf, bf, 0, st, s, n_act);
-    for (int r = 0; r < R; ++r) {
+    // G step sizes per round (round_group; the last round takes what is left of R)
+    for (int r0 = 0; r0 < R;) {
+      const int G = (round_group >= 4 && R - r0 >= 4) ? 4 : ((round_group >= 2 && R - r0 >= 2) ? 2 : 1);
       // later rounds carry a fraction of the batch: shrink the grids, stride inside
-      const int shrink = (r == 0) ? 1 : (r == 1 ? 2 : 8);
+      const int shrink = (r0 == 0) ? 1 : ((r0 == 1 || G > 1) ? 2 : 8);
       const int n_grid = (n_act + shrink - 1) / shrink;
-      launch_round_cost(s, r, n_act, n_grid, st);
-      // one lane per pending problem (never strided: a lane sums a whole cost column)
-      hipLaunchKernelGGL(k_round_pick, dim3((n_act + 63) / 64), dim3(64), 0, st, s, r, n_act, (r + 1 == R) ? 1 : 0);
+      launch_round_cost(s, r0, G, n_act, n_grid, st);
+      // one lane per pending problem (never strided: a lane sums whole cost columns)
+      hipLaunchKernelGGL(k_round_pick, dim3((n_act + 63) / 64), dim3(64), 0, st, s, r0, G, n_act, (r0 + G == R) ? 1 : 0);
+      r0 += G;
     }
     hipLaunchKernelGGL(k_multi_copy, dim3((n_act + 255) / 256, s.p.K), dim3(256), 0, st, s, n_act, R);
     if (R < kNumAlpha) {

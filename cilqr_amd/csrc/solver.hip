@@ -418,6 +418,10 @@ int cilqr_set_option(cilqr_handle h, int32_t option, int64_t value) {
       if (value < 0) return CILQR_ERR_ARG;
       h->team_threshold = (int)(value > 0x7fffffff ? 0x7fffffff : value);
       return CILQR_OK;
+    case CILQR_OPT_ROUND_GROUP:
+      if (value != 1 && value != 2 && value != 4) return CILQR_ERR_ARG;
+      h->round_group = (int)value;
+      return CILQR_OK;
     case CILQR_OPT_WAVE_THRESHOLD:
       if (value < 0) return CILQR_ERR_ARG;
       h->wave_threshold = (int)(value > 0x7fffffff ? 0x7fffffff : value);
@@ -638,7 +642,7 @@ static int solve_core(cilqr_handle h, const cilqr_problem_batch* in, cilqr_solut
     launch_backward(d, d.act, n_hint, nullptr, h->team_threshold, h->wave_threshold, st);    // cc:218
     if (tm.end() || tm.begin(2)) return CILQR_ERR_DEVICE;
     bwd_iter.push_back(it);
-    launch_linesearch(d, n_hint, h->spec_threshold, h->seq_rounds, st);  // cc:235-270
+    launch_linesearch(d, n_hint, h->spec_threshold, h->seq_rounds, h->round_group, st);  // cc:235-270
     launch_update(d, n_hint, st);                      // cc:272-308
     launch_export_done(d, n_hint, o_traj, st);         // cc:238,285,303,319
     if (o_it) launch_export_iter_traj(d, d.act, n_hint, o_it, out->max_iter_trajs, st);

@@ -52,6 +52,7 @@ struct cilqr_solver {
   int stage = 0;           // bit0 loaded, bit1 iterate, bit2 quadratized, bit3 gains
   int spec_threshold = 8192;  // active sets up to this size evaluate all 11 step sizes at once
   int team_threshold = 4096;  // active sets up to this size run the backward pass with 8 lanes per problem
+  int round_group = 2;        // step sizes costed per sequential round (1, 2 or 4)
   int wave_threshold = 1024;  // active sets up to this size run the backward pass with a wavefront per problem
   int seq_rounds = 4;         // larger sets: this many round-by-round trials, then the rest at once
   int tail_threshold = 256;   // active sets up to this size leave the lockstep loop: one workgroup per problem (kernels_tail.hip)

@@ -185,7 +185,7 @@ void launch_cost_knots(const DeviceState& s, const int* list, const int* n_ptr, 
                        int cand, int skip_done, hipStream_t st);
 void launch_spec_cost(const DeviceState& s, const int* list, const int* n_ptr, int n_max, int n_grid, int r0,
                       int sparse, hipStream_t st);
-void launch_round_cost(const DeviceState& s, int r, int n_max, int n_grid, hipStream_t st);
+void launch_round_cost(const DeviceState& s, int r0, int group, int n_max, int n_grid, hipStream_t st);
 void launch_init_cost_commit(const DeviceState& s, int n, hipStream_t st);
 void launch_quadratize(const DeviceState& s, const int* list, int n, int only_upd, hipStream_t st);
 void launch_backward(const DeviceState& s, const int* list, int n, const double* lambda_override,
@@ -193,7 +193,8 @@ void launch_backward(const DeviceState& s, const int* list, int n, const double*
 void launch_forward(const DeviceState& s, const int* list, int n, double alpha, int skip_done,
                     hipStream_t st);
 // the 11-round line search of one lockstep iteration (forward/cost/accept with compaction)
-void launch_linesearch(const DeviceState& s, int n_act, int spec_threshold, int seq_rounds, hipStream_t st);
+void launch_linesearch(const DeviceState& s, int n_act, int spec_threshold, int seq_rounds, int round_group,
+                       hipStream_t st);
 void launch_init_counters(const DeviceState& s, int first_n, hipStream_t st);
 // kernels_tail.hip: one workgroup per problem finishes every problem of the active list (all remaining iterations)
 size_t tail_workspace_bytes(const DeviceState& s);   // private arena of one problem

@@ -816,6 +816,11 @@ def test_speculative_line_search_is_bit_identical_to_round_by_round(lockstep_onl
     for rounds in (1, 2, 3, 5, 11):
         opt.set_option(api.OPT_SEQ_ROUNDS, rounds)
         outs.append(opt.plan(sc, max_iter_trajs=3))
+    # ... with one, two or four step sizes costed per round (CILQR_OPT_ROUND_GROUP; the default is two)
+    for rounds, group in ((4, 1), (4, 2), (4, 4), (6, 4), (5, 2), (3, 4)):
+        opt.set_option(api.OPT_SEQ_ROUNDS, rounds)
+        opt.set_option(api.OPT_ROUND_GROUP, group)
+        outs.append(opt.plan(sc, max_iter_trajs=3))
     for k in ("traj", "cost_hist", "n_cost", "status", "n_iter", "iter_trajs", "n_iter_trajs"):
         for other in outs:
             assert np.array_equal(a[k], other[k]), k

@@ -58,15 +58,19 @@ def main():
     # the roofline kernel by launch size (grid x = problems rounded up to 64)
     sizes = {}
     for name, s_, e_, gx, *_ in rows:
-        if short(name) not in ("k_backward", "k_backward_team"):
+        if short(name) not in ("k_backward", "k_backward_team", "k_backward_wave"):
             continue
         if short(name) == "k_backward_team":
             gx = gx // 8          # eight lanes per problem
+        if short(name) == "k_backward_wave":
+            gx = gx // 64         # a wavefront per problem
         b = ">=65536" if gx >= 65536 else (">=8192" if gx >= 8192 else (">=1024" if gx >= 1024 else "<1024"))
         st = sizes.setdefault(b, [0, 0, 0])
         st[0] += 1; st[1] += e_ - s_; st[2] += gx
     if sizes:
-        print("\nk_backward / k_backward_team by launch size (problems per launch; the team kernel, eight lanes per\nproblem, takes the launches of at most CILQR_OPT_TEAM_THRESHOLD = 4096 problems):")
+        print("\nbackward kernels by launch size (problems per launch; k_backward: one lane per problem; k_backward_team,\n"
+              "eight lanes, launches of at most CILQR_OPT_TEAM_THRESHOLD = 4096 problems; k_backward_wave, a wavefront,\n"
+              "at most CILQR_OPT_WAVE_THRESHOLD = 1024; with N = 50 as in the default bench):")
         for b in (">=65536", ">=8192", ">=1024", "<1024"):
             if b in sizes:
                 n, t, g = sizes[b]
