@@ -48,8 +48,10 @@ CILQR_DEV void load_fwd_step(const DeviceState& s, int buf, int i, int slot, Fwd
   for (int r = 0; r < kGainPairs; ++r) f.kk[r] = g[(size_t)r * Bc];
 }
 
-// roll the closed-loop policy out from goals_[0] (cc:392-415)
-template <class Out>
+// roll the closed-loop policy out from goals_[0] (cc:392-415).  kAhead: steps whose operands are requested ahead of
+// the arithmetic -- 4 where a lane is alone on its SIMD (176 VGPRs of loads in flight), 1 where several waves per
+// SIMD hide each other's latency instead.
+template <class Out, int kAhead = kFwdAhead>
 CILQR_DEV void forward_core(const DeviceState& s, int slot, double alpha, const Out& out) {
   const Params& p = s.p;
   const int Bc = s.Bcap, N = p.N;
@@ -64,17 +66,17 @@ CILQR_DEV void forward_core(const DeviceState& s, int slot, double alpha, const 
   // The nominal (xs, us) and the gains of a step do not depend on the rollout, and one lane's step
   // is short (~0.5 us of arithmetic) against the latency of a load that misses L2 (the gains were
   // just written by another kernel): keep the loads of the next kFwdAhead steps in flight.
-  FwdStep pf[kFwdAhead];
+  FwdStep pf[kAhead];
 #pragma unroll
-  for (int d = 0; d < kFwdAhead; ++d)
+  for (int d = 0; d < kAhead; ++d)
     if (d < N) load_fwd_step(s, buf, d, slot, pf[d]);
-  for (int i0 = 0; i0 < N; i0 += kFwdAhead) {
+  for (int i0 = 0; i0 < N; i0 += kAhead) {
 #pragma unroll
-    for (int d = 0; d < kFwdAhead; ++d) {
+    for (int d = 0; d < kAhead; ++d) {
       const int i = i0 + d;
       if (i < N) {
         const FwdStep c = pf[d];
-        if (i + kFwdAhead < N) load_fwd_step(s, buf, i + kFwdAhead, slot, pf[d]);
+        if (i + kAhead < N) load_fwd_step(s, buf, i + kAhead, slot, pf[d]);
         const double xs[6] = {c.x0.x, c.x0.y, c.x1.x, c.x1.y, c.x2.x, c.x2.y};
         const double us[2] = {c.u.x, c.u.y};
         double dx[6];
