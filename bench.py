@@ -231,7 +231,8 @@ def main():
         pc = opt.profile()
         single = dict(quad_ms=pc.quadratize_ms, bwd_ms=pc.backward_ms, ls_ms=pc.linesearch_ms, other_ms=pc.other_ms,
                       tail_ms=pc.tail_ms, tail_problems=pc.tail_problems, lockstep_launches=pc.backward_launches,
-                      total_ms=pc.total_ms, iterations=pc.iterations,
+                      total_ms=pc.total_ms, iterations=pc.iterations, bwd_launches=pc.backward_launches,
+                      bwd_problem_steps=pc.backward_problem_steps,
                       bwd_full_ms=(pc.backward_full_ms / pc.backward_full_launches) if pc.backward_full_launches else None)
         for c in ctx:
             c.opt.set_profiling(2)      # timed steps: events around the backward launches only (< 1 %)
@@ -402,8 +403,10 @@ def main():
             real_all = rec["hbm_bytes_per_problem_step_all_launches"] * prof_acc["bwd_steps"] if rec else None
             roof = {
                 "bound": "hbm", "kernel": "cilqr::k_backward + cilqr::k_backward_team",
-                "launch": "every backward launch of the timed region, time-weighted (65536 problems down to a handful; "
-                          "launches under ~4000 problems run the 8-lanes-per-problem kernel and sit on the latency of N dependent steps)",
+                "launch": "every backward launch of the timed region, time-weighted (65536 problems down to the tail threshold; "
+                          "launches of <= 4096 / <= 1024 problems run the 8-lanes / wave-per-problem kernels and sit on the latency of "
+                          "N dependent steps; the last problems finish inside k_tail, not in backward launches).  With "
+                          "batches_in_flight > 1 the kernels of other batches share the GPU during these launches: see `uncontended`",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(real_all / t_all / 1e9 / HBM_PEAK_GBS, 4) if real_all else None,
                 "frac_basis": "HBM bytes really moved (PMC-recorded bytes per problem-step x this run's problem-steps) / time / peak",
@@ -418,6 +421,34 @@ def main():
                 "mean_problems_per_launch": n_act_sum / prof_acc["bwd_launches"],
                 "batches_in_flight": P,
             }
+            if single and single["bwd_ms"] > 0:
+                # the same launches with nothing else on the GPU: the calibration solve (HIP events around every
+                # backward launch, one batch in flight).  In the timed region P batches share the GPU and a kernel's
+                # duration includes the time its CUs spent on other streams' kernels.
+                t1 = single["bwd_ms"] * 1e-3
+                alg1 = single["bwd_problem_steps"] / N * per_problem
+                real1 = rec["hbm_bytes_per_problem_step_all_launches"] * single["bwd_problem_steps"] if rec else None
+                roof["uncontended"] = {
+                    "what": "all backward launches of ONE solve alone on the GPU (calibration step, HIP events)",
+                    "achieved": round(alg1 / t1 / 1e9, 1),
+                    "frac": round(real1 / t1 / 1e9 / HBM_PEAK_GBS, 4) if real1 else None,
+                    "frac_algorithmic": round(alg1 / t1 / 1e9 / HBM_PEAK_GBS, 4),
+                    "avg_launch_ms": single["bwd_ms"] / single["bwd_launches"], "launches": single["bwd_launches"],
+                    "full_batch_frac": (round(rec["full_batch_launch"]["hbm_bytes_per_problem_step"] * B * N / (single["bwd_full_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                        if rec and single["bwd_full_ms"] else None),
+                    "full_batch_avg_launch_ms": single["bwd_full_ms"],
+                }
+            try:   # fp64-issue / stall record of the other kernels (rocprofv3 PMC, tools/kernel_rooflines.py): recorded, not measured here
+                with open(os.path.join(ROOT, "profiles", "r02_kernel_rooflines.json")) as f:
+                    kr = json.load(f)
+                if args.scene == "mix11" and N == 50 and B == 65536:
+                    roof["other_kernels_recorded"] = {
+                        "source": "profiles/r02_kernel_rooflines.json (separate rocprofv3 --pmc passes of this workload, one batch in flight)",
+                        "kernels": {k: {f: v[f] for f in ("ms_per_solve", "bound", "valu_issue_frac", "hbm_frac", "wait_share", "valu_per_wave") if f in v}
+                                    for k, v in kr["kernels"].items()
+                                    if k.split("<")[0] in ("k_round_cost", "k_spec_cost", "k_spec_cost_packed", "k_quadratize", "k_multi_forward_packed", "k_multi_forward", "k_tail")}}
+            except Exception:
+                pass
             if prof_acc["full_launches"] > 0:
                 t_full = prof_acc["full_ms"] / prof_acc["full_launches"] * 1e-3
                 fb = B * per_problem / t_full / 1e9

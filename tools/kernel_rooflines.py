@@ -31,10 +31,10 @@ def table(path):
     lines = open(path).read().strip().split("\n")
     head = lines[0].split()
     for l in lines[1:]:
-        t = l.split()
-        if len(t) != len(head):
+        name, t = l[:28].strip().replace(" ", ""), l[28:].split()   # the name column is 28 wide (template arguments hold spaces)
+        if len(t) != len(head) - 1:
             continue
-        rows[t[0]] = {h: float(v) for h, v in zip(head[1:], t[1:])}
+        rows[name] = {h: float(v) for h, v in zip(head[1:], t)}
     return rows
 
 
@@ -47,9 +47,10 @@ def main():
     # durations
     dur = {}
     for l in open(f"{d}/{tag}_kernel_stats.txt"):
-        m = re.match(r"^(\S+)\s+(\d+)\s+([\d.]+)\s+([\d.]+)", l)
-        if m and m.group(1).startswith("k_"):
-            dur[m.group(1)] = (int(m.group(2)), float(m.group(3)))
+        m = re.match(r"^\s*(\d+)\s+([\d.]+)\s+([\d.]+)", l[44:])   # the name column is 44 wide
+        name = l[:44].strip().replace(" ", "")
+        if m and name.startswith("k_"):
+            dur[name] = (int(m.group(1)), float(m.group(2)))
     solves_trace = dur["k_load_goals"][0]
     solves_pmc = int(sq["k_load_goals"]["disp"])
     out = {"source": [f"{tag}_pmc_all_kernels_{i}.txt" for i in (1, 2, 3, 4)] + [f"{tag}_kernel_stats.txt"],

@@ -36,6 +36,8 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_
   rocprofv3 --pmc $set -d "$out/pmc_all_$i" -- python bench.py --steps 1 --warmup 0 --pipeline 1 --cpu-sample 0 > "$out/pmc_all_$i.json" 2> "$out/pmc_all_$i.err"
   python tools/pmc_summary.py "$out/pmc_all_$i" > "$out/${tag}_pmc_all_kernels_$i.txt" 2>&1
 done
+python tools/kernel_rooflines.py "$out" "$tag" > "$out/${tag}_kernel_rooflines.json" 2> "$out/kr.err"
+python bench.py --tail-threshold 0 --pipeline 1 --cpu-sample 0 > "$out/${tag}_bench_lockstep_only_pipeline1.json" 2> "$out/ls.err"
 python bench.py --scene ped6 --batch 4096 --cpu-sample 0 > "$out/${tag}_bench_config1_ped6_b4096.json" 2> "$out/c1.err"
 python bench.py --scene dyn20 --cpu-sample 0 > "$out/${tag}_bench_config4_dyn20_n100.json" 2> "$out/c4.err"
 python bench.py --scene dyn20x --cpu-sample 0 > "$out/${tag}_bench_config4_dyn20x_n100.json" 2> "$out/c4x.err"
