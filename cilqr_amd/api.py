@@ -117,7 +117,7 @@ class Profile(C.Structure):
 
 
 EXPORTS = [
-    "cilqr_abi_version", "cilqr_default_config", "cilqr_create", "cilqr_destroy", "cilqr_set_stream",
+    "cilqr_abi_version", "cilqr_build_id", "cilqr_default_config", "cilqr_create", "cilqr_destroy", "cilqr_set_stream",
     "cilqr_set_option", "cilqr_set_profiling", "cilqr_get_profile", "cilqr_device_bytes", "cilqr_solve_batch",
     "cilqr_submit", "cilqr_wait", "cilqr_device_math", "cilqr_stage_load", "cilqr_stage_init_guess", "cilqr_stage_set_trajectory",
     "cilqr_stage_total_cost", "cilqr_stage_quadratize", "cilqr_stage_backward", "cilqr_stage_forward",

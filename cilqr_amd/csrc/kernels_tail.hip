@@ -176,7 +176,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(DeviceState g, TailArgs a
     }
     __syncthreads();
     if (!flag[0]) {
-      if (tid < kNumAlpha) forward_core(t, 0, kAlpha[tid], OutSpec{t, tid, 0});   // cc:246-250, all step sizes
+      if (tid < kNumAlpha) forward_core<OutSpec, 1>(t, 0, kAlpha[tid], OutSpec{t, tid, 0});   // cc:246-250, all step sizes
       __syncthreads();
       int acc = -1;
       for (int r0 = 0; r0 < kNumAlpha && acc < 0; r0 += kTailChunk) {

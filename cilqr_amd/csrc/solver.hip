@@ -14,6 +14,7 @@
 #include <new>
 #include <vector>
 
+#include "build_id.h"
 #include "solver_priv.hpp"
 
 using namespace cilqr;
@@ -221,6 +222,8 @@ struct Timer {  // event pairs, resolved after the final sync
 extern "C" {
 
 int cilqr_abi_version(void) { return CILQR_ABI_VERSION; }
+
+const char* cilqr_build_id(void) { return CILQR_BUILD_ID; }
 
 const char* cilqr_error_string(int code) {
   switch (code) {
@@ -1071,7 +1074,7 @@ int cilqr_lane_constraints(const double* boundary, int32_t n, double segment_len
 
 int cilqr_device_math(cilqr_handle h, int32_t fn, int32_t n, const double* in, double* out) {
   if (h == nullptr || in == nullptr || out == nullptr) return CILQR_ERR_NULL;
-  if (n <= 0 || fn < 0 || fn > 5) return CILQR_ERR_ARG;
+  if (n <= 0 || fn < 0 || fn > 6) return CILQR_ERR_ARG;
   HIP_TRY(hipSetDevice(h->device));
   double* d = nullptr;
   if (hipMalloc(reinterpret_cast<void**>(&d), (size_t)n * 16) != hipSuccess) return CILQR_ERR_DEVICE;

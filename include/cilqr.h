@@ -161,6 +161,8 @@ typedef struct cilqr_profile {
 } cilqr_profile;
 
 int cilqr_abi_version(void);
+/* first 32 hex digits of the SHA-256 over the library's sources (cilqr_amd/csrc/Makefile): which sources this binary was built from */
+const char* cilqr_build_id(void);
 int cilqr_default_config(cilqr_config* cfg, int32_t n_steps);
 
 /* device: HIP ordinal.  batch_capacity/cmax/max_lane_segments size the HBM arena once. */
@@ -316,7 +318,7 @@ int cilqr_lane_constraints(const double* boundary, int32_t n, double segment_len
 /* Test hook for the kernels' own fp64 routines (host arrays of n doubles):
  * fn 0: log(x) for normal finite x > 0;  fn 1: 1 / x for normal finite x != 0;
  * fn 2: log(x) with mantissa and exponent handed over separately (the long-product path);
- * fn 3 / 4 / 5: sin / cos / tan(x) for |x| <= 1e5. */
+ * fn 3 / 4 / 5: sin / cos / tan(x) for |x| <= 1e5;  fn 6: NormalizeAngle(x) (math_utils.cpp:53-59). */
 int cilqr_device_math(cilqr_handle h, int32_t fn, int32_t n, const double* in, double* out);
 
 /* X[b][0] = x0[b]; X[b][i+1] = Dynamics(X[b][i], U[b][i]).  x0 [B][6], U [B][N][2], X [B][K][6] */

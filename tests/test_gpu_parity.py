@@ -650,6 +650,28 @@ def test_lean_sin_cos_tan_are_accurate_to_a_few_ulp():
     opt.close()
 
 
+def test_normalize_angle_is_the_reference_expression_bit_for_bit():
+    """NormalizeAngle (math_utils.cpp:53-59): a = fmod(angle + pi, 2 pi); if (a < 0) a += 2 pi; return a - pi.
+    The device function takes exact short cuts for arguments within a turn of the principal range and the
+    library fmod otherwise; fmod is exact, so every result must equal the reference expression evaluated in
+    numpy -- including the ends of the range, multiples of pi, huge and tiny arguments."""
+    sc = scenario.generate("ped6", 4, seed=3)
+    opt = _opt(sc)
+    rng = np.random.default_rng(8)
+    k = np.arange(-9, 10)
+    edges = np.concatenate([k * np.pi + d for d in (0.0, 1e-16, -1e-16, 4e-16, -4e-16, 1e-9, -1e-9)])
+    edges = np.concatenate([edges, np.nextafter(k * np.pi, np.inf), np.nextafter(k * np.pi, -np.inf)])
+    x = np.concatenate([rng.uniform(-np.pi, np.pi, 100000), rng.uniform(-4 * np.pi, 4 * np.pi, 100000),
+                        rng.uniform(-1e3, 1e3, 50000), rng.uniform(-1e9, 1e9, 20000), rng.uniform(-1e-6, 1e-6, 5000),
+                        edges, np.array([0.0, -0.0, np.pi, -np.pi, 2 * np.pi, -2 * np.pi, 1e300, -1e300, 5e-324])])
+    a = np.fmod(x + np.pi, 2.0 * np.pi)
+    ref = np.where(a < 0.0, a + 2.0 * np.pi, a) - np.pi
+    got = opt.device_math(6, x)
+    assert np.array_equal(got, ref), (x[got != ref][:5], got[got != ref][:5], ref[got != ref][:5])
+    assert ((got >= -np.pi) & (got <= np.pi)).all()
+    opt.close()
+
+
 def test_team_backward_is_bit_identical_to_one_lane_per_problem(lockstep_only):
     """CILQR_OPT_TEAM_THRESHOLD / CILQR_OPT_WAVE_THRESHOLD: small backward launches spread a problem over eight
     lanes (k_backward_team) or over a whole wavefront (k_backward_wave).  Stage outputs (gains, delta_V, gradient

@@ -30,6 +30,25 @@ def test_library_exports_every_declared_symbol(built):
     assert exported == set(declared)     # nothing else leaks through the C-ABI prefix
 
 
+def test_library_was_built_from_the_sources_in_the_tree(built):
+    """cilqr_build_id: the first 32 hex digits of the SHA-256 over the library's sources, compiled in by the
+    Makefile.  The .so is a prebuilt artefact that travels to the GPU box; this pins it to the sources beside it."""
+    import ctypes
+    import glob
+    import hashlib
+    csrc = os.path.join(ROOT, "cilqr_amd", "csrc")
+    files = sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.hpp")), key=os.path.basename)
+    files = sorted([os.path.basename(f) for f in files if os.path.basename(f) != "build_id.h"])
+    h = hashlib.sha256()   # same order as the Makefile's $(sort ...): the ../../include paths sort first
+    for f in ("cilqr.h", os.path.join("cilqr", "dp_planner.hpp")):
+        h.update(open(os.path.join(ROOT, "include", f), "rb").read())
+    for f in files:
+        h.update(open(os.path.join(csrc, f), "rb").read())
+    L = api.lib()
+    L.cilqr_build_id.restype = ctypes.c_char_p
+    assert L.cilqr_build_id().decode() == h.hexdigest()[:32]
+
+
 def test_product_does_not_reference_the_oracle():
     for dirpath, _, files in os.walk(os.path.join(ROOT, "cilqr_amd")):
         for f in files:
