@@ -542,6 +542,10 @@ CILQR_DEV void backward_wave_problem(const DeviceState& s, int slot, double lamb
   const int Bc = s.Bcap, N = p.N;
   const double dt = p.dt;
   const int buf = s.cur[slot];
+  // the pointers as locals: when the state is a large by-value copy (kernels_tail.hip) its fields live in scratch
+  const double2* __restrict__ lin_p = s.lin;
+  const double2* __restrict__ u_p = s.U;
+  double2* __restrict__ gains_p = s.gains;
   // ---- per-lane roles ----
   const bool mat = lane < 36, row2 = lane >= 36 && lane < 48, vec = lane >= 48 && lane < 54;
   const int r = mat ? lane / 6 : (vec ? lane - 48 : 0);
@@ -604,8 +608,8 @@ CILQR_DEV void backward_wave_problem(const DeviceState& s, int slot, double lamb
     if (lane < 18) { in0 = t0[lane]; in1 = t1[lane]; }
   }
   auto fetch = [&](int i) -> double2 {
-    if (lane < kLinPairs) return s.lin[((size_t)i * kLinPairs + lane) * Bc + slot];
-    if (lane == kLinPairs) return s.U[((size_t)buf * N + i) * Bc + slot];
+    if (lane < kLinPairs) return lin_p[((size_t)i * kLinPairs + lane) * Bc + slot];
+    if (lane == kLinPairs) return u_p[((size_t)buf * N + i) * Bc + slot];
     return make_double2(0.0, 0.0);
   };
   double2 pre = fetch(N - 1);
@@ -678,7 +682,7 @@ CILQR_DEV void backward_wave_problem(const DeviceState& s, int slot, double lamb
       } else {
         g2 = make_double2(kc0, kc1);
       }
-      s.gains[((size_t)i * kGainPairs + lane) * Bc + slot] = g2;
+      gains_p[((size_t)i * kGainPairs + lane) * Bc + slot] = g2;
     }
     // ---- stage 4: new Vxx (unsymmetrised) and new Vx ----
     double own;

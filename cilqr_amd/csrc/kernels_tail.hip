@@ -110,6 +110,13 @@ CILQR_DEV DeviceState tail_view(const DeviceState& g, const TailArgs& a, int blk
   return t;
 }
 
+#ifdef CILQR_TAIL_PROFILE
+#define TP_DECL long long tp_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long tp_t = __builtin_readcyclecounter(); int tp_it = 0;
+#define TP(k) do { const long long n_ = __builtin_readcyclecounter(); tp_[k] += n_ - tp_t; tp_t = n_; } while (0)
+#else
+#define TP_DECL
+#define TP(k)
+#endif
 template <int D>
 __global__ __launch_bounds__(kTailThreads) void k_tail(DeviceState g, TailArgs a, int n_max) {
   extern __shared__ double lds[];
@@ -160,14 +167,17 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(DeviceState g, TailArgs a
   }
   __syncthreads();
   const int pb = t.pid[0];
-
+  TP_DECL
   for (;;) {
+    TP(7);
     if (t.upd[0]) {                                                        // cc:203-214
       for (int i = tid; i < K; i += kTailThreads) knot_quadratize<D>(t, lanes, t.cur[0], i, 0);
     }
     __syncthreads();
+    TP(0);
     if (tid < 64) backward_wave_problem(t, 0, t.lambda[0], tid, T, WaveSync{});   // cc:218 (wave 0)
     __syncthreads();
+    TP(1);
     if (tid == 0) {                                                        // cc:235-241
       const bool leave = leaves_before_search(t, 0, true);
       t.acc_idx[0] = leave ? -2 : -1;
@@ -178,6 +188,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(DeviceState g, TailArgs a
     if (!flag[0]) {
       if (tid < kNumAlpha) forward_core<OutSpec, 1>(t, 0, kAlpha[tid], OutSpec{t, tid, 0});   // cc:246-250, all step sizes
       __syncthreads();
+      TP(2);
       int acc = -1;
       for (int r0 = 0; r0 < kNumAlpha && acc < 0; r0 += kTailChunk) {
         const int nr = min(kTailChunk, kNumAlpha - r0);
@@ -194,6 +205,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(DeviceState g, TailArgs a
           knot_cost<D>(t, lanes, i, 0, x, u, t.parts + ((size_t)r * K + i) * kPartPairs, 1);
         }
         __syncthreads();
+        TP(3);
         if (tid < nr) {   // total of candidate r: knot partials in index order (k_spec_reduce)
           const int r = r0 + tid;
           double jj = 0.0, dx = 0.0, du = 0.0, cc = 0.0, lc = 0.0;
@@ -248,6 +260,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(DeviceState g, TailArgs a
         }
         __syncthreads();
         acc = flag[1];
+        TP(4);
       }
       if (acc >= 0) {   // the accepted candidate becomes the iterate
         const int nb = t.cur[0];
@@ -265,6 +278,13 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(DeviceState g, TailArgs a
     if (tid == 0) flag[2] = update_state(t, g, 0) ? 1 : 0;                // cc:272-319
     __syncthreads();
     const bool done = flag[2] != 0;
+    TP(5);
+#ifdef CILQR_TAIL_PROFILE
+    ++tp_it;
+    if (done && tid == 0 && (blk & 31) == 0)
+      printf("tail blk %d iters %d cycles: quad %lld bwd %lld exit+fwd %lld cost %lld reduce+pick %lld copy+update %lld export %lld\n", blk, tp_it,
+             tp_[0] / tp_it, tp_[1] / tp_it, tp_[2] / tp_it, tp_[3] / tp_it, tp_[4] / tp_it, tp_[5] / tp_it, tp_[7] / tp_it);
+#endif
     if (a.iter_trajs && t.emit[0]) {
       const int idx = g.n_iter_trajs[pb] - 1;
       if (idx < a.it_cap)
