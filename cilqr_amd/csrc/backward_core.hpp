@@ -612,7 +612,12 @@ CILQR_DEV void backward_wave_problem(const DeviceState& s, int slot, double lamb
     if (lane == kLinPairs) return u_p[((size_t)buf * N + i) * Bc + slot];
     return make_double2(0.0, 0.0);
   };
-  double2 pre = fetch(N - 1);
+  // operands of the next kWaveAhead steps in flight (one pair per lane and step): a step is ~0.9 us of arithmetic,
+  // a load that misses L2 takes longer
+  constexpr int kWaveAhead = 3;
+  double2 pre[kWaveAhead];
+#pragma unroll
+  for (int d = 0; d < kWaveAhead; ++d) pre[d] = fetch(N - 1 - d >= 0 ? N - 1 - d : 0);
   double dV0 = 0.0, dV1 = 0.0, gsum = 0.0;
   double kp0 = 0.0, kp1 = 0.0, lup0 = 0.0, lup1 = 0.0, luup0 = 0.0, luup1 = 0.0;   // previous step: k, lu, luu
   // delta_V terms of the step whose B is in Bo, Qu / Quu on the current Vx / Vxx (cc:383-384)
@@ -628,8 +633,10 @@ CILQR_DEV void backward_wave_problem(const DeviceState& s, int slot, double lamb
     // inputs of step i (previous B(2,1) moves to Bo first); step -1 only finishes delta_V of step 0
     if (lane == 0) L[oBo + 5] = L[oB + 5];
     sync();
-    if (i >= 0 && lane <= kLinPairs) { L[in0] = pre.x; L[in1] = pre.y; }
-    if (i > 0) pre = fetch(i - 1);
+    if (i >= 0 && lane <= kLinPairs) { L[in0] = pre[0].x; L[in1] = pre[0].y; }
+#pragma unroll
+    for (int d = 0; d + 1 < kWaveAhead; ++d) pre[d] = pre[d + 1];
+    if (i - kWaveAhead >= 0) pre[kWaveAhead - 1] = fetch(i - kWaveAhead);
     sync();
     // ---- stage 1 ----
     double res1;

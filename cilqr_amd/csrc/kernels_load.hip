@@ -245,8 +245,10 @@ void launch_load(const DeviceState& s, int B, const ProblemView& in, const doubl
   hipLaunchKernelGGL(k_load_goals, dim3((n + 255) / 256), dim3(256), 0, st, s, B, in);
   dim3 g((B + 63) / 64, s.p.K);
   hipLaunchKernelGGL(k_load_corridor, g, dim3(256), 0, st, s, B, in);
-  hipLaunchKernelGGL(k_load_lanes, dim3(1), dim3(512), 0, st, s, lanes_raw);
-  launch_build_lane_grid(s, st);
+  if (lanes_raw) {   // nullptr: the lane tables and their grid are those of the previous load
+    hipLaunchKernelGGL(k_load_lanes, dim3(1), dim3(512), 0, st, s, lanes_raw);
+    launch_build_lane_grid(s, st);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

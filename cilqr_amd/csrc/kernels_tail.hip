@@ -110,6 +110,15 @@ CILQR_DEV DeviceState tail_view(const DeviceState& g, const TailArgs& a, int blk
   return t;
 }
 
+// The backward phase as a function of its own: inlined, its loop inherits the scalar-register pressure of the whole
+// kernel (exec masks of its lane roles spilled to vector lanes: 57 v_readlane per step); called, it is allocated
+// on its own.  LDS is reached through the kernel's dynamic shared array, so the accesses stay ds_* instructions.
+__device__ __attribute__((noinline)) void tail_backward(int off_T, int off_view) {
+  extern __shared__ double lds[];
+  const DeviceState& t = *reinterpret_cast<const DeviceState*>(reinterpret_cast<const char*>(lds) + off_view);
+  backward_wave_problem(t, 0, t.lambda[0], (int)threadIdx.x, lds + off_T, WaveSync{});
+}
+
 #ifdef CILQR_TAIL_PROFILE
 #define TP_DECL long long tp_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long tp_t = __builtin_readcyclecounter(); int tp_it = 0;
 #define TP(k) do { const long long n_ = __builtin_readcyclecounter(); tp_[k] += n_ - tp_t; tp_t = n_; } while (0)
@@ -128,7 +137,12 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(DeviceState g, TailArgs a
   double* T = lds + ((g.nl + g.nr) * kLaneFields + 1) / 2 * 2;   // operands of the backward pass
   double* tot = T + wave::kDoubles;                              // [11][5] candidate totals
   int* flag = reinterpret_cast<int*>(tot + kNumAlpha * 5);       // [0] leaves before the search [1] accepted index [2] done
-  const DeviceState t = tail_view(g, a, blk);
+  // The view sits in LDS, not in registers: its ~70 uniform fields on top of the kernel's own would spill the scalar
+  // registers into vector lanes (385 spills, 159 v_readlane per backward step measured: +60 % on that phase).
+  DeviceState* tv = reinterpret_cast<DeviceState*>(flag + 16);
+  if (tid == 0) *tv = tail_view(g, a, blk);
+  __syncthreads();
+  const DeviceState& t = *tv;
   const int K = g.p.K, N = g.p.N;
   const size_t Bc = (size_t)g.Bcap;
 
@@ -175,7 +189,8 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(DeviceState g, TailArgs a
     }
     __syncthreads();
     TP(0);
-    if (tid < 64) backward_wave_problem(t, 0, t.lambda[0], tid, T, WaveSync{});   // cc:218 (wave 0)
+    if (tid < 64)                                                          // cc:218 (wave 0)
+      tail_backward((int)(T - lds), (int)(reinterpret_cast<const char*>(tv) - reinterpret_cast<const char*>(lds)));
     __syncthreads();
     TP(1);
     if (tid == 0) {                                                        // cc:235-241
@@ -186,7 +201,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(DeviceState g, TailArgs a
     }
     __syncthreads();
     if (!flag[0]) {
-      if (tid < kNumAlpha) forward_core<OutSpec, 1>(t, 0, kAlpha[tid], OutSpec{t, tid, 0});   // cc:246-250, all step sizes
+      if (tid < kNumAlpha) forward_core<OutSpec, 4>(t, 0, kAlpha[tid], OutSpec{t, tid, 0});   // cc:246-250, all step sizes
       __syncthreads();
       TP(2);
       int acc = -1;
@@ -312,7 +327,7 @@ void launch_tail(const DeviceState& g, void* workspace, int n_max, double* traj,
   a.it_cap = max_iter_trajs;
   a.max_iter = max_iter_dev;
   const size_t lane_d = (size_t)((g.nl + g.nr) * kLaneFields + 1) / 2 * 2;
-  const size_t lds = (lane_d + wave::kDoubles + kNumAlpha * 5) * sizeof(double) + 16 * sizeof(int);
+  const size_t lds = (lane_d + wave::kDoubles + kNumAlpha * 5) * sizeof(double) + 16 * sizeof(int) + sizeof(DeviceState) + 16;
   if (g.p.num_of_disc == 5) hipLaunchKernelGGL(k_tail<5>, dim3(n_max), dim3(kTailThreads), lds, st, g, a, n_max);
   else hipLaunchKernelGGL(k_tail<0>, dim3(n_max), dim3(kTailThreads), lds, st, g, a, n_max);
 }

@@ -338,7 +338,12 @@ CILQR_DEV void knot_quadratize(const DeviceState& s, const double* __restrict__ 
   // nearest left / right lane plane, all discs (cc:729-769)
 #pragma unroll 1
   for (int j = 0; j < nd; ++j) {
-    const double lcj = p.disc_off[j] * cs, lsj = p.disc_off[j] * sn;
+    // the offset of disc j without indexing the parameter block by a run-time value: where the state is a local
+    // copy (kernels_tail.hip) a dynamically indexed member would put the whole structure into scratch memory
+    double doff;
+    if constexpr (D == 5) doff = (j == 0) ? p.disc_off[0] : (j == 1) ? p.disc_off[1] : (j == 2) ? p.disc_off[2] : (j == 3) ? p.disc_off[3] : p.disc_off[4];
+    else doff = p.disc_off[j];
+    const double lcj = doff * cs, lsj = doff * sn;
     const double px = x[0] + lcj, py = x[1] + lsj;
     const double* L = lanes + nearest_segment(s, lanes, 0, px, py) * kLaneFields;
     PlaneSums ml, mr;

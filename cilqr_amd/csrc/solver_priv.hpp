@@ -45,6 +45,8 @@ struct cilqr_solver {
   void* out_stage = nullptr;
   size_t out_stage_bytes = 0;
   double* lanes_raw = nullptr;  // device [2*smax][7]
+  std::vector<double> lane_cache;   // the lane tables whose device image and grid are current (left rows, then right rows)
+  int lane_cache_nl = -1, lane_cache_nr = -1;
   double* lambda_stage = nullptr;
   int* h_count = nullptr;  // pinned, written by k_update through h_count_dev
   int* h_count_dev = nullptr;
