@@ -119,6 +119,35 @@ __device__ __attribute__((noinline)) void tail_backward(int off_T, int off_view)
   backward_wave_problem(t, 0, t.lambda[0], (int)threadIdx.x, lds + off_T, WaveSync{});
 }
 
+// ... and so are the other three heavy phases (the lane tables sit at the start of the dynamic shared array)
+__device__ __attribute__((noinline)) void tail_forward(int off_view) {
+  extern __shared__ double lds[];
+  const DeviceState& t = *reinterpret_cast<const DeviceState*>(reinterpret_cast<const char*>(lds) + off_view);
+  const int tid = (int)threadIdx.x;
+  forward_core<OutSpec, 4>(t, 0, kAlpha[tid], OutSpec{t, tid, 0});
+}
+template <int D>
+__device__ __attribute__((noinline)) void tail_quadratize(int off_view, int i) {
+  extern __shared__ double lds[];
+  const DeviceState& t = *reinterpret_cast<const DeviceState*>(reinterpret_cast<const char*>(lds) + off_view);
+  knot_quadratize<D>(t, lds, t.cur[0], i, 0);
+}
+template <int D>
+__device__ __attribute__((noinline)) void tail_knot_cost(int off_view, int r, int i) {
+  extern __shared__ double lds[];
+  const DeviceState& t = *reinterpret_cast<const DeviceState*>(reinterpret_cast<const char*>(lds) + off_view);
+  const int K = t.p.K, N = t.p.N;
+  const double2* xb = t.Xs + ((size_t)r * K + i) * 3;
+  const double2 p0 = xb[0], p1 = xb[1], p2 = xb[2];
+  const double x[6] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y};
+  double u[2] = {0.0, 0.0};
+  if (i < N) {
+    const double2 q = t.Us[(size_t)r * N + i];
+    u[0] = q.x; u[1] = q.y;
+  }
+  knot_cost<D>(t, lds, i, 0, x, u, t.parts + ((size_t)r * K + i) * kPartPairs, 1);
+}
+
 #ifdef CILQR_TAIL_PROFILE
 #define TP_DECL long long tp_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long tp_t = __builtin_readcyclecounter(); int tp_it = 0;
 #define TP(k) do { const long long n_ = __builtin_readcyclecounter(); tp_[k] += n_ - tp_t; tp_t = n_; } while (0)
@@ -133,7 +162,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(DeviceState g, TailArgs a
   const int blk = blockIdx.x;
   if (blk >= n) return;
   const int tid = threadIdx.x;
-  const double* lanes = stage_lanes(g, lds);
+  (void)stage_lanes(g, lds);   // lane tables -> the start of the dynamic shared array (read by the phase functions)
   double* T = lds + ((g.nl + g.nr) * kLaneFields + 1) / 2 * 2;   // operands of the backward pass
   double* tot = T + wave::kDoubles;                              // [11][5] candidate totals
   int* flag = reinterpret_cast<int*>(tot + kNumAlpha * 5);       // [0] leaves before the search [1] accepted index [2] done
@@ -143,6 +172,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(DeviceState g, TailArgs a
   if (tid == 0) *tv = tail_view(g, a, blk);
   __syncthreads();
   const DeviceState& t = *tv;
+  const int off_view = (int)(reinterpret_cast<const char*>(tv) - reinterpret_cast<const char*>(lds));
   const int K = g.p.K, N = g.p.N;
   const size_t Bc = (size_t)g.Bcap;
 
@@ -185,12 +215,12 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(DeviceState g, TailArgs a
   for (;;) {
     TP(7);
     if (t.upd[0]) {                                                        // cc:203-214
-      for (int i = tid; i < K; i += kTailThreads) knot_quadratize<D>(t, lanes, t.cur[0], i, 0);
+      for (int i = tid; i < K; i += kTailThreads) tail_quadratize<D>(off_view, i);
     }
     __syncthreads();
     TP(0);
     if (tid < 64)                                                          // cc:218 (wave 0)
-      tail_backward((int)(T - lds), (int)(reinterpret_cast<const char*>(tv) - reinterpret_cast<const char*>(lds)));
+      tail_backward((int)(T - lds), off_view);
     __syncthreads();
     TP(1);
     if (tid == 0) {                                                        // cc:235-241
@@ -201,7 +231,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(DeviceState g, TailArgs a
     }
     __syncthreads();
     if (!flag[0]) {
-      if (tid < kNumAlpha) forward_core<OutSpec, 4>(t, 0, kAlpha[tid], OutSpec{t, tid, 0});   // cc:246-250, all step sizes
+      if (tid < kNumAlpha) tail_forward(off_view);                         // cc:246-250, all step sizes
       __syncthreads();
       TP(2);
       int acc = -1;
@@ -209,15 +239,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(DeviceState g, TailArgs a
         const int nr = min(kTailChunk, kNumAlpha - r0);
         for (int e = tid; e < nr * K; e += kTailThreads) {
           const int rr = e / K, i = e - rr * K, r = r0 + rr;
-          const double2* xb = t.Xs + ((size_t)r * K + i) * 3;
-          const double2 p0 = xb[0], p1 = xb[1], p2 = xb[2];
-          const double x[6] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y};
-          double u[2] = {0.0, 0.0};
-          if (i < N) {
-            const double2 q = t.Us[(size_t)r * N + i];
-            u[0] = q.x; u[1] = q.y;
-          }
-          knot_cost<D>(t, lanes, i, 0, x, u, t.parts + ((size_t)r * K + i) * kPartPairs, 1);
+          tail_knot_cost<D>(off_view, r, i);
         }
         __syncthreads();
         TP(3);
