@@ -730,6 +730,22 @@ def test_short_horizons_empty_knots_and_single_segment_lanes(N, both_paths):
         opt.close()
 
 
+def test_long_horizon_more_knots_than_a_tail_workgroup_has_threads(both_paths):
+    """N = 280 (K = 281 knots): more knots than the 256 threads of a tail workgroup, 5.6 times the bench horizon for
+    the wave / team backward kernels and the rollouts.  Whole solves and every step against the oracle, both loops."""
+    import dataclasses
+    spec = dataclasses.replace(scenario.SPECS["mix11"], n_steps=280)
+    sc = scenario.generate(spec, 12, seed=333)
+    opt = _opt(sc)
+    g = _plan(opt, sc)
+    ocfg = oracle_cfg_from(opt.cfg)
+    ref = oracle_reference(sc, ocfg)
+    rep = assert_parity(g, ref, max_unstable_frac=0.34, what="N=280")
+    steps = assert_steps(g, sc, ocfg, what="N=280", max_excused_frac=0.05)
+    print(f"\nN=280: whole solves {rep}; steps {steps}")
+    opt.close()
+
+
 def test_full_size_batch_properties():
     """BASELINE configs[2] size (B = 65536, N = 50): 256 distinct scenes tiled 256x.  Size-independent
     properties: every copy of a scene gives bit-identical output wherever it sits in the batch, all
