@@ -13,6 +13,8 @@
 // wave-step, every access 16 B/lane and 1 KiB contiguous per wave.  Structural zeros/ones of A and
 // B are skipped at compile time; adding an exact zero never changes an IEEE sum, so the results
 // are those of the dense recursion.
+#include <hip/hip_ext.h>
+
 #include "backward_core.hpp"
 
 namespace cilqr {
@@ -55,14 +57,16 @@ __global__ __launch_bounds__(64) void k_backward_wave(DeviceState s, const int* 
 // wave_threshold: active sets up to this size give every problem a wavefront; team_threshold: up to this size,
 // eight lanes; larger ones, one lane (the HBM-bound form)
 void launch_backward(const DeviceState& s, const int* list, int n, const double* lambda_override,
-                     int team_threshold, int wave_threshold, hipStream_t st) {
+                     int team_threshold, int wave_threshold, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
   if (n == 0) return;
+  // ev_start / ev_stop (profiling): the kernel's OWN start and end (dispatch timestamps, what rocprofv3 reports) --
+  // events recorded around the launch would also count the time the dispatch waits for CUs that other streams hold
   if (n <= wave_threshold)
-    hipLaunchKernelGGL(k_backward_wave, dim3(n), dim3(64), 0, st, s, list, n, lambda_override);
+    hipExtLaunchKernelGGL(k_backward_wave, dim3(n), dim3(64), 0, st, ev_start, ev_stop, 0, s, list, n, lambda_override);
   else if (n <= team_threshold)
-    hipLaunchKernelGGL(k_backward_team, dim3((n + 7) / 8), dim3(64), 0, st, s, list, n, lambda_override);
+    hipExtLaunchKernelGGL(k_backward_team, dim3((n + 7) / 8), dim3(64), 0, st, ev_start, ev_stop, 0, s, list, n, lambda_override);
   else
-    hipLaunchKernelGGL(k_backward, dim3((n + 63) / 64), dim3(64), 0, st, s, list, n, lambda_override);
+    hipExtLaunchKernelGGL(k_backward, dim3((n + 63) / 64), dim3(64), 0, st, ev_start, ev_stop, 0, s, list, n, lambda_override);
 }
 
 }  // namespace cilqr

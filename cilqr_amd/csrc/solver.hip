@@ -196,6 +196,21 @@ struct Timer {  // event pairs, resolved after the final sync
     kind.push_back(k);
     return hipEventRecord(h->ev[next++], h->stream) == hipSuccess ? 0 : -1;
   }
+  // an event pair for a kernel that stamps its own start and end (hipExtLaunchKernelGGL); nullptrs when off
+  int pair(int k, hipEvent_t* a, hipEvent_t* b) {
+    *a = nullptr; *b = nullptr;
+    if (!(h->profiling && (h->profiling_level != 2 || k == 1))) return 0;
+    if (next + 2 > h->ev.size()) {
+      const size_t old = h->ev.size();
+      h->ev.resize(old + 64);
+      for (size_t i = old; i < h->ev.size(); ++i)
+        if (hipEventCreate(&h->ev[i]) != hipSuccess) return -1;
+    }
+    kind.push_back(k);
+    *a = h->ev[next++];
+    *b = h->ev[next++];
+    return 0;
+  }
   int end() {
     if (!open) return 0;
     open = false;
@@ -652,9 +667,10 @@ static int solve_core(cilqr_handle h, const cilqr_problem_batch* in, cilqr_solut
     }
     if (tm.begin(0)) return CILQR_ERR_DEVICE;
     launch_quadratize(d, d.act, n_hint, 1, st);        // cc:203-214
-    if (tm.end() || tm.begin(1)) return CILQR_ERR_DEVICE;
-    launch_backward(d, d.act, n_hint, nullptr, h->team_threshold, h->wave_threshold, st);    // cc:218
-    if (tm.end() || tm.begin(2)) return CILQR_ERR_DEVICE;
+    hipEvent_t eb0, eb1;
+    if (tm.end() || tm.pair(1, &eb0, &eb1)) return CILQR_ERR_DEVICE;
+    launch_backward(d, d.act, n_hint, nullptr, h->team_threshold, h->wave_threshold, st, eb0, eb1);    // cc:218
+    if (tm.begin(2)) return CILQR_ERR_DEVICE;
     bwd_iter.push_back(it);
     launch_linesearch(d, n_hint, h->spec_threshold, h->seq_rounds, h->round_group, st);  // cc:235-270
     launch_update(d, n_hint, st);                      // cc:272-308

@@ -189,7 +189,8 @@ void launch_round_cost(const DeviceState& s, int r0, int group, int n_max, int n
 void launch_init_cost_commit(const DeviceState& s, int n, hipStream_t st);
 void launch_quadratize(const DeviceState& s, const int* list, int n, int only_upd, hipStream_t st);
 void launch_backward(const DeviceState& s, const int* list, int n, const double* lambda_override,
-                     int team_threshold, int wave_threshold, hipStream_t st);
+                     int team_threshold, int wave_threshold, hipStream_t st, hipEvent_t ev_start = nullptr,
+                     hipEvent_t ev_stop = nullptr);
 void launch_forward(const DeviceState& s, const int* list, int n, double alpha, int skip_done,
                     hipStream_t st);
 // the 11-round line search of one lockstep iteration (forward/cost/accept with compaction)
