@@ -42,7 +42,7 @@ WORKLOADS = {("ped6", 4096): "configs[1]", ("mix11", 65536): "configs[2] (config
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
@@ -69,7 +69,104 @@ def main():
     ap.add_argument("--end-to-end", action="store_true",
                     help="extra (never `value`): obstacle points -> cilqr_build_corridors -> solve on the device")
     ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "backward_traffic.json"))
-    args = ap.parse_args()
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch plumbing only, on CPU: the ranks rendezvous over gloo, exchange made-up results through the same "
+                         "gather and rank 0 prints a line with \"dry_run\": true and no value (tests/test_host.py)")
+    return ap.parse_args(argv)
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks here (one process per GPU, the environment
+    torch.distributed.run would have set), pass rank 0's JSON line through, fail if any rank fails."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(port), CILQR_BENCH_SPAWNED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(args.gpus):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno()))
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()               # rank 0's pipe is drained while it runs
+    failed = None
+    pending = set(range(args.gpus))
+    while pending and failed is None:
+        for r in sorted(pending):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            pending.discard(r)
+            if rc != 0:
+                failed = (r, rc)
+        time.sleep(0.1)
+    for p in procs:   # a failed rank leaves the others inside a collective: end exactly the processes started here
+        if p.poll() is None:
+            p.kill()
+        p.wait()
+    reader.join(30.0)
+    out0 = b"".join(c for c in chunks if c)
+    if failed is not None:
+        sys.stderr.write(f"bench.py: rank {failed[0]} exited with code {failed[1]}\n")
+        raise SystemExit(1)
+    lines = [ln for ln in out0.decode().splitlines() if ln.strip()]
+    if len(lines) != 1:
+        sys.stderr.write(f"bench.py: expected one JSON line from rank 0, got {len(lines)}\n")
+        raise SystemExit(1)
+    rec = json.loads(lines[0])
+    if rec.get("n_gpus") != args.gpus:
+        sys.stderr.write(f"bench.py: asked for {args.gpus} GPUs, the line reports {rec.get('n_gpus')}\n")
+        raise SystemExit(1)
+    sys.stdout.write(lines[0] + "\n")
+    sys.stdout.flush()
+
+
+def dry_run(args, rank, world):
+    """Launch plumbing without a GPU (see --dry-run): the rendezvous, the rank census and the results gather of the
+    timed region, over gloo, on made-up results whose values encode (rank, problem)."""
+    import torch
+    import torch.distributed as dist
+    from cilqr_amd.distributed import gather_results
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    one = torch.ones(1, dtype=torch.int32)
+    if world > 1:
+        dist.all_reduce(one)
+    ranks = int(one.item())
+    B, K, M = min(args.batch, 16), 6, 4
+    traj = torch.zeros((B, K, 10), dtype=torch.float64)
+    traj[:] = (rank * B + torch.arange(B, dtype=torch.float64))[:, None, None]
+    hist = torch.zeros((B, M + 1, 5), dtype=torch.float64)
+    nc = torch.full((B,), 2, dtype=torch.int32)
+    st = torch.full((B,), 1 + rank % 5, dtype=torch.int32)
+    order_ok = None
+    if world > 1:
+        g = gather_results(traj, hist, nc, st, dst=0, densify=False)
+        if rank == 0:
+            order_ok = bool(torch.equal(g["traj"][:, 0, 0], torch.arange(world * B, dtype=torch.float64)))
+        dist.barrier()
+        dist.destroy_process_group()
+    if ranks != world:
+        raise SystemExit(f"bench.py: {ranks} ranks answered the all-reduce, WORLD_SIZE is {world}")
+    if rank == 0:
+        return {"metric": "CILQR solves/sec (dry run: launch plumbing only, nothing solved)", "value": None, "unit": "solves/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True, "ranks_reporting": ranks,
+                "gather_in_rank_order": order_ok, "spawned_by_bench": os.environ.get("CILQR_BENCH_SPAWNED") == "1"}
+    return None
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args)       # no launcher: be the launcher
 
     # stdout carries exactly one line (rank 0's JSON); everything else any library prints on fd 1
     # (RCCL's version banner, for one) is sent to stderr
@@ -82,6 +179,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if args.dry_run:
+        rec = dry_run(args, rank, world)
+        if rank == 0:
+            os.write(real_stdout, (json.dumps(rec) + "\n").encode())
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path exists)")
     torch.cuda.set_device(local_rank)
@@ -100,6 +204,8 @@ def main():
         one = torch.ones(1, dtype=torch.int32, device=dev)
         dist.all_reduce(one)
         rccl_ranks = int(one.item())
+        if rccl_ranks != world:
+            raise SystemExit(f"bench.py: {rccl_ranks} ranks answered the RCCL all-reduce, WORLD_SIZE is {world}")
 
     from cilqr_amd import api, scenario
     from cilqr_amd.distributed import gather_results

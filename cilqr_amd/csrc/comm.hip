@@ -71,6 +71,18 @@ Rccl* rccl() {
     }                                                                                               \
   } while (0)
 
+// inside ncclGroupStart .. ncclGroupEnd: close the group before leaving, or the communicator stays in an open group
+#define NCCL_TRY_G(expr)                                                                            \
+  do {                                                                                              \
+    ncclResult_t r_ = (expr);                                                                       \
+    if (r_ != ncclSuccess) {                                                                        \
+      std::snprintf(g_last_hip_error, sizeof(g_last_hip_error), "%s -> %s", #expr,                  \
+                    R->GetErrorString ? R->GetErrorString(r_) : "rccl error");                      \
+      (void)R->GroupEnd();                                                                          \
+      return CILQR_ERR_DEVICE;                                                                      \
+    }                                                                                               \
+  } while (0)
+
 constexpr int kTravelCols = 8;   // x y theta v a delta jerk delta_rate
 
 // exclusive prefix sum of n_cost (one block; B is at most a few hundred thousand) -> off[B], total
@@ -173,7 +185,8 @@ struct cilqr_comm {
   void* recv = nullptr;     // root: the payloads of all ranks, back to back
   size_t recv_bytes = 0;
   long long* off = nullptr;       // [capacity] row offsets
-  long long* totals = nullptr;    // device: [world + 1] live rows per rank (root), [world] = own
+  // device: (live rows, batch) of every rank [2 p], of this rank [2 world], the root's verdict [2 world + 2]
+  long long* totals = nullptr;
   long long* h_totals = nullptr;  // pinned copy
   size_t off_cap = 0;
 };
@@ -227,8 +240,8 @@ int cilqr_comm_create(cilqr_handle h, const uint8_t* id, int32_t rank, int32_t w
   h->comm = c;
   ncclResult_t r_ = R->CommInitRank(&c->comm, world, u, rank);
   if (r_ != ncclSuccess ||
-      hipMalloc(reinterpret_cast<void**>(&c->totals), (size_t)(world + 1) * sizeof(long long)) != hipSuccess ||
-      hipHostMalloc(reinterpret_cast<void**>(&c->h_totals), (size_t)(world + 1) * sizeof(long long), hipHostMallocDefault) != hipSuccess) {
+      hipMalloc(reinterpret_cast<void**>(&c->totals), (size_t)(2 * world + 4) * sizeof(long long)) != hipSuccess ||
+      hipHostMalloc(reinterpret_cast<void**>(&c->h_totals), (size_t)(2 * world + 4) * sizeof(long long), hipHostMallocDefault) != hipSuccess) {
     std::snprintf(g_last_hip_error, sizeof(g_last_hip_error), "ncclCommInitRank(rank %d of %d) -> %s", rank, world,
                   (r_ != ncclSuccess && R->GetErrorString) ? R->GetErrorString(r_) : "allocation failed");
     cilqr_comm_release(h);
@@ -283,27 +296,60 @@ int cilqr_gather_results(cilqr_handle h, int32_t batch, const cilqr_solution_bat
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->off), (size_t)B * W * sizeof(long long)));
     c->off_cap = (size_t)B * W;
   }
-  // 1. live rows of this rank, told to the root
-  hipLaunchKernelGGL(k_row_offsets, dim3(1), dim3(1024), 0, st, local->n_cost, B, c->off, c->totals + W);
+  // 1. (live rows, batch) of this rank, told to the root; the root checks that every rank holds the same batch and
+  //    a plausible row count, and tells every rank its verdict before anything is sized from those numbers
+  long long* own_meta = c->totals + 2 * W;
+  long long* verdict = c->totals + 2 * W + 2;
+  hipLaunchKernelGGL(k_row_offsets, dim3(1), dim3(1024), 0, st, local->n_cost, B, c->off, own_meta);
+  c->h_totals[2 * W + 1] = B;
+  HIP_TRY(hipMemcpyAsync(own_meta + 1, c->h_totals + 2 * W + 1, sizeof(long long), hipMemcpyHostToDevice, st));
   NCCL_TRY(R->GroupStart());
   if (is_root) {
     for (int p = 0; p < W; ++p)
-      if (p != root) NCCL_TRY(R->Recv(c->totals + p, 1, ncclInt64, p, c->comm, st));
+      if (p != root) NCCL_TRY_G(R->Recv(c->totals + 2 * p, 2, ncclInt64, p, c->comm, st));
   } else {
-    NCCL_TRY(R->Send(c->totals + W, 1, ncclInt64, root, c->comm, st));
+    NCCL_TRY_G(R->Send(own_meta, 2, ncclInt64, root, c->comm, st));
   }
   NCCL_TRY(R->GroupEnd());
-  HIP_TRY(hipMemcpyAsync(c->h_totals, c->totals, (size_t)(W + 1) * sizeof(long long), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(c->h_totals, c->totals, (size_t)(2 * W + 1) * sizeof(long long), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
-  c->h_totals[c->rank] = c->h_totals[W];
+  c->h_totals[2 * c->rank] = c->h_totals[2 * W];
+  c->h_totals[2 * c->rank + 1] = B;
+  long long ok = 1;
+  if (is_root) {
+    for (int p = 0; p < W; ++p) {
+      const long long rows_p = c->h_totals[2 * p], batch_p = c->h_totals[2 * p + 1];
+      if (batch_p != B || rows_p < 0 || rows_p > (long long)B * M1) ok = 0;
+    }
+    c->h_totals[2 * W + 2] = ok;
+    if (W > 1) HIP_TRY(hipMemcpyAsync(verdict, c->h_totals + 2 * W + 2, sizeof(long long), hipMemcpyHostToDevice, st));
+  }
+  if (W > 1) {
+    NCCL_TRY(R->GroupStart());
+    if (is_root) {
+      for (int p = 0; p < W; ++p)
+        if (p != root) NCCL_TRY_G(R->Send(verdict, 1, ncclInt64, p, c->comm, st));
+    } else {
+      NCCL_TRY_G(R->Recv(verdict, 1, ncclInt64, root, c->comm, st));
+    }
+    NCCL_TRY(R->GroupEnd());
+    if (!is_root) HIP_TRY(hipMemcpyAsync(c->h_totals + 2 * W + 2, verdict, sizeof(long long), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    ok = c->h_totals[2 * W + 2];
+  }
+  if (ok != 1) {
+    std::snprintf(g_last_hip_error, sizeof(g_last_hip_error), "cilqr_gather_results: the ranks do not hold the same batch");
+    return CILQR_ERR_ARG;
+  }
+  const size_t own_rows = (size_t)c->h_totals[2 * W];
   const size_t fixed = (size_t)B * K * kTravelCols + (size_t)3 * B;   // doubles besides the rows
-  const size_t own = fixed + (size_t)c->h_totals[W] * CILQR_COST_FIELDS;
+  const size_t own = fixed + own_rows * CILQR_COST_FIELDS;
   // 2. pack
   int rc = grow_dev(&c->send, &c->send_bytes, own * sizeof(double));
   if (rc != CILQR_OK) return rc;
   double* sp = static_cast<double*>(c->send);
   double* s_rows = sp + (size_t)B * K * kTravelCols;
-  double* s_ints = s_rows + (size_t)c->h_totals[W] * CILQR_COST_FIELDS;
+  double* s_ints = s_rows + own_rows * CILQR_COST_FIELDS;
   hipLaunchKernelGGL(k_pack_traj, dim3(((size_t)B * K + 255) / 256), dim3(256), 0, st, local->traj, B, K, sp);
   hipLaunchKernelGGL(k_pack_rows, dim3(nb), dim3(256), 0, st, local->cost_hist, local->n_cost, local->status,
                      local->n_iter, c->off, B, M1, s_rows, s_ints);
@@ -312,7 +358,7 @@ int cilqr_gather_results(cilqr_handle h, int32_t batch, const cilqr_solution_bat
   std::vector<size_t> at(W + 1, 0);
   if (is_root) {
     for (int p = 0; p < W; ++p)
-      at[p + 1] = at[p] + ((p == root) ? 0 : fixed + (size_t)c->h_totals[p] * CILQR_COST_FIELDS);
+      at[p + 1] = at[p] + ((p == root) ? 0 : fixed + (size_t)c->h_totals[2 * p] * CILQR_COST_FIELDS);
     rc = grow_dev(&c->recv, &c->recv_bytes, (at[W] + 1) * sizeof(double));
     if (rc != CILQR_OK) return rc;
   }
@@ -320,9 +366,9 @@ int cilqr_gather_results(cilqr_handle h, int32_t batch, const cilqr_solution_bat
   if (is_root) {
     for (int p = 0; p < W; ++p)
       if (p != root)
-        NCCL_TRY(R->Recv(static_cast<double*>(c->recv) + at[p], at[p + 1] - at[p], ncclFloat64, p, c->comm, st));
+        NCCL_TRY_G(R->Recv(static_cast<double*>(c->recv) + at[p], at[p + 1] - at[p], ncclFloat64, p, c->comm, st));
   } else {
-    NCCL_TRY(R->Send(sp, own, ncclFloat64, root, c->comm, st));
+    NCCL_TRY_G(R->Send(sp, own, ncclFloat64, root, c->comm, st));
   }
   NCCL_TRY(R->GroupEnd());
   // 4. unpack on the root, blocks in rank order
@@ -330,7 +376,7 @@ int cilqr_gather_results(cilqr_handle h, int32_t batch, const cilqr_solution_bat
     for (int p = 0; p < W; ++p) {
       const double* src = (p == root) ? sp : static_cast<const double*>(c->recv) + at[p];
       const double* rows = src + (size_t)B * K * kTravelCols;
-      const double* ints = rows + (size_t)c->h_totals[p] * CILQR_COST_FIELDS;
+      const double* ints = rows + (size_t)c->h_totals[2 * p] * CILQR_COST_FIELDS;
       const size_t b0 = (size_t)p * B;
       int* g_nc = gathered->n_cost + b0;
       hipLaunchKernelGGL(k_unpack_ints, dim3(nb), dim3(256), 0, st, ints, B, g_nc, gathered->status + b0,
@@ -338,7 +384,7 @@ int cilqr_gather_results(cilqr_handle h, int32_t batch, const cilqr_solution_bat
       hipLaunchKernelGGL(k_unpack_traj, dim3(((size_t)B * K + 255) / 256), dim3(256), 0, st, src, B, K, h->cfg.dt,
                          h->cfg.wheel_base, gathered->traj + b0 * K * CILQR_TRAJ_FIELDS);
       long long* off_p = c->off + b0;
-      hipLaunchKernelGGL(k_row_offsets, dim3(1), dim3(1024), 0, st, g_nc, B, off_p, c->totals + W);
+      hipLaunchKernelGGL(k_row_offsets, dim3(1), dim3(1024), 0, st, g_nc, B, off_p, own_meta);
       hipLaunchKernelGGL(k_unpack_rows, dim3(nb), dim3(256), 0, st, rows, g_nc, off_p, B, M1,
                          gathered->cost_hist + b0 * M1 * CILQR_COST_FIELDS);
     }

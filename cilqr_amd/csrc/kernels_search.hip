@@ -369,10 +369,6 @@ void launch_linesearch(const DeviceState& s, int n_act, int spec_threshold, int 
       if (R <= 2) hipLaunchKernelGGL(k_multi_forward_packed<2>, dim3((n_act * 2 + 63) / 64), bf, 0, st, s, n_act, R);
       else hipLaunchKernelGGL(k_multi_forward_packed<4>, dim3((n_act * 4 + 63) / 64), bf, 0, st, s, n_act, R);
     }
-    else if (R == 1) hipLaunchKernelGGL(k_multi_forward<1>, gf, bf, 0, st, s, n_act);
-    else if (R == 2) hipLaunchKernelGGL(k_multi_forward<2>, gf, bf, 0, st, s, n_act);
-    else if (R == 3) hipLaunchKernelGGL(k_multi_forward<3>, gf, bf, 0, st, s, n_act);
-    else if (R == 4) hipLaunchKernelGGL(k_multi_forward<4>, gf, bf, 0, st, s, n_act);
     else if (R == 5) hipLaunchKernelGGL(k_multi_forward<5>, gf, bf, 0, st, s, n_act);
     else hipLaunchKernelGGL(k_multi_forward<6>, gf, bf, 0, st, s, n_act);
     // G step sizes per round (round_group; the last round takes what is left of R)

@@ -137,11 +137,13 @@ int do_load(cilqr_solver* h, const cilqr_problem_batch* in) {
                     std::memcmp(h->lane_cache.data(), in->left_lane, (size_t)in->n_left * 7 * 8) == 0 &&
                     std::memcmp(h->lane_cache.data() + (size_t)in->n_left * 7, in->right_lane, (size_t)in->n_right * 7 * 8) == 0;
   if (!same_lanes) {
+    // the cache key is committed only once the upload and the grid build were enqueued without error (below):
+    // until then a failure must not let the next load believe the device image is current
+    h->lane_cache_nl = -1;
+    h->lane_cache_nr = -1;
     h->lane_cache.resize(n_lane_d);
     std::memcpy(h->lane_cache.data(), in->left_lane, (size_t)in->n_left * 7 * 8);
     std::memcpy(h->lane_cache.data() + (size_t)in->n_left * 7, in->right_lane, (size_t)in->n_right * 7 * 8);
-    h->lane_cache_nl = in->n_left;
-    h->lane_cache_nr = in->n_right;
     // from the handle's own copy: the caller's arrays need not outlive the call
     HIP_TRY(hipMemcpyAsync(h->lanes_raw, h->lane_cache.data(), n_lane_d * 8, hipMemcpyHostToDevice, h->stream));
   }
@@ -173,6 +175,8 @@ int do_load(cilqr_solver* h, const cilqr_problem_batch* in) {
   }
   launch_load(h->ds, B, pv, same_lanes ? nullptr : h->lanes_raw, h->stream);
   HIP_TRY(hipGetLastError());
+  h->lane_cache_nl = in->n_left;
+  h->lane_cache_nr = in->n_right;
   h->B = B;
   h->stage = 1;
   return CILQR_OK;
@@ -527,6 +531,7 @@ int cilqr_solve_batch(cilqr_handle h, const cilqr_problem_batch* in, cilqr_solut
       pi.coarse = in->coarse ? in->coarse + (size_t)b0 * K * 6 : nullptr;
       pi.corridor = in->corridor ? in->corridor + (size_t)b0 * K * in->cmax * 3 : nullptr;
       pi.corridor_count = in->corridor_count ? in->corridor_count + (size_t)b0 * K : nullptr;
+      pi.coarse_station = in->coarse_station ? in->coarse_station + (size_t)b0 * K : nullptr;
       pi.n_left = in->lane_group_left[g];
       pi.n_right = in->lane_group_right[g];
       pi.left_lane = in->left_lane + lrow * CILQR_LANE_FIELDS;
@@ -549,6 +554,8 @@ int cilqr_solve_batch(cilqr_handle h, const cilqr_problem_batch* in, cilqr_solut
       acc.backward_problem_steps += h->prof.backward_problem_steps;
       acc.backward_full_launches += h->prof.backward_full_launches;
       acc.backward_full_ms += h->prof.backward_full_ms;
+      acc.tail_ms += h->prof.tail_ms;
+      acc.tail_problems += h->prof.tail_problems;
     }
     lrow += (size_t)in->lane_group_left[g];
     rrow += (size_t)in->lane_group_right[g];

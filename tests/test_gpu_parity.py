@@ -488,6 +488,15 @@ def test_tracker_init_guess():
         assert ((res["status"] >= 1) & (res["status"] <= 5)).all()
         assert traj_err(res["iter_trajs"][:, 0, :, 1:7], X) == 0.0            # iter_trajs[0] is the init guess (cc:170)
         assert_steps(res, sc, oracle_cfg_from(opt.cfg), what=f"tracker init guess, stations {with_station}")
+        if with_station:
+            # the same batch as two lane groups (the table twice): every group must project onto ITS problems' stations
+            n0 = B // 2
+            grouped = dict(sc, left=np.concatenate([sc["left"], sc["left"]]), right=np.concatenate([sc["right"], sc["right"]]),
+                           lane_groups=[(0, len(sc["left"]), len(sc["right"])), (n0, len(sc["left"]), len(sc["right"]))])
+            assert not np.array_equal(sc["coarse_station"][:B - n0], sc["coarse_station"][n0:])
+            gr = _plan(opt, grouped)
+            for k in ("traj", "cost_hist", "n_cost", "status", "n_iter", "alpha_trace", "iter_trajs"):
+                assert np.array_equal(gr[k], res[k]), k
         opt.close()
     with pytest.raises(api.CilqrError):
         api.BatchIlqrOptimizer(api.default_config(50, init_guess=7), batch_capacity=4)

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(built):
     assert exported == set(declared)     # nothing else leaks through the C-ABI prefix
 
 
-def test_library_was_built_from_the_sources_in_the_tree(built):
+def _check_library_fingerprint():
     """cilqr_build_id: the first 32 hex digits of the SHA-256 over the library's sources, compiled in by the
     Makefile.  The .so is a prebuilt artefact that travels to the GPU box; this pins it to the sources beside it."""
     import ctypes
@@ -47,6 +47,17 @@ def test_library_was_built_from_the_sources_in_the_tree(built):
     L = api.lib()
     L.cilqr_build_id.restype = ctypes.c_char_p
     assert L.cilqr_build_id().decode() == h.hexdigest()[:32]
+
+
+def test_library_was_built_from_the_sources_in_the_tree(built):
+    _check_library_fingerprint()
+
+
+@pytest.mark.gpu
+def test_library_on_the_gpu_box_was_built_from_the_sources_in_the_tree():
+    """The same pin inside the -m gpu set: the .so that travelled to the GPU box is the one these sources build
+    (no `built` fixture: a rebuild on the box would make the test vacuous)."""
+    _check_library_fingerprint()
 
 
 def test_product_does_not_reference_the_oracle():
@@ -191,6 +202,36 @@ def test_sharded_solve_and_gather_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=300)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "GATHER_OK" in outs[0]
+
+
+def _one_json_line(stdout):
+    import json
+    lines = [ln for ln in stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, stdout
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_n_starts_n_ranks_by_itself():
+    """`python bench.py --gpus 2` with no launcher environment must start two ranks itself (dry mode: gloo, nothing
+    solved) and report them; a launcher-provided environment keeps working; a mismatch is an error, not a 1-rank run."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    bench = os.path.join(ROOT, "bench.py")
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--dry-run"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    rec = _one_json_line(r.stdout)
+    assert rec["n_gpus"] == 2 and rec["ranks_reporting"] == 2 and rec["gather_in_rank_order"] is True
+    assert rec["spawned_by_bench"] is True and rec["dry_run"] is True and rec["value"] is None
+    # the driver's own launcher
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29531", bench, "--gpus", "2", "--dry-run"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    rec = _one_json_line(r.stdout)
+    assert rec["n_gpus"] == 2 and rec["ranks_reporting"] == 2 and rec["spawned_by_bench"] is False
+    # --gpus disagrees with the launcher: refuse
+    r = subprocess.run([sys.executable, bench, "--gpus", "4", "--dry-run"], env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and r.stdout.strip() == ""
 
 
 def build_adapter_test(tmp_path):
