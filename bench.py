@@ -8,12 +8,12 @@ Workload (config.workload): BASELINE.json configs[2] -- batch 65536 per GPU, 50-
 --gpus N every rank solves its own 65536 scenes (weak scaling, configs[3] at N=8) and the
 results are gathered to rank 0 with one RCCL gather per step inside the timed region.
 
-The K timed steps go through `--pipeline` P handles (default 3; cilqr_submit / cilqr_wait, one HIP
-stream and one host thread each): step s is submitted on handle s mod P as soon as that handle's
-previous step has been collected, so the latency-bound tail of one solve (a few hundred straggler
-problems for ~60 lockstep iterations) overlaps the throughput-bound start of the next.  Every step
-is a complete, independent solve of the batch; `value` = problems solved / wall time of the K
-steps.  P = 1 is the strictly sequential form (`single_batch` reports it from extra steps).
+The K timed steps go through ONE solver handle with two solves in flight (cilqr_submit / cilqr_wait,
+`--in-flight 2`): the handle iterates the bulk of step s+1 in its main arena while the last <= 8192
+problems of step s -- the latency-bound part of a solve -- finish in its small finishing arena on a
+second stream (include/cilqr.h, CILQR_OPT_FINISH_THRESHOLD).  Every step is a complete, independent
+solve of the batch; `value` = problems solved / wall time of the K steps.  `--in-flight 1` is the
+strictly sequential form (`single_batch` reports it from extra steps); `--pipeline P` adds handles.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     backward-pass kernel, every launch of the timed region (time-weighted) and the launches
@@ -60,8 +60,12 @@ def parse_args(argv=None):
     ap.add_argument("--round-group", type=int, default=-1, help="CILQR_OPT_ROUND_GROUP value (tuning experiments)")
     ap.add_argument("--wave-threshold", type=int, default=-1, help="CILQR_OPT_WAVE_THRESHOLD value (tuning experiments)")
     ap.add_argument("--tail-threshold", type=int, default=-1, help="CILQR_OPT_TAIL_THRESHOLD value (tuning experiments; 0 = lockstep to the end)")
-    ap.add_argument("--pipeline", type=int, default=3,
-                    help="batches in flight during the timed region (handles, each with its own stream and host thread); 1 = sequential")
+    ap.add_argument("--pipeline", type=int, default=1,
+                    help="solver handles used in the timed region (each with its own arenas, streams and host threads)")
+    ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2],
+                    help="solves in flight per handle (cilqr_submit / cilqr_wait): 2 = the stragglers of one solve finish in the "
+                         "handle's finishing arena while the next solve is iterated in its main arena; 1 = one after the other")
+    ap.add_argument("--finish-threshold", type=int, default=-1, help="CILQR_OPT_FINISH_THRESHOLD value (tuning experiments)")
     ap.add_argument("--coarse", default="generator", choices=["generator", "dp"],
                     help="where the coarse trajectories come from: the generator's smooth best-clearance pick, or the DP coarse "
                          "planner (cilqr_dp_plan: the reference's own producer, kinked paths) with corridors built from the "
@@ -240,6 +244,7 @@ def main():
     M = cfg.max_iter
     smax = max(sc["left"].shape[0], sc["right"].shape[0])
     P = max(1, args.pipeline)
+    D = args.in_flight
 
     d_start = torch.from_numpy(sc["start"]).to(dev)
     d_coarse = torch.from_numpy(sc["coarse"]).to(dev)
@@ -248,7 +253,17 @@ def main():
     left = np.ascontiguousarray(sc["left"])
     right = np.ascontiguousarray(sc["right"])
 
-    class Ctx:   # one handle of the pipeline: solver, stream, output buffers
+    class Slot:   # result buffers of one solve in flight
+        def __init__(self):
+            self.traj = torch.zeros((B, K, 10), dtype=torch.float64, device=dev)
+            self.hist = torch.zeros((B, M + 1, 5), dtype=torch.float64, device=dev)
+            self.nc = torch.zeros(B, dtype=torch.int32, device=dev)
+            self.st = torch.zeros(B, dtype=torch.int32, device=dev)
+            self.ni = torch.zeros(B, dtype=torch.int32, device=dev)
+            self.sol = api.SolutionBatch(api.MEM_DEVICE, 0, self.traj.data_ptr(), self.hist.data_ptr(), self.nc.data_ptr(),
+                                         self.st.data_ptr(), self.ni.data_ptr(), None, None)
+
+    class Ctx:   # one handle: solver, stream, result buffers of the solves it keeps in flight
         def __init__(self):
             self.opt = api.BatchIlqrOptimizer(cfg, device=local_rank, batch_capacity=B, cmax=cmax, max_lane_segments=smax)
             self.stream = torch.cuda.Stream()
@@ -268,14 +283,14 @@ def main():
                 o.set_option(api.OPT_ROUND_GROUP, args.round_group)
             if args.wave_threshold >= 0:
                 o.set_option(api.OPT_WAVE_THRESHOLD, args.wave_threshold)
-            self.traj = torch.zeros((B, K, 10), dtype=torch.float64, device=dev)
-            self.hist = torch.zeros((B, M + 1, 5), dtype=torch.float64, device=dev)
-            self.nc = torch.zeros(B, dtype=torch.int32, device=dev)
-            self.st = torch.zeros(B, dtype=torch.int32, device=dev)
-            self.ni = torch.zeros(B, dtype=torch.int32, device=dev)
-            self.sol = api.SolutionBatch(api.MEM_DEVICE, 0, self.traj.data_ptr(), self.hist.data_ptr(), self.nc.data_ptr(),
-                                         self.st.data_ptr(), self.ni.data_ptr(), None, None)
-            self.inflight = False
+            if args.finish_threshold >= 0:
+                o.set_option(api.OPT_FINISH_THRESHOLD, args.finish_threshold)
+            self.slots = [Slot() for _ in range(D)]
+            self.free = list(self.slots)
+            self.fifo = []          # submitted, oldest first
+            # the first slot doubles as the buffers of the synchronous calls below
+            s0 = self.slots[0]
+            self.traj, self.hist, self.nc, self.st, self.ni, self.sol = s0.traj, s0.hist, s0.nc, s0.st, s0.ni, s0.sol
 
     ctx = [Ctx() for _ in range(P)]
     opt = ctx[0].opt
@@ -285,11 +300,12 @@ def main():
     torch.cuda.synchronize()   # inputs uploaded and outputs zero-filled before the solvers' own streams start
 
     prof_acc = dict(bwd_ms=0.0, bwd_launches=0, bwd_steps=0, iters=0, full_ms=0.0, full_launches=0)
-    last_gather = [None]
+    last_gather = [None]   # [0]: result of the last gather; [-1]: the slot it gathered (when any)
 
     def collect(c, timed):
-        rc = c.opt.wait()
-        c.inflight = False
+        rc = c.opt.wait()           # the oldest solve in flight on this handle
+        sl = c.fifo.pop(0)
+        c.free.append(sl)
         if rc != api.OK:
             raise api.CilqrError(rc, "in bench step")
         if timed and not args.no_profile:
@@ -302,19 +318,21 @@ def main():
             prof_acc["full_launches"] += p.backward_full_launches
         if use_dist:
             # 8 of the 10 trajectory columns travel (time and kappa are functions of the others)
-            last_gather[0] = gather_results(c.traj, c.hist, c.nc, c.st, dst=0, densify=False, derive=(cfg.dt, cfg.wheel_base))
+            last_gather[0] = gather_results(sl.traj, sl.hist, sl.nc, sl.st, dst=0, densify=False, derive=(cfg.dt, cfg.wheel_base))
+            last_gather.append(sl)
 
     def run_steps(n, timed):
         for s_ in range(n):
             c = ctx[s_ % P]
-            if c.inflight:
+            if len(c.fifo) == D:
                 collect(c, timed)
-            rc = c.opt.submit_raw(prob, c.sol)
+            sl = c.free.pop(0)
+            rc = c.opt.submit_raw(prob, sl.sol)
             if rc != api.OK:
                 raise api.CilqrError(rc, "in bench submit")
-            c.inflight = True
+            c.fifo.append(sl)
         for c in ctx:
-            if c.inflight:
+            while c.fifo:
                 collect(c, timed)
 
     def fence():
@@ -379,7 +397,7 @@ def main():
                 times = []
                 for _ in range(3):
                     t1 = time.perf_counter()
-                    rc_ = opt.gather_results_raw(B, ctx[0].sol, 0, gsol if rank == 0 else None)
+                    rc_ = opt.gather_results_raw(B, last_gather[-1].sol, 0, gsol if rank == 0 else None)
                     times.append(time.perf_counter() - t1)
                     if rc_ != api.OK:
                         raise api.CilqrError(rc_, "in cilqr_gather_results")
@@ -396,7 +414,7 @@ def main():
                         and torch.equal(g["hist"][torch.arange(M + 1, device=dev)[None, :] < g["nc"][:, None].long()],
                                         tg["hist_rows"])
                         and bool(torch.allclose(g["traj"][:, :, 7], tg["traj"][:, :, 7], rtol=1e-15, atol=0.0)))
-                    res["rank0_block_identical_to_local"] = bool(torch.equal(g["traj"][:B], ctx[0].traj))
+                    res["rank0_block_identical_to_local"] = bool(torch.equal(g["traj"][:B], last_gather[-1].traj))
                 opt.comm_destroy()
                 res["ok"] = True
             except Exception as e:   # noqa: BLE001
@@ -413,7 +431,7 @@ def main():
 
     # sequential form: two more steps back to back on one handle, no events
     seq = None
-    if world == 1 and P > 1:
+    if world == 1 and P * D > 1:
         opt.set_profiling(0)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -422,8 +440,8 @@ def main():
                 raise api.CilqrError(-1, "in sequential step")
         torch.cuda.synchronize()
         seq = (time.perf_counter() - t1) / 2
-    same = all(bool(torch.equal(c.traj, ctx[0].traj)) and bool(torch.equal(c.nc, ctx[0].nc)) and
-               bool(torch.equal(c.st, ctx[0].st)) for c in ctx[1:])
+    same = all(bool(torch.equal(sl.traj, ctx[0].traj)) and bool(torch.equal(sl.nc, ctx[0].nc)) and
+               bool(torch.equal(sl.st, ctx[0].st)) and bool(torch.equal(sl.ni, ctx[0].ni)) for c in ctx for sl in c.slots)
 
     # Extra (never `value`): the producer in front of the solve.  Obstacle corner
     # points per knot -> cilqr_build_corridors -> cilqr_solve_batch, everything resident in HBM.
@@ -525,7 +543,7 @@ def main():
                 "avg_launch_ms": prof_acc["bwd_ms"] / prof_acc["bwd_launches"],
                 "launches": prof_acc["bwd_launches"],
                 "mean_problems_per_launch": n_act_sum / prof_acc["bwd_launches"],
-                "batches_in_flight": P,
+                "batches_in_flight": P * D,
             }
             if single and single["bwd_ms"] > 0:
                 # the same launches with nothing else on the GPU: the calibration solve (HIP events around every
@@ -636,7 +654,7 @@ def main():
                                    f"{N}-step horizon, scene family {args.scene} ({spec.n_pedestrians} pedestrians + "
                                    f"{spec.n_dynamic} moving + {spec.n_static} static vehicles), reference road, "
                                    f"seed {args.seed}",
-                       "batch_per_gpu": B, "n_steps": N, "cmax": cmax, "batches_in_flight": P,
+                       "batch_per_gpu": B, "n_steps": N, "cmax": cmax, "batches_in_flight": P * D, "handles": P, "in_flight_per_handle": D,
                        "coarse_trajectories": ("DP coarse planner (cilqr_dp_plan) + cilqr_build_corridors" if dp_info else "scene generator"),
                        "dp_scene_source": dp_info,
                        "results_gather": "rccl" if use_dist else "none", "rccl_ranks": rccl_ranks},
@@ -645,7 +663,7 @@ def main():
             "single_batch": ({"value": round(B / seq, 1), "unit": "solves/s", "ms_per_step": round(seq * 1e3, 3),
                               "note": "one batch in flight: the same solve called back to back, nothing overlapped"}
                              if seq else None),
-            "results_identical_across_handles": same,
+            "results_identical_across_solves_in_flight": same,
             "c_abi_gather": cabi,
             "end_to_end": end_to_end,
             # per-phase HIP-event times of the calibration step (one batch alone, events around every phase)

@@ -577,12 +577,12 @@ __global__ void k_export_hist(DeviceState s, int B, double* __restrict__ hist, i
     double* o = hist + (size_t)slot * (s.p.max_iter + 1) * 5;
     for (int r = 0; r < nc; ++r)
 #pragma unroll
-      for (int c = 0; c < 5; ++c) o[r * 5 + c] = s.hist[((size_t)r * 5 + c) * s.Bcap + slot];
+      for (int c = 0; c < 5; ++c) o[r * 5 + c] = s.hist[((size_t)r * 5 + c) * s.Pcap + slot];
   }
   if (alpha_trace) {   // [B][max_iter]; iterations that never ran: -3
     signed char* o = alpha_trace + (size_t)slot * s.p.max_iter;
     const int ni = s.iter[slot];
-    for (int r = 0; r < s.p.max_iter; ++r) o[r] = (r < ni) ? s.atrace[(size_t)r * s.Bcap + slot] : (signed char)-3;
+    for (int r = 0; r < s.p.max_iter; ++r) o[r] = (r < ni) ? s.atrace[(size_t)r * s.Pcap + slot] : (signed char)-3;
   }
 }
 void launch_export_hist(const DeviceState& s, int B, double* cost_hist, int* n_cost, int* status,

@@ -211,7 +211,7 @@ __global__ void k_init_cost_commit(DeviceState s, int n) {
   if (slot >= n) return;
   const int pb = s.pid[slot];
 #pragma unroll
-  for (int c = 0; c < 5; ++c) s.hist[(size_t)c * s.Bcap + pb] = s.trial[(size_t)c * s.Bcap + slot];
+  for (int c = 0; c < 5; ++c) s.hist[(size_t)c * s.Pcap + pb] = s.trial[(size_t)c * s.Bcap + slot];
   s.cost_old[slot] = s.trial[slot];
   s.n_cost[pb] = 1;
   s.n_iter_trajs[pb] = 1;

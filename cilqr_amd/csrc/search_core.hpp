@@ -191,10 +191,10 @@ CILQR_DEV bool update_state(const DeviceState& s, const DeviceState& g, int slot
   const int it0 = g.iter[pb];
   if (st == 3 || st == 6) {
     done = true;
-    g.atrace[(size_t)it0 * g.Bcap + pb] = (signed char)-2;
+    g.atrace[(size_t)it0 * g.Pcap + pb] = (signed char)-2;
   } else {
     const int a = s.acc_idx[slot];
-    g.atrace[(size_t)it0 * g.Bcap + pb] = (signed char)a;
+    g.atrace[(size_t)it0 * g.Pcap + pb] = (signed char)a;
     const double lam = s.lambda[slot], dl = s.dlambda[slot];
     if (a >= 0) {
       const double ndl = fmin(dl / 1.6, 1.0 / 1.6);                                // cc:273
@@ -205,7 +205,7 @@ CILQR_DEV bool update_state(const DeviceState& s, const DeviceState& g, int slot
       const int nc = g.n_cost[pb];
 #pragma unroll
       for (int c = 0; c < 5; ++c)
-        g.hist[((size_t)nc * 5 + c) * g.Bcap + pb] = s.trial[(size_t)c * s.Bcap + slot];
+        g.hist[((size_t)nc * 5 + c) * g.Pcap + pb] = s.trial[(size_t)c * s.Bcap + slot];
       g.n_cost[pb] = nc + 1;
       if (dc < p.abs_tol || dc / co < p.rel_tol) {                                 // cc:281-293
         st = (dc < p.abs_tol) ? 1 : 2;

@@ -94,8 +94,17 @@ int check_problem(const cilqr_solver* h, const cilqr_problem_batch* in) {
   return CILQR_OK;
 }
 
-// upload (if needed) + prepare kernels
-int do_load(cilqr_solver* h, const cilqr_problem_batch* in) {
+// the main arena as solve `js` sees it: its own problem-indexed tensors, lane tables and counters
+DeviceState main_view(const cilqr_solver* h, const cilqr_job_set& js) {
+  DeviceState v = h->ds;
+  v.hist = js.hist; v.iter = js.iter; v.status = js.status; v.n_cost = js.n_cost;
+  v.n_iter_trajs = js.n_iter_trajs; v.atrace = js.atrace;
+  v.lanes = js.lanes; v.lgrid = js.lgrid;
+  return v;
+}
+
+// upload (if needed) + prepare kernels, on stream `st`, into the arena `*v` (whose lane geometry is filled in here)
+int do_load(cilqr_solver* h, const cilqr_problem_batch* in, cilqr_job_set& js, DeviceState* v, hipStream_t st) {
   const int rc = check_problem(h, in);
   if (rc != CILQR_OK) return rc;
   HIP_TRY(hipSetDevice(h->device));
@@ -112,17 +121,17 @@ int do_load(cilqr_solver* h, const cilqr_problem_batch* in) {
     const int g = grow(&h->in_stage, &h->in_stage_bytes, bytes);
     if (g != CILQR_OK) return g;
     double* d = static_cast<double*>(h->in_stage);
-    HIP_TRY(hipMemcpyAsync(d, in->start, n_start * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(d, in->start, n_start * 8, hipMemcpyHostToDevice, st));
     pv.start = d; d += n_start;
-    HIP_TRY(hipMemcpyAsync(d, in->coarse, n_coarse * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(d, in->coarse, n_coarse * 8, hipMemcpyHostToDevice, st));
     pv.coarse = d; d += n_coarse;
-    HIP_TRY(hipMemcpyAsync(d, in->corridor, n_cor * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(d, in->corridor, n_cor * 8, hipMemcpyHostToDevice, st));
     pv.corridor = d; d += n_cor;
     if (want_station) {
-      HIP_TRY(hipMemcpyAsync(d, in->coarse_station, n_sta * 8, hipMemcpyHostToDevice, h->stream));
+      HIP_TRY(hipMemcpyAsync(d, in->coarse_station, n_sta * 8, hipMemcpyHostToDevice, st));
       pv.station = d; d += n_sta;
     }
-    HIP_TRY(hipMemcpyAsync(d, in->corridor_count, n_cnt * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(d, in->corridor_count, n_cnt * 4, hipMemcpyHostToDevice, st));
     pv.ccount = reinterpret_cast<const int*>(d);
   } else {
     pv.start = in->start; pv.coarse = in->coarse; pv.corridor = in->corridor;
@@ -133,22 +142,22 @@ int do_load(cilqr_solver* h, const cilqr_problem_batch* in) {
   // The lane tables of consecutive solves are usually the same road: their device image and the lane grid built
   // from them (0.35 ms per solve) are kept while the caller's tables do not change by a bit.
   const size_t n_lane_d = (size_t)(in->n_left + in->n_right) * 7;
-  bool same_lanes = h->lane_cache_nl == in->n_left && h->lane_cache_nr == in->n_right && h->lane_cache.size() == n_lane_d &&
-                    std::memcmp(h->lane_cache.data(), in->left_lane, (size_t)in->n_left * 7 * 8) == 0 &&
-                    std::memcmp(h->lane_cache.data() + (size_t)in->n_left * 7, in->right_lane, (size_t)in->n_right * 7 * 8) == 0;
+  bool same_lanes = js.lane_cache_nl == in->n_left && js.lane_cache_nr == in->n_right && js.lane_cache.size() == n_lane_d &&
+                    std::memcmp(js.lane_cache.data(), in->left_lane, (size_t)in->n_left * 7 * 8) == 0 &&
+                    std::memcmp(js.lane_cache.data() + (size_t)in->n_left * 7, in->right_lane, (size_t)in->n_right * 7 * 8) == 0;
   if (!same_lanes) {
     // the cache key is committed only once the upload and the grid build were enqueued without error (below):
     // until then a failure must not let the next load believe the device image is current
-    h->lane_cache_nl = -1;
-    h->lane_cache_nr = -1;
-    h->lane_cache.resize(n_lane_d);
-    std::memcpy(h->lane_cache.data(), in->left_lane, (size_t)in->n_left * 7 * 8);
-    std::memcpy(h->lane_cache.data() + (size_t)in->n_left * 7, in->right_lane, (size_t)in->n_right * 7 * 8);
+    js.lane_cache_nl = -1;
+    js.lane_cache_nr = -1;
+    js.lane_cache.resize(n_lane_d);
+    std::memcpy(js.lane_cache.data(), in->left_lane, (size_t)in->n_left * 7 * 8);
+    std::memcpy(js.lane_cache.data() + (size_t)in->n_left * 7, in->right_lane, (size_t)in->n_right * 7 * 8);
     // from the handle's own copy: the caller's arrays need not outlive the call
-    HIP_TRY(hipMemcpyAsync(h->lanes_raw, h->lane_cache.data(), n_lane_d * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(js.lanes_raw, js.lane_cache.data(), n_lane_d * 8, hipMemcpyHostToDevice, st));
   }
-  h->ds.nl = in->n_left;
-  h->ds.nr = in->n_right;
+  v->nl = in->n_left;
+  v->nr = in->n_right;
   {  // lane grid geometry: bounding box of the segment end points + 60 m, cells >= 1 m
     double lo[2] = {1e300, 1e300}, hi[2] = {-1e300, -1e300};
     for (int side = 0; side < 2; ++side) {
@@ -157,9 +166,9 @@ int do_load(cilqr_solver* h, const cilqr_problem_batch* in) {
       for (int k = 0; k < n; ++k)
         for (int e = 0; e < 2; ++e)
           for (int c = 0; c < 2; ++c) {
-            const double v = tab[k * 7 + 3 + 2 * e + c];
-            if (v < lo[c]) lo[c] = v;
-            if (v > hi[c]) hi[c] = v;
+            const double val = tab[k * 7 + 3 + 2 * e + c];
+            if (val < lo[c]) lo[c] = val;
+            if (val > hi[c]) hi[c] = val;
           }
     }
     const double margin = 60.0;  // rejected line-search candidates overshoot far off the road
@@ -167,87 +176,85 @@ int do_load(cilqr_solver* h, const cilqr_problem_batch* in) {
     if (!(w > 0.0) || !(hgt > 0.0) || !std::isfinite(w) || !std::isfinite(hgt)) return CILQR_ERR_ARG;
     double cell = 1.0;
     while (std::ceil(w / cell) * std::ceil(hgt / cell) > (double)kGridMaxCells) cell *= 1.25;
-    h->ds.gx0 = lo[0] - margin;
-    h->ds.gy0 = lo[1] - margin;
-    h->ds.ginv_h = 1.0 / cell;
-    h->ds.gnx = (int)std::ceil(w / cell);
-    h->ds.gny = (int)std::ceil(hgt / cell);
+    v->gx0 = lo[0] - margin;
+    v->gy0 = lo[1] - margin;
+    v->ginv_h = 1.0 / cell;
+    v->gnx = (int)std::ceil(w / cell);
+    v->gny = (int)std::ceil(hgt / cell);
   }
-  launch_load(h->ds, B, pv, same_lanes ? nullptr : h->lanes_raw, h->stream);
+  launch_load(*v, B, pv, same_lanes ? nullptr : js.lanes_raw, st);
   HIP_TRY(hipGetLastError());
-  h->lane_cache_nl = in->n_left;
-  h->lane_cache_nr = in->n_right;
-  h->B = B;
-  h->stage = 1;
+  js.lane_cache_nl = in->n_left;
+  js.lane_cache_nr = in->n_right;
   return CILQR_OK;
 }
 
-struct Timer {  // event pairs, resolved after the final sync
-  cilqr_solver* h;
-  size_t next = 0;
-  std::vector<int> kind;  // 0 quad, 1 backward, 2 linesearch, 3 other, 4 tail
-  std::vector<char> full_flags, live_flags;  // per backward launch: covered the whole batch / had work
-  bool open = false;   // the last begin() recorded an event, so the matching end() must too
-  int begin(int k) {
-    open = h->profiling && (h->profiling_level != 2 || k == 1);   // level 2: the backward launches only
-    if (!open) return 0;
-    if (next + 2 > h->ev.size()) {
-      const size_t old = h->ev.size();
-      h->ev.resize(old + 64);
-      for (size_t i = old; i < h->ev.size(); ++i)
-        if (hipEventCreate(&h->ev[i]) != hipSuccess) return -1;
-    }
-    kind.push_back(k);
-    return hipEventRecord(h->ev[next++], h->stream) == hipSuccess ? 0 : -1;
-  }
-  // an event pair for a kernel that stamps its own start and end (hipExtLaunchKernelGGL); nullptrs when off
-  int pair(int k, hipEvent_t* a, hipEvent_t* b) {
-    *a = nullptr; *b = nullptr;
-    if (!(h->profiling && (h->profiling_level != 2 || k == 1))) return 0;
-    if (next + 2 > h->ev.size()) {
-      const size_t old = h->ev.size();
-      h->ev.resize(old + 64);
-      for (size_t i = old; i < h->ev.size(); ++i)
-        if (hipEventCreate(&h->ev[i]) != hipSuccess) return -1;
-    }
-    kind.push_back(k);
-    *a = h->ev[next++];
-    *b = h->ev[next++];
-    return 0;
-  }
-  int end() {
-    if (!open) return 0;
-    open = false;
-    return hipEventRecord(h->ev[next++], h->stream) == hipSuccess ? 0 : -1;
-  }
-  void resolve(cilqr_profile* p) {
-    if (!h->profiling) return;
-    size_t nb = 0;
-    for (size_t i = 0; i < kind.size(); ++i) {
-      float ms = 0.f;
-      (void)hipEventElapsedTime(&ms, h->ev[2 * i], h->ev[2 * i + 1]);
-      switch (kind[i]) {
-        case 0: p->quadratize_ms += ms; break;
-        case 1:
-          if (nb < live_flags.size() && !live_flags[nb]) { ++nb; p->other_ms += ms; break; }  // run-ahead no-op
-          p->backward_ms += ms;
-          if (nb < full_flags.size() && full_flags[nb]) { p->backward_full_ms += ms; p->backward_full_launches += 1; }
-          ++nb;
-          break;
-        case 2: p->linesearch_ms += ms; break;
-        case 4: p->tail_ms += ms; break;
-        default: p->other_ms += ms; break;
-      }
-    }
-    if (!kind.empty() && h->profiling_level == 1) {
-      float ms = 0.f;
-      (void)hipEventElapsedTime(&ms, h->ev[0], h->ev[next - 1]);
-      p->total_ms = ms;
-    }
-  }
-};
+// solve on a given job: the three parts of a solve (see cilqr_job)
+int job_begin(cilqr_solver* h, cilqr_job& j);
+int job_iterate(cilqr_solver* h, cilqr_job& j, int stage);
+int job_finish(cilqr_solver* h, cilqr_job& j);
+void release_fin(cilqr_solver* h, cilqr_job& j);
 
 }  // namespace
+
+bool cilqr_timer::on() const { return h->profiling; }
+bool cilqr_timer::wants(int k) const { return h->profiling && (h->profiling_level != 2 || k == 1); }   // level 2: the backward launches only
+int cilqr_timer::reserve() {
+  if (next + 2 > js->ev.size()) {
+    const size_t old = js->ev.size();
+    js->ev.resize(old + 64);
+    for (size_t i = old; i < js->ev.size(); ++i)
+      if (hipEventCreate(&js->ev[i]) != hipSuccess) return -1;
+  }
+  return 0;
+}
+int cilqr_timer::begin(int k) {
+  open = wants(k);
+  if (!open) return 0;
+  if (reserve()) return -1;
+  kind.push_back(k);
+  return hipEventRecord(js->ev[next++], stream) == hipSuccess ? 0 : -1;
+}
+// an event pair for a kernel that stamps its own start and end (hipExtLaunchKernelGGL); nullptrs when off
+int cilqr_timer::pair(int k, hipEvent_t* a, hipEvent_t* b) {
+  *a = nullptr; *b = nullptr;
+  if (!wants(k)) return 0;
+  if (reserve()) return -1;
+  kind.push_back(k);
+  *a = js->ev[next++];
+  *b = js->ev[next++];
+  return 0;
+}
+int cilqr_timer::end() {
+  if (!open) return 0;
+  open = false;
+  return hipEventRecord(js->ev[next++], stream) == hipSuccess ? 0 : -1;
+}
+void cilqr_timer::resolve(cilqr_profile* p) {
+  if (!on()) return;
+  size_t nb = 0;
+  for (size_t i = 0; i < kind.size(); ++i) {
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, js->ev[2 * i], js->ev[2 * i + 1]);
+    switch (kind[i]) {
+      case 0: p->quadratize_ms += ms; break;
+      case 1:
+        if (nb < live_flags.size() && !live_flags[nb]) { ++nb; p->other_ms += ms; break; }  // run-ahead no-op
+        p->backward_ms += ms;
+        if (nb < full_flags.size() && full_flags[nb]) { p->backward_full_ms += ms; p->backward_full_launches += 1; }
+        ++nb;
+        break;
+      case 2: p->linesearch_ms += ms; break;
+      case 4: p->tail_ms += ms; break;
+      default: p->other_ms += ms; break;
+    }
+  }
+  if (!kind.empty() && h->profiling_level == 1) {
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, js->ev[0], js->ev[next - 1]);
+    p->total_ms = ms;
+  }
+}
 
 extern "C" {
 
@@ -332,65 +339,92 @@ int cilqr_create(const cilqr_config* cfg, int32_t device, int32_t batch_capacity
     (void)cilqr_set_tracker_config(h, &tc);
   }
   const size_t N = cfg->n_steps, K = N + 1, B = Bc;
+  d.Pcap = Bc;
   int rc = CILQR_OK;
-#define ALLOC(field, count) \
-  if (rc == CILQR_OK) rc = dev_alloc(h, &d.field, (size_t)(count))
-  ALLOC(X, 2 * K * 3 * B);
-  ALLOC(U, 2 * N * B);
-  ALLOC(cur, B);
-  ALLOC(goals, K * 3 * B);
-  ALLOC(coarse0, 2 * B);
-  ALLOC(cstation, K * B);
-  ALLOC(cor, K * cmax * 3 * B);
-  ALLOC(ccnt, K * B);
-  ALLOC(lanes, (size_t)2 * max_lane_segments * kLaneFields);
-  ALLOC(lgrid, (size_t)2 * kGridMaxCells * kGridCellBytes);
-  ALLOC(lin, N * kLinPairs * B);
-  ALLOC(term, (size_t)kTermPairs * B);
-  ALLOC(gains, N * kGainPairs * B);
-  ALLOC(dV, 2 * B);
-  ALLOC(gnorm, B);
-  ALLOC(part, K * kPartPairs * B);
-  ALLOC(trial, 5 * B);
-  ALLOC(hist, (size_t)(cfg->max_iter + 1) * 5 * B);
-  ALLOC(lambda, B); ALLOC(dlambda, B); ALLOC(cost_old, B); ALLOC(dcost, B);
-  ALLOC(iter, B); ALLOC(status, B); ALLOC(n_cost, B); ALLOC(upd, B); ALLOC(acc_idx, B);
-  ALLOC(n_iter_trajs, B); ALLOC(emit, B); ALLOC(pid, B); ALLOC(done_now, B);
-  ALLOC(atrace, (size_t)cfg->max_iter * B);
-  d.spec_cap = (int)B;   // every active problem can have all 11 candidates in flight (4 GB at B = 65536)
-  ALLOC(Xs, (size_t)kNumAlpha * K * 3 * d.spec_cap);
-  ALLOC(Us, (size_t)kNumAlpha * N * d.spec_cap);
-  ALLOC(parts, (size_t)kNumAlpha * K * kPartPairs * d.spec_cap);
-  ALLOC(spec_tot, (size_t)kNumAlpha * 5 * d.spec_cap);
-  ALLOC(act, B); ALLOC(act_next, B);
-  ALLOC(pend, (size_t)(kNumAlpha + 1) * B);
-  ALLOC(counters, 64);
-#undef ALLOC
-  // twin arena for re-packing the survivors (k_compact)
-  DeviceState& t = h->twin;
-  t = d;
-#define ALLOC2(field, count) \
+  // tensors the survivor re-packing moves (k_compact): every arena and every twin has its own
+  auto alloc_moved = [&](DeviceState& t, size_t cap) {
+#define ALLOCM(field, count) \
   if (rc == CILQR_OK) rc = dev_alloc(h, &t.field, (size_t)(count))
-  ALLOC2(X, 2 * K * 3 * B);
-  ALLOC2(U, 2 * N * B);
-  ALLOC2(cur, B);
-  ALLOC2(goals, K * 3 * B);
-  ALLOC2(cor, K * cmax * 3 * B);
-  ALLOC2(ccnt, K * B);
-  ALLOC2(lambda, B); ALLOC2(dlambda, B); ALLOC2(cost_old, B); ALLOC2(dcost, B);
-  ALLOC2(upd, B); ALLOC2(acc_idx, B); ALLOC2(emit, B); ALLOC2(pid, B); ALLOC2(done_now, B);
-  ALLOC2(act, B); ALLOC2(act_next, B);
-#undef ALLOC2
-  if (rc == CILQR_OK) rc = dev_alloc(h, &h->lanes_raw, (size_t)2 * max_lane_segments * 7);
+    ALLOCM(X, 2 * K * 3 * cap);
+    ALLOCM(U, 2 * N * cap);
+    ALLOCM(cur, cap);
+    ALLOCM(goals, K * 3 * cap);
+    ALLOCM(cor, K * cmax * 3 * cap);
+    ALLOCM(ccnt, K * cap);
+    ALLOCM(lambda, cap); ALLOCM(dlambda, cap); ALLOCM(cost_old, cap); ALLOCM(dcost, cap);
+    ALLOCM(upd, cap); ALLOCM(acc_idx, cap); ALLOCM(emit, cap); ALLOCM(pid, cap); ALLOCM(done_now, cap);
+    ALLOCM(act, cap); ALLOCM(act_next, cap);
+#undef ALLOCM
+  };
+  // per-iteration scratch of an arena (shared with its twin)
+  auto alloc_scratch = [&](DeviceState& t, size_t cap) {
+#define ALLOCS(field, count) \
+  if (rc == CILQR_OK) rc = dev_alloc(h, &t.field, (size_t)(count))
+    ALLOCS(lin, N * kLinPairs * cap);
+    ALLOCS(term, (size_t)kTermPairs * cap);
+    ALLOCS(gains, N * kGainPairs * cap);
+    ALLOCS(dV, 2 * cap);
+    ALLOCS(gnorm, cap);
+    ALLOCS(part, K * kPartPairs * cap);
+    ALLOCS(trial, 5 * cap);
+    t.spec_cap = (int)cap;   // every active problem can have all 11 candidates in flight (4 GB at B = 65536)
+    ALLOCS(Xs, (size_t)kNumAlpha * K * 3 * cap);
+    ALLOCS(Us, (size_t)kNumAlpha * N * cap);
+    ALLOCS(parts, (size_t)kNumAlpha * K * kPartPairs * cap);
+    ALLOCS(spec_tot, (size_t)kNumAlpha * 5 * cap);
+    ALLOCS(pend, (size_t)(kNumAlpha + 1) * cap);
+    ALLOCS(counters, 64);
+#undef ALLOCS
+  };
+  alloc_moved(d, B);
+  alloc_scratch(d, B);
+  if (rc == CILQR_OK) rc = dev_alloc(h, &d.coarse0, 2 * B);
+  if (rc == CILQR_OK) rc = dev_alloc(h, &d.cstation, K * B);
+  // twin arena for re-packing the survivors (k_compact)
+  h->twin = d;
+  alloc_moved(h->twin, B);
+  // finishing arena + twin: a solve moves here once at most fin_cap problems are left (job_iterate)
+  h->fin_cap = (int)std::min<size_t>(B, 8192);
+  h->fin_threshold = h->fin_cap;
+  h->fin = d;
+  h->fin.Bcap = h->fin_cap;
+  alloc_moved(h->fin, (size_t)h->fin_cap);
+  alloc_scratch(h->fin, (size_t)h->fin_cap);
+  h->fin_twin = h->fin;
+  alloc_moved(h->fin_twin, (size_t)h->fin_cap);
+  // what a solve in flight owns (two sets: see cilqr_job_set)
+  for (int k = 0; k < 2 && rc == CILQR_OK; ++k) {
+    cilqr_job_set& js = h->sets[k];
+    if (rc == CILQR_OK) rc = dev_alloc(h, &js.hist, (size_t)(cfg->max_iter + 1) * 5 * B);
+    if (rc == CILQR_OK) rc = dev_alloc(h, &js.iter, B);
+    if (rc == CILQR_OK) rc = dev_alloc(h, &js.status, B);
+    if (rc == CILQR_OK) rc = dev_alloc(h, &js.n_cost, B);
+    if (rc == CILQR_OK) rc = dev_alloc(h, &js.n_iter_trajs, B);
+    if (rc == CILQR_OK) rc = dev_alloc(h, &js.atrace, (size_t)cfg->max_iter * B);
+    if (rc == CILQR_OK) rc = dev_alloc(h, &js.lanes, (size_t)2 * max_lane_segments * kLaneFields);
+    if (rc == CILQR_OK) rc = dev_alloc(h, &js.lgrid, (size_t)2 * kGridMaxCells * kGridCellBytes);
+    if (rc == CILQR_OK) rc = dev_alloc(h, &js.lanes_raw, (size_t)2 * max_lane_segments * 7);
+    if (rc == CILQR_OK) rc = dev_alloc(h, &js.tail_iter_dev, 4);
+    if (rc == CILQR_OK && hipHostMalloc(reinterpret_cast<void**>(&js.h_count), (size_t)(cfg->max_iter + 64) * sizeof(int),
+                                        hipHostMallocMapped) != hipSuccess)
+      rc = CILQR_ERR_DEVICE;
+    if (rc == CILQR_OK && hipHostGetDevicePointer(reinterpret_cast<void**>(&js.h_count_dev), js.h_count, 0) != hipSuccess)
+      rc = CILQR_ERR_DEVICE;
+    if (rc == CILQR_OK && hipEventCreateWithFlags(&js.handoff, hipEventDisableTiming) != hipSuccess) rc = CILQR_ERR_DEVICE;
+  }
+  if (rc == CILQR_OK) {   // the stage API works on the main arena with the first set
+    const DeviceState v = main_view(h, h->sets[0]);
+    d.hist = v.hist; d.iter = v.iter; d.status = v.status; d.n_cost = v.n_cost; d.n_iter_trajs = v.n_iter_trajs;
+    d.atrace = v.atrace; d.lanes = v.lanes; d.lgrid = v.lgrid;
+  }
   if (rc == CILQR_OK) rc = dev_alloc(h, &h->lambda_stage, B);
-  if (rc == CILQR_OK) rc = dev_alloc(h, &h->tail_iter_dev, 4);
   if (rc == CILQR_OK && hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess)
     rc = CILQR_ERR_DEVICE;
-  if (rc == CILQR_OK && hipHostMalloc(reinterpret_cast<void**>(&h->h_count), (size_t)(cfg->max_iter + 64) * sizeof(int),
-                                      hipHostMallocMapped) != hipSuccess)
-    rc = CILQR_ERR_DEVICE;
-  if (rc == CILQR_OK && hipHostGetDevicePointer(reinterpret_cast<void**>(&h->h_count_dev), h->h_count, 0) != hipSuccess)
-    rc = CILQR_ERR_DEVICE;
+  if (rc == CILQR_OK) {
+    int lo = 0, hi = 0;   // numerically lower = higher priority
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, hi) != hipSuccess) rc = CILQR_ERR_DEVICE;
+  }
   if (rc != CILQR_OK) {
     cilqr_destroy(h);
     return rc;
@@ -402,25 +436,31 @@ int cilqr_create(const cilqr_config* cfg, int32_t device, int32_t batch_capacity
 
 int cilqr_destroy(cilqr_handle h) {
   if (h == nullptr) return CILQR_ERR_NULL;
-  if (h->worker_started) {
+  if (h->workers_started) {
     {
       std::lock_guard<std::mutex> lk(h->mu);
       h->quit = true;
     }
     h->cv.notify_all();
-    h->worker.join();
+    h->worker1.join();
+    h->worker2.join();
   }
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->stream2) (void)hipStreamSynchronize(h->stream2);
   cilqr_comm_release(h);
   for (void* p : h->allocs) (void)hipFree(p);
   if (h->in_stage) (void)hipFree(h->in_stage);
-  if (h->out_stage) (void)hipFree(h->out_stage);
   if (h->tail_ws) (void)hipFree(h->tail_ws);
-  if (h->h_count) (void)hipHostFree(h->h_count);
-  for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
-  for (hipEvent_t e : h->iter_ev) (void)hipEventDestroy(e);
+  for (cilqr_job_set& js : h->sets) {
+    if (js.out_stage) (void)hipFree(js.out_stage);
+    if (js.h_count) (void)hipHostFree(js.h_count);
+    for (hipEvent_t e : js.ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : js.iter_ev) (void)hipEventDestroy(e);
+    if (js.handoff) (void)hipEventDestroy(js.handoff);
+  }
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  if (h->stream2) (void)hipStreamDestroy(h->stream2);
   delete h;
   return CILQR_OK;
 }
@@ -463,6 +503,10 @@ int cilqr_set_option(cilqr_handle h, int32_t option, int64_t value) {
       if (value < 0) return CILQR_ERR_ARG;
       h->tail_threshold = (int)(value > kTailMaxProblems ? kTailMaxProblems : value);
       return CILQR_OK;
+    case CILQR_OPT_FINISH_THRESHOLD:
+      if (value < 0) return CILQR_ERR_ARG;
+      h->fin_threshold = (int)(value > h->fin_cap ? h->fin_cap : value);
+      return CILQR_OK;
     default:
       return CILQR_ERR_ARG;
   }
@@ -503,14 +547,50 @@ int cilqr_get_profile(cilqr_handle h, cilqr_profile* out) {
 
 int64_t cilqr_device_bytes(cilqr_handle h) {
   if (h == nullptr) return 0;
-  return h->bytes + (int64_t)h->in_stage_bytes + (int64_t)h->out_stage_bytes;
+  return h->bytes + (int64_t)h->in_stage_bytes + (int64_t)h->sets[0].out_stage_bytes + (int64_t)h->sets[1].out_stage_bytes +
+         (int64_t)h->tail_ws_bytes;
 }
 
-static int solve_core(cilqr_handle h, const cilqr_problem_batch* in, cilqr_solution_batch* out);
+static int solve_sync(cilqr_solver* h, const cilqr_problem_batch* in, cilqr_solution_batch* out);
 
 int cilqr_solve_batch(cilqr_handle h, const cilqr_problem_batch* in, cilqr_solution_batch* out) {
   if (h == nullptr || out == nullptr) return CILQR_ERR_NULL;
-  if (in == nullptr || in->n_lane_groups <= 1) return solve_core(h, in, out);
+  {
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (h->job_count != 0) return CILQR_ERR_STATE;   // submitted solves not collected yet (cilqr_wait)
+  }
+  return solve_sync(h, in, out);
+}
+
+// one synchronous solve (both stages on the handle's stream), lane groups one after the other
+static int solve_groups(cilqr_solver* h, cilqr_job& j, const cilqr_problem_batch* in, cilqr_solution_batch* out);
+
+static int solve_one(cilqr_solver* h, cilqr_job& j, const cilqr_problem_batch* in, cilqr_solution_batch* out) {
+  if (in) j.in = *in; else std::memset(&j.in, 0, sizeof(j.in));
+  j.out = *out;
+  int rc = (in == nullptr) ? CILQR_ERR_NULL : job_begin(h, j);
+  if (rc == CILQR_OK) rc = job_iterate(h, j, 1);
+  if (rc == CILQR_OK && j.handed) rc = job_iterate(h, j, 2);
+  if (rc == CILQR_OK) rc = job_finish(h, j);
+  else if (j.handed) (void)hipStreamSynchronize(j.st2);
+  release_fin(h, j);
+  return rc;
+}
+
+static int solve_sync(cilqr_solver* h, const cilqr_problem_batch* in, cilqr_solution_batch* out) {
+  cilqr_job& j = h->jobs[0];
+  j.set = 0;
+  j.st1 = h->stream;
+  j.st2 = h->stream;
+  return solve_groups(h, j, in, out);
+}
+
+static int solve_groups(cilqr_solver* h, cilqr_job& j, const cilqr_problem_batch* in, cilqr_solution_batch* out) {
+  if (in == nullptr || in->n_lane_groups <= 1) {
+    const int rc = solve_one(h, j, in, out);
+    h->prof = j.prof;
+    return rc;
+  }
   // problems grouped by lane table: one solve per group on contiguous sub-ranges of every array
   if (in->lane_group_start == nullptr || in->lane_group_left == nullptr || in->lane_group_right == nullptr ||
       in->left_lane == nullptr || in->right_lane == nullptr)
@@ -545,240 +625,401 @@ int cilqr_solve_batch(cilqr_handle h, const cilqr_problem_batch* in, cilqr_solut
       po.iter_trajs = out->iter_trajs ? out->iter_trajs + (size_t)b0 * out->max_iter_trajs * K * CILQR_TRAJ_FIELDS : nullptr;
       po.n_iter_trajs = out->n_iter_trajs ? out->n_iter_trajs + b0 : nullptr;
       po.alpha_trace = out->alpha_trace ? out->alpha_trace + (size_t)b0 * h->cfg.max_iter : nullptr;
-      const int rc = solve_core(h, &pi, &po);
+      const int rc = solve_one(h, j, &pi, &po);
       if (rc != CILQR_OK) return rc;
-      acc.iterations += h->prof.iterations;
-      acc.backward_launches += h->prof.backward_launches;
-      acc.backward_ms += h->prof.backward_ms; acc.quadratize_ms += h->prof.quadratize_ms;
-      acc.linesearch_ms += h->prof.linesearch_ms; acc.other_ms += h->prof.other_ms; acc.total_ms += h->prof.total_ms;
-      acc.backward_problem_steps += h->prof.backward_problem_steps;
-      acc.backward_full_launches += h->prof.backward_full_launches;
-      acc.backward_full_ms += h->prof.backward_full_ms;
-      acc.tail_ms += h->prof.tail_ms;
-      acc.tail_problems += h->prof.tail_problems;
+      acc.iterations += j.prof.iterations;
+      acc.backward_launches += j.prof.backward_launches;
+      acc.backward_ms += j.prof.backward_ms; acc.quadratize_ms += j.prof.quadratize_ms;
+      acc.linesearch_ms += j.prof.linesearch_ms; acc.other_ms += j.prof.other_ms; acc.total_ms += j.prof.total_ms;
+      acc.backward_problem_steps += j.prof.backward_problem_steps;
+      acc.backward_full_launches += j.prof.backward_full_launches;
+      acc.backward_full_ms += j.prof.backward_full_ms;
+      acc.tail_ms += j.prof.tail_ms;
+      acc.tail_problems += j.prof.tail_problems;
     }
     lrow += (size_t)in->lane_group_left[g];
     rrow += (size_t)in->lane_group_right[g];
   }
+  j.prof = acc;
   h->prof = acc;
   return CILQR_OK;
 }
 
-static int solve_core(cilqr_handle h, const cilqr_problem_batch* in, cilqr_solution_batch* out) {
-  if (h == nullptr || out == nullptr) return CILQR_ERR_NULL;
+}  // extern "C"
+
+namespace {
+
+// the fields of `src` that belong to the solve rather than to an arena: problem-indexed tensors, lane tables
+void adopt_job_fields(DeviceState* t, const DeviceState& src) {
+  t->hist = src.hist; t->iter = src.iter; t->status = src.status; t->n_cost = src.n_cost;
+  t->n_iter_trajs = src.n_iter_trajs; t->atrace = src.atrace;
+  t->lanes = src.lanes; t->lgrid = src.lgrid;
+  t->nl = src.nl; t->nr = src.nr;
+  t->gx0 = src.gx0; t->gy0 = src.gy0; t->ginv_h = src.ginv_h; t->gnx = src.gnx; t->gny = src.gny;
+  t->Pcap = src.Pcap;
+}
+
+// `t` = arena `own` with the twin's copies of what k_compact moves
+DeviceState twin_of(const DeviceState& own, const DeviceState& tw) {
+  DeviceState t = own;
+  t.X = tw.X; t.U = tw.U; t.cur = tw.cur; t.goals = tw.goals; t.cor = tw.cor; t.ccnt = tw.ccnt;
+  t.lambda = tw.lambda; t.dlambda = tw.dlambda; t.cost_old = tw.cost_old; t.dcost = tw.dcost;
+  t.upd = tw.upd; t.acc_idx = tw.acc_idx; t.emit = tw.emit; t.pid = tw.pid; t.done_now = tw.done_now;
+  t.act = tw.act; t.act_next = tw.act_next;
+  return t;
+}
+
+// Arguments, staging, load, init guess and its cost (cc:64-78, 141-173), on the first stage's stream.
+int job_begin(cilqr_solver* h, cilqr_job& j) {
+  const cilqr_problem_batch* in = &j.in;
+  const cilqr_solution_batch* out = &j.out;
   if (out->traj == nullptr || out->cost_hist == nullptr || out->n_cost == nullptr || out->status == nullptr)
     return CILQR_ERR_NULL;                                                     // cc:64-66
   if (out->memory != CILQR_MEM_HOST && out->memory != CILQR_MEM_DEVICE) return CILQR_ERR_ARG;
   if (out->iter_trajs != nullptr && (out->max_iter_trajs <= 0 || out->n_iter_trajs == nullptr)) return CILQR_ERR_ARG;
   HIP_TRY(hipSetDevice(h->device));
-  Timer tm{h};
-  std::memset(&h->prof, 0, sizeof(h->prof));
-  if (tm.begin(3)) return CILQR_ERR_DEVICE;
-  int rc = do_load(h, in);
+  cilqr_job_set& js = h->sets[j.set];
+  hipStream_t st = j.st1;
+  j.tm = cilqr_timer();
+  j.tm.h = h; j.tm.js = &js; j.tm.stream = st;
+  std::memset(&j.prof, 0, sizeof(j.prof));
+  j.handed = false; j.tail_used = false; j.tail_n = 0; j.it = 0;
+  j.bwd_iter.clear();
+  if (j.tm.begin(3)) return CILQR_ERR_DEVICE;
+  j.gmain = main_view(h, js);
+  int rc = do_load(h, in, js, &j.gmain, st);
   if (rc != CILQR_OK) return rc;
+  h->stage = 0;   // the main arena no longer holds what cilqr_stage_load put there
   const int B = in->batch, K = in->n_knots, M = h->cfg.max_iter;
+  j.B = B;
   // two views of the device state: `d` is the arena the active problems live in, `o` the other one
-  DeviceState d = h->ds;
-  DeviceState o = h->twin;
-  {  // the twin aliases everything k_compact does not move; refresh the per-solve fields
-    DeviceState t = h->ds;
-    t.X = o.X; t.U = o.U; t.cur = o.cur; t.goals = o.goals; t.cor = o.cor; t.ccnt = o.ccnt;
-    t.lambda = o.lambda; t.dlambda = o.dlambda; t.cost_old = o.cost_old; t.dcost = o.dcost;
-    t.upd = o.upd; t.acc_idx = o.acc_idx; t.emit = o.emit; t.pid = o.pid; t.done_now = o.done_now;
-    t.act = o.act; t.act_next = o.act_next;
-    o = t;
-  }
-  hipStream_t st = h->stream;
+  j.d = j.gmain;
+  j.o = twin_of(j.gmain, h->twin);
 
   // output staging when the caller's buffers live in host memory
-  double* o_traj = out->traj; double* o_hist = out->cost_hist; double* o_it = out->iter_trajs;
-  int* o_nc = out->n_cost; int* o_st = out->status; int* o_ni = out->n_iter; int* o_nit = out->n_iter_trajs;
-  signed char* o_at = reinterpret_cast<signed char*>(out->alpha_trace);
-  const size_t n_traj = (size_t)B * K * 10, n_hist = (size_t)B * (M + 1) * 5;
-  const size_t n_it = out->iter_trajs ? (size_t)B * out->max_iter_trajs * K * 10 : 0;
-  const size_t n_at = out->alpha_trace ? (size_t)B * M : 0;
+  j.o_traj = out->traj; j.o_hist = out->cost_hist; j.o_it = out->iter_trajs;
+  j.o_nc = out->n_cost; j.o_st = out->status; j.o_ni = out->n_iter; j.o_nit = out->n_iter_trajs;
+  j.o_at = reinterpret_cast<signed char*>(out->alpha_trace);
+  j.n_traj = (size_t)B * K * 10; j.n_hist = (size_t)B * (M + 1) * 5;
+  j.n_itr = out->iter_trajs ? (size_t)B * out->max_iter_trajs * K * 10 : 0;
+  j.n_at = out->alpha_trace ? (size_t)B * M : 0;
   if (out->memory == CILQR_MEM_HOST) {
-    const size_t bytes = (n_traj + n_hist + n_it) * 8 + (size_t)4 * B * 4 + n_at + 1024;
-    rc = grow(&h->out_stage, &h->out_stage_bytes, bytes);
+    const size_t bytes = (j.n_traj + j.n_hist + j.n_itr) * 8 + (size_t)4 * B * 4 + j.n_at + 1024;
+    rc = grow(&js.out_stage, &js.out_stage_bytes, bytes);
     if (rc != CILQR_OK) return rc;
-    double* p = static_cast<double*>(h->out_stage);
-    o_traj = p; p += n_traj;
-    o_hist = p; p += n_hist;
-    o_it = out->iter_trajs ? p : nullptr; p += n_it;
+    double* p = static_cast<double*>(js.out_stage);
+    j.o_traj = p; p += j.n_traj;
+    j.o_hist = p; p += j.n_hist;
+    j.o_it = out->iter_trajs ? p : nullptr; p += j.n_itr;
     int* q = reinterpret_cast<int*>(p);
-    o_nc = q; o_st = q + B; o_ni = q + 2 * B; o_nit = q + 3 * B;
-    o_at = out->alpha_trace ? reinterpret_cast<signed char*>(q + 4 * B) : nullptr;
+    j.o_nc = q; j.o_st = q + B; j.o_ni = q + 2 * B; j.o_nit = q + 3 * B;
+    j.o_at = out->alpha_trace ? reinterpret_cast<signed char*>(q + 4 * B) : nullptr;
     // the staging buffer is reused between solves: rows the kernels do not write (cost rows
     // >= n_cost, iterates >= n_iter_trajs) must reach the caller as zeros, not as an earlier solve's data
-    HIP_TRY(hipMemsetAsync(o_hist, 0, (n_hist + n_it) * 8, h->stream));
+    HIP_TRY(hipMemsetAsync(j.o_hist, 0, (j.n_hist + j.n_itr) * 8, st));
   }
 
-  if (h->cfg.init_guess == CILQR_INIT_TRACKER) launch_init_guess_tracker(d, h->tracker, B, st);   // cc:168 (InitGuess)
-  else launch_init_guess(d, B, st);                    // cc:169
-  launch_cost_only(d, nullptr, B, 0, st);              // cc:172
-  launch_init_cost_commit(d, B, st);                   // cc:170,173
-  if (o_it) launch_export_iter_traj(d, nullptr, B, o_it, out->max_iter_trajs, st);
-  if (tm.end()) return CILQR_ERR_DEVICE;
+  if (h->cfg.init_guess == CILQR_INIT_TRACKER) launch_init_guess_tracker(j.d, h->tracker, B, st);   // cc:168 (InitGuess)
+  else launch_init_guess(j.d, B, st);                  // cc:169
+  launch_cost_only(j.d, nullptr, B, 0, st);            // cc:172
+  launch_init_cost_commit(j.d, B, st);                 // cc:170,173
+  if (j.o_it) launch_export_iter_traj(j.d, nullptr, B, j.o_it, out->max_iter_trajs, st);
+  if (j.tm.end()) return CILQR_ERR_DEVICE;
 
+  if ((int)js.iter_ev.size() < M) {
+    const size_t old = js.iter_ev.size();
+    js.iter_ev.resize(M);
+    for (size_t i = old; i < js.iter_ev.size(); ++i)
+      HIP_TRY(hipEventCreateWithFlags(&js.iter_ev[i], hipEventDisableTiming));
+  }
+  // The tail of the batch (kernels_tail.hip) needs a private arena per problem; sized before the first kernel so
+  // that no allocation falls into the solve.  (Grown only while no other solve is finishing: see cilqr_submit.)
+  if (h->tail_threshold > 0) {
+    const size_t need = (size_t)std::min(B, h->tail_threshold) * tail_workspace_bytes(j.d);
+    if (need > h->tail_ws_bytes) {
+      std::unique_lock<std::mutex> lk(h->mu);
+      h->cv.wait(lk, [h] { return !h->fin_busy; });
+      rc = grow(&h->tail_ws, &h->tail_ws_bytes, need);
+      if (rc != CILQR_OK) return rc;
+    }
+  }
+  launch_init_counters(j.d, B, st);
+  j.n_hint = B;   // upper bound of the active count of the iteration being enqueued
+  j.span = B;     // slots occupied in the current arena (upper bound)
+  return CILQR_OK;
+}
+
+__global__ void k_seed_counters(int* __restrict__ dst, const int* __restrict__ src_count, int ring_entry) {
+  if (threadIdx.x < 64) dst[threadIdx.x] = (threadIdx.x == ring_entry) ? *src_count : 0;
+}
+
+// The lockstep iterations of Optimize() (cc:201-319).  stage 1: in the main arena, until at most fin_threshold
+// problems are left -- then the survivors are copied into the finishing arena and the function returns with
+// j.handed set; stage 2: the rest, there, on j.st2, down to the tail kernel.
+int job_iterate(cilqr_solver* h, cilqr_job& j, int stage) {
+  HIP_TRY(hipSetDevice(h->device));
+  cilqr_job_set& js = h->sets[j.set];
+  const int M = h->cfg.max_iter, B = j.B;
+  hipStream_t st = (stage == 1) ? j.st1 : j.st2;
+  DeviceState& d = j.d;
+  DeviceState& o = j.o;
+  if (stage == 2) {
+    if (j.st2 != j.st1) HIP_TRY(hipStreamWaitEvent(j.st2, js.handoff, 0));
+    j.tm.stream = st;
+  }
   // The host runs kLead iterations ahead of the GPU: before enqueueing iteration `it` it waits only
   // for the active count produced by iteration it - kLead (normally long finished), which bounds
   // the grids of iteration `it`; the kernels clamp to the exact device-side count (n_dev).
   constexpr int kLead = 2;
-  if ((int)h->iter_ev.size() < M) {
-    const size_t old = h->iter_ev.size();
-    h->iter_ev.resize(M);
-    for (size_t i = old; i < h->iter_ev.size(); ++i)
-      HIP_TRY(hipEventCreateWithFlags(&h->iter_ev[i], hipEventDisableTiming));
-  }
-  // The tail of the batch (kernels_tail.hip) needs a private arena per problem; sized before the first kernel so
-  // that no allocation falls into the solve.
 #ifdef CILQR_REF_ORDER
   const int tail_threshold = 0;   // the test-only build re-evaluates whole trajectories in the reference's order
 #else
   const int tail_threshold = h->tail_threshold;
 #endif
-  if (tail_threshold > 0) {
-    rc = grow(&h->tail_ws, &h->tail_ws_bytes, (size_t)std::min(B, tail_threshold) * tail_workspace_bytes(d));
-    if (rc != CILQR_OK) return rc;
-  }
-  bool tail_used = false;
-  int tail_n = 0;
-  launch_init_counters(d, B, st);
-  int n_hint = B;   // upper bound of the active count of the iteration being enqueued
-  int span = B;     // slots occupied in the current arena (upper bound)
-  int it = 0;
-  std::vector<int> bwd_iter;   // iteration index of every profiled backward launch
+  int& it = j.it;
+  int& n_hint = j.n_hint;
   for (; it < M; ++it) {                               // cc:201
     if (it >= kLead) {
-      HIP_TRY(hipEventSynchronize(h->iter_ev[it - kLead]));
-      n_hint = h->h_count[it - kLead];
+      HIP_TRY(hipEventSynchronize(js.iter_ev[it - kLead]));
+      n_hint = js.h_count[it - kLead];
       if (n_hint == 0) break;                          // iterations it-kLead+1 .. it-1 were no-ops
+    }
+    if (stage == 1 && h->fin_threshold > 0 && n_hint <= h->fin_threshold && n_hint > tail_threshold) {
+      // few enough problems left: they continue in the finishing arena, the main arena is free for the next solve.
+      // The active list of iteration `it` is d.act, its exact length entry it % 3 of the ring of counts.
+      {
+        std::unique_lock<std::mutex> lk(h->mu);
+        h->cv.wait(lk, [h] { return !h->fin_busy; });   // the previous solve still finishing there
+        h->fin_busy = true;
+      }
+      if (j.tm.begin(3)) return CILQR_ERR_DEVICE;
+      DeviceState a = d;
+      a.act_next = d.act;
+      a.n_next = d.counters + kCntActive + it % 3;
+      DeviceState f = h->fin;
+      adopt_job_fields(&f, j.gmain);
+      launch_compact(a, f, n_hint, st);
+      hipLaunchKernelGGL(k_seed_counters, dim3(1), dim3(64), 0, st, f.counters, a.n_next, kCntActive + it % 3);
+      HIP_TRY(hipGetLastError());
+      if (j.tm.end()) return CILQR_ERR_DEVICE;
+      HIP_TRY(hipEventRecord(js.handoff, st));
+      d = f;
+      o = twin_of(f, h->fin_twin);
+      j.span = n_hint;
+      j.handed = true;
+      return CILQR_OK;
     }
     // iteration `it` reads entry it % 3 of the ring of active counts, counts its survivors into
     // the next entry and clears the one after that
     d.n_dev = d.counters + kCntActive + it % 3;
     d.n_next = d.counters + kCntActive + (it + 1) % 3;
     d.n_clear = d.counters + kCntActive + (it + 2) % 3;
-    d.h_count_dev = h->h_count_dev + it;
+    d.h_count_dev = js.h_count_dev + it;
     o.n_dev = d.n_dev; o.n_next = d.n_next; o.n_clear = d.n_clear; o.h_count_dev = d.h_count_dev;
     if (n_hint <= tail_threshold) {
       // few problems left: each gets a workgroup that runs all its remaining iterations (cc:201-319) in one launch
-      if (tm.begin(4)) return CILQR_ERR_DEVICE;
-      HIP_TRY(hipMemsetAsync(h->tail_iter_dev, 0, sizeof(int), st));
-      launch_tail(d, h->tail_ws, n_hint, o_traj, o_it, out->max_iter_trajs, h->tail_iter_dev, st);
-      HIP_TRY(hipMemcpyAsync(h->h_count + M + 32, h->tail_iter_dev, sizeof(int), hipMemcpyDeviceToHost, st));
-      if (tm.end()) return CILQR_ERR_DEVICE;
-      tail_used = true;
-      tail_n = n_hint;
+      if (j.tm.begin(4)) return CILQR_ERR_DEVICE;
+      HIP_TRY(hipMemsetAsync(js.tail_iter_dev, 0, sizeof(int), st));
+      launch_tail(d, h->tail_ws, n_hint, j.o_traj, j.o_it, j.out.max_iter_trajs, js.tail_iter_dev, st);
+      HIP_TRY(hipMemcpyAsync(js.h_count + M + 32, js.tail_iter_dev, sizeof(int), hipMemcpyDeviceToHost, st));
+      if (j.tm.end()) return CILQR_ERR_DEVICE;
+      j.tail_used = true;
+      j.tail_n = n_hint;
       break;
     }
-    if (tm.begin(0)) return CILQR_ERR_DEVICE;
+    if (j.tm.begin(0)) return CILQR_ERR_DEVICE;
     launch_quadratize(d, d.act, n_hint, 1, st);        // cc:203-214
     hipEvent_t eb0, eb1;
-    if (tm.end() || tm.pair(1, &eb0, &eb1)) return CILQR_ERR_DEVICE;
+    if (j.tm.end() || j.tm.pair(1, &eb0, &eb1)) return CILQR_ERR_DEVICE;
     launch_backward(d, d.act, n_hint, nullptr, h->team_threshold, h->wave_threshold, st, eb0, eb1);    // cc:218
-    if (tm.begin(2)) return CILQR_ERR_DEVICE;
-    bwd_iter.push_back(it);
+    if (j.tm.begin(2)) return CILQR_ERR_DEVICE;
+    j.bwd_iter.push_back(it);
     launch_linesearch(d, n_hint, h->spec_threshold, h->seq_rounds, h->round_group, st);  // cc:235-270
     launch_update(d, n_hint, st);                      // cc:272-308
-    launch_export_done(d, n_hint, o_traj, st);         // cc:238,285,303,319
-    if (o_it) launch_export_iter_traj(d, d.act, n_hint, o_it, out->max_iter_trajs, st);
-    if (tm.end()) return CILQR_ERR_DEVICE;
-    HIP_TRY(hipEventRecord(h->iter_ev[it], st));
-    if (h->compaction && (int64_t)100 * n_hint <= (int64_t)h->compact_percent * span) {
+    launch_export_done(d, n_hint, j.o_traj, st);       // cc:238,285,303,319
+    if (j.o_it) launch_export_iter_traj(d, d.act, n_hint, j.o_it, j.out.max_iter_trajs, st);
+    if (j.tm.end()) return CILQR_ERR_DEVICE;
+    HIP_TRY(hipEventRecord(js.iter_ev[it], st));
+    if (h->compaction && (int64_t)100 * n_hint <= (int64_t)h->compact_percent * j.span) {
       // the survivors have thinned out: re-pack them densely (k_compact reads the exact count)
-      if (tm.begin(3)) return CILQR_ERR_DEVICE;
+      if (j.tm.begin(3)) return CILQR_ERR_DEVICE;
       launch_compact(d, o, n_hint, st);
-      if (tm.end()) return CILQR_ERR_DEVICE;
+      if (j.tm.end()) return CILQR_ERR_DEVICE;
       DeviceState t = d; d = o; o = t;
-      span = n_hint;
+      j.span = n_hint;
     } else {
       int* t = d.act; d.act = d.act_next; d.act_next = t;
     }
   }
-  HIP_TRY(hipStreamSynchronize(st));
-  {  // lockstep iterations that had work, and the problem-steps each backward launch covered
-    int used = 0;
-    for (int i = 0; i < it; ++i) {
-      const int n_in = (i == 0) ? B : h->h_count[i - 1];
-      if (n_in > 0) used = i + 1;
-    }
-    for (int i : bwd_iter) {
-      const int n_in = (i == 0) ? B : h->h_count[i - 1];
-      if (n_in <= 0) continue;
-      h->prof.backward_launches += 1;
-      h->prof.backward_problem_steps += (int64_t)n_in * h->cfg.n_steps;
-    }
-    tm.full_flags.assign(bwd_iter.size(), 0);
-    tm.live_flags.assign(bwd_iter.size(), 0);
-    for (size_t k = 0; k < bwd_iter.size(); ++k) {
-      const int n_in = (bwd_iter[k] == 0) ? B : h->h_count[bwd_iter[k] - 1];
-      tm.full_flags[k] = (n_in == B);
-      tm.live_flags[k] = (n_in > 0);
-    }
-    it = used;
-    if (tail_used) {
-      it = std::max(it, h->h_count[M + 32]);
-      h->prof.tail_problems = tail_n;   // upper bound (the count the host knew when it enqueued the tail)
-    }
-  }
-  h->prof.iterations = it;
-  if (tm.begin(3)) return CILQR_ERR_DEVICE;
-  launch_export_hist(h->ds, B, o_hist, o_nc, o_st, o_ni, o_nit, o_at, st);
-  if (tm.end()) return CILQR_ERR_DEVICE;
-  HIP_TRY(hipGetLastError());
-  if (out->memory == CILQR_MEM_HOST) {
-    HIP_TRY(hipMemcpyAsync(out->traj, o_traj, n_traj * 8, hipMemcpyDeviceToHost, st));
-    // rows >= n_cost were zero-filled above
-    HIP_TRY(hipMemcpyAsync(out->cost_hist, o_hist, n_hist * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(out->n_cost, o_nc, (size_t)B * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(out->status, o_st, (size_t)B * 4, hipMemcpyDeviceToHost, st));
-    if (out->n_iter) HIP_TRY(hipMemcpyAsync(out->n_iter, o_ni, (size_t)B * 4, hipMemcpyDeviceToHost, st));
-    if (out->iter_trajs) {
-      HIP_TRY(hipMemcpyAsync(out->iter_trajs, o_it, n_it * 8, hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipMemcpyAsync(out->n_iter_trajs, o_nit, (size_t)B * 4, hipMemcpyDeviceToHost, st));
-    }
-    if (out->alpha_trace) HIP_TRY(hipMemcpyAsync(out->alpha_trace, o_at, n_at, hipMemcpyDeviceToHost, st));
-  }
-  HIP_TRY(hipStreamSynchronize(st));
-  tm.resolve(&h->prof);
-  // Survivor re-packing ping-pongs the working set between the two arenas, so after a solve the
-  // slots of arena A no longer hold the loaded batch in problem order: the stage entry points
-  // refuse to run (CILQR_ERR_STATE) until cilqr_stage_load is called again.
-  h->stage = 0;
+  (void)B;
   return CILQR_OK;
 }
 
+// Everything enqueued: wait, export the problem-indexed results, copy out, resolve the profile.
+int job_finish(cilqr_solver* h, cilqr_job& j) {
+  cilqr_job_set& js = h->sets[j.set];
+  const cilqr_solution_batch* out = &j.out;
+  const int M = h->cfg.max_iter, B = j.B;
+  hipStream_t st = j.handed ? j.st2 : j.st1;
+  j.tm.stream = st;
+  HIP_TRY(hipStreamSynchronize(st));
+  int it = j.it;
+  {  // lockstep iterations that had work, and the problem-steps each backward launch covered
+    int used = 0;
+    for (int i = 0; i < it; ++i) {
+      const int n_in = (i == 0) ? B : js.h_count[i - 1];
+      if (n_in > 0) used = i + 1;
+    }
+    for (int i : j.bwd_iter) {
+      const int n_in = (i == 0) ? B : js.h_count[i - 1];
+      if (n_in <= 0) continue;
+      j.prof.backward_launches += 1;
+      j.prof.backward_problem_steps += (int64_t)n_in * h->cfg.n_steps;
+    }
+    j.tm.full_flags.assign(j.bwd_iter.size(), 0);
+    j.tm.live_flags.assign(j.bwd_iter.size(), 0);
+    for (size_t k = 0; k < j.bwd_iter.size(); ++k) {
+      const int n_in = (j.bwd_iter[k] == 0) ? B : js.h_count[j.bwd_iter[k] - 1];
+      j.tm.full_flags[k] = (n_in == B);
+      j.tm.live_flags[k] = (n_in > 0);
+    }
+    it = used;
+    if (j.tail_used) {
+      it = std::max(it, js.h_count[M + 32]);
+      j.prof.tail_problems = j.tail_n;   // upper bound (the count the host knew when it enqueued the tail)
+    }
+  }
+  j.prof.iterations = it;
+  if (j.tm.begin(3)) return CILQR_ERR_DEVICE;
+  launch_export_hist(j.gmain, B, j.o_hist, j.o_nc, j.o_st, j.o_ni, j.o_nit, j.o_at, st);
+  if (j.tm.end()) return CILQR_ERR_DEVICE;
+  HIP_TRY(hipGetLastError());
+  if (out->memory == CILQR_MEM_HOST) {
+    HIP_TRY(hipMemcpyAsync(out->traj, j.o_traj, j.n_traj * 8, hipMemcpyDeviceToHost, st));
+    // rows >= n_cost were zero-filled above
+    HIP_TRY(hipMemcpyAsync(out->cost_hist, j.o_hist, j.n_hist * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(out->n_cost, j.o_nc, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(out->status, j.o_st, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    if (out->n_iter) HIP_TRY(hipMemcpyAsync(out->n_iter, j.o_ni, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    if (out->iter_trajs) {
+      HIP_TRY(hipMemcpyAsync(out->iter_trajs, j.o_it, j.n_itr * 8, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(out->n_iter_trajs, j.o_nit, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    }
+    if (out->alpha_trace) HIP_TRY(hipMemcpyAsync(out->alpha_trace, j.o_at, j.n_at, hipMemcpyDeviceToHost, st));
+  }
+  HIP_TRY(hipStreamSynchronize(st));
+  j.tm.resolve(&j.prof);
+  return CILQR_OK;
+}
+
+// the finishing arena is free again (also after an error on the way)
+void release_fin(cilqr_solver* h, cilqr_job& j) {
+  if (!j.handed) return;
+  j.handed = false;
+  {
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->fin_busy = false;
+  }
+  h->cv.notify_all();
+}
+
 // ------------------------------------------------------------------------------------------
-// asynchronous solves: several handles (each with its own stream) keep several batches in flight,
-// so the latency-bound tail of one solve overlaps the throughput-bound start of the next
+// asynchronous solves: two jobs in flight on one handle.  Worker 1 drives the first stage of a solve on the
+// handle's stream, worker 2 the finishing stage on a second (high-priority) stream, so the few hundred
+// stragglers of solve i finish while the bulk of solve i+1 is being iterated.
 // ------------------------------------------------------------------------------------------
-static void worker_main(cilqr_solver* h) {
+void worker1_main(cilqr_solver* h) {
+  (void)hipSetDevice(h->device);
   std::unique_lock<std::mutex> lk(h->mu);
   for (;;) {
-    h->cv.wait(lk, [h] { return h->quit || h->job_pending; });
+    cilqr_job* job = nullptr;
+    h->cv.wait(lk, [&] {
+      if (h->quit) return true;
+      for (int k = 0; k < h->job_count; ++k) {   // oldest first
+        cilqr_job& c = h->jobs[(h->job_head + k) % 2];
+        if (c.phase == 1) { job = &c; return true; }
+      }
+      return false;
+    });
     if (h->quit) return;
+    job->phase = 2;
     lk.unlock();
-    const int rc = cilqr_solve_batch(h, &h->job_in, &h->job_out);
+    cilqr_job& j = *job;
+    int rc;
+    bool to_stage2 = false;
+    if (j.in.n_lane_groups > 1) {
+      // grouped lane tables: the groups are solved one after the other on this thread, nothing overlaps
+      j.st2 = j.st1;
+      cilqr_problem_batch in = j.in;
+      cilqr_solution_batch out = j.out;
+      rc = solve_groups(h, j, &in, &out);
+    } else {
+      rc = job_begin(h, j);
+      if (rc == CILQR_OK) rc = job_iterate(h, j, 1);
+      if (rc == CILQR_OK && j.handed) to_stage2 = true;
+      else {
+        if (rc == CILQR_OK) rc = job_finish(h, j);
+        release_fin(h, j);
+      }
+    }
     lk.lock();
-    h->job_rc = rc;
-    h->job_pending = false;
-    h->job_done = true;
+    j.rc = rc;
+    j.phase = to_stage2 ? 3 : 5;
     h->cv.notify_all();
   }
 }
 
+void worker2_main(cilqr_solver* h) {
+  (void)hipSetDevice(h->device);
+  std::unique_lock<std::mutex> lk(h->mu);
+  for (;;) {
+    cilqr_job* job = nullptr;
+    h->cv.wait(lk, [&] {
+      if (h->quit) return true;
+      for (int k = 0; k < h->job_count; ++k) {
+        cilqr_job& c = h->jobs[(h->job_head + k) % 2];
+        if (c.phase == 3) { job = &c; return true; }
+      }
+      return false;
+    });
+    if (h->quit) return;
+    job->phase = 4;
+    lk.unlock();
+    cilqr_job& j = *job;
+    int rc = job_iterate(h, j, 2);
+    if (rc == CILQR_OK) rc = job_finish(h, j);
+    else (void)hipStreamSynchronize(j.st2);
+    release_fin(h, j);
+    lk.lock();
+    j.rc = rc;
+    j.phase = 5;
+    h->cv.notify_all();
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
 int cilqr_submit(cilqr_handle h, const cilqr_problem_batch* in, cilqr_solution_batch* out) {
   if (h == nullptr || in == nullptr || out == nullptr) return CILQR_ERR_NULL;
   std::lock_guard<std::mutex> lk(h->mu);
-  if (h->job_pending || h->job_done) return CILQR_ERR_STATE;   // previous job not collected yet
-  if (!h->worker_started) {
-    h->worker = std::thread(worker_main, h);
-    h->worker_started = true;
+  if (h->job_count >= 2) return CILQR_ERR_STATE;   // two solves in flight: collect the oldest first (cilqr_wait)
+  if (!h->workers_started) {
+    h->worker1 = std::thread(worker1_main, h);
+    h->worker2 = std::thread(worker2_main, h);
+    h->workers_started = true;
   }
-  h->job_in = *in;
-  h->job_out = *out;
-  h->job_pending = true;
+  const int slot = (h->job_head + h->job_count) % 2;
+  cilqr_job& j = h->jobs[slot];
+  j.in = *in;
+  j.out = *out;
+  j.set = slot;
+  j.st1 = h->stream;
+  j.st2 = h->stream2;
+  j.rc = CILQR_OK;
+  j.phase = 1;
+  h->job_count += 1;
   h->cv.notify_all();
   return CILQR_OK;
 }
@@ -786,10 +1027,15 @@ int cilqr_submit(cilqr_handle h, const cilqr_problem_batch* in, cilqr_solution_b
 int cilqr_wait(cilqr_handle h) {
   if (h == nullptr) return CILQR_ERR_NULL;
   std::unique_lock<std::mutex> lk(h->mu);
-  if (!h->job_pending && !h->job_done) return CILQR_ERR_STATE;
-  h->cv.wait(lk, [h] { return h->job_done; });
-  h->job_done = false;
-  return h->job_rc;
+  if (h->job_count == 0) return CILQR_ERR_STATE;
+  cilqr_job& j = h->jobs[h->job_head];
+  h->cv.wait(lk, [&] { return j.phase == 5; });
+  const int rc = j.rc;
+  h->prof = j.prof;
+  j.phase = 0;
+  h->job_head = (h->job_head + 1) % 2;
+  h->job_count -= 1;
+  return rc;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -797,9 +1043,16 @@ int cilqr_wait(cilqr_handle h) {
 // ------------------------------------------------------------------------------------------
 int cilqr_stage_load(cilqr_handle h, const cilqr_problem_batch* in) {
   if (h == nullptr) return CILQR_ERR_NULL;
-  const int rc = do_load(h, in);
+  {
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (h->job_count != 0) return CILQR_ERR_STATE;   // the main arena belongs to the submitted solves
+  }
+  h->stage = 0;
+  const int rc = do_load(h, in, h->sets[0], &h->ds, h->stream);
   if (rc != CILQR_OK) return rc;
   HIP_TRY(hipStreamSynchronize(h->stream));
+  h->B = in->batch;
+  h->stage = 1;
   return CILQR_OK;
 }
 

@@ -27,29 +27,94 @@ extern thread_local char g_last_hip_error[256];
 
 struct cilqr_comm;   // comm.hip: RCCL communicator + staging of cilqr_gather_results
 
+// What ONE solve in flight owns besides the arenas: the tensors indexed by PROBLEM (they outlive the hand-over of
+// the survivors to the finishing arena and are read by the final export), the lane tables it was loaded with,
+// its host-visible iteration counters and its events.  A handle has two of these, so that the finishing stage of
+// solve i and the first stage of solve i+1 can be in flight together.
+struct cilqr_job_set {
+  double* hist = nullptr;
+  int *iter = nullptr, *status = nullptr, *n_cost = nullptr, *n_iter_trajs = nullptr;
+  signed char* atrace = nullptr;
+  double* lanes = nullptr;
+  unsigned char* lgrid = nullptr;
+  double* lanes_raw = nullptr;      // device [2*smax][7]
+  std::vector<double> lane_cache;   // the lane tables whose device image and grid are current (left rows, then right rows)
+  int lane_cache_nl = -1, lane_cache_nr = -1;
+  int* h_count = nullptr;           // pinned, written by k_update through h_count_dev
+  int* h_count_dev = nullptr;
+  int* tail_iter_dev = nullptr;     // largest iteration count reached inside the tail kernel
+  void* out_stage = nullptr;        // problem-major results on the device when the caller's buffers are host memory
+  size_t out_stage_bytes = 0;
+  std::vector<hipEvent_t> iter_ev;  // one per lockstep iteration (count read-back)
+  std::vector<hipEvent_t> ev;       // profiling
+  hipEvent_t handoff = nullptr;     // survivors copied into the finishing arena (recorded on the first stage's stream)
+};
+
+struct cilqr_timer {  // event pairs around kernels / phases, resolved after the final sync
+  cilqr_solver* h = nullptr;
+  cilqr_job_set* js = nullptr;
+  hipStream_t stream = nullptr;     // where the next events are recorded (changes at the hand-over)
+  size_t next = 0;
+  std::vector<int> kind;  // 0 quad, 1 backward, 2 linesearch, 3 other, 4 tail
+  std::vector<char> full_flags, live_flags;  // per backward launch: covered the whole batch / had work
+  bool open = false;   // the last begin() recorded an event, so the matching end() must too
+  bool on() const;
+  bool wants(int k) const;
+  int reserve();
+  int begin(int k);
+  int pair(int k, hipEvent_t* a, hipEvent_t* b);
+  int end();
+  void resolve(cilqr_profile* p);
+};
+
+// One solve on its way through the handle: first stage (load, init guess, the lockstep iterations over the bulk of
+// the batch, in the main arena), hand-over of the survivors, finishing stage (remaining lockstep iterations + the
+// per-problem tail kernel in the small finishing arena, final export).
+struct cilqr_job {
+  cilqr_problem_batch in;
+  cilqr_solution_batch out;
+  int set = 0;
+  int phase = 0;            // 0 free, 1 queued, 2 first stage, 3 waiting for the finishing stage, 4 finishing, 5 done
+  int rc = CILQR_OK;
+  hipStream_t st1 = nullptr, st2 = nullptr;
+  cilqr::DeviceState gmain;   // main arena with this job's problem-indexed tensors and lane tables
+  cilqr::DeviceState d, o;    // the arena the active problems live in, and its twin
+  int B = 0, it = 0, n_hint = 0, span = 0;
+  bool handed = false, tail_used = false;
+  int tail_n = 0;
+  std::vector<int> bwd_iter;  // iteration index of every profiled backward launch
+  cilqr_timer tm;
+  cilqr_profile prof;
+  // where the kernels write the results (the caller's device buffers, or the staging of the job set)
+  double *o_traj = nullptr, *o_hist = nullptr, *o_it = nullptr;
+  int *o_nc = nullptr, *o_st = nullptr, *o_ni = nullptr, *o_nit = nullptr;
+  signed char* o_at = nullptr;
+  size_t n_traj = 0, n_hist = 0, n_itr = 0, n_at = 0;
+};
+
 struct cilqr_solver {
   cilqr_config cfg;
   int device = 0;
   int Bcap = 0, capacity = 0, cmax = 0, smax = 0;
   cilqr::DeviceState ds;      // arena A (also what the stage API works on)
   cilqr::DeviceState twin;    // arena B: only the fields k_compact moves are its own, the rest alias ds
+  // finishing arena (capacity fin_cap slots) and its twin: where a solve continues once few enough problems are
+  // left, so that the main arena is free for the next solve (cilqr_submit) while the stragglers finish
+  cilqr::DeviceState fin, fin_twin;
+  int fin_cap = 0;
+  int fin_threshold = 0;     // hand the survivors over at this active count (CILQR_OPT_FINISH_THRESHOLD); 0 = never
   bool compaction = true;
   int compact_percent = 75;  // re-pack when the survivors fill at most this share of the occupied slots
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;   // finishing stage of asynchronous solves (high priority: short, latency-bound kernels)
   std::vector<void*> allocs;
   int64_t bytes = 0;
-  // staging (lazily grown): problem-major copies of host inputs / outputs on the device
+  // staging (lazily grown): problem-major copy of host inputs on the device
   void* in_stage = nullptr;
   size_t in_stage_bytes = 0;
-  void* out_stage = nullptr;
-  size_t out_stage_bytes = 0;
-  double* lanes_raw = nullptr;  // device [2*smax][7]
-  std::vector<double> lane_cache;   // the lane tables whose device image and grid are current (left rows, then right rows)
-  int lane_cache_nl = -1, lane_cache_nr = -1;
+  cilqr_job_set sets[2];
   double* lambda_stage = nullptr;
-  int* h_count = nullptr;  // pinned, written by k_update through h_count_dev
-  int* h_count_dev = nullptr;
   int B = 0;               // problems loaded
   int stage = 0;           // bit0 loaded, bit1 iterate, bit2 quadratized, bit3 gains
   int spec_threshold = 8192;  // active sets up to this size evaluate all 11 step sizes at once
@@ -60,21 +125,19 @@ struct cilqr_solver {
   int tail_threshold = 256;   // active sets up to this size leave the lockstep loop: one workgroup per problem (kernels_tail.hip)
   void* tail_ws = nullptr;    // private arenas of the tail's problems (lazily grown)
   size_t tail_ws_bytes = 0;
-  int* tail_iter_dev = nullptr;   // largest iteration count reached inside the tail kernel
-  // asynchronous submit / wait: one worker thread per handle, one job in flight
-  std::thread worker;
+  // asynchronous submit / wait: two jobs in flight, one worker thread per stage
+  std::thread worker1, worker2;
   std::mutex mu;
   std::condition_variable cv;
-  bool worker_started = false, job_pending = false, job_done = false, quit = false;
-  cilqr_problem_batch job_in;
-  cilqr_solution_batch job_out;
-  int job_rc = CILQR_OK;
+  bool workers_started = false, quit = false;
+  bool fin_busy = false;      // the finishing arena holds a solve
+  cilqr_job jobs[2];          // ring: jobs[k] uses sets[k]
+  int job_head = 0;           // oldest job not yet collected by cilqr_wait
+  int job_count = 0;          // submitted and not yet collected
   // profiling
   bool profiling = false;
   int profiling_level = 1;
-  std::vector<hipEvent_t> ev;
-  std::vector<hipEvent_t> iter_ev;  // one per lockstep iteration (count read-back)
-  cilqr_profile prof;
+  cilqr_profile prof;         // of the last solve that completed
   cilqr_comm* comm = nullptr;   // multi-GPU results gather (cilqr_comm_create)
   cilqr::TrackerParams tracker;   // CILQR_INIT_TRACKER
 };

@@ -82,7 +82,9 @@ struct TrackerParams {
 };
 
 struct DeviceState {
-  int Bcap;  // arena capacity (slots)
+  int Bcap;  // arena capacity (slots): stride of every SLOT-indexed tensor
+  int Pcap;  // stride of the PROBLEM-indexed tensors (hist, atrace): the capacity of the batch, whatever arena the
+             // active problems currently live in (the finishing arena of solver.hip is smaller than the batch)
   int cmax;
   int nl, nr;  // lane segments
   Params p;

@@ -200,6 +200,11 @@ int cilqr_set_stream(cilqr_handle h, void* hip_stream);
  * (kernels_tail.hip), so the stragglers of a batch no longer cost nine launches per iteration.  0 = lockstep to
  * the end.  Bit-identical results. */
 #define CILQR_OPT_TAIL_THRESHOLD 5
+/* CILQR_OPT_FINISH_THRESHOLD (default min(batch capacity, 8192), which is also the most): once at most this many
+ * problems are still iterating, the survivors move into a small finishing arena of the handle and the main arena is free:
+ * with cilqr_submit, the next solve starts there while this one's stragglers finish on a second stream.  0 = never
+ * (a submitted solve then runs start to end before the next begins).  Bit-identical results. */
+#define CILQR_OPT_FINISH_THRESHOLD 8
 int cilqr_set_option(cilqr_handle h, int32_t option, int64_t value);
 /* enable = 1: HIP events around every phase of every lockstep iteration (cilqr_profile complete; about 4 %
  * slower: ~800 event records per solve); enable = 2: around the backward launches only (backward_* fields;
@@ -224,10 +229,16 @@ void cilqr_default_tracker_config(cilqr_tracker_config* cfg);
 int cilqr_set_tracker_config(cilqr_handle h, const cilqr_tracker_config* cfg);
 
 /* Asynchronous form of cilqr_solve_batch: submit returns at once (the structs are copied, the
- * arrays they point to must stay valid), wait blocks for the result code.  One job in flight per
- * handle; several handles on different streams keep several batches in flight, which lets the
- * latency-bound tail of one solve overlap the start of the next.  A handle is not re-entrant:
- * do not call anything else on it between submit and wait. */
+ * arrays they point to -- inputs and outputs -- must stay valid and distinct per solve until its wait),
+ * wait blocks for the result code of the OLDEST submitted solve.  Up to TWO solves may be in flight on a
+ * handle (a third submit returns CILQR_ERR_STATE): the handle iterates the bulk of solve i+1 in its main
+ * arena while the last few thousand problems of solve i -- the latency-bound part of a solve: lockstep
+ * iterations over few problems, then the per-problem tail kernel -- finish in a small second arena on a
+ * second stream (CILQR_OPT_FINISH_THRESHOLD).  Keep the handle fed:
+ *     submit(A); submit(B); wait(); submit(C); wait(); submit(D); ...
+ * Results are bit-identical to cilqr_solve_batch.  cilqr_get_profile reports the solve the last wait
+ * collected.  A handle is not re-entrant: between a submit and the wait that collects it, call only
+ * cilqr_submit / cilqr_wait on it (cilqr_solve_batch and cilqr_stage_load return CILQR_ERR_STATE). */
 int cilqr_submit(cilqr_handle h, const cilqr_problem_batch* in, cilqr_solution_batch* out);
 int cilqr_wait(cilqr_handle h);
 

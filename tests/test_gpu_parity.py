@@ -583,7 +583,6 @@ def test_submit_wait_keeps_batches_in_flight_on_separate_handles():
     for rep in range(2):                               # a handle is reusable after wait()
         for j in jobs:
             assert j[0].submit_raw(j[4], j[5]) == api.OK
-        assert jobs[0][0].submit_raw(jobs[0][4], jobs[0][5]) == api.ERR_STATE
         for j in jobs:
             assert j[0].wait() == api.OK
         torch.cuda.synchronize()
@@ -593,6 +592,80 @@ def test_submit_wait_keeps_batches_in_flight_on_separate_handles():
             assert np.array_equal(j[3][3].cpu().numpy(), ref["status"])
     for j in jobs:
         j[0].close()
+
+
+@pytest.mark.parametrize("finish_threshold", [-1, 3000, 0])
+def test_two_solves_in_flight_on_one_handle(finish_threshold):
+    """cilqr_submit keeps TWO solves in flight on one handle: the survivors of solve i move into the handle's finishing
+    arena (CILQR_OPT_FINISH_THRESHOLD) and finish on a second stream while solve i+1 is iterated in the main arena.
+    Five different batches -- larger than the finishing arena, smaller than it (handed over before the first iteration),
+    smaller than the tail threshold (never handed over) -- through one handle, results bit-identical to
+    cilqr_solve_batch on the same handle, in submission order; a third submit and a synchronous call in between are
+    refused; host and device result buffers."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    sizes = [9000, 700, 8500, 100, 9000]
+    scenes = [scenario.generate("mix11", n, seed=140 + i) for i, n in enumerate(sizes)]
+    Bmax = max(sizes)
+    opt = api.BatchIlqrOptimizer(api.default_config(scenes[0]["n_steps"]), batch_capacity=Bmax, cmax=scenes[0]["cmax"],
+                                 max_lane_segments=64)
+    if finish_threshold >= 0:
+        opt.set_option(api.OPT_FINISH_THRESHOLD, finish_threshold)
+    sync = [opt.plan(sc, alpha_trace=True) for sc in scenes]
+    K, M = scenes[0]["n_steps"] + 1, opt.cfg.max_iter
+    jobs = []
+    for i, sc in enumerate(scenes):
+        B = sc["coarse"].shape[0]
+        keep = {k: np.ascontiguousarray(sc[k]) for k in ("start", "coarse", "corridor", "ccount", "left", "right")}
+        prob = opt.make_problem(B, keep["start"].ctypes.data, keep["coarse"].ctypes.data, keep["corridor"].ctypes.data,
+                                keep["ccount"].ctypes.data, sc["cmax"], keep["left"].ctypes.data,
+                                keep["right"].ctypes.data, keep["left"].shape[0], keep["right"].shape[0], api.MEM_HOST)
+        if i % 2 == 0:   # device buffers
+            bufs = (torch.zeros((B, K, 10), dtype=torch.float64, device=dev), torch.zeros((B, M + 1, 5), dtype=torch.float64, device=dev),
+                    torch.zeros(B, dtype=torch.int32, device=dev), torch.zeros(B, dtype=torch.int32, device=dev),
+                    torch.zeros(B, dtype=torch.int32, device=dev))
+            sol = api.SolutionBatch(api.MEM_DEVICE, 0, bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr(),
+                                    bufs[3].data_ptr(), bufs[4].data_ptr(), None, None)
+        else:            # host buffers
+            bufs = (np.zeros((B, K, 10)), np.zeros((B, M + 1, 5)), np.zeros(B, np.int32), np.zeros(B, np.int32), np.zeros(B, np.int32))
+            sol = api.SolutionBatch(api.MEM_HOST, 0, bufs[0].ctypes.data, bufs[1].ctypes.data, bufs[2].ctypes.data,
+                                    bufs[3].ctypes.data, bufs[4].ctypes.data, None, None)
+        jobs.append((keep, bufs, prob, sol))
+    torch.cuda.synchronize()
+    assert opt.wait() == api.ERR_STATE                       # nothing submitted
+    host = lambda a: a.cpu().numpy() if hasattr(a, "cpu") else a
+    for rep in range(2):
+        for b in jobs:
+            for a in b[1]:
+                if hasattr(a, "zero_"):
+                    a.zero_()
+                else:
+                    a[...] = 0
+        torch.cuda.synchronize()
+        assert opt.submit_raw(jobs[0][2], jobs[0][3]) == api.OK
+        assert opt.submit_raw(jobs[1][2], jobs[1][3]) == api.OK
+        assert opt.submit_raw(jobs[2][2], jobs[2][3]) == api.ERR_STATE     # two in flight: collect first
+        assert opt.solve_raw(jobs[2][2], jobs[2][3]) == api.ERR_STATE
+        nxt = 2
+        for i in range(len(jobs)):
+            assert opt.wait() == api.OK                       # the oldest one
+            if nxt < len(jobs):
+                assert opt.submit_raw(jobs[nxt][2], jobs[nxt][3]) == api.OK
+                nxt += 1
+            ref, got = sync[i], jobs[i][1]
+            torch.cuda.synchronize()
+            assert np.array_equal(host(got[0]), ref["traj"]), (rep, i)
+            nc = ref["n_cost"]
+            assert np.array_equal(host(got[2]), nc) and np.array_equal(host(got[3]), ref["status"])
+            assert np.array_equal(host(got[4]), ref["n_iter"])
+            hist = host(got[1])
+            for b in range(0, sizes[i], 37):
+                assert np.array_equal(hist[b, :nc[b]], ref["cost_hist"][b, :nc[b]])
+        assert opt.wait() == api.ERR_STATE
+    again = opt.plan(scenes[0], alpha_trace=True)            # the synchronous call works again
+    for k in ("traj", "cost_hist", "n_cost", "status", "n_iter", "alpha_trace"):
+        assert np.array_equal(again[k], sync[0][k]), k
+    opt.close()
 
 
 def test_lean_log_and_reciprocal_are_accurate_to_an_ulp_or_two():
