@@ -683,7 +683,7 @@ int job_begin(cilqr_solver* h, cilqr_job& j) {
   j.tm = cilqr_timer();
   j.tm.h = h; j.tm.js = &js; j.tm.stream = st;
   std::memset(&j.prof, 0, sizeof(j.prof));
-  j.handed = false; j.tail_used = false; j.tail_n = 0; j.it = 0;
+  j.handed = false; j.owns_fin = false; j.tail_used = false; j.tail_n = 0; j.it = 0;
   j.bwd_iter.clear();
   if (j.tm.begin(3)) return CILQR_ERR_DEVICE;
   j.gmain = main_view(h, js);
@@ -784,7 +784,7 @@ int job_iterate(cilqr_solver* h, cilqr_job& j, int stage) {
       n_hint = js.h_count[it - kLead];
       if (n_hint == 0) break;                          // iterations it-kLead+1 .. it-1 were no-ops
     }
-    if (stage == 1 && h->fin_threshold > 0 && n_hint <= h->fin_threshold && n_hint > tail_threshold) {
+    if (stage == 1 && h->fin_threshold > 0 && n_hint <= h->fin_threshold) {
       // few enough problems left: they continue in the finishing arena, the main arena is free for the next solve.
       // The active list of iteration `it` is d.act, its exact length entry it % 3 of the ring of counts.
       {
@@ -807,6 +807,7 @@ int job_iterate(cilqr_solver* h, cilqr_job& j, int stage) {
       o = twin_of(f, h->fin_twin);
       j.span = n_hint;
       j.handed = true;
+      j.owns_fin = true;
       return CILQR_OK;
     }
     // iteration `it` reads entry it % 3 of the ring of active counts, counts its survivors into
@@ -818,6 +819,14 @@ int job_iterate(cilqr_solver* h, cilqr_job& j, int stage) {
     o.n_dev = d.n_dev; o.n_next = d.n_next; o.n_clear = d.n_clear; o.h_count_dev = d.h_count_dev;
     if (n_hint <= tail_threshold) {
       // few problems left: each gets a workgroup that runs all its remaining iterations (cc:201-319) in one launch
+      if (stage == 1 && !j.handed) {
+        // never handed over (CILQR_OPT_FINISH_THRESHOLD 0): the tail's workspace is shared with the finishing stage
+        // of the solve before this one -- take the finishing stage's place
+        std::unique_lock<std::mutex> lk(h->mu);
+        h->cv.wait(lk, [h] { return !h->fin_busy; });
+        h->fin_busy = true;
+        j.owns_fin = true;
+      }
       if (j.tm.begin(4)) return CILQR_ERR_DEVICE;
       HIP_TRY(hipMemsetAsync(js.tail_iter_dev, 0, sizeof(int), st));
       launch_tail(d, h->tail_ws, n_hint, j.o_traj, j.o_it, j.out.max_iter_trajs, js.tail_iter_dev, st);
@@ -914,8 +923,8 @@ int job_finish(cilqr_solver* h, cilqr_job& j) {
 
 // the finishing arena is free again (also after an error on the way)
 void release_fin(cilqr_solver* h, cilqr_job& j) {
-  if (!j.handed) return;
-  j.handed = false;
+  if (!j.owns_fin) return;
+  j.owns_fin = false;
   {
     std::lock_guard<std::mutex> lk(h->mu);
     h->fin_busy = false;

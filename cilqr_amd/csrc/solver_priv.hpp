@@ -80,7 +80,9 @@ struct cilqr_job {
   cilqr::DeviceState gmain;   // main arena with this job's problem-indexed tensors and lane tables
   cilqr::DeviceState d, o;    // the arena the active problems live in, and its twin
   int B = 0, it = 0, n_hint = 0, span = 0;
-  bool handed = false, tail_used = false;
+  bool handed = false;      // the survivors live in the finishing arena
+  bool owns_fin = false;    // this solve holds the finishing arena / the tail workspace (cilqr_solver::fin_busy)
+  bool tail_used = false;
   int tail_n = 0;
   std::vector<int> bwd_iter;  // iteration index of every profiled backward launch
   cilqr_timer tm;
