@@ -36,9 +36,14 @@ __global__ __launch_bounds__(256) CILQR_COST_ATTR void k_cost_knots(DeviceState 
                                                     const int* __restrict__ n_ptr, int n_max, int cand,
                                                     int skip_done) {
   extern __shared__ double lds[];
+#ifdef CILQR_COST_PROFILE
+  unsigned long long cp_t = wall_clock64();
+  const unsigned long long cp_t0 = cp_t;
+#endif
   const int n = n_ptr ? min(*n_ptr, n_max) : active_count(s, n_max);
   if ((int)(blockIdx.x * blockDim.x) >= n) return;   // whole block idle: skip the LDS staging too
   const double* lanes = stage_lanes(s, lds);
+  CP_STAMP(0);   // kernel arguments + lane tables staged
   const int i = blockIdx.y;
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
     const int slot = list ? list[j] : j;
@@ -47,9 +52,26 @@ __global__ __launch_bounds__(256) CILQR_COST_ATTR void k_cost_knots(DeviceState 
     double x[6], u[2] = {0.0, 0.0};
     load_x(s, buf, i, slot, x);
     if (i < s.p.N) load_u(s, buf, i, slot, u);
+#ifdef CILQR_COST_PROFILE
+    asm volatile("" :: "v"(x[0]), "v"(x[5]), "v"(u[0]));
+    CP_STAMP(1);   // cur[slot] -> state loaded
+#endif
     knot_cost<D>(s, lanes, i, slot, x, u, s.part + (size_t)i * kPartPairs * s.Bcap + slot, (size_t)s.Bcap);
   }
+#ifdef CILQR_COST_PROFILE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if ((threadIdx.x & 63) == 0) {
+    g_cost_prof[CP_WAVE * 8 + 5] = wall_clock64() - cp_t0;   // whole life of the wave
+    g_cost_prof[CP_WAVE * 8 + 6] = cp_t0;                    // its start
+  }
+#endif
 }
+#ifdef CILQR_COST_PROFILE
+extern "C" void cilqr_debug_cost_profile(unsigned long long* out, int reset) {   // tuning build only, not part of the C-ABI
+  if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cost_prof), sizeof(g_cost_prof));
+  if (reset) { void* p = nullptr; (void)hipGetSymbolAddress(&p, HIP_SYMBOL(g_cost_prof)); (void)hipMemset(p, 0, sizeof(g_cost_prof)); }
+}
+#endif
 
 // speculative line search: knot i of candidate alpha_{r0 + blockIdx.z} of list entry j
 template <int D>

@@ -89,10 +89,23 @@ CILQR_DEV double2 knot_bound_cost(const Params& p, int i, const double* x, const
   return make_double2(bar_group_value(p, g), du);
 }
 
+#ifdef CILQR_COST_PROFILE
+// Tuning build only (make OBJDIR=build/costprof OUT=../lib/variants/libcilqr_hip_costprof.so EXTRA=-DCILQR_COST_PROFILE;
+// tools/cost_phase_profile.py): wall-clock stamps (100 MHz) of the phases of a knot cost, one record per wave.
+constexpr int kCostProfWaves = 1 << 16;
+__device__ unsigned long long g_cost_prof[kCostProfWaves * 8];
+#define CP_WAVE ((int)(((blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (kCostProfWaves - 1)))
+#define CP_STAMP(k) do { const unsigned long long n_ = wall_clock64(); if ((threadIdx.x & 63) == 0) g_cost_prof[CP_WAVE * 8 + (k)] = n_ - cp_t; cp_t = n_; } while (0)
+#else
+#define CP_STAMP(k)
+#endif
 template <int D>
 CILQR_DEV void knot_cost_core(const DeviceState& s, const double* __restrict__ lanes, int i, int slot,
                               const double* x, const double* u, double2* __restrict__ out, size_t stride) {
   constexpr int C = kCostChunk;
+#ifdef CILQR_COST_PROFILE
+  unsigned long long cp_t = wall_clock64();
+#endif
   const Params& p = s.p;
   const int Bc = s.Bcap;
   const double2* gp = s.goals + (size_t)i * 3 * Bc + slot;
@@ -110,6 +123,10 @@ CILQR_DEV void knot_cost_core(const DeviceState& s, const double* __restrict__ l
   const double2 dyn = knot_bound_cost(p, i, x, u);
   double sn, cs;
   lean_sincos(x[2], &sn, &cs);
+#ifdef CILQR_COST_PROFILE
+  asm volatile("" :: "v"(jx), "v"(dyn.x), "v"(sn), "v"(pc.a[0]));
+  CP_STAMP(2);   // operands arrived + J, bounds, sincos
+#endif
   double px[D], py[D];
   BarGroup grp[D];
 #pragma unroll
@@ -141,6 +158,10 @@ CILQR_DEV void knot_cost_core(const DeviceState& s, const double* __restrict__ l
     bar_merge(call, grp[j]);
   }
   const double ccost = bar_group_value(p, call);
+#ifdef CILQR_COST_PROFILE
+  asm volatile("" :: "v"(ccost));
+  CP_STAMP(3);   // corridor
+#endif
   // LaneBoundaryCost cc:583-603, disc by disc (a rolled loop: fetching the ten candidate lists up front hides
   // their latency but holds 40 registers through the searches, which costs the third wave per SIMD)
   BarGroup lall;
@@ -154,6 +175,10 @@ CILQR_DEV void knot_cost_core(const DeviceState& s, const double* __restrict__ l
     bar_accumulate(p, g, lall);
   }
   const double lcost = bar_group_value(p, lall);
+#ifdef CILQR_COST_PROFILE
+  asm volatile("" :: "v"(lcost));
+  CP_STAMP(4);   // lanes
+#endif
   out[0] = make_double2(jx, ju);
   out[stride] = dyn;
   out[2 * stride] = make_double2(ccost, lcost);

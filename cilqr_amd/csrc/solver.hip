@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <mutex>
 #include <thread>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -423,7 +424,9 @@ int cilqr_create(const cilqr_config* cfg, int32_t device, int32_t batch_capacity
   if (rc == CILQR_OK) {
     int lo = 0, hi = 0;   // numerically lower = higher priority
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    if (hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, hi) != hipSuccess) rc = CILQR_ERR_DEVICE;
+    const char* pe = std::getenv("CILQR_FIN_PRIORITY");   // tuning experiments: 0 = same priority as the first stage
+    const int prio = (pe && pe[0] == '0') ? lo : hi;
+    if (hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio) != hipSuccess) rc = CILQR_ERR_DEVICE;
   }
   if (rc != CILQR_OK) {
     cilqr_destroy(h);
