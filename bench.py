@@ -73,6 +73,9 @@ def parse_args(argv=None):
     ap.add_argument("--end-to-end", action="store_true",
                     help="extra (never `value`): obstacle points -> cilqr_build_corridors -> solve on the device")
     ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "backward_traffic.json"))
+    ap.add_argument("--no-latency", action="store_true",
+                    help="skip the drop-in latency section (planning::IlqrOptimizer::Plan with a batch of one, C++ program under tests/cpp)")
+    ap.add_argument("--latency-scenes", type=int, default=256, help="scenes per family for the latency section")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch plumbing only, on CPU: the ranks rendezvous over gloo, exchange made-up results through the same "
                          "gather and rank 0 prints a line with \"dry_run\": true and no value (tests/test_host.py)")
@@ -129,6 +132,48 @@ def spawn_ranks(args):
         raise SystemExit(1)
     sys.stdout.write(lines[0] + "\n")
     sys.stdout.flush()
+
+
+def plan_latency(scenario, families, n_scenes, seed, workers, batch=64):
+    """Extra (never `value`): latency of the drop-in call.  tests/cpp/latency_bench.cc drives planning::IlqrOptimizer::Plan
+    (include/cilqr/ilqr_optimizer.hpp: batch of ONE, the reference's containers in and out) and cilqr_solve_batch with
+    `batch` scenes of host arrays, one call at a time, timed per call with steady_clock (ilqr_optimizer.cc:82-94)."""
+    import shutil
+    import subprocess
+    import tempfile
+    from cilqr_amd import api
+    tmp = tempfile.mkdtemp(prefix="cilqr_latency_")
+    out = {}
+    try:
+        exe = os.path.join(tmp, "latency_bench")
+        lib_dir = os.path.dirname(api.LIB_PATH)
+        subprocess.check_call(["g++", "-std=c++14", "-O2", "-I" + os.path.join(ROOT, "include"),
+                               os.path.join(ROOT, "tests", "cpp", "latency_bench.cc"), "-o", exe, "-L" + lib_dir, "-lcilqr_hip",
+                               "-Wl,-rpath," + lib_dir, "-Wl,-rpath-link,/opt/rocm/lib"], stdout=sys.stderr, stderr=sys.stderr)
+        for fam in families:
+            sc = scenario.generate(fam, n_scenes, seed=seed, workers=workers)
+            K, cmax = sc["n_steps"] + 1, sc["cmax"]
+            path = os.path.join(tmp, fam + ".bin")
+            with open(path, "wb") as f:
+                np.array([n_scenes, K, cmax, sc["left"].shape[0], sc["right"].shape[0]], np.int32).tofile(f)
+                np.ascontiguousarray(sc["left"], np.float64).tofile(f)
+                np.ascontiguousarray(sc["right"], np.float64).tofile(f)
+                for b in range(n_scenes):
+                    np.ascontiguousarray(sc["start"][b], np.float64).tofile(f)
+                    np.ascontiguousarray(sc["coarse"][b], np.float64).tofile(f)
+                    np.ascontiguousarray(sc["ccount"][b], np.int32).tofile(f)
+                    np.ascontiguousarray(sc["corridor"][b], np.float64).tofile(f)
+            r = subprocess.run([exe, path, str(batch)], stdout=subprocess.PIPE, stderr=sys.stderr, timeout=600)
+            if r.returncode != 0:
+                out[fam] = {"error": f"latency_bench exited with {r.returncode}"}
+                continue
+            out[fam] = json.loads(r.stdout.decode().strip().splitlines()[-1])
+            out[fam]["_scene"] = sc
+    except Exception as e:   # noqa: BLE001
+        out["error"] = repr(e)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out
 
 
 def dry_run(args, rank, world):
@@ -495,6 +540,10 @@ def main():
                               "generator's simplified ones: a different, larger feasible set, hence another "
                               "iteration count than the timed region; sequential (one batch in flight)"}
 
+    latency = None
+    if world == 1 and not args.no_latency:
+        latency = plan_latency(scenario, ("ped6", "mix11"), args.latency_scenes, 100 + args.seed, workers)
+
     # sanity: every problem must have terminated with a valid status
     st = ctx[0].st.cpu().numpy()
     nc = ctx[0].nc.cpu().numpy()
@@ -647,6 +696,15 @@ def main():
                                 "mean_accepted_iterations": round(float((rf["n_cost"] - 1).mean()), 2),
                                 "mean_line_search_trials": round(float(np.mean(trials)), 2)}
                 cpu["per_config"] = per
+            if latency:   # the CPU restatement on the scenes of the latency section, one solve at a time
+                for fam, rec in latency.items():
+                    if not isinstance(rec, dict) or "_scene" not in rec:
+                        continue
+                    scf = rec["_scene"]
+                    rf = orc.solve_batch(scf, ocfg_for(scf["n_steps"]), want_margin=False, want_times=True)
+                    ms = rf["problem_seconds"] * 1e3
+                    rec["cpu_restatement"] = {"mean_ms": round(float(ms.mean()), 3), "median_ms": round(float(np.median(ms)), 3),
+                                              "p95_ms": round(float(np.quantile(ms, 0.95)), 3), "threads": 1}
         out = {
             "metric": f"CILQR solves/sec ({N}-step horizon, batch={B} per GPU)",
             "value": round(value, 1), "unit": "solves/s", "n_gpus": world, "steps": args.steps,
@@ -668,6 +726,9 @@ def main():
             "results_identical_across_solves_in_flight": same,
             "c_abi_gather": cabi,
             "end_to_end": end_to_end,
+            # drop-in latency (never `value`): Plan through the C++ adapter with a batch of one, and small host batches
+            "latency": ({fam: ({k: v for k, v in rec.items() if k != "_scene"} if isinstance(rec, dict) else rec)
+                         for fam, rec in latency.items()} if latency else None),
             # per-phase HIP-event times of the calibration step (one batch alone, events around every phase)
             # quad / bwd / ls / other: the lockstep iterations; tail: the per-problem kernel that finishes the
             # last `tail_problems` problems in one launch (CILQR_OPT_TAIL_THRESHOLD)

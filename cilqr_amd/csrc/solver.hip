@@ -385,7 +385,9 @@ int cilqr_create(const cilqr_config* cfg, int32_t device, int32_t batch_capacity
   h->twin = d;
   alloc_moved(h->twin, B);
   // finishing arena + twin: a solve moves here once at most fin_cap problems are left (job_iterate)
-  h->fin_cap = (int)std::min<size_t>(B, 8192);
+  size_t fin_want = 8192;
+  if (const char* fe = std::getenv("CILQR_FIN_CAP")) fin_want = (size_t)std::max(64, std::atoi(fe)) / 64 * 64;   // tuning experiments
+  h->fin_cap = (int)std::min<size_t>(B, fin_want);
   h->fin_threshold = h->fin_cap;
   h->fin = d;
   h->fin.Bcap = h->fin_cap;
