@@ -9,6 +9,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
 from cilqr_amd import api, scenario  # noqa: E402
 
+if os.environ.get("CILQR_LIB"):
+    api.LIB_PATH = os.path.abspath(os.environ["CILQR_LIB"])
 sizes = [int(a) for a in sys.argv[1:]] or [64, 256, 2048, 65536]
 base = scenario.generate("mix11", 256, seed=3)
 for B in sizes:
@@ -27,5 +29,5 @@ for B in sizes:
     for _ in range(n):
         opt.stage_backward(lam)
     dt = (time.perf_counter() - t0) / n
-    print(f"B={B:6d}  stage_backward {dt * 1e6:8.1f} us per call (incl. lambda upload + sync)")
+    print(f"{os.path.basename(api.LIB_PATH):28s} B={B:6d}  stage_backward {dt * 1e6:8.1f} us per call (incl. lambda upload + sync)")
     opt.close()
