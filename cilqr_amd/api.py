@@ -26,6 +26,7 @@ OPT_TAIL_THRESHOLD = 5
 OPT_WAVE_THRESHOLD = 6
 OPT_ROUND_GROUP = 7
 OPT_FINISH_THRESHOLD = 8
+OPT_EXACT_LANE_TIES = 9
 ST_RUNNING, ST_CONVERGED_ABS, ST_CONVERGED_REL, ST_GNORM, ST_UNSOLVED, ST_MAX_ITER, ST_NO_CORRIDOR = range(7)
 ABI_VERSION = 3
 

@@ -290,6 +290,27 @@ CILQR_DEV double segment_dist2(const double* __restrict__ r, double px, double p
   return (len <= kMathEps || proj <= 0.0) ? d_start : (proj >= len ? d_end : d_perp);
 }
 
+// segment_dist2 that also reports WHERE the distance was taken: the offset from the end point used (ox, oy), NaN for
+// the foot of the perpendicular.  Two candidates with the same offset are the same distance in any arithmetic (the
+// shared end point of consecutive segments: the wedge outside every joint) -- no tie to re-examine.
+CILQR_DEV double segment_dist2_where(const double* __restrict__ r, double px, double py, double* ox, double* oy) {
+  double sx = r[3], sy = r[4], ux = r[5], uy = r[6], len = r[7], ex = r[8], ey = r[9];
+  asm volatile("" : "+v"(sx), "+v"(sy), "+v"(ux), "+v"(uy), "+v"(len), "+v"(ex), "+v"(ey));
+  const double x0 = px - sx, y0 = py - sy;
+  double d_start = x0 * x0 + y0 * y0;
+  const double proj = x0 * ux + y0 * uy;
+  const double x1 = px - ex, y1 = py - ey;
+  double d_end = x1 * x1 + y1 * y1;
+  const double c = x0 * uy - y0 * ux;
+  double d_perp = c * c;
+  asm volatile("" : "+v"(d_start), "+v"(d_end), "+v"(d_perp));
+  const bool at_start = (len <= kMathEps || proj <= 0.0), at_end = proj >= len;
+  const double nan = __builtin_nan("");
+  *ox = at_start ? x0 : (at_end ? x1 : nan);
+  *oy = at_start ? y0 : (at_end ? y1 : nan);
+  return at_start ? d_start : (at_end ? d_end : d_perp);
+}
+
 // Squared distances order like distances, with one exception that is left as it is.  The reference compares
 // DISTANCES (hypot / |cross|, line_segment2d.cpp:61-75): two squared distances one or two ulp apart have the same
 // square root, which its strict '<' treats as a tie (first index wins).  That happens on a strip ~1e-7 m wide along
@@ -298,17 +319,87 @@ CILQR_DEV double segment_dist2(const double* __restrict__ r, double px, double p
 // alternatives (k_cost_knots at full batch, 481 us as is): comparing the roots inside a 4-ulp window, inline +34 %,
 // out of line +18 %; a plain 2-ulp margin costs nothing but only moves the disagreement to the fuzzy edge of the
 // strip.  The parity tests recognise the case (an exact tie of the oracle's own distances) and say so.
-CILQR_DEV int nearest_segment_scan(const double* __restrict__ tab, int n, double px, double py) {
+// hypot as the reference's libm evaluates it.  glibc 2.35 (sysdeps/ieee754/dbl-64/e_hypot.c, the build without FMA
+// that x86-64 -O2 binaries get): h = sqrt(ax^2 + ay^2) with ax >= ay, corrected by one Newton step whose residual is
+// evaluated in two exact-ish parts.  The device library's hypot differs from it in the last bit on ~0.6 % of
+// arguments (measured against numpy on 200 000 pairs; this routine on none) -- enough to turn the reference's exact
+// ties into non-ties.  Arguments here are lengths in metres: the scaling branches for huge / tiny values are not needed.
+CILQR_DEV double hypot_ref(double x, double y) {
+  x = fabs(x);
+  y = fabs(y);
+  const double ax = x < y ? y : x, ay = x < y ? x : y;
+  if (ax >= ay * 0x1p54) return ax + ay;
+  double h = sqrt(ax * ax + ay * ay);
+  double t1, t2;
+  if (h <= 2.0 * ay) {
+    const double delta = h - ay;
+    t1 = ax * (2.0 * delta - ax);
+    t2 = (delta - 2.0 * (ax - ay)) * delta;
+  } else {
+    const double delta = h - ax;
+    t1 = 2.0 * delta * (ax - 2.0 * ay);
+    t2 = (4.0 * delta - ay) * ay + delta * delta;
+  }
+  h -= (t1 + t2) / (2.0 * h);
+  return h;
+}
+
+// LineSegment2d::DistanceTo as the reference evaluates it (line_segment2d.cpp:61-75): hypot to an end point, |cross| to
+// the foot.  Only the exact-tie rule below calls it.
+CILQR_DEV double segment_dist_ref(const double* __restrict__ r, double px, double py) {
+  const double sx = r[3], sy = r[4], ux = r[5], uy = r[6], len = r[7], ex = r[8], ey = r[9];
+  const double x0 = px - sx, y0 = py - sy;
+  if (len <= kMathEps) return hypot_ref(x0, y0);
+  const double proj = x0 * ux + y0 * uy;
+  if (proj <= 0.0) return hypot_ref(x0, y0);
+  if (proj >= len) return hypot_ref(px - ex, py - ey);
+  return fabs(x0 * uy - y0 * ux);
+}
+// CILQR_OPT_EXACT_LANE_TIES.  Squared distances order like the reference's distances except when the two smallest are
+// within rounding of each other.  The search notes when a candidate comes within kTieWindow (relative; far wider
+// than any rounding difference between the two forms) of the best so far; only then the candidate list is searched
+// again with the reference's own distance values and its strict '<' (first index wins) -- once, after the loop, out
+// of line.  Whichever of the two smallest comes first in the list, the other meets it as "best so far", so no near-tie
+// escapes.  A rare branch: the iterates that come to rest on a tie strip.
+constexpr double kTieWindow = 1e-13;
+CILQR_DEV bool near_tie(double d2, double best) { return fabs(d2 - best) <= kTieWindow * best; }   // best = DBL_MAX at first: false
+// segments first, first + step, ... (n of them; list == nullptr) or the n bytes of a grid cell's candidate list
+__device__ __attribute__((noinline)) int nearest_by_reference_distance(const double* __restrict__ tab, int n, uint4 raw, int from_cell,
+                                                                       double px, double py) {
+  const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
   double best = DBL_MAX;
   int bi = 0;
 #pragma unroll 1
+  for (int k = 0; k < n; ++k) {
+    const int kk = k + 1;
+    const unsigned word = (kk < 4) ? w[0] : (kk < 8) ? w[1] : (kk < 12) ? w[2] : w[3];
+    const int seg = from_cell ? (int)((word >> ((kk & 3) * 8)) & 0xffu) : k;
+    const double d = segment_dist_ref(tab + seg * kLaneFields, px, py);
+    if (d < best) {                                             // cc:611-614
+      best = d;
+      bi = seg;
+    }
+  }
+  return bi;
+}
+CILQR_DEV int nearest_segment_scan(const double* __restrict__ tab, int n, double px, double py, bool exact) {
+  double best = DBL_MAX;
+  int bi = 0;
+  bool suspect = false;
+  double box = 0.0, boy = 0.0;
+#pragma unroll 1
   for (int s = 0; s < n; ++s) {
-    const double d2 = segment_dist2(tab + s * kLaneFields, px, py);
+    double ox = 0.0, oy = 0.0;
+    const double d2 = exact ? segment_dist2_where(tab + s * kLaneFields, px, py, &ox, &oy) : segment_dist2(tab + s * kLaneFields, px, py);
+    if (exact) suspect |= near_tie(d2, best) && !(ox == box && oy == boy);
     if (d2 < best) {
       best = d2;
       bi = s;
+      box = ox;
+      boy = oy;
     }
   }
+  if (exact && suspect) bi = nearest_by_reference_distance(tab, n, make_uint4(0u, 0u, 0u, 0u), 0, px, py);
   return bi;
 }
 
@@ -325,15 +416,21 @@ CILQR_DEV uint4 lane_cell_fetch(const DeviceState& s, int side, double px, doubl
   const int cell = (int)fy * s.gnx + (int)fx;
   return *reinterpret_cast<const uint4*>(s.lgrid + ((size_t)side * s.gnx * s.gny + cell) * kGridCellBytes);
 }
+// EX: CILQR_OPT_EXACT_LANE_TIES as a compile-time choice -- the kernels exist in both forms, so that the rare-branch
+// code (a call, live ranges across it) costs the default form nothing (it cost 2 % as a run-time flag, measured).
+template <bool EX = false>
 CILQR_DEV int nearest_from_cell(const DeviceState& s, const double* __restrict__ lanes, int side, uint4 raw,
                                 double px, double py) {
   const double* __restrict__ tab = lanes + (side ? s.nl * kLaneFields : 0);
   const int n = side ? s.nr : s.nl;
   const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
   const int cnt = (int)(w[0] & 0xffu);
-  if (cnt == kGridFullScan) return nearest_segment_scan(tab, n, px, py);
+  constexpr bool exact = EX;
+  if (cnt == kGridFullScan) return nearest_segment_scan(tab, n, px, py, exact);
   double best = DBL_MAX;
   int bi = 0;
+  bool suspect = false;
+  double box = 0.0, boy = 0.0;   // EX: where the best distance was taken (segment_dist2_where)
   // Compact loop (not unrolled: this function is inlined at every disc of three kernels and an
   // unrolled 15-way test made them instruction-cache bound).  The trip count is the longest list
   // of the wave, tested with a ballot, so the loop is a scalar branch around straight-line
@@ -343,17 +440,32 @@ CILQR_DEV int nearest_from_cell(const DeviceState& s, const double* __restrict__
   for (int k = 1; __builtin_amdgcn_ballot_w64(k <= cnt) != 0; ++k) {
     const unsigned word = (k < 4) ? w[0] : (k < 8) ? w[1] : (k < 12) ? w[2] : w[3];
     const int seg = (k <= cnt) ? (int)((word >> ((k & 3) * 8)) & 0xffu) : 0;
-    const double d2 = segment_dist2(tab + seg * kLaneFields, px, py);
-    const bool take = (k <= cnt) && (d2 < best);
+    double d2;
+    bool take;
+    if constexpr (exact) {
+      double ox, oy;
+      d2 = segment_dist2_where(tab + seg * kLaneFields, px, py, &ox, &oy);
+      suspect |= (k <= cnt) && near_tie(d2, best) && !(ox == box && oy == boy);
+      take = (k <= cnt) && (d2 < best);
+      box = take ? ox : box;
+      boy = take ? oy : boy;
+    } else {
+      d2 = segment_dist2(tab + seg * kLaneFields, px, py);
+      take = (k <= cnt) && (d2 < best);
+    }
     best = take ? d2 : best;
     bi = take ? seg : bi;
+  }
+  if constexpr (exact) {
+    if (suspect) bi = nearest_by_reference_distance(tab, cnt, raw, 1, px, py);
   }
   return bi;
 }
 // `lanes`: the lane table (left rows then right rows), in global memory or staged in LDS.
+template <bool EX = false>
 CILQR_DEV int nearest_segment(const DeviceState& s, const double* __restrict__ lanes, int side, double px,
                               double py) {
-  return nearest_from_cell(s, lanes, side, lane_cell_fetch(s, side, px, py), px, py);
+  return nearest_from_cell<EX>(s, lanes, side, lane_cell_fetch(s, side, px, py), px, py);
 }
 
 // number of list entries a kernel of the solve loop has to process (see DeviceState::n_dev)

@@ -46,8 +46,8 @@ __global__ __launch_bounds__(256) void k_load_corridor(DeviceState s, int B, Pro
       double a = tile[pb * ld + (c - c0) * 3 + 0];
       double b = tile[pb * ld + (c - c0) * 3 + 1];
       double cc = tile[pb * ld + (c - c0) * 3 + 2];
-      cc = cc - s.p.shrink_corridor * (a * a + b * b) / hypot(a, b);   // cc:448
-      const double nrm = hypot(hypot(a, b), cc);                       // cc:479
+      cc = cc - s.p.shrink_corridor * (a * a + b * b) / hypot_ref(a, b);   // cc:448
+      const double nrm = hypot_ref(hypot_ref(a, b), cc);                       // cc:479
       double* o = s.cor + ((size_t)(i * s.cmax + c) * 3) * s.Bcap + slot;
       o[0] = a / nrm;
       o[(size_t)s.Bcap] = b / nrm;
@@ -104,11 +104,11 @@ __global__ void k_load_lanes(DeviceState s, const double* __restrict__ raw) {
   if (t >= s.nl + s.nr) return;
   const double* r = raw + t * 7;
   double a = r[0], b = r[1], c = r[2];
-  c = c - s.p.shrink_lane * (a * a + b * b) / hypot(a, b);
-  const double nrm = hypot(hypot(a, b), c);
+  c = c - s.p.shrink_lane * (a * a + b * b) / hypot_ref(a, b);
+  const double nrm = hypot_ref(hypot_ref(a, b), c);
   const double sx = r[3], sy = r[4], ex = r[5], ey = r[6];
   const double dx = ex - sx, dy = ey - sy;
-  const double len = hypot(dx, dy);
+  const double len = hypot_ref(dx, dy);
   double* o = s.lanes + t * kLaneFields;
   o[0] = a / nrm; o[1] = b / nrm; o[2] = c / nrm;
   o[3] = sx; o[4] = sy;
@@ -211,11 +211,11 @@ __global__ void k_nearest_lane(DeviceState s, int n, const double* __restrict__ 
   if (t >= n) return;
   const double px = xy[2 * t], py = xy[2 * t + 1];
   if (use_grid) {
-    left[t] = nearest_segment(s, s.lanes, 0, px, py);
-    right[t] = nearest_segment(s, s.lanes, 1, px, py);
+    left[t] = s.exact_ties ? nearest_segment<true>(s, s.lanes, 0, px, py) : nearest_segment<false>(s, s.lanes, 0, px, py);
+    right[t] = s.exact_ties ? nearest_segment<true>(s, s.lanes, 1, px, py) : nearest_segment<false>(s, s.lanes, 1, px, py);
   } else {
-    left[t] = nearest_segment_scan(s.lanes, s.nl, px, py);
-    right[t] = nearest_segment_scan(s.lanes + s.nl * kLaneFields, s.nr, px, py);
+    left[t] = nearest_segment_scan(s.lanes, s.nl, px, py, s.exact_ties != 0);
+    right[t] = nearest_segment_scan(s.lanes + s.nl * kLaneFields, s.nr, px, py, s.exact_ties != 0);
   }
 }
 void launch_nearest_lane(const DeviceState& s, int n, const double* xy, int* left, int* right, int use_grid,

@@ -24,14 +24,20 @@ namespace cilqr {
 // generic path does not set the register budget of the common one.  Three waves per SIMD: the 5-disc cost function
 // fits 168 VGPRs (quad_core.hpp), and the attribute keeps the allocator from trading that for a shorter schedule.
 #define CILQR_COST_ATTR __attribute__((amdgpu_waves_per_eu(3, 3)))
-#define CILQR_LAUNCH_BY_DISCS(kernel, grid, block, lds, st, ...)                                   \
-  do {                                                                                            \
-    if (s.p.num_of_disc == 5) hipLaunchKernelGGL(kernel<5>, grid, block, lds, st, __VA_ARGS__);   \
-    else hipLaunchKernelGGL(kernel<0>, grid, block, lds, st, __VA_ARGS__);                        \
+// ... and per tie rule (EX: CILQR_OPT_EXACT_LANE_TIES, see nearest_from_cell)
+#define CILQR_LAUNCH_BY_DISCS(kernel, grid, block, lds, st, ...)                                            \
+  do {                                                                                                     \
+    if (s.p.num_of_disc == 5) {                                                                            \
+      if (s.exact_ties) hipLaunchKernelGGL((kernel<5, true>), grid, block, lds, st, __VA_ARGS__);          \
+      else hipLaunchKernelGGL((kernel<5, false>), grid, block, lds, st, __VA_ARGS__);                      \
+    } else {                                                                                               \
+      if (s.exact_ties) hipLaunchKernelGGL((kernel<0, true>), grid, block, lds, st, __VA_ARGS__);          \
+      else hipLaunchKernelGGL((kernel<0, false>), grid, block, lds, st, __VA_ARGS__);                      \
+    }                                                                                                      \
   } while (0)
 
 // list == nullptr: slots 0..n-1.  skip_done: ignore slots that already left the iteration.
-template <int D>
+template <int D, bool EX>
 __global__ __launch_bounds__(256) CILQR_COST_ATTR void k_cost_knots(DeviceState s, const int* __restrict__ list,
                                                     const int* __restrict__ n_ptr, int n_max, int cand,
                                                     int skip_done) {
@@ -56,7 +62,7 @@ __global__ __launch_bounds__(256) CILQR_COST_ATTR void k_cost_knots(DeviceState 
     asm volatile("" :: "v"(x[0]), "v"(x[5]), "v"(u[0]));
     CP_STAMP(1);   // cur[slot] -> state loaded
 #endif
-    knot_cost<D>(s, lanes, i, slot, x, u, s.part + (size_t)i * kPartPairs * s.Bcap + slot, (size_t)s.Bcap);
+    knot_cost<D, EX>(s, lanes, i, slot, x, u, s.part + (size_t)i * kPartPairs * s.Bcap + slot, (size_t)s.Bcap);
   }
 #ifdef CILQR_COST_PROFILE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -74,7 +80,7 @@ extern "C" void cilqr_debug_cost_profile(unsigned long long* out, int reset) {  
 #endif
 
 // speculative line search: knot i of candidate alpha_{r0 + blockIdx.z} of list entry j
-template <int D>
+template <int D, bool EX>
 __global__ __launch_bounds__(256) CILQR_COST_ATTR void k_spec_cost(DeviceState s, const int* __restrict__ list,
                                                    const int* __restrict__ n_ptr, int n_max, int r0) {
   extern __shared__ double lds[];
@@ -94,7 +100,7 @@ __global__ __launch_bounds__(256) CILQR_COST_ATTR void k_spec_cost(DeviceState s
       const double2 q = s.Us[((size_t)r * s.p.N + i) * cap + j];
       u[0] = q.x; u[1] = q.y;
     }
-    knot_cost<D>(s, lanes, i, slot, x, u, s.parts + ((size_t)r * s.p.K + i) * kPartPairs * cap + j, cap);
+    knot_cost<D, EX>(s, lanes, i, slot, x, u, s.parts + ((size_t)r * s.p.K + i) * kPartPairs * cap + j, cap);
   }
 }
 // The same with P consecutive lanes per problem: knot i of candidates alpha_{r0} .. alpha_{r_end-1} of list entry j; the lanes
@@ -103,7 +109,7 @@ __global__ __launch_bounds__(256) CILQR_COST_ATTR void k_spec_cost(DeviceState s
 // per lane.  For the SPARSE list of the hybrid schedule (the problems that rejected every sequential round: a few
 // percent of the slots, in no particular order) one lane per problem made every such load touch 64 different lines;
 // packed, the same knot costs are 4.6x faster (measured: 897 -> 155 us in the first iteration of the bench batch).
-template <int D, int P>
+template <int D, int P, bool EX>
 __global__ __launch_bounds__(256) CILQR_COST_ATTR void k_spec_cost_packed(DeviceState s, const int* __restrict__ list,
                                                                           const int* __restrict__ n_ptr, int n_max,
                                                                           int r0, int r_end) {
@@ -126,7 +132,7 @@ __global__ __launch_bounds__(256) CILQR_COST_ATTR void k_spec_cost_packed(Device
       const double2 q = s.Us[((size_t)r * s.p.N + i) * cap + j];
       u[0] = q.x; u[1] = q.y;
     }
-    knot_cost<D>(s, lanes, i, slot, x, u, s.parts + ((size_t)r * s.p.K + i) * kPartPairs * cap + j, cap);
+    knot_cost<D, EX>(s, lanes, i, slot, x, u, s.parts + ((size_t)r * s.p.K + i) * kPartPairs * cap + j, cap);
   }
 }
 
@@ -149,11 +155,13 @@ void launch_spec_cost(const DeviceState& s, const int* list, const int* n_ptr, i
     const int e = a + (P < left ? P : left);
     const int per_block = 256 / P;
     dim3 g((n_grid + per_block - 1) / per_block, s.p.K);
-#define CILQR_SC(DD, PP) hipLaunchKernelGGL((k_spec_cost_packed<DD, PP>), g, dim3(256), lds, st, s, list, n_ptr, n_max, a, e)
+#define CILQR_SC1(DD, PP, EE) hipLaunchKernelGGL((k_spec_cost_packed<DD, PP, EE>), g, dim3(256), lds, st, s, list, n_ptr, n_max, a, e)
+#define CILQR_SC(DD, PP) do { if (s.exact_ties) CILQR_SC1(DD, PP, true); else CILQR_SC1(DD, PP, false); } while (0)
     if (P == 8) { if (five) CILQR_SC(5, 8); else CILQR_SC(0, 8); }
     else if (P == 4) { if (five) CILQR_SC(5, 4); else CILQR_SC(0, 4); }
     else if (P == 2) { if (five) CILQR_SC(5, 2); else CILQR_SC(0, 2); }
     else { if (five) CILQR_SC(5, 1); else CILQR_SC(0, 1); }
+#undef CILQR_SC1
 #undef CILQR_SC
     a = e;
   }
@@ -164,7 +172,7 @@ void launch_spec_cost(const DeviceState& s, const int* list, const int* n_ptr, i
 // its corridor planes and goals travel once per G knot costs (see k_spec_cost_packed); with G = 2 a round costs
 // a candidate that the sequential loop might not have reached (alpha_1 for the 15 % that accept alpha_0), and saves
 // half of the plane traffic and half of the launches.  The first passing index still wins (k_round_pick).
-template <int D, int G>
+template <int D, int G, bool EX>
 __global__ __launch_bounds__(256) CILQR_COST_ATTR void k_round_cost(DeviceState s, int r0, int n_max) {
   extern __shared__ double lds[];
   const int* __restrict__ list = s.pend + (size_t)r0 * s.Bcap;
@@ -186,7 +194,7 @@ __global__ __launch_bounds__(256) CILQR_COST_ATTR void k_round_cost(DeviceState 
       const double2 q = s.Us[((size_t)r * s.p.N + i) * cap + j];
       u[0] = q.x; u[1] = q.y;
     }
-    knot_cost<D>(s, lanes, i, slot, x, u, s.parts + ((size_t)r * s.p.K + i) * kPartPairs * cap + j, cap);
+    knot_cost<D, EX>(s, lanes, i, slot, x, u, s.parts + ((size_t)r * s.p.K + i) * kPartPairs * cap + j, cap);
   }
 }
 
@@ -196,11 +204,13 @@ void launch_round_cost(const DeviceState& s, int r0, int group, int n_max, int n
   dim3 g((n_grid + per_block - 1) / per_block, s.p.K);
   const size_t lds = lane_lds_bytes(s);
   const bool five = s.p.num_of_disc == 5;
-#define CILQR_RC(DD, GG) hipLaunchKernelGGL((k_round_cost<DD, GG>), g, dim3(256), lds, st, s, r0, n_max)
+#define CILQR_RC1(DD, GG, EE) hipLaunchKernelGGL((k_round_cost<DD, GG, EE>), g, dim3(256), lds, st, s, r0, n_max)
+#define CILQR_RC(DD, GG) do { if (s.exact_ties) CILQR_RC1(DD, GG, true); else CILQR_RC1(DD, GG, false); } while (0)
   if (group == 1) { if (five) CILQR_RC(5, 1); else CILQR_RC(0, 1); }
   else if (group == 2) { if (five) CILQR_RC(5, 2); else CILQR_RC(0, 2); }
   else { if (five) CILQR_RC(5, 4); else CILQR_RC(0, 4); }
 #undef CILQR_RC
+#undef CILQR_RC1
 }
 
 __global__ __launch_bounds__(64) void k_reduce_only(DeviceState s, const int* __restrict__ list, int n) {
@@ -243,6 +253,7 @@ void launch_init_cost_commit(const DeviceState& s, int n, hipStream_t st) {
   hipLaunchKernelGGL(k_init_cost_commit, dim3((n + 255) / 256), dim3(256), 0, st, s, n);
 }
 
+template <int D, bool EX>
 __global__ __launch_bounds__(256) void k_quadratize(DeviceState s, const int* __restrict__ list, int n,
                                                     int only_upd) {
   extern __shared__ double lds[];
@@ -257,15 +268,14 @@ __global__ __launch_bounds__(256) void k_quadratize(DeviceState s, const int* __
   (void)lanes;
   knot_quadratize_ref(s, s.cur[slot], blockIdx.y, slot);
 #else
-  if (s.p.num_of_disc == 5) knot_quadratize<5>(s, lanes, s.cur[slot], blockIdx.y, slot);
-  else knot_quadratize<0>(s, lanes, s.cur[slot], blockIdx.y, slot);
+  knot_quadratize<D, EX>(s, lanes, s.cur[slot], blockIdx.y, slot);
 #endif
 }
 
 void launch_quadratize(const DeviceState& s, const int* list, int n, int only_upd, hipStream_t st) {
   if (n == 0) return;
   dim3 g((n + 255) / 256, s.p.K);
-  hipLaunchKernelGGL(k_quadratize, g, dim3(256), lane_lds_bytes(s), st, s, list, n, only_upd);
+  CILQR_LAUNCH_BY_DISCS(k_quadratize, g, dim3(256), lane_lds_bytes(s), st, s, list, n, only_upd);
 }
 
 }  // namespace cilqr

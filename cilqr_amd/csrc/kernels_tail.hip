@@ -126,13 +126,13 @@ __device__ __attribute__((noinline)) void tail_forward(int off_view) {
   const int tid = (int)threadIdx.x;
   forward_core<OutSpec, 4>(t, 0, kAlpha[tid], OutSpec{t, tid, 0});
 }
-template <int D>
+template <int D, bool EX>
 __device__ __attribute__((noinline)) void tail_quadratize(int off_view, int i) {
   extern __shared__ double lds[];
   const DeviceState& t = *reinterpret_cast<const DeviceState*>(reinterpret_cast<const char*>(lds) + off_view);
-  knot_quadratize<D>(t, lds, t.cur[0], i, 0);
+  knot_quadratize<D, EX>(t, lds, t.cur[0], i, 0);
 }
-template <int D>
+template <int D, bool EX>
 __device__ __attribute__((noinline)) void tail_knot_cost(int off_view, int r, int i) {
   extern __shared__ double lds[];
   const DeviceState& t = *reinterpret_cast<const DeviceState*>(reinterpret_cast<const char*>(lds) + off_view);
@@ -145,7 +145,7 @@ __device__ __attribute__((noinline)) void tail_knot_cost(int off_view, int r, in
     const double2 q = t.Us[(size_t)r * N + i];
     u[0] = q.x; u[1] = q.y;
   }
-  knot_cost<D>(t, lds, i, 0, x, u, t.parts + ((size_t)r * K + i) * kPartPairs, 1);
+  knot_cost<D, EX>(t, lds, i, 0, x, u, t.parts + ((size_t)r * K + i) * kPartPairs, 1);
 }
 
 #ifdef CILQR_TAIL_PROFILE
@@ -155,7 +155,7 @@ __device__ __attribute__((noinline)) void tail_knot_cost(int off_view, int r, in
 #define TP_DECL
 #define TP(k)
 #endif
-template <int D>
+template <int D, bool EX>
 __global__ __launch_bounds__(kTailThreads) void k_tail(DeviceState g, TailArgs a, int n_max) {
   extern __shared__ double lds[];
   const int n = active_count(g, n_max);
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(DeviceState g, TailArgs a
   for (;;) {
     TP(7);
     if (t.upd[0]) {                                                        // cc:203-214
-      for (int i = tid; i < K; i += kTailThreads) tail_quadratize<D>(off_view, i);
+      for (int i = tid; i < K; i += kTailThreads) tail_quadratize<D, EX>(off_view, i);
     }
     __syncthreads();
     TP(0);
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(DeviceState g, TailArgs a
         const int nr = min(kTailChunk, kNumAlpha - r0);
         for (int e = tid; e < nr * K; e += kTailThreads) {
           const int rr = e / K, i = e - rr * K, r = r0 + rr;
-          tail_knot_cost<D>(off_view, r, i);
+          tail_knot_cost<D, EX>(off_view, r, i);
         }
         __syncthreads();
         TP(3);
@@ -350,8 +350,13 @@ void launch_tail(const DeviceState& g, void* workspace, int n_max, double* traj,
   a.max_iter = max_iter_dev;
   const size_t lane_d = (size_t)((g.nl + g.nr) * kLaneFields + 1) / 2 * 2;
   const size_t lds = (lane_d + wave::kDoubles + kNumAlpha * 5) * sizeof(double) + 16 * sizeof(int) + sizeof(DeviceState) + 16;
-  if (g.p.num_of_disc == 5) hipLaunchKernelGGL(k_tail<5>, dim3(n_max), dim3(kTailThreads), lds, st, g, a, n_max);
-  else hipLaunchKernelGGL(k_tail<0>, dim3(n_max), dim3(kTailThreads), lds, st, g, a, n_max);
+  if (g.p.num_of_disc == 5) {
+    if (g.exact_ties) hipLaunchKernelGGL((k_tail<5, true>), dim3(n_max), dim3(kTailThreads), lds, st, g, a, n_max);
+    else hipLaunchKernelGGL((k_tail<5, false>), dim3(n_max), dim3(kTailThreads), lds, st, g, a, n_max);
+  } else {
+    if (g.exact_ties) hipLaunchKernelGGL((k_tail<0, true>), dim3(n_max), dim3(kTailThreads), lds, st, g, a, n_max);
+    else hipLaunchKernelGGL((k_tail<0, false>), dim3(n_max), dim3(kTailThreads), lds, st, g, a, n_max);
+  }
 }
 
 }  // namespace cilqr

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(64) void k_init_guess_tracker(DeviceState s, Tracke
     for (int i = 1; i < K; ++i) {
       double x, y;
       follow_xy(i, x, y);
-      acc = acc + hypot(x - px, y - py);
+      acc = acc + hypot_ref(x - px, y - py);
       s.cstation[(size_t)i * Bc + slot] = acc;
       px = x;
       py = y;

@@ -99,7 +99,7 @@ __device__ unsigned long long g_cost_prof[kCostProfWaves * 8];
 #else
 #define CP_STAMP(k)
 #endif
-template <int D>
+template <int D, bool EX>
 CILQR_DEV void knot_cost_core(const DeviceState& s, const double* __restrict__ lanes, int i, int slot,
                               const double* x, const double* u, double2* __restrict__ out, size_t stride) {
   constexpr int C = kCostChunk;
@@ -169,8 +169,8 @@ CILQR_DEV void knot_cost_core(const DeviceState& s, const double* __restrict__ l
   for (int j = 0; j < D; ++j) {
     const uint4 cl = lane_cell_fetch(s, 0, px[j], py[j]);
     const uint4 cr = lane_cell_fetch(s, 1, px[j], py[j]);
-    const double* L = lanes + nearest_from_cell(s, lanes, 0, cl, px[j], py[j]) * kLaneFields;
-    const double* Rr = lanes + (s.nl + nearest_from_cell(s, lanes, 1, cr, px[j], py[j])) * kLaneFields;
+    const double* L = lanes + nearest_from_cell<EX>(s, lanes, 0, cl, px[j], py[j]) * kLaneFields;
+    const double* Rr = lanes + (s.nl + nearest_from_cell<EX>(s, lanes, 1, cr, px[j], py[j])) * kLaneFields;
     const double g[2] = {L[0] * px[j] + L[1] * py[j] - L[2], Rr[0] * px[j] + Rr[1] * py[j] - Rr[2]};
     bar_accumulate(p, g, lall);
   }
@@ -185,6 +185,7 @@ CILQR_DEV void knot_cost_core(const DeviceState& s, const double* __restrict__ l
 }
 
 // discs as a run-time count (any num_of_disc != 5): same arithmetic, disc-major loops
+template <bool EX>
 CILQR_DEV void knot_cost_generic(const DeviceState& s, const double* __restrict__ lanes, int i, int slot,
                                  const double* x, const double* u, double2* __restrict__ out, size_t stride) {
   const Params& p = s.p;
@@ -210,8 +211,8 @@ CILQR_DEV void knot_cost_generic(const DeviceState& s, const double* __restrict_
       if ((c & 63) == 63) bar_renormalize(call);
     }
     bar_renormalize(call);
-    const double* L = lanes + nearest_segment(s, lanes, 0, px, py) * kLaneFields;
-    const double* Rr = lanes + (s.nl + nearest_segment(s, lanes, 1, px, py)) * kLaneFields;
+    const double* L = lanes + nearest_segment<EX>(s, lanes, 0, px, py) * kLaneFields;
+    const double* Rr = lanes + (s.nl + nearest_segment<EX>(s, lanes, 1, px, py)) * kLaneFields;
     const double g[2] = {L[0] * px + L[1] * py - L[2], Rr[0] * px + Rr[1] * py - Rr[2]};
     bar_accumulate(p, g, lall);
     bar_renormalize(lall);
@@ -222,11 +223,11 @@ CILQR_DEV void knot_cost_generic(const DeviceState& s, const double* __restrict_
 }
 
 // D = 5: the reference's disc count, unrolled (knot_cost_core); D = 0: any other count
-template <int D>
+template <int D, bool EX = false>
 CILQR_DEV void knot_cost(const DeviceState& s, const double* __restrict__ lanes, int i, int slot,
                          const double* x, const double* u, double2* __restrict__ out, size_t stride) {
-  if constexpr (D == 5) knot_cost_core<5>(s, lanes, i, slot, x, u, out, stride);
-  else knot_cost_generic(s, lanes, i, slot, x, u, out, stride);
+  if constexpr (D == 5) knot_cost_core<5, EX>(s, lanes, i, slot, x, u, out, stride);
+  else knot_cost_generic<EX>(s, lanes, i, slot, x, u, out, stride);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -279,7 +280,7 @@ CILQR_DEV void plane_commit(Quad& q, double a, double b, const PlaneSums& m) {
   q.h[6] += h02; q.h[7] += h12; q.h[8] += m.S2 - m.W;
 }
 
-template <int D>
+template <int D, bool EX = false>
 CILQR_DEV void knot_quadratize(const DeviceState& s, const double* __restrict__ lanes, int buf, int i, int slot) {
   const Params& p = s.p;
   const int Bc = s.Bcap;
@@ -370,11 +371,11 @@ CILQR_DEV void knot_quadratize(const DeviceState& s, const double* __restrict__ 
     else doff = p.disc_off[j];
     const double lcj = doff * cs, lsj = doff * sn;
     const double px = x[0] + lcj, py = x[1] + lsj;
-    const double* L = lanes + nearest_segment(s, lanes, 0, px, py) * kLaneFields;
+    const double* L = lanes + nearest_segment<EX>(s, lanes, 0, px, py) * kLaneFields;
     PlaneSums ml, mr;
     plane_disc(p, L[0], L[1], L[2], px, py, lcj, lsj, ml);
     plane_commit(q, L[0], L[1], ml);
-    const double* Rr = lanes + (s.nl + nearest_segment(s, lanes, 1, px, py)) * kLaneFields;
+    const double* Rr = lanes + (s.nl + nearest_segment<EX>(s, lanes, 1, px, py)) * kLaneFields;
     plane_disc(p, Rr[0], Rr[1], Rr[2], px, py, lcj, lsj, mr);
     plane_commit(q, Rr[0], Rr[1], mr);
   }

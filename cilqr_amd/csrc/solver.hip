@@ -508,6 +508,10 @@ int cilqr_set_option(cilqr_handle h, int32_t option, int64_t value) {
       if (value < 0) return CILQR_ERR_ARG;
       h->tail_threshold = (int)(value > kTailMaxProblems ? kTailMaxProblems : value);
       return CILQR_OK;
+    case CILQR_OPT_EXACT_LANE_TIES:
+      if (value != 0 && value != 1) return CILQR_ERR_ARG;
+      h->ds.exact_ties = h->twin.exact_ties = h->fin.exact_ties = h->fin_twin.exact_ties = (int)value;
+      return CILQR_OK;
     case CILQR_OPT_FINISH_THRESHOLD:
       if (value < 0) return CILQR_ERR_ARG;
       h->fin_threshold = (int)(value > h->fin_cap ? h->fin_cap : value);
@@ -660,6 +664,7 @@ void adopt_job_fields(DeviceState* t, const DeviceState& src) {
   t->n_iter_trajs = src.n_iter_trajs; t->atrace = src.atrace;
   t->lanes = src.lanes; t->lgrid = src.lgrid;
   t->nl = src.nl; t->nr = src.nr;
+  t->exact_ties = src.exact_ties;
   t->gx0 = src.gx0; t->gy0 = src.gy0; t->ginv_h = src.ginv_h; t->gnx = src.gnx; t->gny = src.gny;
   t->Pcap = src.Pcap;
 }

@@ -87,6 +87,7 @@ struct DeviceState {
              // active problems currently live in (the finishing arena of solver.hip is smaller than the batch)
   int cmax;
   int nl, nr;  // lane segments
+  int exact_ties;   // CILQR_OPT_EXACT_LANE_TIES: near-ties of the nearest-segment search decided by the reference's distances
   Params p;
 
   double2* X;      // [2][K][3][Bcap]

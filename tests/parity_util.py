@@ -246,7 +246,7 @@ def lane_tie(scene: dict, ocfg, X) -> bool:
 
 
 def check_steps(gpu: dict, scene: dict, ocfg, problems=None, tol=STEP_TOL, eps=PERTURB_EPS, n_perturb=8,
-                seed=777):
+                seed=777, allow_lane_tie=True):
     """Replay every step of the listed problems (default: all) in the oracle, starting each step from
     the HIP path's own iterate.  `gpu` must come from plan(..., max_iter_trajs=cap, alpha_trace=True).
     Returns dict(steps, tight, excused, failed[list], worst (among tight), truncated)."""
@@ -305,7 +305,8 @@ def check_steps(gpu: dict, scene: dict, ocfg, problems=None, tol=STEP_TOL, eps=P
                     unstable = True
                     out["knife_edge"] += 1
                 # or does the iterate (or the one the step arrives at) sit on a nearest-lane-segment tie?
-                if not unstable and (lane_tie(scene, ocfg, X) or (nxt is not None and lane_tie(scene, ocfg, np.asarray(nxt)[:, 1:7]))):
+                # (allow_lane_tie=False: the solve ran with CILQR_OPT_EXACT_LANE_TIES, which follows the reference there)
+                if not unstable and allow_lane_tie and (lane_tie(scene, ocfg, X) or (nxt is not None and lane_tie(scene, ocfg, np.asarray(nxt)[:, 1:7]))):
                     unstable = True
                     out["lane_tie"] += 1
                 # or is the step itself discontinuous in the oracle?
@@ -333,8 +334,8 @@ def check_steps(gpu: dict, scene: dict, ocfg, problems=None, tol=STEP_TOL, eps=P
     return out
 
 
-def assert_steps(gpu, scene, ocfg, what="", problems=None, tol=STEP_TOL, max_excused_frac=0.02):
-    rep = check_steps(gpu, scene, ocfg, problems=problems, tol=tol)
+def assert_steps(gpu, scene, ocfg, what="", problems=None, tol=STEP_TOL, max_excused_frac=0.02, allow_lane_tie=True):
+    rep = check_steps(gpu, scene, ocfg, problems=problems, tol=tol, allow_lane_tie=allow_lane_tie)
     assert rep["steps"] > 0, f"{what}: nothing was replayed"
     assert not rep["failed"], f"{what}: {len(rep['failed'])} of {rep['steps']} steps differ from the oracle: {rep['failed'][:5]}"
     assert rep["excused"] <= max(1, int(np.ceil(max_excused_frac * rep["steps"]))), \

@@ -914,6 +914,66 @@ def test_nearest_lane_grid_equals_linear_scan():
     opt.close()
 
 
+def test_exact_lane_ties_follow_the_reference_rule():
+    """CILQR_OPT_EXACT_LANE_TIES: FindNeastLaneSegment (ilqr_optimizer.cc:605-618) compares DistanceTo values (hypot /
+    |cross|, line_segment2d.cpp:61-75) with a strict '<', first index wins.  With the option on, the device search --
+    grid and full scan -- must return numpy's first minimum of those distances on EVERY point, the tie strips included:
+    joints, points on the normal through a joint (perpendicular distance to one segment = end-point distance to its
+    neighbour, the strip the iteration parks on), the same points moved by a few ulp."""
+    sc = scenario.generate("ped6", 4, seed=3)
+    opt = _opt(sc)
+    opt.set_option(api.OPT_EXACT_LANE_TIES, 1)
+    opt.stage_load(sc)
+    rng = np.random.default_rng(11)
+    road = scenario.build_road()
+    s_ = rng.uniform(0, road.length, 100000)
+    x, y = road.cartesian(s_, rng.uniform(-14.0, 10.0, s_.size))
+    pts = [np.stack([x, y], axis=1), np.concatenate([sc["left"][:, 3:5], sc["right"][:, 5:7]])]
+    for tab in (sc["left"], sc["right"]):
+        d = tab[:, 5:7] - tab[:, 3:5]
+        u = d / np.hypot(d[:, 0], d[:, 1])[:, None]
+        nrm = np.stack([-u[:, 1], u[:, 0]], axis=1)
+        for r in (-6.0, -2.5, -0.7, 0.3, 2.0, 6.0):
+            for end in (tab[:, 3:5], tab[:, 5:7]):
+                base = end + r * nrm                       # on the normal through the joint
+                pts.append(base)
+                for k in (-3, -1, 1, 3):                   # and a few ulp along the segment on either side
+                    pts.append(base + k * np.spacing(np.abs(base)) * np.sign(u))
+                pts.append(base + 1e-9 * u)
+                pts.append(base - 1e-9 * u)
+    pts = np.concatenate(pts)
+    gl, gr = opt.nearest_lane(pts, use_grid=True)
+    sl, sr = opt.nearest_lane(pts, use_grid=False)
+    n_tie = 0
+    for tab, grid, scan in ((sc["left"], gl, sl), (sc["right"], gr, sr)):
+        ref, srt = _nearest_numpy(tab, pts)
+        n_tie += int((srt[:, 1] == srt[:, 0]).sum())
+        bad = np.nonzero((grid != ref) | (scan != ref))[0]
+        assert bad.size == 0, (bad[:5], pts[bad[:5]], grid[bad[:5]], scan[bad[:5]], ref[bad[:5]])
+    assert n_tie > 100          # the set does contain exact ties of the reference's distances
+    # the default search differs on some of them (that is what the option is for)
+    opt.set_option(api.OPT_EXACT_LANE_TIES, 0)
+    dl, dr = opt.nearest_lane(pts, use_grid=True)
+    print(f"\nexact ties in the point set: {n_tie}; default search differs from the reference on "
+          f"{int((dl != _nearest_numpy(sc['left'], pts)[0]).sum() + (dr != _nearest_numpy(sc['right'], pts)[0]).sum())} points")
+    opt.close()
+
+
+def test_exact_lane_ties_need_no_excuse():
+    """With CILQR_OPT_EXACT_LANE_TIES the step replay runs with the `lane_tie` excuse switched OFF: the zero-tolerance
+    configuration that iterates into the noise plateau (where iterates come to rest on tie strips), and a default run."""
+    for over, n, frac in ((dict(rel_cost_tol=0.0, abs_cost_tol=0.0, max_iter=60), 48, 0.25), (dict(), 160, 0.02)):
+        sc = scenario.generate("mix11", n, seed=77)
+        cfg = api.default_config(sc["n_steps"], **over)
+        opt = api.BatchIlqrOptimizer(cfg, batch_capacity=n, cmax=sc["cmax"])
+        opt.set_option(api.OPT_EXACT_LANE_TIES, 1)
+        g = _plan(opt, sc)
+        rep = assert_steps(g, sc, oracle_cfg_from(cfg), what=f"exact ties {over}", max_excused_frac=frac, allow_lane_tie=False)
+        assert rep["lane_tie"] == 0
+        print(f"\nexact ties, {over}: steps {rep}")
+        opt.close()
+
+
 def test_speculative_line_search_is_bit_identical_to_round_by_round(lockstep_only):
     """Small active sets evaluate all 11 step sizes at once; the first passing index must win exactly
     as in the sequential loop (ilqr_optimizer.cc:246-265), so both modes give the same bits."""
