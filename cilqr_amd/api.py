@@ -28,7 +28,7 @@ OPT_ROUND_GROUP = 7
 OPT_FINISH_THRESHOLD = 8
 OPT_EXACT_LANE_TIES = 9
 ST_RUNNING, ST_CONVERGED_ABS, ST_CONVERGED_REL, ST_GNORM, ST_UNSOLVED, ST_MAX_ITER, ST_NO_CORRIDOR = range(7)
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 T_GOALS, T_CORRIDOR, T_LANES, T_X, T_U, T_XCAND, T_UCAND, T_A, T_B, T_LX, T_LU, T_LXX, T_LUU, \
     T_KFB, T_KFF, T_DV, T_GNORM = range(17)
@@ -127,6 +127,8 @@ EXPORTS = [
     "cilqr_default_corridor_config", "cilqr_build_corridors", "cilqr_lane_constraints",
     "cilqr_default_dp_config", "cilqr_dp_plan", "cilqr_road_barriers", "cilqr_default_tracker_config",
     "cilqr_set_tracker_config",
+    "cilqr_multi_create", "cilqr_multi_destroy", "cilqr_multi_solve", "cilqr_multi_set_option", "cilqr_multi_shards",
+    "cilqr_multi_device_bytes",
     "cilqr_comm_unique_id", "cilqr_comm_create", "cilqr_comm_destroy", "cilqr_comm_info", "cilqr_gather_results",
 ]
 UNIQUE_ID_BYTES = 128
@@ -188,6 +190,14 @@ def lib():
         L.cilqr_default_tracker_config.restype = None
         L.cilqr_set_tracker_config.argtypes = [C.c_void_p, C.POINTER(TrackerConfig)]
         L.cilqr_road_barriers.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]
+        L.cilqr_multi_create.argtypes = [C.POINTER(Config), C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                         C.POINTER(C.c_void_p)]
+        L.cilqr_multi_destroy.argtypes = [C.c_void_p]
+        L.cilqr_multi_solve.argtypes = [C.c_void_p, C.POINTER(ProblemBatch), C.POINTER(SolutionBatch)]
+        L.cilqr_multi_set_option.argtypes = [C.c_void_p, C.c_int32, C.c_int64]
+        L.cilqr_multi_shards.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]
+        L.cilqr_multi_device_bytes.argtypes = [C.c_void_p]
+        L.cilqr_multi_device_bytes.restype = C.c_int64
         L.cilqr_comm_unique_id.argtypes = [C.c_void_p]
         L.cilqr_comm_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
         L.cilqr_comm_destroy.argtypes = [C.c_void_p]
@@ -528,3 +538,66 @@ def lane_constraints(boundary, segment_length: float = 5.0, is_left: bool = True
     if m < 0:
         raise CilqrError(m, "lane_constraints")
     return rows[:m].copy()
+
+
+class MultiDeviceOptimizer:
+    """cilqr_multi_*: ONE host process, several GPUs (include/cilqr.h).  The batch of a plan() call is cut into
+    contiguous shards, one per entry of `devices` (an entry may repeat: logical shards on one GPU), solved
+    concurrently, and every shard writes its rows of the caller's arrays: results in problem order, bit-identical to
+    one BatchIlqrOptimizer.plan over the whole batch."""
+
+    def __init__(self, cfg: "Config | None" = None, devices=(0,), batch_capacity: int = 1, cmax: int = 16,
+                 max_lane_segments: int = 64, n_steps: int = 50):
+        self.L = lib()
+        self.cfg = cfg if cfg is not None else default_config(n_steps)
+        self.K = self.cfg.n_steps + 1
+        self.devices = np.asarray(list(devices), dtype=np.int32)
+        self.h = C.c_void_p()
+        rc = self.L.cilqr_multi_create(C.byref(self.cfg), self.devices.ctypes.data, len(self.devices), batch_capacity, cmax,
+                                       max_lane_segments, C.byref(self.h))
+        if rc != OK:
+            raise CilqrError(rc, "in cilqr_multi_create")
+
+    def close(self):
+        if self.h:
+            self.L.cilqr_multi_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def set_option(self, option: int, value: int):
+        rc = self.L.cilqr_multi_set_option(self.h, option, value)
+        if rc != OK:
+            raise CilqrError(rc, "in cilqr_multi_set_option")
+
+    def shards(self, batch: int):
+        n = len(self.devices)
+        first, dev = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        got = self.L.cilqr_multi_shards(self.h, batch, first.ctypes.data, dev.ctypes.data, n)
+        return got, first, dev
+
+    def device_bytes(self) -> int:
+        return int(self.L.cilqr_multi_device_bytes(self.h))
+
+    def solve_raw(self, prob: ProblemBatch, sol: SolutionBatch) -> int:
+        return self.L.cilqr_multi_solve(self.h, C.byref(prob), C.byref(sol))
+
+    def plan(self, scene: dict, max_iter_trajs: int = 0, check: bool = True, alpha_trace: bool = False):
+        prob, keep = BatchIlqrOptimizer._host_problem(self, scene)
+        B, K, M = prob.batch, self.K, self.cfg.max_iter
+        traj = np.zeros((B, K, 10))
+        hist = np.zeros((B, M + 1, 5))
+        n_cost = np.zeros(B, np.int32)
+        status = np.zeros(B, np.int32)
+        n_iter = np.zeros(B, np.int32)
+        it = np.zeros((B, max_iter_trajs, K, 10)) if max_iter_trajs else None
+        n_it = np.zeros(B, np.int32) if max_iter_trajs else None
+        at = np.full((B, M), -3, np.int8) if alpha_trace else None
+        sol = SolutionBatch(MEM_HOST, max_iter_trajs, _ptr(traj), _ptr(hist), _ptr(n_cost), _ptr(status),
+                            _ptr(n_iter), _ptr(it), _ptr(n_it), _ptr(at))
+        rc = self.solve_raw(prob, sol)
+        del keep
+        if rc != OK:
+            if check:
+                raise CilqrError(rc, "in cilqr_multi_solve")
+            return dict(rc=rc)
+        return dict(rc=rc, traj=traj, cost_hist=hist, n_cost=n_cost, status=status, n_iter=n_iter,
+                    iter_trajs=it, n_iter_trajs=n_it, alpha_trace=at)

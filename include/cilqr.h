@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define CILQR_ABI_VERSION 3
+#define CILQR_ABI_VERSION 4
 
 #define CILQR_NX 6  /* state  (x, y, theta, v, a, delta)   vehicle_model.h:11 */
 #define CILQR_NU 2  /* control (jerk, delta_rate)           vehicle_model.h:12 */
@@ -385,6 +385,27 @@ int cilqr_road_barriers(const double* center, int32_t n_center, double* left, do
  * the reference, whose caller then stops: trajectory_planner.cpp:32-35). */
 int cilqr_dp_plan(const cilqr_dp_config* cfg, const cilqr_scene* scene, const double* start3, double* coarse,
                   int32_t n_knots);
+
+/* ---- several GPUs from ONE host process (the reference's caller is one process:
+ * algorithm/planning_node.cc:9-31) ----
+ * A multi handle owns one solver handle per listed device.  cilqr_multi_solve cuts the batch into contiguous shards
+ * (the first batch % n shards hold one problem more), solves them concurrently -- each shard on its own device,
+ * stream and host threads -- and every shard writes its results into the caller's arrays at its offset: problem order
+ * is preserved, nothing is copied between devices, results are bit-identical to one cilqr_solve_batch over the whole
+ * batch.  `devices` may list a device more than once (logical shards on one GPU).  The arrays of `in` / `out` must be
+ * reachable from every listed device: host memory (CILQR_MEM_HOST), or device memory when all shards share the
+ * device that holds it.  One lane table per call (n_lane_groups <= 1).  batch_capacity is for all shards together. */
+typedef struct cilqr_multi* cilqr_multi_handle;
+int cilqr_multi_create(const cilqr_config* cfg, const int32_t* devices, int32_t n_devices, int32_t batch_capacity,
+                       int32_t cmax, int32_t max_lane_segments, cilqr_multi_handle* out);
+int cilqr_multi_destroy(cilqr_multi_handle m);
+int cilqr_multi_solve(cilqr_multi_handle m, const cilqr_problem_batch* in, cilqr_solution_batch* out);
+/* cilqr_set_option on every shard */
+int cilqr_multi_set_option(cilqr_multi_handle m, int32_t option, int64_t value);
+/* the split of a batch: first problem and device of every shard (arrays of max_shards entries, NULL to skip);
+ * returns the number of shards */
+int cilqr_multi_shards(cilqr_multi_handle m, int32_t batch, int32_t* first_problem, int32_t* device, int32_t max_shards);
+int64_t cilqr_multi_device_bytes(cilqr_multi_handle m);
 
 /* ---- multi-GPU (nothing in the single-process reference to replace) ----
  * One process per GPU.  Problems are independent: rank r solves a contiguous block of `batch` problems with

@@ -668,6 +668,61 @@ def test_two_solves_in_flight_on_one_handle(finish_threshold):
     opt.close()
 
 
+def test_one_process_several_devices_sharded_solve():
+    """cilqr_multi_*: one host call cut into contiguous shards, one solver handle per listed device, results written
+    into the caller's arrays at each shard's offset.  On a one-GPU box the device is listed several times (logical
+    shards): the sharded solve equals cilqr_solve_batch over the whole batch bit for bit -- uneven splits, the tracker
+    init guess with caller-supplied stations (a per-problem input that must be offset per shard), and the argument
+    errors."""
+    sc = scenario.generate("mix11", 203, seed=190)
+    one = _opt(sc)
+    ref = _plan(one, sc)
+    one.close()
+    for devices in ((0, 0), (0, 0, 0), (0,)):
+        m = api.MultiDeviceOptimizer(api.default_config(sc["n_steps"]), devices=devices, batch_capacity=203, cmax=sc["cmax"])
+        n, first, dev = m.shards(203)
+        assert n == len(devices) and first[0] == 0 and list(dev) == list(devices)
+        assert np.all(np.diff(np.append(first, 203)) >= 203 // len(devices))          # contiguous, balanced
+        g = m.plan(sc, max_iter_trajs=ITER_CAP, alpha_trace=True)
+        for k in ("traj", "cost_hist", "n_cost", "status", "n_iter", "alpha_trace", "iter_trajs", "n_iter_trajs"):
+            assert np.array_equal(g[k], ref[k]), (devices, k)
+        sub = {k: (v[:77] if isinstance(v, np.ndarray) and v.shape[:1] == (203,) else v) for k, v in sc.items()}
+        g2 = m.plan(sub)                                                                # a smaller batch on the same handle
+        assert np.array_equal(g2["traj"], ref["traj"][:77]) and np.array_equal(g2["n_cost"], ref["n_cost"][:77])
+        if len(devices) == 2:
+            assert m.device_bytes() > 0
+            grouped = dict(sc, lane_groups=[(0, len(sc["left"]), len(sc["right"])), (100, len(sc["left"]), len(sc["right"]))],
+                           left=np.concatenate([sc["left"], sc["left"]]), right=np.concatenate([sc["right"], sc["right"]]))
+            assert m.plan(grouped, check=False)["rc"] == api.ERR_ARG                   # one lane table per sharded call
+            big = scenario.generate("mix11", 204, seed=1)
+            assert m.plan(big, check=False)["rc"] == api.ERR_CAPACITY
+        m.close()
+    with pytest.raises(api.CilqrError):
+        api.MultiDeviceOptimizer(api.default_config(50), devices=(0, 97), batch_capacity=8)   # no such device
+    # per-problem stations follow their shard
+    gdp = scenario.generate_dp("demo80", 16, seed=181, workers=8)
+    ok = np.nonzero(gdp["found"])[0]
+    take = lambda a_: np.ascontiguousarray(a_[ok])
+    B, K = len(ok), 81
+    th = take(gdp["coarse"])[:, :, 2]
+    nrm = np.stack([np.stack([np.cos(th), np.sin(th)], -1), np.stack([-np.cos(th), -np.sin(th)], -1),
+                    np.stack([-np.sin(th), np.cos(th)], -1), np.stack([np.sin(th), -np.cos(th)], -1)], 2)
+    cor = np.zeros((B, K, 16, 3))
+    cor[:, :, :4, :2] = nrm
+    cor[:, :, :4, 2] = (nrm * take(gdp["coarse"])[:, :, None, :2]).sum(-1) + 10.0
+    sct = dict(start=take(gdp["start"]), coarse=take(gdp["coarse"]), left=gdp["left"], right=gdp["right"], n_steps=80, cmax=16,
+               corridor=cor, ccount=np.full((B, K), 4, np.int32), coarse_station=take(gdp["dp"][:, :, 1]))
+    cfg = api.default_config(80, init_guess=api.INIT_TRACKER)
+    one = api.BatchIlqrOptimizer(cfg, batch_capacity=B, cmax=16, max_lane_segments=64)
+    ref = one.plan(sct)
+    one.close()
+    m = api.MultiDeviceOptimizer(cfg, devices=(0, 0), batch_capacity=B, cmax=16)
+    g = m.plan(sct)
+    for k in ("traj", "cost_hist", "n_cost", "status"):
+        assert np.array_equal(g[k], ref[k]), k
+    m.close()
+
+
 def test_lean_log_and_reciprocal_are_accurate_to_an_ulp_or_two():
     """The barrier kernels use their own log / reciprocal (dev_model.hpp: log_pos, fast_rcp) instead
     of the library routines.  Against numpy on 400k points spanning the whole normal range and the
