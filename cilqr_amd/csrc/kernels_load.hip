@@ -232,7 +232,8 @@ __global__ void k_device_math(int fn, int n, const double* __restrict__ in, doub
   lean_sincos(x, &sn, &cs);
   out[t] = (fn == 0) ? log_pos(x, 0) : (fn == 1) ? fast_rcp(x)
          : (fn == 2) ? log_pos(__builtin_amdgcn_frexp_mant(x), __builtin_amdgcn_frexp_exp(x))
-         : (fn == 3) ? sn : (fn == 4) ? cs : (fn == 5) ? lean_tan(x) : normalize_angle(x);
+         : (fn == 3) ? sn : (fn == 4) ? cs : (fn == 5) ? lean_tan(x) : (fn == 6) ? normalize_angle(x)
+         : (fn == 7) ? cos(x) : (fn == 8) ? sin(x) : hypot_ref(x, 1.0);
 }
 void launch_device_math(int fn, int n, const double* in, double* out, hipStream_t st) {
   hipLaunchKernelGGL(k_device_math, dim3((n + 255) / 256), dim3(256), 0, st, fn, n, in, out);

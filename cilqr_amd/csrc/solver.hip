@@ -1380,7 +1380,7 @@ int cilqr_lane_constraints(const double* boundary, int32_t n, double segment_len
 
 int cilqr_device_math(cilqr_handle h, int32_t fn, int32_t n, const double* in, double* out) {
   if (h == nullptr || in == nullptr || out == nullptr) return CILQR_ERR_NULL;
-  if (n <= 0 || fn < 0 || fn > 6) return CILQR_ERR_ARG;
+  if (n <= 0 || fn < 0 || fn > 9) return CILQR_ERR_ARG;
   HIP_TRY(hipSetDevice(h->device));
   double* d = nullptr;
   if (hipMalloc(reinterpret_cast<void**>(&d), (size_t)n * 16) != hipSuccess) return CILQR_ERR_DEVICE;

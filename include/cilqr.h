@@ -340,7 +340,9 @@ int cilqr_lane_constraints(const double* boundary, int32_t n, double segment_len
 /* Test hook for the kernels' own fp64 routines (host arrays of n doubles):
  * fn 0: log(x) for normal finite x > 0;  fn 1: 1 / x for normal finite x != 0;
  * fn 2: log(x) with mantissa and exponent handed over separately (the long-product path);
- * fn 3 / 4 / 5: sin / cos / tan(x) for |x| <= 1e5;  fn 6: NormalizeAngle(x) (math_utils.cpp:53-59). */
+ * fn 3 / 4 / 5: sin / cos / tan(x) for |x| <= 1e5;  fn 6: NormalizeAngle(x) (math_utils.cpp:53-59);
+ * fn 7 / 8: the device library's cos / sin as the corridor producer uses them for the box corners (corridor.cc:96-99);
+ * fn 9: hypot(x, 1) by the libm-identical routine of the lane search and the constraint normalisation. */
 int cilqr_device_math(cilqr_handle h, int32_t fn, int32_t n, const double* in, double* out);
 
 /* X[b][0] = x0[b]; X[b][i+1] = Dynamics(X[b][i], U[b][i]).  x0 [B][6], U [B][N][2], X [B][K][6] */

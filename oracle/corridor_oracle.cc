@@ -79,7 +79,7 @@ extern "C" {
 // pts: n obstacle points (x, y) valid at this knot's time (Environment::Query*ObstaclesPoints).
 // Appends the box points (AddCorridorPoints: both ends of every edge, or six samples per edge when cfg[5] =
 // is_multiple_sample is set) and builds the corridor.  cfg = max_diff_x, max_diff_y, radius, max_axis_x, max_axis_y,
-// is_multiple_sample.
+// is_multiple_sample, trig override flag, cos(theta), sin(theta)  (9 entries; see the hook below).
 // Outputs: cons[.][3] = (a, b, c) with a x + b y <= c; poly[.][2] the polygon vertices.
 // Returns the number of half-planes, or -1 (no points), -2 (fewer than 4 flipped points), -3 (more
 // than max_out half-planes), -4 (degenerate hull).
@@ -93,7 +93,9 @@ int oracle_build_corridor(double ox, double oy, double theta, const double* pts,
     py.push_back(pts[2 * i + 1]);
   }
   {  // AddCorridorPoints cc:89-120
-    const double ch = std::cos(theta), sh = std::sin(theta);
+    // cfg[6] != 0 (test hook): cos / sin of theta handed in as cfg[7], cfg[8] -- the values of ANOTHER libm, to show that
+    // a knot on which two implementations differ differs through the last bit of a box corner and nothing else
+    const double ch = (cfg[6] != 0.0) ? cfg[7] : std::cos(theta), sh = (cfg[6] != 0.0) ? cfg[8] : std::sin(theta);
     const double dx1 = ch * max_axis_x, dy1 = sh * max_axis_x;
     const double dx2 = sh * max_axis_y, dy2 = -ch * max_axis_y;
     const double cx[4] = {ox + dx1 + dx2, ox + dx1 - dx2, ox - dx1 - dx2, ox - dx1 + dx2};

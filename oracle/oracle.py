@@ -274,11 +274,13 @@ def solve_batch(scene: dict, cfg: OracleConfig | None = None, want_margin: bool 
 CORRIDOR_CFG = (25.0, 25.0, 150.0, 10.0, 10.0, 0.0)   # max_diff_x/y, radius, max_axis_x/y, is_multiple_sample (planner_config.h:75-86)
 
 
-def build_corridor(ox, oy, theta, pts, cfg=CORRIDOR_CFG, max_out=64):
+def build_corridor(ox, oy, theta, pts, cfg=CORRIDOR_CFG, max_out=64, trig=None):
     """Corridor::AddCorridorPoints + BuildCorridor for one knot.  Returns (cons [m,3], poly [m,2]);
-    raises ValueError with the oracle's code on failure."""
+    raises ValueError with the oracle's code on failure.  trig=(cos theta, sin theta): test hook, the box corners are
+    built from these values instead of this libm's."""
     pts = _f64(np.asarray(pts, dtype=np.float64).reshape(-1, 2))
-    cfg = _f64(np.asarray(list(cfg) + [0.0] * (6 - len(cfg)), dtype=np.float64))
+    cfg = list(cfg) + [0.0] * (6 - len(cfg))
+    cfg = _f64(np.asarray(cfg + ([1.0, trig[0], trig[1]] if trig is not None else [0.0, 0.0, 0.0]), dtype=np.float64))
     cons = np.zeros((max_out, 3))
     poly = np.zeros((max_out, 2))
     m = lib().oracle_build_corridor(float(ox), float(oy), float(theta), pts.ctypes.data, pts.shape[0],

@@ -127,10 +127,23 @@ def test_build_corridors_matches_oracle(built, family, B, seed):
     assert n_failed == 0 and (cnt >= 3).all()
     ocor, ocnt = _oracle_corridors(sc, sc["cmax"])
     same_count = cnt == ocnt
-    # device cos/sin and libm's may differ in the last bit of a box corner, which can move a
-    # float32 hull decision: allow a handful of knots to differ in their plane count
+    # The device library's cos / sin and libm's may differ in the last bit, hence a box corner, hence a float32 hull
+    # decision: a handful of knots may differ in their plane count -- and EVERY such knot must be explained by exactly
+    # that: the oracle re-run with the device's cos / sin of the knot's heading (cilqr_device_math 7 / 8) gives the
+    # device's corridor.
     assert same_count.mean() > 0.995
     K = cnt.shape[1]
+    for b, k in zip(*np.nonzero(~same_count)):
+        th = sc["coarse"][b, k, 2]
+        trig = (float(opt.device_math(7, [th])[0]), float(opt.device_math(8, [th])[0]))
+        assert trig != (float(np.cos(th)), float(np.sin(th))), (b, k)
+        n = sc["obstacle_count"][b, k]
+        cons, _ = orc.build_corridor(*sc["coarse"][b, k, :3], sc["obstacle_points"][b, k, :n], max_out=sc["cmax"], trig=trig)
+        assert len(cons) == cnt[b, k], (b, k, len(cons), cnt[b, k], ocnt[b, k])
+        ocor[b, k] = 0.0
+        ocor[b, k, :len(cons)] = cons
+        same_count[b, k] = True
+    print(f"\n{family}: {int((cnt != ocnt).sum())} of {cnt.size} knots differ from the libm oracle, all explained by the last bit of cos / sin")
     worst = 0.0
     for b in range(B):
         for k in range(K):
@@ -187,6 +200,7 @@ def test_build_corridors_with_multiple_sample_points(built):
     assert nf == 0 and (ccnt >= 3).all()
     ocfg = (25.0, 25.0, 150.0, 10.0, 10.0, 1.0)
     same = 0
+    explained = 0
     worst = 0.0
     unsound = 0
     for b in range(B):
@@ -204,11 +218,17 @@ def test_build_corridors_with_multiple_sample_points(built):
                 unsound += 1
             if oracle_sound and len(cons) == m:
                 _check_corridor(cor[b, k, :m], knots[b, k, 0], knots[b, k, 1], pts[b, k, :cnt[b, k]])
-            if len(cons) == m:
-                same += 1
-                scale = np.abs(cons).max(axis=1, keepdims=True)
-                worst = max(worst, float((np.abs(cor[b, k, :m] - cons) / scale).max()))
-    assert same >= 0.99 * B * K and worst < 1e-5 and unsound <= 0.02 * B * K, (same, worst, unsound)
+            if len(cons) != m:   # must be the last bit of cos / sin (see test_build_corridors_matches_oracle)
+                th = knots[b, k, 2]
+                trig = (float(opt.device_math(7, [th])[0]), float(opt.device_math(8, [th])[0]))
+                assert trig != (float(np.cos(th)), float(np.sin(th))), (b, k)
+                cons, _ = orc.build_corridor(*knots[b, k], pts[b, k, :cnt[b, k]], cfg=ocfg, max_out=32, trig=trig)
+                assert len(cons) == m, (b, k, len(cons), m)
+                explained += 1
+            same += 1
+            scale = np.abs(cons).max(axis=1, keepdims=True)
+            worst = max(worst, float((np.abs(cor[b, k, :m] - cons) / scale).max()))
+    assert same == B * K and explained <= 0.01 * B * K and worst < 1e-5 and unsound <= 0.02 * B * K, (same, explained, worst, unsound)
     # and the corridors are no larger than the ones from the corners alone (more points can only cut more)
     cfg0 = api.default_corridor_config()
     p0 = [scene_io.environment_points(sf.scenes[b], t) for b in range(B)]

@@ -293,29 +293,39 @@ def test_golden_fixtures_through_the_c_abi():
 ])
 def test_exit_paths(over, expect, both_paths):
     """Every exit of Optimize() (max-iter, abs tol, lambda > 1e11 / gnorm) agrees with the oracle."""
-    sc = scenario.generate("ped6", 48, seed=51)
+    noisy = over.get("rel_cost_tol", 1.0) == 0.0 and over.get("abs_cost_tol", 1.0) == 0.0
+    if noisy:
+        # With both tolerances at 0 the solver iterates into the rounding-noise plateau, where accept / reject decisions
+        # hang on the last bits of a cost difference and most problems are not reproducible by the oracle itself.  The
+        # scenes of this case are screened (tests/golden/make_zero_tolerance_set.py): 32 of the 48 are problems whose
+        # zero-tolerance solve the oracle reproduces under 4e-16 input noise with every decision >= 1e-9 from its threshold.
+        import json
+        sel = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "zero_tolerance_scenes.json")))
+        assert sel["config"] == {k: over[k] for k in sel["config"]}
+        pool = scenario.generate(sel["family"], sel["pool"], seed=sel["pool_seed"])
+        idx = np.asarray(sel["indices"])
+        sc = {k: (np.ascontiguousarray(v[idx]) if isinstance(v, np.ndarray) and v.shape[:1] == (sel["pool"],) else v) for k, v in pool.items()}
+    else:
+        sc = scenario.generate("ped6", 48, seed=51)
     opt = _opt(sc, **over)
     g = _plan(opt, sc)
     ocfg = oracle_cfg_from(opt.cfg)
     ref = oracle_reference(sc, ocfg)
-    # With both tolerances at 0 the solver iterates into the rounding-noise plateau, where accept /
-    # reject decisions hang on the last bits of a cost difference: 12 of these 48 problems (25 %) are
-    # not reproducible by the oracle itself there (1 and 5 of 48 for the other two configurations), and
-    # single steps are excused more often -- but every step still has to replay or be shown unstable.
-    noisy = over.get("rel_cost_tol", 1.0) == 0.0 and over.get("abs_cost_tol", 1.0) == 0.0
     if noisy:
         # whole solves are only comparable where no decision of the oracle hung on the last bits of a cost
         # difference (relative distance to its threshold under 1e-9): the others count as unstable too
         ref["stable"] &= ref["min_margin"] >= 1e-9
-        assert ref["stable"].sum() >= 8, "nothing left to compare"
-    assert_parity(g, ref, max_unstable_frac=0.85 if noisy else 0.125, what=str(over))
-    steps = assert_steps(g, sc, ocfg, what=str(over), max_excused_frac=0.25 if noisy else 0.02)
+        assert ref["stable"].sum() >= 24, "the screened set must be stable for at least half of its problems"
+    assert_parity(g, ref, max_unstable_frac=0.5 if noisy else 0.125, what=str(over))
+    # the lambda > 1e11 exit is reached through noisy rejections by nature: no stable problem ends there, every one of
+    # its steps still has to replay in the oracle or be shown discontinuous there
+    steps = assert_steps(g, sc, ocfg, what=str(over), max_excused_frac=0.10 if noisy else 0.02)
     print(f"\n{over}: steps {steps}")
     if expect is not None:
         assert (g["status"] == expect).sum() >= 1
     else:
         assert set(np.unique(g["status"])) <= {api.ST_GNORM, api.ST_UNSOLVED, api.ST_MAX_ITER}
-        assert (g["status"] == api.ST_UNSOLVED).sum() >= 1
+        assert (g["status"] == api.ST_UNSOLVED).sum() >= 1 and (g["status"] == api.ST_GNORM).sum() >= 1
     opt.close()
 
 
@@ -883,29 +893,30 @@ def test_long_horizon_more_knots_than_a_tail_workgroup_has_threads(both_paths):
     opt.close()
 
 
-def test_full_size_batch_properties():
-    """BASELINE configs[2] size (B = 65536, N = 50): 256 distinct scenes tiled 256x.  Size-independent
-    properties: every copy of a scene gives bit-identical output wherever it sits in the batch, all
-    problems terminate, accepted costs decrease monotonically, and the 256 distinct scenes match
-    the oracle."""
-    base = scenario.generate("mix11", 256, seed=91)
-    rep = 256
-    sc = {k: (np.tile(v, (rep,) + (1,) * (v.ndim - 1)) if isinstance(v, np.ndarray) and v.shape[:1] == (256,) else v)
+@pytest.mark.parametrize("family,distinct", [("mix11", 256), ("dyn20x", 128)])
+def test_full_size_batch_properties(family, distinct):
+    """BASELINE configs[2] (B = 65536, N = 50, mix11) and configs[4] (B = 65536, N = 100, 20 dynamic obstacles, barriers
+    active at the init guess: dyn20x) at full size: `distinct` scenes tiled to 65536.  Size-independent properties: every
+    copy of a scene gives bit-identical output wherever it sits in the batch, all problems terminate, accepted costs
+    decrease monotonically, and the distinct scenes match the oracle."""
+    base = scenario.generate(family, distinct, seed=91)
+    rep = 65536 // distinct
+    sc = {k: (np.tile(v, (rep,) + (1,) * (v.ndim - 1)) if isinstance(v, np.ndarray) and v.shape[:1] == (distinct,) else v)
           for k, v in base.items()}
-    B = 256 * rep
+    B = distinct * rep
     opt = _opt(sc)
     g = opt.plan(sc, alpha_trace=True)
     assert ((g["status"] >= 1) & (g["status"] <= 5)).all()
-    tr = g["traj"].reshape(rep, 256, *g["traj"].shape[1:])
+    tr = g["traj"].reshape(rep, distinct, *g["traj"].shape[1:])
     assert np.array_equal(tr, np.broadcast_to(tr[:1], tr.shape))
-    nc = g["n_cost"].reshape(rep, 256)
+    nc = g["n_cost"].reshape(rep, distinct)
     assert np.array_equal(nc, np.broadcast_to(nc[:1], nc.shape))
-    tot = g["cost_hist"][:256, :, 0]
-    for b in range(256):
+    tot = g["cost_hist"][:distinct, :, 0]
+    for b in range(distinct):
         assert np.all(np.diff(tot[b, :g["n_cost"][b]]) < 0)
-    first = {k: v[:256] for k, v in g.items() if isinstance(v, np.ndarray)}
+    first = {k: v[:distinct] for k, v in g.items() if isinstance(v, np.ndarray)}
     ref = oracle_reference(base, oracle_cfg_from(opt.cfg))
-    assert_parity(first, ref, what="full-size batch")
+    assert_parity(first, ref, what=f"full-size batch {family}", max_unstable_frac=0.125 if family == "mix11" else 0.2)
     assert B == 65536
     opt.close()
 
