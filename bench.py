@@ -617,11 +617,11 @@ def main():
                     "full_batch_avg_launch_ms": single["bwd_full_ms"],
                 }
             try:   # fp64-issue / stall record of the other kernels (rocprofv3 PMC, tools/kernel_rooflines.py): recorded, not measured here
-                with open(os.path.join(ROOT, "profiles", "r02_kernel_rooflines.json")) as f:
+                with open(os.path.join(ROOT, "profiles", "r03_kernel_rooflines.json")) as f:
                     kr = json.load(f)
                 if args.scene == "mix11" and N == 50 and B == 65536:
                     roof["other_kernels_recorded"] = {
-                        "source": "profiles/r02_kernel_rooflines.json (separate rocprofv3 --pmc passes of this workload, one batch in flight)",
+                        "source": "profiles/r03_kernel_rooflines.json (separate rocprofv3 --pmc passes of this workload, one batch in flight)",
                         "kernels": {k: {f: v[f] for f in ("ms_per_solve", "bound", "valu_issue_frac", "hbm_frac", "wait_share", "valu_per_wave") if f in v}
                                     for k, v in kr["kernels"].items()
                                     if k.split("<")[0] in ("k_round_cost", "k_spec_cost", "k_spec_cost_packed", "k_quadratize", "k_multi_forward_packed", "k_multi_forward", "k_tail")}}

@@ -457,6 +457,7 @@ int cilqr_destroy(cilqr_handle h) {
   for (void* p : h->allocs) (void)hipFree(p);
   if (h->in_stage) (void)hipFree(h->in_stage);
   if (h->tail_ws) (void)hipFree(h->tail_ws);
+  if (h->tail_ws1) (void)hipFree(h->tail_ws1);
   for (cilqr_job_set& js : h->sets) {
     if (js.out_stage) (void)hipFree(js.out_stage);
     if (js.h_count) (void)hipHostFree(js.h_count);
@@ -557,7 +558,7 @@ int cilqr_get_profile(cilqr_handle h, cilqr_profile* out) {
 int64_t cilqr_device_bytes(cilqr_handle h) {
   if (h == nullptr) return 0;
   return h->bytes + (int64_t)h->in_stage_bytes + (int64_t)h->sets[0].out_stage_bytes + (int64_t)h->sets[1].out_stage_bytes +
-         (int64_t)h->tail_ws_bytes;
+         (int64_t)h->tail_ws_bytes + (int64_t)h->tail_ws1_bytes;
 }
 
 static int solve_sync(cilqr_solver* h, const cilqr_problem_batch* in, cilqr_solution_batch* out);
@@ -752,6 +753,8 @@ int job_begin(cilqr_solver* h, cilqr_job& j) {
       rc = grow(&h->tail_ws, &h->tail_ws_bytes, need);
       if (rc != CILQR_OK) return rc;
     }
+    rc = grow(&h->tail_ws1, &h->tail_ws1_bytes, need);   // only ever used by the first stage (this thread)
+    if (rc != CILQR_OK) return rc;
   }
   launch_init_counters(j.d, B, st);
   j.n_hint = B;   // upper bound of the active count of the iteration being enqueued
@@ -794,14 +797,19 @@ int job_iterate(cilqr_solver* h, cilqr_job& j, int stage) {
       n_hint = js.h_count[it - kLead];
       if (n_hint == 0) break;                          // iterations it-kLead+1 .. it-1 were no-ops
     }
+    bool hand_over = false;
     if (stage == 1 && h->fin_threshold > 0 && n_hint <= h->fin_threshold) {
       // few enough problems left: they continue in the finishing arena, the main arena is free for the next solve.
-      // The active list of iteration `it` is d.act, its exact length entry it % 3 of the ring of counts.
-      {
-        std::unique_lock<std::mutex> lk(h->mu);
-        h->cv.wait(lk, [h] { return !h->fin_busy; });   // the previous solve still finishing there
+      // Only if that arena is free -- while the solve before this one still finishes there, this one keeps iterating
+      // where it is and asks again next iteration (small batches then run side by side, one in each arena).
+      std::lock_guard<std::mutex> lk(h->mu);
+      if (!h->fin_busy) {
         h->fin_busy = true;
+        hand_over = true;
       }
+    }
+    if (hand_over) {
+      // The active list of iteration `it` is d.act, its exact length entry it % 3 of the ring of counts.
       if (j.tm.begin(3)) return CILQR_ERR_DEVICE;
       DeviceState a = d;
       a.act_next = d.act;
@@ -829,17 +837,11 @@ int job_iterate(cilqr_solver* h, cilqr_job& j, int stage) {
     o.n_dev = d.n_dev; o.n_next = d.n_next; o.n_clear = d.n_clear; o.h_count_dev = d.h_count_dev;
     if (n_hint <= tail_threshold) {
       // few problems left: each gets a workgroup that runs all its remaining iterations (cc:201-319) in one launch
-      if (stage == 1 && !j.handed) {
-        // never handed over (CILQR_OPT_FINISH_THRESHOLD 0): the tail's workspace is shared with the finishing stage
-        // of the solve before this one -- take the finishing stage's place
-        std::unique_lock<std::mutex> lk(h->mu);
-        h->cv.wait(lk, [h] { return !h->fin_busy; });
-        h->fin_busy = true;
-        j.owns_fin = true;
-      }
+      // a solve that was never handed over has the tail workspace of the first stage to itself
+      void* ws = (stage == 1 && !j.handed) ? h->tail_ws1 : h->tail_ws;
       if (j.tm.begin(4)) return CILQR_ERR_DEVICE;
       HIP_TRY(hipMemsetAsync(js.tail_iter_dev, 0, sizeof(int), st));
-      launch_tail(d, h->tail_ws, n_hint, j.o_traj, j.o_it, j.out.max_iter_trajs, js.tail_iter_dev, st);
+      launch_tail(d, ws, n_hint, j.o_traj, j.o_it, j.out.max_iter_trajs, js.tail_iter_dev, st);
       HIP_TRY(hipMemcpyAsync(js.h_count + M + 32, js.tail_iter_dev, sizeof(int), hipMemcpyDeviceToHost, st));
       if (j.tm.end()) return CILQR_ERR_DEVICE;
       j.tail_used = true;

@@ -127,6 +127,8 @@ struct cilqr_solver {
   int tail_threshold = 256;   // active sets up to this size leave the lockstep loop: one workgroup per problem (kernels_tail.hip)
   void* tail_ws = nullptr;    // private arenas of the tail's problems (lazily grown)
   size_t tail_ws_bytes = 0;
+  void* tail_ws1 = nullptr;   // the same for a solve that reaches the tail without having been handed over (first stage)
+  size_t tail_ws1_bytes = 0;
   // asynchronous submit / wait: two jobs in flight, one worker thread per stage
   std::thread worker1, worker2;
   std::mutex mu;

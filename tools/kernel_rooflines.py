@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Per-kernel roofline record from the committed rocprofv3 summaries of one round:
     python tools/kernel_rooflines.py profiles r02 > profiles/r02_kernel_rooflines.json
-Inputs (written by tools/record_profiles.sh, all from `python bench.py --steps 1 --warmup 0 --pipeline 1`):
+Inputs (written by tools/record_profiles.sh, all from `python bench.py --steps 1 --warmup 0 --in-flight 1`):
     <tag>_pmc_all_kernels_1.txt  SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY ...
     <tag>_pmc_all_kernels_2.txt  LDS / VMEM / SALU instruction counts, SQ_LDS_BANK_CONFLICT
     <tag>_pmc_all_kernels_3.txt  FETCH_SIZE (KiB)     <tag>_pmc_all_kernels_4.txt  WRITE_SIZE (KiB)
@@ -54,7 +54,7 @@ def main():
     solves_trace = dur["k_load_goals"][0]
     solves_pmc = int(sq["k_load_goals"]["disp"])
     out = {"source": [f"{tag}_pmc_all_kernels_{i}.txt" for i in (1, 2, 3, 4)] + [f"{tag}_kernel_stats.txt"],
-           "command": "python bench.py --steps 1 --warmup 0 --pipeline 1 --cpu-sample 0 (counters: one rocprofv3 --pmc pass per file)",
+           "command": "python bench.py --steps 1 --warmup 0 --in-flight 1 --cpu-sample 0 (counters: one rocprofv3 --pmc pass per file)",
            "per": "solve of 65536 problems", "clock_hz_assumed": CLOCK_HZ, "kernels": {}}
     for k, (calls, total_ms) in sorted(dur.items(), key=lambda kv: -kv[1][1]):
         if k not in sq:
