@@ -74,6 +74,9 @@ def parse_args(argv=None):
     ap.add_argument("--end-to-end", action="store_true",
                     help="extra (never `value`): obstacle points -> cilqr_build_corridors -> solve on the device")
     ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "backward_traffic.json"))
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="do not measure the backward kernels' HBM traffic (two rocprofv3 --pmc passes over a one-step run of this "
+                         "script, about 25 s); roofline.traffic is then null and roofline.frac uses the bytes recorded under profiles/")
     ap.add_argument("--no-latency", action="store_true",
                     help="skip the drop-in latency section (planning::IlqrOptimizer::Plan with a batch of one, C++ program under tests/cpp)")
     ap.add_argument("--latency-scenes", type=int, default=256, help="scenes per family for the latency section")
@@ -133,6 +136,64 @@ def spawn_ranks(args):
         raise SystemExit(1)
     sys.stdout.write(lines[0] + "\n")
     sys.stdout.flush()
+
+
+def measure_backward_traffic(args, problem_steps_per_solve):
+    """HBM bytes the backward kernels move, from the PMC counters, as MI355X_MICROARCH.md prescribes: FETCH_SIZE and
+    WRITE_SIZE in SEPARATE rocprofv3 --pmc passes (counters only, no trace), each over a one-step, one-batch-in-flight run
+    of this script on the same workload; both in KiB; FETCH_SIZE x 2 on gfx950 (it tallies 64 B per 128 B request of the
+    16 B/lane coalesced loads).  Returns HBM bytes per problem-step over all backward launches of the capture, or None."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    tmp = tempfile.mkdtemp(prefix="cilqr_pmc_", dir="/tmp")
+    try:
+        sums = {}
+        full = {}
+        solves = None
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, c)
+            cmd = ["rocprofv3", "--pmc", c, "-d", d, "--", sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0",
+                   "--in-flight", "1", "--pipeline", "1", "--cpu-sample", "0", "--no-latency", "--no-traffic", "--batch", str(args.batch),
+                   "--scene", args.scene, "--seed", str(args.seed), "--coarse", args.coarse]
+            env = dict(os.environ, TMPDIR="/tmp")
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+                env.pop(k, None)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+            dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return None
+            con = sqlite3.connect(dbs[0])
+            cols = [x[1] for x in con.execute("pragma table_info(counters_collection)")]
+            kcol = "kernel_name" if "kernel_name" in cols else "name"
+            sums[c] = con.execute(f"select sum(value) from counters_collection where {kcol} like '%k_backward%' and counter_name = ?", (c,)).fetchone()[0]
+            # the launch over the whole batch: the first backward dispatch of a solve (largest grid, fewest bytes among those)
+            gcol = "grid_size_x" if "grid_size_x" in cols else ("grid_size" if "grid_size" in cols else None)
+            if gcol:
+                per = con.execute(f"select sum(value), max({gcol}) from counters_collection where {kcol} like '%k_backward%' and "
+                                  f"counter_name = ? group by dispatch_id", (c,)).fetchall()
+                gmax = max(p[1] for p in per)
+                full[c] = min(p[0] for p in per if p[1] == gmax)
+            n = con.execute(f"select count(distinct dispatch_id) from counters_collection where {kcol} like '%k_load_goals%'").fetchone()[0]
+            solves = n if solves is None else min(solves, n)
+            con.close()
+        if not solves or not sums.get("FETCH_SIZE") or not sums.get("WRITE_SIZE"):
+            return None
+        hbm = sums["FETCH_SIZE"] * 1024.0 * 2.0 + sums["WRITE_SIZE"] * 1024.0
+        return {"hbm_bytes_per_problem_step": hbm / (solves * problem_steps_per_solve), "solves_in_capture": int(solves),
+                "fetch_size_kib": sums["FETCH_SIZE"], "write_size_kib": sums["WRITE_SIZE"],
+                "full_batch_launch_hbm_bytes": (full["FETCH_SIZE"] * 2048.0 + full["WRITE_SIZE"] * 1024.0) if len(full) == 2 else None,
+                "method": "rocprofv3 --pmc FETCH_SIZE and, separately, --pmc WRITE_SIZE over `bench.py --steps 1 --warmup 0 --in-flight 1` "
+                          "of this workload; KiB; FETCH_SIZE x 2 (gfx950: 64 B tallied per 128 B request); k_backward + k_backward_team + "
+                          "k_backward_wave dispatches"}
+    except Exception:   # noqa: BLE001
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def plan_latency(scenario, families, n_scenes, seed, workers, batch=64):
@@ -543,6 +604,9 @@ def main():
                               "generator's simplified ones: a different, larger feasible set, hence another "
                               "iteration count than the timed region; sequential (one batch in flight)"}
 
+    traffic = None
+    if world == 1 and not args.no_traffic and not args.no_profile and single and single["bwd_problem_steps"] > 0:
+        traffic = measure_backward_traffic(args, single["bwd_problem_steps"])
     latency = None
     if world == 1 and not args.no_latency:
         latency = plan_latency(scenario, ("ped6", "mix11"), args.latency_scenes, 100 + args.seed, workers)
@@ -578,6 +642,12 @@ def main():
                 rec = tf.get("by_workload", {}).get(f"{args.scene}_n{N}") or (tf if args.scene == "mix11" and N == 50 else None)
             except Exception:
                 rec = None
+            if traffic:   # measured for this run's workload (counter passes over a one-step run): supersedes the recorded figure
+                rec = dict(rec or {}, hbm_bytes_per_problem_step_all_launches=traffic["hbm_bytes_per_problem_step"])
+                if traffic.get("full_batch_launch_hbm_bytes"):
+                    rec["full_batch_launch"] = {"hbm_bytes_per_problem_step": traffic["full_batch_launch_hbm_bytes"] / (B * N)}
+            if rec is not None and "full_batch_launch" not in rec:
+                rec = None if not traffic else dict(rec, full_batch_launch={"hbm_bytes_per_problem_step": rec["hbm_bytes_per_problem_step_all_launches"]})
             real_all = rec["hbm_bytes_per_problem_step_all_launches"] * prof_acc["bwd_steps"] if rec else None
             roof = {
                 "bound": "hbm", "kernel": "cilqr::k_backward + cilqr::k_backward_team",
@@ -589,10 +659,13 @@ def main():
                 "frac": round(real_all / t_all / 1e9 / HBM_PEAK_GBS, 4) if real_all else None,
                 "frac_basis": "HBM bytes really moved (PMC-recorded bytes per problem-step x this run's problem-steps) / time / peak",
                 "frac_algorithmic": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None,
+                # HBM bytes per launch (average over the backward launches of the timed region) from the PMC counters of this
+                # box, this workload; null when the counter passes could not run (then `frac` rests on traffic_recorded)
+                "traffic": (real_all / prof_acc["bwd_launches"]) if (traffic and real_all) else None,
+                "traffic_measured": traffic,
                 "traffic_recorded": ({"bytes_per_launch": real_all / prof_acc["bwd_launches"],
                                       "bytes_per_problem_step": rec["hbm_bytes_per_problem_step_all_launches"],
-                                      "source": os.path.relpath(args.traffic_file, ROOT)} if rec else None),
+                                      "source": os.path.relpath(args.traffic_file, ROOT)} if (rec and not traffic) else None),
                 "algorithmic_bytes_per_launch": alg_bytes / prof_acc["bwd_launches"],
                 "avg_launch_ms": prof_acc["bwd_ms"] / prof_acc["bwd_launches"],
                 "launches": prof_acc["bwd_launches"],
