@@ -37,7 +37,8 @@ int dev_alloc(cilqr_solver* h, T** p, size_t count) {
   return CILQR_OK;
 }
 
-constexpr int64_t kTailMaxProblems = 8192;   // CILQR_OPT_TAIL_THRESHOLD is clamped to this
+constexpr int64_t kTailMaxProblems = 8192;
+constexpr size_t kSmallTransfer = (size_t)4 << 20;   // host batches up to this many bytes travel as one pinned block each way   // CILQR_OPT_TAIL_THRESHOLD is clamped to this
 
 int grow(void** p, size_t* have, size_t need) {
   if (need <= *have) return CILQR_OK;
@@ -122,18 +123,43 @@ int do_load(cilqr_solver* h, const cilqr_problem_batch* in, cilqr_job_set& js, D
     const int g = grow(&h->in_stage, &h->in_stage_bytes, bytes);
     if (g != CILQR_OK) return g;
     double* d = static_cast<double*>(h->in_stage);
-    HIP_TRY(hipMemcpyAsync(d, in->start, n_start * 8, hipMemcpyHostToDevice, st));
-    pv.start = d; d += n_start;
-    HIP_TRY(hipMemcpyAsync(d, in->coarse, n_coarse * 8, hipMemcpyHostToDevice, st));
-    pv.coarse = d; d += n_coarse;
-    HIP_TRY(hipMemcpyAsync(d, in->corridor, n_cor * 8, hipMemcpyHostToDevice, st));
-    pv.corridor = d; d += n_cor;
-    if (want_station) {
-      HIP_TRY(hipMemcpyAsync(d, in->coarse_station, n_sta * 8, hipMemcpyHostToDevice, st));
-      pv.station = d; d += n_sta;
+    const size_t payload = (n_start + n_coarse + n_cor + n_sta) * sizeof(double) + n_cnt * sizeof(int);
+    if (payload <= kSmallTransfer) {
+      // a small batch (the drop-in call is a batch of one): the five arrays go through ONE pinned block and ONE copy --
+      // five pageable copies cost ~10 us each before the first kernel can start
+      if (h->in_pinned == nullptr) {
+        HIP_TRY(hipHostMalloc(&h->in_pinned, kSmallTransfer, hipHostMallocDefault));
+        HIP_TRY(hipEventCreateWithFlags(&h->in_pinned_ev, hipEventDisableTiming));
+      } else {
+        HIP_TRY(hipEventSynchronize(h->in_pinned_ev));   // the previous load's copy has left the block
+      }
+      char* q = static_cast<char*>(h->in_pinned);
+      std::memcpy(q, in->start, n_start * 8); q += n_start * 8;
+      std::memcpy(q, in->coarse, n_coarse * 8); q += n_coarse * 8;
+      std::memcpy(q, in->corridor, n_cor * 8); q += n_cor * 8;
+      if (want_station) { std::memcpy(q, in->coarse_station, n_sta * 8); q += n_sta * 8; }
+      std::memcpy(q, in->corridor_count, n_cnt * 4);
+      HIP_TRY(hipMemcpyAsync(d, h->in_pinned, payload, hipMemcpyHostToDevice, st));
+      HIP_TRY(hipEventRecord(h->in_pinned_ev, st));
+      pv.start = d; d += n_start;
+      pv.coarse = d; d += n_coarse;
+      pv.corridor = d; d += n_cor;
+      if (want_station) { pv.station = d; d += n_sta; }
+      pv.ccount = reinterpret_cast<const int*>(d);
+    } else {
+      HIP_TRY(hipMemcpyAsync(d, in->start, n_start * 8, hipMemcpyHostToDevice, st));
+      pv.start = d; d += n_start;
+      HIP_TRY(hipMemcpyAsync(d, in->coarse, n_coarse * 8, hipMemcpyHostToDevice, st));
+      pv.coarse = d; d += n_coarse;
+      HIP_TRY(hipMemcpyAsync(d, in->corridor, n_cor * 8, hipMemcpyHostToDevice, st));
+      pv.corridor = d; d += n_cor;
+      if (want_station) {
+        HIP_TRY(hipMemcpyAsync(d, in->coarse_station, n_sta * 8, hipMemcpyHostToDevice, st));
+        pv.station = d; d += n_sta;
+      }
+      HIP_TRY(hipMemcpyAsync(d, in->corridor_count, n_cnt * 4, hipMemcpyHostToDevice, st));
+      pv.ccount = reinterpret_cast<const int*>(d);
     }
-    HIP_TRY(hipMemcpyAsync(d, in->corridor_count, n_cnt * 4, hipMemcpyHostToDevice, st));
-    pv.ccount = reinterpret_cast<const int*>(d);
   } else {
     pv.start = in->start; pv.coarse = in->coarse; pv.corridor = in->corridor;
     pv.ccount = in->corridor_count;
@@ -456,10 +482,13 @@ int cilqr_destroy(cilqr_handle h) {
   cilqr_comm_release(h);
   for (void* p : h->allocs) (void)hipFree(p);
   if (h->in_stage) (void)hipFree(h->in_stage);
+  if (h->in_pinned) (void)hipHostFree(h->in_pinned);
+  if (h->in_pinned_ev) (void)hipEventDestroy(h->in_pinned_ev);
   if (h->tail_ws) (void)hipFree(h->tail_ws);
   if (h->tail_ws1) (void)hipFree(h->tail_ws1);
   for (cilqr_job_set& js : h->sets) {
     if (js.out_stage) (void)hipFree(js.out_stage);
+    if (js.out_pinned) (void)hipHostFree(js.out_pinned);
     if (js.h_count) (void)hipHostFree(js.h_count);
     for (hipEvent_t e : js.ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : js.iter_ev) (void)hipEventDestroy(e);
@@ -915,7 +944,14 @@ int job_finish(cilqr_solver* h, cilqr_job& j) {
   launch_export_hist(j.gmain, B, j.o_hist, j.o_nc, j.o_st, j.o_ni, j.o_nit, j.o_at, st);
   if (j.tm.end()) return CILQR_ERR_DEVICE;
   HIP_TRY(hipGetLastError());
-  if (out->memory == CILQR_MEM_HOST) {
+  const size_t out_payload = (j.n_traj + j.n_hist + j.n_itr) * 8 + (size_t)4 * B * 4 + j.n_at;
+  const bool small_out = out->memory == CILQR_MEM_HOST && out_payload <= kSmallTransfer;
+  if (small_out) {
+    // a small batch: the whole staging block in one copy into pinned memory, handed out on the host below (seven
+    // pageable copies cost ~25 us each after the last kernel)
+    if (js.out_pinned == nullptr) HIP_TRY(hipHostMalloc(&js.out_pinned, kSmallTransfer, hipHostMallocDefault));
+    HIP_TRY(hipMemcpyAsync(js.out_pinned, js.out_stage, out_payload, hipMemcpyDeviceToHost, st));
+  } else if (out->memory == CILQR_MEM_HOST) {
     HIP_TRY(hipMemcpyAsync(out->traj, j.o_traj, j.n_traj * 8, hipMemcpyDeviceToHost, st));
     // rows >= n_cost were zero-filled above
     HIP_TRY(hipMemcpyAsync(out->cost_hist, j.o_hist, j.n_hist * 8, hipMemcpyDeviceToHost, st));
@@ -929,6 +965,26 @@ int job_finish(cilqr_solver* h, cilqr_job& j) {
     if (out->alpha_trace) HIP_TRY(hipMemcpyAsync(out->alpha_trace, j.o_at, j.n_at, hipMemcpyDeviceToHost, st));
   }
   HIP_TRY(hipStreamSynchronize(st));
+  if (small_out) {   // same layout as the staging block (job_begin)
+    const char* q = static_cast<const char*>(js.out_pinned);
+    std::memcpy(out->traj, q, j.n_traj * 8); q += j.n_traj * 8;
+    std::memcpy(out->cost_hist, q, j.n_hist * 8); q += j.n_hist * 8;
+    const char* q_it = q;
+    q += j.n_itr * 8;
+    if (out->iter_trajs) {   // only the iterates that exist (the capacity is max_iter + 1 in the drop-in adapter: 820 KB per problem)
+      const int32_t* nit = reinterpret_cast<const int32_t*>(q + (size_t)3 * B * 4);
+      const size_t one = (size_t)h->cfg.n_steps + 1, per = (size_t)out->max_iter_trajs * one * 10 * 8;
+      for (int b = 0; b < B; ++b) {
+        const size_t used = (size_t)std::min(std::max(nit[b], 0), out->max_iter_trajs) * one * 10 * 8;
+        std::memcpy(reinterpret_cast<char*>(out->iter_trajs) + (size_t)b * per, q_it + (size_t)b * per, used);
+      }
+    }
+    std::memcpy(out->n_cost, q, (size_t)B * 4);
+    std::memcpy(out->status, q + (size_t)B * 4, (size_t)B * 4);
+    if (out->n_iter) std::memcpy(out->n_iter, q + (size_t)2 * B * 4, (size_t)B * 4);
+    if (out->iter_trajs) std::memcpy(out->n_iter_trajs, q + (size_t)3 * B * 4, (size_t)B * 4);
+    if (out->alpha_trace) std::memcpy(out->alpha_trace, q + (size_t)4 * B * 4, j.n_at);
+  }
   j.tm.resolve(&j.prof);
   return CILQR_OK;
 }

@@ -45,6 +45,7 @@ struct cilqr_job_set {
   int* tail_iter_dev = nullptr;     // largest iteration count reached inside the tail kernel
   void* out_stage = nullptr;        // problem-major results on the device when the caller's buffers are host memory
   size_t out_stage_bytes = 0;
+  void* out_pinned = nullptr;       // small host batches: the staging block lands here in one copy
   std::vector<hipEvent_t> iter_ev;  // one per lockstep iteration (count read-back)
   std::vector<hipEvent_t> ev;       // profiling
   hipEvent_t handoff = nullptr;     // survivors copied into the finishing arena (recorded on the first stage's stream)
@@ -115,6 +116,8 @@ struct cilqr_solver {
   // staging (lazily grown): problem-major copy of host inputs on the device
   void* in_stage = nullptr;
   size_t in_stage_bytes = 0;
+  void* in_pinned = nullptr;        // small host batches: the input arrays leave from here in one copy
+  hipEvent_t in_pinned_ev = nullptr;
   cilqr_job_set sets[2];
   double* lambda_stage = nullptr;
   int B = 0;               // problems loaded

@@ -136,7 +136,8 @@ typedef struct cilqr_solution_batch {
   int32_t* n_cost;               /* [B] */
   int32_t* status;               /* [B] CILQR_ST_* */
   int32_t* n_iter;               /* [B] iterations started */
-  double* iter_trajs;            /* [B][max_iter_trajs][K][10]: init guess + accepted non-final iterates (cc:170,294) */
+  double* iter_trajs;            /* [B][max_iter_trajs][K][10]: init guess + accepted non-final iterates (cc:170,294);
+                                    entries >= n_iter_trajs[b] are unspecified */
   int32_t* n_iter_trajs;         /* [B] number that would have been produced (may exceed the capacity) */
   int8_t* alpha_trace;           /* optional (NULL to skip) [B][max_iter]: per iteration of Optimize() the index
                                     into the step-size list (cc:197) that the line search accepted, -1 = all

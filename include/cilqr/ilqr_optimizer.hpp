@@ -168,9 +168,13 @@ class IlqrOptimizerT {
     in.lane_group_right = nullptr;
 
     const int max_it = cfg_.max_iter + 1;
-    std::vector<double> traj(static_cast<size_t>(K) * CILQR_TRAJ_FIELDS);
-    std::vector<double> hist(static_cast<size_t>(max_it) * CILQR_COST_FIELDS, 0.0);
-    std::vector<double> iters(static_cast<size_t>(max_it) * K * CILQR_TRAJ_FIELDS);
+    // result buffers live with the object: 0.8 MB of iterates need not be allocated and cleared per call
+    std::vector<double>& traj = traj_buf_;
+    std::vector<double>& hist = hist_buf_;
+    std::vector<double>& iters = iters_buf_;
+    traj.resize(static_cast<size_t>(K) * CILQR_TRAJ_FIELDS);
+    hist.resize(static_cast<size_t>(max_it) * CILQR_COST_FIELDS);
+    iters.resize(static_cast<size_t>(max_it) * K * CILQR_TRAJ_FIELDS);
     int32_t n_cost = 0, status = 0, n_iter = 0, n_it = 0;
     cilqr_solution_batch out;
     out.memory = CILQR_MEM_HOST;
@@ -281,6 +285,7 @@ class IlqrOptimizerT {
   int cmax_ = 0, smax_ = 0;
   int status_ = 0;
   std::vector<Cost> cost_;
+  std::vector<double> traj_buf_, hist_buf_, iters_buf_;
 };
 
 }  // namespace cilqr
