@@ -630,9 +630,10 @@ CILQR_DEV void backward_wave_problem(const DeviceState& s, int slot, double lamb
     dV1 += r0 * kp0 + r1 * kp1;
   };
   for (int i = N - 1; i >= -1; --i) {
-    // inputs of step i (previous B(2,1) moves to Bo first); step -1 only finishes delta_V of step 0
-    if (lane == 0) L[oBo + 5] = L[oB + 5];
-    sync();
+    // inputs of step i; step -1 only finishes delta_V of step 0.  The previous B(2,1) moves to Bo first -- by the lane
+    // that overwrites B(2,1) (lane 5), so the move needs no exchange of its own (every reader of the old Bo is at least
+    // one exchange behind)
+    if (lane == 5) L[oBo + 5] = L[oB + 5];
     if (i >= 0 && lane <= kLinPairs) { L[in0] = pre[0].x; L[in1] = pre[0].y; }
 #pragma unroll
     for (int d = 0; d + 1 < kWaveAhead; ++d) pre[d] = pre[d + 1];
