@@ -35,9 +35,12 @@ constexpr int kTailChunk = 5;   // step sizes costed together: 5 x 51 knots = 25
 struct TailLayout {
   size_t X, U, goals, cor, ccnt, lin, term, gains, Xs, Us, parts, spec_tot, dbl, ints, stride;
 };
+constexpr size_t kNotInLds = ~(size_t)0;
 struct TailArgs {
   char* ws;
   TailLayout L;
+  TailLayout S;     // byte offsets of the tensors that live in LDS instead (kNotInLds: in the private arena of `ws`)
+  int lds_base;     // byte offset of that block inside the kernel's dynamic shared memory
   double* traj;
   double* iter_trajs;
   int it_cap;
@@ -73,24 +76,26 @@ static TailLayout tail_layout(const DeviceState& s) {
 size_t tail_workspace_bytes(const DeviceState& s) { return tail_layout(s).stride; }
 
 // the state as the problem of block `blk` sees it: itself in slot 0 of an arena of capacity 1
-CILQR_DEV DeviceState tail_view(const DeviceState& g, const TailArgs& a, int blk) {
+CILQR_DEV DeviceState tail_view(const DeviceState& g, const TailArgs& a, int blk, char* lds_block) {
   DeviceState t = g;
   char* p = a.ws + (size_t)blk * a.L.stride;
+  // a tensor of the problem lives in LDS when the launch found room for it (tail_lds_layout), else in the arena
+  auto at = [&](size_t in_arena, size_t in_lds) -> char* { return in_lds != kNotInLds ? lds_block + in_lds : p + in_arena; };
   t.Bcap = 1;
   t.spec_cap = 1;
-  t.X = reinterpret_cast<double2*>(p + a.L.X);
-  t.U = reinterpret_cast<double2*>(p + a.L.U);
-  t.goals = reinterpret_cast<double2*>(p + a.L.goals);
-  t.cor = reinterpret_cast<double*>(p + a.L.cor);
-  t.ccnt = reinterpret_cast<int*>(p + a.L.ccnt);
-  t.lin = reinterpret_cast<double2*>(p + a.L.lin);
-  t.term = reinterpret_cast<double2*>(p + a.L.term);
-  t.gains = reinterpret_cast<double2*>(p + a.L.gains);
-  t.Xs = reinterpret_cast<double2*>(p + a.L.Xs);
-  t.Us = reinterpret_cast<double2*>(p + a.L.Us);
-  t.parts = reinterpret_cast<double2*>(p + a.L.parts);
-  t.spec_tot = reinterpret_cast<double*>(p + a.L.spec_tot);
-  double* d = reinterpret_cast<double*>(p + a.L.dbl);
+  t.X = reinterpret_cast<double2*>(at(a.L.X, a.S.X));
+  t.U = reinterpret_cast<double2*>(at(a.L.U, a.S.U));
+  t.goals = reinterpret_cast<double2*>(at(a.L.goals, a.S.goals));
+  t.cor = reinterpret_cast<double*>(at(a.L.cor, a.S.cor));
+  t.ccnt = reinterpret_cast<int*>(at(a.L.ccnt, a.S.ccnt));
+  t.lin = reinterpret_cast<double2*>(at(a.L.lin, a.S.lin));
+  t.term = reinterpret_cast<double2*>(at(a.L.term, a.S.term));
+  t.gains = reinterpret_cast<double2*>(at(a.L.gains, a.S.gains));
+  t.Xs = reinterpret_cast<double2*>(at(a.L.Xs, a.S.Xs));
+  t.Us = reinterpret_cast<double2*>(at(a.L.Us, a.S.Us));
+  t.parts = reinterpret_cast<double2*>(at(a.L.parts, a.S.parts));
+  t.spec_tot = reinterpret_cast<double*>(at(a.L.spec_tot, a.S.spec_tot));
+  double* d = reinterpret_cast<double*>(at(a.L.dbl, a.S.dbl));
   t.dV = d;            // [2]
   t.gnorm = d + 2;
   t.trial = d + 3;     // [5]
@@ -98,7 +103,7 @@ CILQR_DEV DeviceState tail_view(const DeviceState& g, const TailArgs& a, int blk
   t.dlambda = d + 9;
   t.cost_old = d + 10;
   t.dcost = d + 11;
-  int* q = reinterpret_cast<int*>(p + a.L.ints);
+  int* q = reinterpret_cast<int*>(at(a.L.ints, a.S.ints));
   t.cur = q;
   t.pid = q + 1;
   t.done_now = q + 2;
@@ -169,7 +174,11 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(DeviceState g, TailArgs a
   // The view sits in LDS, not in registers: its ~70 uniform fields on top of the kernel's own would spill the scalar
   // registers into vector lanes (385 spills, 159 v_readlane per backward step measured: +60 % on that phase).
   DeviceState* tv = reinterpret_cast<DeviceState*>(flag + 16);
-  if (tid == 0) *tv = tail_view(g, a, blk);
+  // The problem's working set lives in LDS as far as it fits (all of it at N = 50, Cmax = 16: 111 KB; a workgroup has
+  // a CU to itself anyway): every phase of an iteration is a chain of dependent loads and stores -- 51 L2 round trips
+  // for a candidate's total, a round trip per step of the backward pass and of a rollout -- and LDS answers in a tenth
+  // of the time of L2.  What does not fit (the corridor planes of long horizons first) stays in the private arena.
+  if (tid == 0) *tv = tail_view(g, a, blk, reinterpret_cast<char*>(lds) + a.lds_base);
   __syncthreads();
   const DeviceState& t = *tv;
   const int off_view = (int)(reinterpret_cast<const char*>(tv) - reinterpret_cast<const char*>(lds));
@@ -349,7 +358,38 @@ void launch_tail(const DeviceState& g, void* workspace, int n_max, double* traj,
   a.it_cap = max_iter_trajs;
   a.max_iter = max_iter_dev;
   const size_t lane_d = (size_t)((g.nl + g.nr) * kLaneFields + 1) / 2 * 2;
-  const size_t lds = (lane_d + wave::kDoubles + kNumAlpha * 5) * sizeof(double) + 16 * sizeof(int) + sizeof(DeviceState) + 16;
+  const size_t fixed = ((lane_d + wave::kDoubles + kNumAlpha * 5) * sizeof(double) + 16 * sizeof(int) + sizeof(DeviceState) + 31) / 16 * 16;
+  // tensors into LDS by priority until the workgroup's share (one workgroup per CU: 160 KiB less a margin) is used up
+  const size_t budget = (size_t)160 * 1024 - 2048 - fixed;
+  const size_t K = g.p.K, N = g.p.N;
+  struct Item { size_t TailLayout::*field; size_t bytes; };
+  const Item items[] = {
+      {&TailLayout::dbl, 16 * sizeof(double)}, {&TailLayout::ints, 8 * sizeof(int)}, {&TailLayout::spec_tot, (size_t)kNumAlpha * 5 * sizeof(double)},
+      {&TailLayout::term, kTermPairs * sizeof(double2)}, {&TailLayout::gains, N * kGainPairs * sizeof(double2)},
+      {&TailLayout::X, 2 * K * 3 * sizeof(double2)}, {&TailLayout::U, 2 * N * sizeof(double2)},
+      {&TailLayout::lin, N * kLinPairs * sizeof(double2)}, {&TailLayout::parts, (size_t)kNumAlpha * K * kPartPairs * sizeof(double2)},
+      {&TailLayout::Xs, (size_t)kNumAlpha * K * 3 * sizeof(double2)}, {&TailLayout::Us, (size_t)kNumAlpha * N * sizeof(double2)},
+      {&TailLayout::goals, K * 3 * sizeof(double2)}, {&TailLayout::ccnt, K * sizeof(int)}, {&TailLayout::cor, K * g.cmax * 3 * sizeof(double)}};
+  size_t used = 0;
+  a.S = a.L;
+  for (const Item& it : items) {
+    const size_t b = (it.bytes + 15) / 16 * 16;
+    if (used + b <= budget) { a.S.*(it.field) = used; used += b; }
+    else a.S.*(it.field) = kNotInLds;
+  }
+  a.lds_base = (int)fixed;
+  const size_t lds = fixed + used;
+  static bool attr_done[64] = {};   // dynamic shared memory beyond 64 KiB has to be asked for, once per kernel and device
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  bool& attr_set = attr_done[dev & 63];
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tail<5, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tail<5, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tail<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tail<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
   if (g.p.num_of_disc == 5) {
     if (g.exact_ties) hipLaunchKernelGGL((k_tail<5, true>), dim3(n_max), dim3(kTailThreads), lds, st, g, a, n_max);
     else hipLaunchKernelGGL((k_tail<5, false>), dim3(n_max), dim3(kTailThreads), lds, st, g, a, n_max);
