@@ -611,7 +611,10 @@ static int solve_one(cilqr_solver* h, cilqr_job& j, const cilqr_problem_batch* i
   if (rc == CILQR_OK) rc = job_iterate(h, j, 1);
   if (rc == CILQR_OK && j.handed) rc = job_iterate(h, j, 2);
   if (rc == CILQR_OK) rc = job_finish(h, j);
-  else if (j.handed) (void)hipStreamSynchronize(j.st2);
+  else {   // nothing of a failed solve may still be running when its buffers go back to the caller
+    (void)hipStreamSynchronize(j.st1);
+    if (j.st2 != j.st1) (void)hipStreamSynchronize(j.st2);
+  }
   release_fin(h, j);
   return rc;
 }
@@ -778,7 +781,8 @@ int job_begin(cilqr_solver* h, cilqr_job& j) {
     const size_t need = (size_t)std::min(B, h->tail_threshold) * tail_workspace_bytes(j.d);
     if (need > h->tail_ws_bytes) {
       std::unique_lock<std::mutex> lk(h->mu);
-      h->cv.wait(lk, [h] { return !h->fin_busy; });
+      h->cv.wait(lk, [h] { return !h->fin_busy || h->quit; });
+      if (h->quit) return CILQR_ERR_STATE;   // the handle is being destroyed
       rc = grow(&h->tail_ws, &h->tail_ws_bytes, need);
       if (rc != CILQR_OK) return rc;
     }
@@ -834,6 +838,7 @@ int job_iterate(cilqr_solver* h, cilqr_job& j, int stage) {
       std::lock_guard<std::mutex> lk(h->mu);
       if (!h->fin_busy) {
         h->fin_busy = true;
+        j.owns_fin = true;      // released by release_fin, also when an error ends the solve before the hand-over is complete
         hand_over = true;
       }
     }
@@ -1036,6 +1041,7 @@ void worker1_main(cilqr_solver* h) {
       if (rc == CILQR_OK && j.handed) to_stage2 = true;
       else {
         if (rc == CILQR_OK) rc = job_finish(h, j);
+        else (void)hipStreamSynchronize(j.st1);
         release_fin(h, j);
       }
     }

@@ -81,6 +81,29 @@ def test_default_config_matches_reference_defaults(built):
     assert C.sizeof(api.Config) == 4 * 4 + 27 * 8
 
 
+def test_option_and_status_constants_match_the_header(built):
+    """cilqr_amd/api.py mirrors the #defines of include/cilqr.h by hand: every CILQR_OPT_* must agree."""
+    hdr = open(api.HEADER_PATH).read()
+    opts = dict(re.findall(r"#define (CILQR_OPT_[A-Z_]+) (\d+)", hdr))
+    assert len(opts) >= 9 and len(set(opts.values())) == len(opts)            # distinct codes
+    for name, val in opts.items():
+        assert getattr(api, name[len("CILQR_"):]) == int(val), name
+
+
+def test_multi_device_entry_points_reject_bad_arguments_without_a_gpu(built):
+    L = api.lib()
+    cfg = api.default_config(50)
+    h = C.c_void_p()
+    dev = np.zeros(2, np.int32)
+    assert L.cilqr_multi_create(None, dev.ctypes.data, 2, 8, 16, 64, C.byref(h)) == api.ERR_NULL
+    assert L.cilqr_multi_create(C.byref(cfg), None, 2, 8, 16, 64, C.byref(h)) == api.ERR_NULL
+    assert L.cilqr_multi_create(C.byref(cfg), dev.ctypes.data, 0, 8, 16, 64, C.byref(h)) == api.ERR_ARG
+    assert L.cilqr_multi_create(C.byref(cfg), dev.ctypes.data, 2, 1, 16, 64, C.byref(h)) == api.ERR_ARG   # fewer problems than shards
+    assert L.cilqr_multi_solve(None, None, None) == api.ERR_NULL
+    assert L.cilqr_multi_destroy(None) == api.ERR_NULL
+    assert L.cilqr_multi_device_bytes(None) == 0
+
+
 def test_errors_without_gpu(built):
     L = api.lib()
     assert L.cilqr_default_config(None, 50) == api.ERR_NULL
