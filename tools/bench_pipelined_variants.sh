@@ -1,12 +1,12 @@
 #!/bin/bash
-# Default (three batches in flight) bench.py for a list of "name|CILQR_LIB path or -|extra bench args" variants.
+# Default (one handle, two solves in flight) bench.py for a list of "name|CILQR_LIB path or -|extra bench args" variants.
 # usage: tools/bench_pipelined_variants.sh <out-prefix> "name|lib|args" ...
 out=$1; shift
 mkdir -p "$(dirname "$out")"
 for v in "$@"; do
   IFS='|' read -r name lib args <<< "$v"
   if [ "$lib" = "-" ]; then unset CILQR_LIB; else export CILQR_LIB="$lib"; fi
-  python bench.py --cpu-sample 0 $args > "${out}_${name}.json" 2> "${out}_${name}.err"
+  python bench.py --cpu-sample 0 --no-latency --no-traffic $args > "${out}_${name}.json" 2> "${out}_${name}.err"
   python - "$name" "${out}_${name}.json" <<'PY'
 import json, sys
 try:

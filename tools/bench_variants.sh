@@ -6,7 +6,7 @@ mkdir -p "$(dirname "$out")"
 for v in "$@"; do
   IFS='|' read -r name lib args <<< "$v"
   if [ "$lib" = "-" ]; then unset CILQR_LIB; else export CILQR_LIB="$lib"; fi
-  python bench.py --steps 4 --warmup 1 --pipeline 0 --cpu-sample 0 $args > "${out}_${name}.json" 2> "${out}_${name}.err"
+  python bench.py --steps 4 --warmup 1 --in-flight 1 --cpu-sample 0 --no-latency --no-traffic $args > "${out}_${name}.json" 2> "${out}_${name}.err"
   python - "$name" "${out}_${name}.json" <<'PY'
 import json, sys
 try:
