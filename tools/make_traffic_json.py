@@ -25,7 +25,7 @@ def entry(fetch_txt, write_txt, bench_json):
     n_act_sum = solves * rf["mean_problems_per_launch"] * rf["launches"] / b["steps"]
     hbm = fs * 1024 * 2 + ws * 1024
     return {
-        "command": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) -- python bench.py --steps 1 --warmup 0 --pipeline 1 --cpu-sample 0 [--scene ...]",
+        "command": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) -- python bench.py --steps 1 --warmup 0 --in-flight 1 --cpu-sample 0 [--scene ...]",
         "kernel": "cilqr::k_backward + cilqr::k_backward_team", "launches": n, "solves_in_capture": solves,
         "correction": "FETCH_SIZE counts 64 B per 128 B request for 16 B/lane coalesced loads on gfx950 -> x2 (MI355X_MICROARCH.md, HBM); WRITE_SIZE as reported; both in KiB",
         "fetch_size_kib_sum": fs, "write_size_kib_sum": ws, "hbm_bytes_sum": hbm,
