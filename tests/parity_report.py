@@ -27,6 +27,9 @@ def family_report(family, seed, nb, lib_path=None):
     sc = scenario.generate(family, nb, seed=seed, workers=8)
     cfg = api.default_config(sc["n_steps"])
     opt = api.BatchIlqrOptimizer(cfg, batch_capacity=nb, cmax=sc["cmax"])
+    exact = "--exact-lane-ties" in sys.argv
+    if exact:   # the reference's nearest-segment tie rule: the step replay then runs without the lane_tie excuse
+        opt.set_option(api.OPT_EXACT_LANE_TIES, 1)
     t0 = time.time()
     gpu = opt.plan(sc, max_iter_trajs=48, alpha_trace=True)
     t_gpu = time.time() - t0
@@ -44,7 +47,7 @@ def family_report(family, seed, nb, lib_path=None):
         _, ec, et = solution_errors(gpu, ref, b)
         worst_cost, worst_traj = max(worst_cost, ec), max(worst_traj, et)
     t0 = time.time()
-    steps = check_steps(gpu, sc, ocfg)
+    steps = check_steps(gpu, sc, ocfg, allow_lane_tie=not exact)
     t_steps = time.time() - t0
     errs = np.asarray(steps.pop("errors"))
     opt.close()
@@ -75,7 +78,8 @@ def build_report(n=1024, families=FAMILIES, with_reference_order=True):
     share of problems that differ from the oracle in THAT build is what the reference's ill-conditioning costs any
     implementation with another libm; the product's share on top of it is what its re-associations add."""
     import torch  # noqa: F401  (one HIP runtime per process: torch's first)
-    report = {"tolerance_whole_solves": 1e-4, "tolerance_steps": 1e-8, "problems_per_family": n, "families": {}}
+    report = {"tolerance_whole_solves": 1e-4, "tolerance_steps": 1e-8, "problems_per_family": n,
+              "exact_lane_ties": "--exact-lane-ties" in sys.argv, "families": {}}
     for family, seed in families:
         report["families"][family] = family_report(family, seed, n)
     if with_reference_order:
