@@ -163,7 +163,7 @@ def measure_backward_traffic(args, problem_steps_per_solve):
             env = dict(os.environ, TMPDIR="/tmp")
             for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
                 env.pop(k, None)
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
             dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
             if r.returncode != 0 or not dbs:
                 return None
@@ -650,7 +650,7 @@ def main():
                 rec = None if not traffic else dict(rec, full_batch_launch={"hbm_bytes_per_problem_step": rec["hbm_bytes_per_problem_step_all_launches"]})
             real_all = rec["hbm_bytes_per_problem_step_all_launches"] * prof_acc["bwd_steps"] if rec else None
             roof = {
-                "bound": "hbm", "kernel": "cilqr::k_backward + cilqr::k_backward_team",
+                "bound": "hbm", "kernel": "cilqr::k_backward (+ k_backward_team / k_backward_wave for launches of <= 4096 / <= 1024 problems)",
                 "launch": "every backward launch of the timed region, time-weighted (65536 problems down to the tail threshold; "
                           "launches of <= 4096 / <= 1024 problems run the 8-lanes / wave-per-problem kernels and sit on the latency of "
                           "N dependent steps; the last problems finish inside k_tail, not in backward launches).  With "
