@@ -395,7 +395,7 @@ def main():
                 o.set_option(api.OPT_FINISH_THRESHOLD, args.finish_threshold)
             if args.exact_lane_ties:
                 o.set_option(api.OPT_EXACT_LANE_TIES, 1)
-            self.slots = [Slot() for _ in range(D)]
+            self.slots = [Slot() for _ in range(D + 1)]   # D in flight + the one whose results are being gathered
             self.free = list(self.slots)
             self.fifo = []          # submitted, oldest first
             # the first slot doubles as the buffers of the synchronous calls below
@@ -412,14 +412,15 @@ def main():
     prof_acc = dict(bwd_ms=0.0, bwd_launches=0, bwd_steps=0, iters=0, full_ms=0.0, full_launches=0)
     last_gather = [None]   # [0]: result of the last gather; [-1]: the slot it gathered (when any)
 
-    def collect(c, timed):
+    def wait_oldest(c):
         rc = c.opt.wait()           # the oldest solve in flight on this handle
         sl = c.fifo.pop(0)
-        c.free.append(sl)
         if rc != api.OK:
             raise api.CilqrError(rc, "in bench step")
-        if timed and not args.no_profile:
-            p = c.opt.profile()
+        return sl, (c.opt.profile() if not args.no_profile else None)
+
+    def finish(c, sl, p, timed):
+        if timed and p is not None:
             prof_acc["bwd_ms"] += p.backward_ms
             prof_acc["bwd_launches"] += p.backward_launches
             prof_acc["bwd_steps"] += p.backward_problem_steps
@@ -430,21 +431,26 @@ def main():
             # 8 of the 10 trajectory columns travel (time and kappa are functions of the others)
             last_gather[0] = gather_results(sl.traj, sl.hist, sl.nc, sl.st, dst=0, densify=False, derive=(cfg.dt, cfg.wheel_base))
             last_gather.append(sl)
+        c.free.append(sl)
 
     def run_steps(n, timed):
+        # a finished step is gathered AFTER the next one has been submitted (its buffers are a slot of their own), so the
+        # handle is never without work while the host packs and sends results
         for s_ in range(n):
             c = ctx[s_ % P]
-            if len(c.fifo) == D:
-                collect(c, timed)
+            done = wait_oldest(c) if len(c.fifo) == D else None
             sl = c.free.pop(0)
             sl.used = True
             rc = c.opt.submit_raw(prob, sl.sol)
             if rc != api.OK:
                 raise api.CilqrError(rc, "in bench submit")
             c.fifo.append(sl)
+            if done is not None:
+                finish(c, done[0], done[1], timed)
         for c in ctx:
             while c.fifo:
-                collect(c, timed)
+                done = wait_oldest(c)
+                finish(c, done[0], done[1], timed)
 
     def fence():
         if use_dist:
