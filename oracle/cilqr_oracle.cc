@@ -1,8 +1,11 @@
 /*
  * oracle/cilqr_oracle.cc -- scalar-fp64 CPU restatement of the reference CILQR solve.
  *
- * TEST INFRASTRUCTURE ONLY (see cilqr_oracle.h).  PARITY UNPINNED: the reference has no
- * tests/golden vectors and cannot be compiled here (needs Eigen 3.4 + ROS + OpenCV).
+ * TEST INFRASTRUCTURE ONLY (see cilqr_oracle.h).  PARITY UNPINNED for the solve as a whole: the reference
+ * has no tests/golden vectors and ilqr_optimizer.cc / vehicle_model.cc / barrier_function.h cannot be compiled
+ * here (Eigen 3.4 + ROS + OpenCV absent).  PINNED against the reference's own code, bit for bit, where that code
+ * builds with g++ alone (oracle/_ref, oracle/ref_shim.cc; tests/test_reference_pins.py): NormalizeAngle
+ * (math_utils.cpp:53-59), LineSegment2d::DistanceTo (line_segment2d.cpp:61-75) and the nearest-segment loop over it.
  *
  * Every function cites the reference file:line it follows ("cc" = algorithm/ilqr/
  * ilqr_optimizer.cc, "vm" = algorithm/ilqr/vehicle_model.cc, "bf" = algorithm/ilqr/
@@ -888,6 +891,17 @@ double oracle_segment_distance(const double* seg4, double px, double py) {
   Segment s;
   s.Set(seg4[0], seg4[1], seg4[2], seg4[3]);
   return s.DistanceTo(px, py);
+}
+// index FindNearestLaneSegment picks among n segments (start x, y, end x, y each); held against the reference's own
+// LineSegment2d by tests/test_reference_pins.py
+int oracle_nearest_segment(void* h, const double* segs, int n, double px, double py) {
+  std::vector<Lane> lanes(n);
+  for (int i = 0; i < n; ++i) {
+    lanes[i].a = lanes[i].b = lanes[i].c = 0.0;
+    lanes[i].seg.Set(segs[4 * i], segs[4 * i + 1], segs[4 * i + 2], segs[4 * i + 3]);
+  }
+  const Lane& l = static_cast<Oracle*>(h)->FindNearestLaneSegment(px, py, lanes);
+  return static_cast<int>(&l - lanes.data());
 }
 double oracle_barrier_value(void* h, double g) { return static_cast<Oracle*>(h)->BarrierValue(g); }
 void oracle_barrier_jacobian(void* h, double g, const double* dg, int n, double* out) {

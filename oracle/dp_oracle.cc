@@ -1,8 +1,11 @@
 /*
  * oracle/dp_oracle.cc -- CPU oracle of the coarse-trajectory producer.
  *
- * TEST INFRASTRUCTURE ONLY (see cilqr_oracle.h).  PARITY UNPINNED: the reference holds no tests or vectors
- * for this stage and cannot be built here (ROS headers).  This is a line-by-line restatement, with the
+ * TEST INFRASTRUCTURE ONLY (see cilqr_oracle.h).  PARITY UNPINNED for DpPlanner and Environment: the reference
+ * holds no tests or vectors for this stage and dp_planner.cpp / environment.cpp cannot be built here (ROS headers).
+ * PINNED against the reference's own code, bit for bit (oracle/_ref built from the reference's files by g++ alone;
+ * tests/test_reference_pins.py): ComputePathProfile, the DiscretizedTrajectory station / projection / cartesian
+ * queries, Polygon2d::HasOverlap(Box2d(AABox2d)) and Polygon2d::IsPointIn.  This is a line-by-line restatement, with the
  * reference's own structure (one small class per reference class, every helper re-evaluated where the
  * reference re-evaluates it, no caching), of
  *   algorithm/planner/dp_planner.{h,cpp}                      DpPlanner
@@ -727,6 +730,64 @@ int oracle_dp_plan(const double* cfg, const double* center, int n_center, const 
     r[0] = p.time; r[1] = p.s; r[2] = p.x; r[3] = p.y; r[4] = p.theta; r[5] = p.kappa; r[6] = p.velocity; r[7] = p.a; r[8] = p.delta;
   }
   return ok ? 1 : 0;
+}
+
+
+/* ---- test hooks: the restated geometry / trajectory pieces one by one, with the signatures of oracle/ref_shim.cc, so
+ * that tests/test_reference_pins.py can hold each against the reference's own code (oracle/_ref) bit for bit ---- */
+namespace {
+DiscretizedTrajectory hook_trajectory(const double* rows, int n) {
+  std::vector<TrajectoryPoint> pts(n);
+  for (int i = 0; i < n; ++i) {
+    const double* r = rows + 9 * i;
+    pts[i].time = r[0]; pts[i].s = r[1]; pts[i].x = r[2]; pts[i].y = r[3]; pts[i].theta = r[4];
+    pts[i].kappa = r[5]; pts[i].velocity = r[6]; pts[i].left_bound = r[7]; pts[i].right_bound = r[8];
+  }
+  return DiscretizedTrajectory(pts);
+}
+void hook_put(const TrajectoryPoint& p, double* o) {
+  o[0] = p.time; o[1] = p.s; o[2] = p.x; o[3] = p.y; o[4] = p.theta; o[5] = p.kappa; o[6] = p.velocity;
+  o[7] = p.left_bound; o[8] = p.right_bound;
+}
+}  // namespace
+
+int oracle_compute_path_profile(double dt, const double* xy, int n, double* headings, double* s, double* v, double* a,
+                                double* kappa) {
+  std::vector<std::pair<double, double>> pts(n);
+  for (int i = 0; i < n; ++i) pts[i] = {xy[2 * i], xy[2 * i + 1]};
+  std::vector<double> h, ss, vv, aa, kk;
+  if (!ComputePathProfile(dt, pts, &h, &ss, &vv, &aa, &kk)) return 0;
+  for (int i = 0; i < n; ++i) {
+    headings[i] = h[i]; s[i] = ss[i]; v[i] = vv[i]; a[i] = aa[i]; kappa[i] = kk[i];
+  }
+  return 1;
+}
+int oracle_polygon_overlaps_aabox(const double* poly, int n, double x0, double y0, double x1, double y1) {
+  using namespace math;
+  std::vector<Vec2d> pts;
+  for (int i = 0; i < n; ++i) pts.emplace_back(poly[2 * i], poly[2 * i + 1]);
+  const Polygon2d polygon(pts);
+  const Box2d box = Box2d::FromAABox(Vec2d(x0, y0), Vec2d(x1, y1), Vec2d(0.0, 0.0));
+  return polygon.HasOverlap(box) ? 1 : 0;
+}
+int oracle_polygon_point_in(const double* poly, int n, double px, double py) {
+  using namespace math;
+  std::vector<Vec2d> pts;
+  for (int i = 0; i < n; ++i) pts.emplace_back(poly[2 * i], poly[2 * i + 1]);
+  return Polygon2d(pts).IsPointIn(Vec2d(px, py)) ? 1 : 0;
+}
+void oracle_trajectory_evaluate_station(const double* rows, int n, double station, double* out9) {
+  hook_put(hook_trajectory(rows, n).EvaluateStation(station), out9);
+}
+void oracle_trajectory_projection(const double* rows, int n, double px, double py, double* out2) {
+  const auto sl = hook_trajectory(rows, n).GetProjection(math::Vec2d(px, py));
+  out2[0] = sl.x();
+  out2[1] = sl.y();
+}
+void oracle_trajectory_cartesian(const double* rows, int n, double station, double lateral, double* out2) {
+  const auto p = hook_trajectory(rows, n).GetCartesian(station, lateral);
+  out2[0] = p.x();
+  out2[1] = p.y();
 }
 
 }  // extern "C"

@@ -40,6 +40,47 @@ def build(force: bool = False) -> str:
     return so
 
 
+REF_LIB_PATH = os.path.join(_HERE, "_ref", "libcilqr_ref.so")
+_REF = [None, False]
+
+
+def _pin_signatures(L, prefix):
+    """argument / result types of the hooks shared by oracle/ref_shim.cc (prefix ref_) and the oracle (prefix oracle_)"""
+    D, I, P = C.c_double, C.c_int, C.c_void_p
+
+    def sig(name, res, args):
+        f = getattr(L, prefix + name, None)
+        if f is not None:
+            f.restype, f.argtypes = res, args
+    sig("normalize_angle", D, [D])
+    sig("segment_distance", D, [P, D, D])
+    sig("nearest_segment", I, [P, I, D, D])
+    sig("compute_path_profile", I, [D, P, I, P, P, P, P, P])
+    sig("polygon_overlaps_aabox", I, [P, I, D, D, D, D])
+    sig("polygon_point_in", I, [P, I, D, D])
+    sig("trajectory_evaluate_station", None, [P, I, D, P])
+    sig("trajectory_evaluate_time", None, [P, I, D, P])
+    sig("trajectory_cartesian", None, [P, I, D, D, P])
+    sig("tracker_evaluate_time", None, [P, I, D, P])
+    sig("tracker_projection", None, [P, I, D, D, P])
+
+
+def ref_lib():
+    """oracle/_ref/libcilqr_ref.so: the parts of the REFERENCE itself that build here with g++ alone (oracle/ref_shim.cc,
+    oracle/Makefile target `ref`), or None when the file is absent (no reference tree and nothing shipped)."""
+    if not _REF[1]:
+        _REF[1] = True
+        if os.path.isdir("/root/reference/algorithm"):
+            subprocess.check_call(["make", "-C", _HERE, "-s", "ref"])
+        if os.path.exists(REF_LIB_PATH):
+            L = C.CDLL(REF_LIB_PATH)
+            _pin_signatures(L, "ref_")
+            L.ref_trajectory_projection.restype = None
+            L.ref_trajectory_projection.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+            _REF[0] = L
+    return _REF[0]
+
+
 def lib():
     global _LIB
     if _LIB is None:
@@ -56,6 +97,11 @@ def lib():
         L.oracle_build_corridor.argtypes = [C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_int, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_int]
         L.oracle_lane_constraints.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_int]
+        _pin_signatures(L, "oracle_")
+        L.oracle_trajectory_projection.restype = None
+        L.oracle_trajectory_projection.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p]
+        L.oracle_nearest_segment.restype = C.c_int
+        L.oracle_nearest_segment.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double]
         _LIB = L
     return _LIB
 

@@ -1,7 +1,9 @@
 /*
  * oracle/tracker_oracle.cc -- CPU oracle of the alternative init guess.
  *
- * TEST INFRASTRUCTURE ONLY (see cilqr_oracle.h).  PARITY UNPINNED (no reference vectors; Eigen absent).
+ * TEST INFRASTRUCTURE ONLY (see cilqr_oracle.h).  PARITY UNPINNED for the tracker as a whole (no reference vectors;
+ * tracker.cc needs Eigen).  PINNED against the reference's own code (oracle/_ref, tests/test_reference_pins.py): the
+ * EvaluateTime / GetProjection interpolation of the followed trajectory (discretized_trajectory.cpp:130-197).
  * Restates, with plain 3x3 arrays instead of Eigen::MatrixXd,
  *   Tracker::Plan / lqr                 algorithm/ilqr/tracker.cc:12-17, 169-215
  *   Tracker::CalcaulateInitState        tracker.cc:19-55
@@ -376,6 +378,34 @@ int oracle_tracker_init_guess(const double* cfg, const double* start4, const dou
     }
   }
   return 0;
+}
+
+
+/* test hooks with the signatures of oracle/ref_shim.cc (tests/test_reference_pins.py): the tracker's trajectory queries */
+void oracle_tracker_evaluate_time(const double* rows, int n, double time, double* out9) {
+  Follow f;
+  f.tr.resize(n);
+  for (int i = 0; i < n; ++i) {
+    const double* r = rows + 9 * i;
+    f.tr[i].time = r[0]; f.tr[i].s = r[1]; f.tr[i].x = r[2]; f.tr[i].y = r[3]; f.tr[i].theta = r[4];
+    f.tr[i].kappa = r[5]; f.tr[i].velocity = r[6]; f.tr[i].left_bound = r[7]; f.tr[i].right_bound = r[8];
+  }
+  const TrajectoryPoint p = f.EvaluateTime(time);
+  out9[0] = p.time; out9[1] = p.s; out9[2] = p.x; out9[3] = p.y; out9[4] = p.theta; out9[5] = p.kappa; out9[6] = p.velocity;
+  out9[7] = p.left_bound; out9[8] = p.right_bound;
+}
+void oracle_tracker_projection(const double* rows, int n, double px, double py, double* out9) {
+  Follow f;
+  f.tr.resize(n);
+  for (int i = 0; i < n; ++i) {
+    const double* r = rows + 9 * i;
+    f.tr[i].time = r[0]; f.tr[i].s = r[1]; f.tr[i].x = r[2]; f.tr[i].y = r[3]; f.tr[i].theta = r[4];
+    f.tr[i].kappa = r[5]; f.tr[i].velocity = r[6]; f.tr[i].left_bound = r[7]; f.tr[i].right_bound = r[8];
+  }
+  TrajectoryPoint p;
+  f.GetProjection(px, py, &p);
+  out9[0] = p.time; out9[1] = p.s; out9[2] = p.x; out9[3] = p.y; out9[4] = p.theta; out9[5] = p.kappa; out9[6] = p.velocity;
+  out9[7] = p.left_bound; out9[8] = p.right_bound;
 }
 
 }  // extern "C"
