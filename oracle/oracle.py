@@ -81,6 +81,30 @@ def ref_lib():
     return _REF[0]
 
 
+_REF_EIGEN = [None, False]
+
+
+def ref_eigen_lib():
+    """oracle/_ref/libcilqr_ref_eigen.so: the reference's own vehicle model and barrier functions, which exist only
+    where an image has Eigen (oracle/Makefile target `ref_eigen`, oracle/ref_eigen_shim.cc); None otherwise."""
+    if not _REF_EIGEN[1]:
+        _REF_EIGEN[1] = True
+        ref_lib()                                  # its make target tries the Eigen part too
+        path = os.path.join(_HERE, "_ref", "libcilqr_ref_eigen.so")
+        if os.path.exists(path):
+            L = C.CDLL(path)
+            D, I, P = C.c_double, C.c_int, C.c_void_p
+            L.ref_model_create.restype, L.ref_model_create.argtypes = P, [D, D, D]
+            L.ref_model_destroy.restype, L.ref_model_destroy.argtypes = None, [P]
+            L.ref_dynamics.restype, L.ref_dynamics.argtypes = None, [P, P, P, P]
+            L.ref_dynamics_jacobian.restype, L.ref_dynamics_jacobian.argtypes = None, [P, P, P, P, P]
+            L.ref_barrier_value.restype, L.ref_barrier_value.argtypes = D, [D, D, D]
+            L.ref_barrier_jacobian.restype, L.ref_barrier_jacobian.argtypes = None, [D, D, D, P, I, P]
+            L.ref_barrier_hessian.restype, L.ref_barrier_hessian.argtypes = None, [D, D, D, P, P, I, P]
+            _REF_EIGEN[0] = L
+    return _REF_EIGEN[0]
+
+
 def lib():
     global _LIB
     if _LIB is None:

@@ -12,7 +12,10 @@ here reads the reference tree at run time.  What these tests pin:
   SURVEY 8(f)-4   DiscretizedTrajectory time / projection queries as the tracker restates them
 
 Everything else on the path (Eigen-based) stays pinned by the reference's parameter set, its scenario and the analytic
-checks of tests/test_oracle.py only.
+checks of tests/test_oracle.py only -- except where an image has Eigen: then `make -C oracle ref_eigen` also builds the
+reference's vehicle_model.cc and barrier_function.h (oracle/ref_eigen_shim.cc), and the two tests marked needs_eigen
+below hold the oracle's dynamics, Jacobians and barrier derivatives against them (first check).  Here they
+are skipped, and say so.
 """
 import ctypes as C
 
@@ -283,6 +286,58 @@ def test_tracker_trajectory_queries_equal_reference():
                 L.oracle_tracker_projection(_p(rows), n, float(p[0]), float(p[1]), _p(g))
                 REF.ref_trajectory_projection(_p(rows), n, float(p[0]), float(p[1]), _p(r2), _p(r))
                 assert _same_bits(g[:7], r[:7]), (n, p, g, r)
+
+
+# ------------------------------------------------------- the Eigen part of the reference (absent in this image)
+REF_EIGEN = orc.ref_eigen_lib()
+needs_eigen = pytest.mark.skipif(REF_EIGEN is None, reason="no Eigen in this image: the reference's vehicle_model.cc / "
+                                 "barrier_function.h are not built (make -C oracle ref_eigen)")
+
+
+@needs_eigen
+def test_dynamics_and_jacobian_oracle_equal_reference():
+    """VehicleModel::Dynamics / DynamicsJacbian (vehicle_model.cc:20-124) against the oracle's restatement, bit for
+    bit: states over the whole box of the barriers and beyond it, headings outside [-pi, pi) (NormalizeAngle acts)."""
+    cfg = orc.default_config(50)
+    o = orc.Oracle(cfg)
+    m = C.c_void_p(REF_EIGEN.ref_model_create(cfg.wheel_base, cfg.n_steps * cfg.dt, cfg.dt))
+    rng = np.random.default_rng(29)
+    for _ in range(20000):
+        x = np.array([rng.uniform(-100, 100), rng.uniform(-100, 100), rng.uniform(-7, 7), rng.uniform(-2, 25),
+                      rng.uniform(-6, 6), rng.uniform(-0.9, 0.9)])
+        u = np.array([rng.uniform(-12, 12), rng.uniform(-0.4, 0.4)])
+        xn, A, B = np.zeros(6), np.zeros((6, 6)), np.zeros((6, 2))
+        REF_EIGEN.ref_dynamics(m, _p(x), _p(u), _p(xn))
+        REF_EIGEN.ref_dynamics_jacobian(m, _p(x), _p(u), _p(A), _p(B))
+        assert _same_bits(o.dynamics(x, u), xn), (x, u)
+        ga, gb = o.dynamics_jacobian(x, u)
+        assert _same_bits(ga, A) and _same_bits(gb, B), (x, u)
+    REF_EIGEN.ref_model_destroy(m)
+
+
+@needs_eigen
+def test_barrier_oracle_equals_reference():
+    """RelaxBarrierFunction<N> value / Jacbian / Hessian (barrier_function.h:80-146) on both branches and at the
+    switch point, with and without the second-derivative term, N = 6 and N = 2."""
+    cfg = orc.default_config(50)
+    o = orc.Oracle(cfg)
+    t, eps = cfg.barrier_t, cfg.barrier_eps
+    rng = np.random.default_rng(31)
+    gs = np.concatenate([rng.uniform(-30, 3, 4000), -eps + rng.uniform(-1e-6, 1e-6, 500), [-eps, 0.0, -1e-300, np.nextafter(-eps, -1.0)]])
+    for g in gs:
+        g = float(g)
+        assert _same_bits([o.barrier_value(g)], [REF_EIGEN.ref_barrier_value(t, eps, g)]), g
+        for n in (6, 2):
+            dg = rng.uniform(-3, 3, n)
+            ddg = rng.uniform(-2, 2, (n, n))
+            ddg = np.ascontiguousarray(ddg + ddg.T)
+            rj, rh, rh2 = np.zeros(n), np.zeros((n, n)), np.zeros((n, n))
+            REF_EIGEN.ref_barrier_jacobian(t, eps, g, _p(dg), n, _p(rj))
+            REF_EIGEN.ref_barrier_hessian(t, eps, g, _p(dg), None, n, _p(rh))
+            REF_EIGEN.ref_barrier_hessian(t, eps, g, _p(dg), _p(ddg), n, _p(rh2))
+            assert _same_bits(o.barrier_jacobian(g, dg), rj), (g, n)
+            assert _same_bits(o.barrier_hessian(g, dg), rh), (g, n)
+            assert _same_bits(o.barrier_hessian(g, dg, ddg), rh2), (g, n)
 
 
 # ------------------------------------------------------------------------------------------------- the device
