@@ -8,12 +8,15 @@ Workload (config.workload): BASELINE.json configs[2] -- batch 65536 per GPU, 50-
 --gpus N every rank solves its own 65536 scenes (weak scaling, configs[3] at N=8) and the
 results are gathered to rank 0 with one RCCL gather per step inside the timed region.
 
-The K timed steps go through ONE solver handle with two solves in flight (cilqr_submit / cilqr_wait,
-`--in-flight 2`): the handle iterates the bulk of step s+1 in its main arena while the last <= 8192
-problems of step s -- the latency-bound part of a solve -- finish in its small finishing arena on a
-second stream (include/cilqr.h, CILQR_OPT_FINISH_THRESHOLD).  Every step is a complete, independent
-solve of the batch; `value` = problems solved / wall time of the K steps.  `--in-flight 1` is the
-strictly sequential form (`single_batch` reports it from extra steps); `--pipeline P` adds handles.
+The K timed steps go round-robin through `--pipeline` = 3 solver handles, each with two solves in flight
+(cilqr_submit / cilqr_wait, `--in-flight 2`): a handle iterates the bulk of one step in its main arena while
+the last <= 8192 problems of its previous step -- the latency-bound part of a solve -- finish in its small
+finishing arena on a second stream (include/cilqr.h, CILQR_OPT_FINISH_THRESHOLD); and the first stages of
+the three handles, which drift apart by themselves, fill each other's gaps (a backward pass or a rollout is
+one lane per problem: a chain of N dependent steps that leaves most of the chip idle once the active set has
+shrunk, exactly where another handle's cost kernels fit).  Every step is a complete, independent solve of
+the batch; `value` = problems solved / wall time of the K steps.  `one_handle` reports the same steps
+through one handle (a third of the memory), `single_batch` the strictly sequential call.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     backward-pass kernel, every launch of the timed region (time-weighted) and the launches
@@ -45,8 +48,8 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=65536, help="problems per GPU")
     ap.add_argument("--scene", default="mix11")
     ap.add_argument("--seed", type=int, default=2)
@@ -60,8 +63,10 @@ def parse_args(argv=None):
     ap.add_argument("--round-group", type=int, default=-1, help="CILQR_OPT_ROUND_GROUP value (tuning experiments)")
     ap.add_argument("--wave-threshold", type=int, default=-1, help="CILQR_OPT_WAVE_THRESHOLD value (tuning experiments)")
     ap.add_argument("--tail-threshold", type=int, default=-1, help="CILQR_OPT_TAIL_THRESHOLD value (tuning experiments; 0 = lockstep to the end)")
-    ap.add_argument("--pipeline", type=int, default=1,
-                    help="solver handles used in the timed region (each with its own arenas, streams and host threads)")
+    ap.add_argument("--pipeline", type=int, default=3,
+                    help="solver handles used round-robin in the timed region (each with its own arenas, streams and host threads): "
+                         "the latency-bound launches of one handle's first stage run in the gaps of the others'; 1 = one handle "
+                         "(also reported as `one_handle` when more are used)")
     ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2],
                     help="solves in flight per handle (cilqr_submit / cilqr_wait): 2 = the stragglers of one solve finish in the "
                          "handle's finishing arena while the next solve is iterated in its main arena; 1 = one after the other")
@@ -433,11 +438,12 @@ def main():
             last_gather.append(sl)
         c.free.append(sl)
 
-    def run_steps(n, timed):
+    def run_steps(n, timed, handles=None):
         # a finished step is gathered AFTER the next one has been submitted (its buffers are a slot of their own), so the
         # handle is never without work while the host packs and sends results
+        handles = handles or ctx
         for s_ in range(n):
-            c = ctx[s_ % P]
+            c = handles[s_ % len(handles)]
             done = wait_oldest(c) if len(c.fifo) == D else None
             sl = c.free.pop(0)
             sl.used = True
@@ -447,7 +453,7 @@ def main():
             c.fifo.append(sl)
             if done is not None:
                 finish(c, done[0], done[1], timed)
-        for c in ctx:
+        for c in handles:
             while c.fifo:
                 done = wait_oldest(c)
                 finish(c, done[0], done[1], timed)
@@ -546,6 +552,17 @@ def main():
     else:
         hung = False
 
+    # the same steps through ONE of the handles (two solves in flight on it): what a caller with one handle's memory gets
+    one_handle = None
+    if world == 1 and P > 1:
+        run_steps(min(args.warmup, 4), False, ctx[:1])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_steps(args.steps, False, ctx[:1])
+        torch.cuda.synchronize()
+        t_one = (time.perf_counter() - t1) / args.steps
+        one_handle = {"value": round(B / t_one, 1), "unit": "solves/s", "ms_per_step": round(t_one * 1e3, 3),
+                      "batches_in_flight": D, "device_bytes": ctx[0].opt.device_bytes()}
     # sequential form: two more steps back to back on one handle, no events
     seq = None
     if world == 1 and P * D > 1:
@@ -806,6 +823,7 @@ def main():
             "single_batch": ({"value": round(B / seq, 1), "unit": "solves/s", "ms_per_step": round(seq * 1e3, 3),
                               "note": "one batch in flight: the same solve called back to back, nothing overlapped"}
                              if seq else None),
+            "one_handle": one_handle,
             "results_identical_across_solves_in_flight": same,
             "c_abi_gather": cabi,
             "end_to_end": end_to_end,

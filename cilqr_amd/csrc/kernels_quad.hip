@@ -23,7 +23,10 @@ namespace cilqr {
 // The cost kernels exist per disc count: D = 5 (the reference's; unrolled) and D = 0 (any other count), so that the
 // generic path does not set the register budget of the common one.  Three waves per SIMD: the 5-disc cost function
 // fits 168 VGPRs (quad_core.hpp), and the attribute keeps the allocator from trading that for a shorter schedule.
-#define CILQR_COST_ATTR __attribute__((amdgpu_waves_per_eu(3, 3)))
+#ifndef CILQR_COST_OCC
+#define CILQR_COST_OCC 3
+#endif
+#define CILQR_COST_ATTR __attribute__((amdgpu_waves_per_eu(CILQR_COST_OCC, CILQR_COST_OCC)))
 // ... and per tie rule (EX: CILQR_OPT_EXACT_LANE_TIES, see nearest_from_cell)
 #define CILQR_LAUNCH_BY_DISCS(kernel, grid, block, lds, st, ...)                                            \
   do {                                                                                                     \
@@ -253,8 +256,13 @@ void launch_init_cost_commit(const DeviceState& s, int n, hipStream_t st) {
   hipLaunchKernelGGL(k_init_cost_commit, dim3((n + 255) / 256), dim3(256), 0, st, s, n);
 }
 
+#ifdef CILQR_QUAD_OCC
+#define CILQR_QUAD_ATTR __attribute__((amdgpu_waves_per_eu(CILQR_QUAD_OCC, CILQR_QUAD_OCC)))
+#else
+#define CILQR_QUAD_ATTR
+#endif
 template <int D, bool EX>
-__global__ __launch_bounds__(256) void k_quadratize(DeviceState s, const int* __restrict__ list, int n,
+__global__ __launch_bounds__(256) CILQR_QUAD_ATTR void k_quadratize(DeviceState s, const int* __restrict__ list, int n,
                                                     int only_upd) {
   extern __shared__ double lds[];
   n = active_count(s, n);

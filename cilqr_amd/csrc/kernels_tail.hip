@@ -160,8 +160,13 @@ __device__ __attribute__((noinline)) void tail_knot_cost(int off_view, int r, in
 #define TP_DECL
 #define TP(k)
 #endif
+#ifdef CILQR_TAIL_OCC
+#define CILQR_TAIL_ATTR __attribute__((amdgpu_waves_per_eu(CILQR_TAIL_OCC, CILQR_TAIL_OCC)))
+#else
+#define CILQR_TAIL_ATTR
+#endif
 template <int D, bool EX>
-__global__ __launch_bounds__(kTailThreads) void k_tail(DeviceState g, TailArgs a, int n_max) {
+__global__ __launch_bounds__(kTailThreads) CILQR_TAIL_ATTR void k_tail(DeviceState g, TailArgs a, int n_max) {
   extern __shared__ double lds[];
   const int n = active_count(g, n_max);
   const int blk = blockIdx.x;

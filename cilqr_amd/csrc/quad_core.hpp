@@ -165,19 +165,35 @@ CILQR_DEV void knot_cost_core(const DeviceState& s, const double* __restrict__ l
   // LaneBoundaryCost cc:583-603, disc by disc (a rolled loop: fetching the ten candidate lists up front hides
   // their latency but holds 40 registers through the searches, which costs the third wave per SIMD)
   BarGroup lall;
+#ifdef CILQR_COST_PROFILE
+  unsigned long long cp_fetch = 0, cp_search = 0;
+#endif
 #pragma unroll 1
   for (int j = 0; j < D; ++j) {
+#ifdef CILQR_COST_PROFILE
+    const unsigned long long cp_a = wall_clock64();
+#endif
     const uint4 cl = lane_cell_fetch(s, 0, px[j], py[j]);
     const uint4 cr = lane_cell_fetch(s, 1, px[j], py[j]);
+#ifdef CILQR_COST_PROFILE
+    asm volatile("" :: "v"(cl.x), "v"(cr.x));
+    const unsigned long long cp_b = wall_clock64();
+#endif
     const double* L = lanes + nearest_from_cell<EX>(s, lanes, 0, cl, px[j], py[j]) * kLaneFields;
     const double* Rr = lanes + (s.nl + nearest_from_cell<EX>(s, lanes, 1, cr, px[j], py[j])) * kLaneFields;
     const double g[2] = {L[0] * px[j] + L[1] * py[j] - L[2], Rr[0] * px[j] + Rr[1] * py[j] - Rr[2]};
     bar_accumulate(p, g, lall);
+#ifdef CILQR_COST_PROFILE
+    asm volatile("" :: "v"(lall.prod));
+    cp_fetch += cp_b - cp_a;
+    cp_search += wall_clock64() - cp_b;
+#endif
   }
   const double lcost = bar_group_value(p, lall);
 #ifdef CILQR_COST_PROFILE
   asm volatile("" :: "v"(lcost));
   CP_STAMP(4);   // lanes
+  if ((threadIdx.x & 63) == 0) g_cost_prof[CP_WAVE * 8 + 7] = (cp_fetch << 32) | (cp_search & 0xffffffffull);   // cell words / searches
 #endif
   out[0] = make_double2(jx, ju);
   out[stride] = dyn;

@@ -36,7 +36,7 @@ constexpr int kGainPairs = 7;   // 14 doubles
 constexpr int kPartPairs = 3;
 constexpr int kNumAlpha = 11;
 constexpr int kMaxDiscs = 16;
-constexpr int kLaneFields = 10;  // a b c | sx sy | ux uy | len | ex ey
+constexpr int kLaneFields = 11;  // a b c | sx sy | ux uy | len | ex ey | pad (an odd row stride: rows of different segments start in different LDS banks)
 constexpr int kGridCellBytes = 16;
 constexpr int kGridMaxCells = 1 << 16;  // per side
 constexpr int kGridFullScan = 255;      // cell marker: too many candidates, scan every segment

@@ -38,4 +38,7 @@ names = ["args + lane tables -> LDS + barrier", "cur[slot] -> state loaded", "go
 print(f"B={B}: stage_total_cost {dt * 1e6:.1f} us for this call; {len(p)} waves recorded; kernel span {p[:, 6].max() + p[np.argmax(p[:, 6]), 5] - p[:, 6].min():.1f} us")
 for k, nm in enumerate(names):
     print(f"  {nm:55s} mean {p[:, k].mean():7.2f}  median {np.median(p[:, k]):7.2f}  p95 {np.quantile(p[:, k], 0.95):7.2f} us")
+f, sr = (buf.reshape(W, 8)[:, 7] >> np.uint64(32)).astype(np.float64) * 0.01, (buf.reshape(W, 8)[:, 7] & np.uint64(0xffffffff)).astype(np.float64) * 0.01
+ok = buf.reshape(W, 8)[:, 5] > 0
+print(f"  lanes, of which: cell words arrived (10 fetches, 5 waits) mean {f[ok].mean():7.2f} us; searches + plane rows + barrier terms mean {sr[ok].mean():7.2f} us")
 opt.close()

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Records the measurement set of one round on the GPU box into gpurun_out/<tag>/ :
 #   bench JSON of the default command; the same command under rocprofv3 --kernel-trace --stats, once as it is (three
-#   batches in flight: what `value` is measured on) and once with --in-flight 1 (one batch at a time: per-kernel
+#   handles with two solves in flight each: what `value` is measured on) and once with --in-flight 1 (one batch at a time: per-kernel
 #   durations that other streams do not inflate, and the per-iteration timeline); PMC passes for the HBM traffic of the
 #   backward kernels (separate runs, counters only) on every bench workload; SQ counter passes over one solve for the
 #   other kernels; the other BASELINE configs, the DP scene source, end to end, PCIe-inclusive.
@@ -16,13 +16,13 @@ cd /tmp && export TMPDIR=/tmp && cd "$root"
 python bench.py > "$out/${tag}_bench.json" 2> "$out/bench.err"
 rocprofv3 --kernel-trace --stats -d "$out/kt3" -- python bench.py --cpu-sample 0 --no-latency > "$out/${tag}_bench_under_rocprofv3.json" 2> "$out/kt3.err"
 python tools/prof_summary.py "$out/kt3" > "$out/${tag}_kernel_stats_pipelined.txt" 2>&1
-rocprofv3 --kernel-trace --stats -d "$out/kt1" -- python bench.py --in-flight 1 --cpu-sample 0 --no-latency > "$out/${tag}_bench_pipeline1_under_rocprofv3.json" 2> "$out/kt1.err"
+rocprofv3 --kernel-trace --stats -d "$out/kt1" -- python bench.py --steps 6 --warmup 2 --in-flight 1 --pipeline 1 --cpu-sample 0 --no-latency > "$out/${tag}_bench_pipeline1_under_rocprofv3.json" 2> "$out/kt1.err"
 { python tools/prof_summary.py "$out/kt1" --iters 1,2,5,10,20,40,80; python tools/phase_summary.py "$out/kt1"; } > "$out/${tag}_kernel_stats.txt" 2>&1
 targs=""
 for wl in "mix11:50:" "dyn20:100:--scene dyn20" "dyn20x:100:--scene dyn20x"; do
   IFS=: read -r name n extra <<< "$wl"
   for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $c -d "$out/pmc_${name}_$c" -- python bench.py --steps 1 --warmup 0 --in-flight 1 --cpu-sample 0 --no-latency $extra > "$out/pmc_${name}_$c.json" 2> "$out/pmc_${name}_$c.err"
+    rocprofv3 --pmc $c -d "$out/pmc_${name}_$c" -- python bench.py --steps 1 --warmup 0 --in-flight 1 --pipeline 1 --cpu-sample 0 --no-latency $extra > "$out/pmc_${name}_$c.json" 2> "$out/pmc_${name}_$c.err"
     python tools/pmc_kernel.py "$out/pmc_${name}_$c" k_backward > "$out/${tag}_pmc_backward_${name}_$c.txt" 2>&1
   done
   targs="$targs ${name}_n${n} $out/${tag}_pmc_backward_${name}_FETCH_SIZE.txt $out/${tag}_pmc_backward_${name}_WRITE_SIZE.txt $out/pmc_${name}_FETCH_SIZE.json"
@@ -33,13 +33,15 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_
            "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_LDS" \
            "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  rocprofv3 --pmc $set -d "$out/pmc_all_$i" -- python bench.py --steps 1 --warmup 0 --in-flight 1 --cpu-sample 0 --no-latency > "$out/pmc_all_$i.json" 2> "$out/pmc_all_$i.err"
+  rocprofv3 --pmc $set -d "$out/pmc_all_$i" -- python bench.py --steps 1 --warmup 0 --in-flight 1 --pipeline 1 --cpu-sample 0 --no-latency > "$out/pmc_all_$i.json" 2> "$out/pmc_all_$i.err"
   python tools/pmc_summary.py "$out/pmc_all_$i" > "$out/${tag}_pmc_all_kernels_$i.txt" 2>&1
 done
 python tools/kernel_rooflines.py "$out" "$tag" > "$out/${tag}_kernel_rooflines.json" 2> "$out/kr.err"
+python bench.py --pipeline 1 --cpu-sample 0 --no-latency > "$out/${tag}_bench_one_handle.json" 2> "$out/h1.err"
 python bench.py --pipeline 2 --cpu-sample 0 --no-latency > "$out/${tag}_bench_two_handles.json" 2> "$out/h2.err"
+python bench.py --steps 20 --warmup 5 --cpu-sample 0 --no-latency > "$out/${tag}_bench_steps20_warmup5.json" 2> "$out/s20.err"
 python bench.py --exact-lane-ties --cpu-sample 0 --no-latency > "$out/${tag}_bench_exact_lane_ties.json" 2> "$out/et.err"
-python bench.py --tail-threshold 0 --in-flight 1 --cpu-sample 0 > "$out/${tag}_bench_lockstep_only_pipeline1.json" 2> "$out/ls.err"
+python bench.py --tail-threshold 0 --in-flight 1 --pipeline 1 --cpu-sample 0 > "$out/${tag}_bench_lockstep_only_pipeline1.json" 2> "$out/ls.err"
 python bench.py --scene ped6 --batch 4096 --cpu-sample 0 > "$out/${tag}_bench_config1_ped6_b4096.json" 2> "$out/c1.err"
 python bench.py --scene dyn20 --cpu-sample 0 > "$out/${tag}_bench_config4_dyn20_n100.json" 2> "$out/c4.err"
 python bench.py --scene dyn20x --cpu-sample 0 > "$out/${tag}_bench_config4_dyn20x_n100.json" 2> "$out/c4x.err"
