@@ -376,9 +376,12 @@ def main():
             self.sol = api.SolutionBatch(api.MEM_DEVICE, 0, self.traj.data_ptr(), self.hist.data_ptr(), self.nc.data_ptr(),
                                          self.st.data_ptr(), self.ni.data_ptr(), None, None)
 
-    class Ctx:   # one handle: solver, stream, result buffers of the solves it keeps in flight
-        def __init__(self):
-            self.opt = api.BatchIlqrOptimizer(cfg, device=local_rank, batch_capacity=B, cmax=cmax, max_lane_segments=smax)
+    # the handles live in ONE pool (cilqr_pool_*): the timed steps are submitted to the pool, which deals them out round-robin
+    pool = api.HandlePool(cfg, device=local_rank, handles=P, batch_capacity=B, cmax=cmax, max_lane_segments=smax)
+
+    class Ctx:   # one handle of the pool: its stream, options and the result buffers of the solves it keeps in flight
+        def __init__(self, k):
+            self.opt = pool.handle_at(k, batch_capacity=B, cmax=cmax)
             self.stream = torch.cuda.Stream()
             self.opt.set_stream(self.stream.cuda_stream)
             o = self.opt
@@ -407,7 +410,7 @@ def main():
             s0 = self.slots[0]
             self.traj, self.hist, self.nc, self.st, self.ni, self.sol = s0.traj, s0.hist, s0.nc, s0.st, s0.ni, s0.sol
 
-    ctx = [Ctx() for _ in range(P)]
+    ctx = [Ctx(k) for k in range(P)]
     opt = ctx[0].opt
     prob = opt.make_problem(B, d_start.data_ptr(), d_coarse.data_ptr(), d_cor.data_ptr(), d_cnt.data_ptr(),
                             cmax, left.ctypes.data, right.ctypes.data, left.shape[0], right.shape[0],
@@ -417,12 +420,17 @@ def main():
     prof_acc = dict(bwd_ms=0.0, bwd_launches=0, bwd_steps=0, iters=0, full_ms=0.0, full_launches=0)
     last_gather = [None]   # [0]: result of the last gather; [-1]: the slot it gathered (when any)
 
-    def wait_oldest(c):
-        rc = c.opt.wait()           # the oldest solve in flight on this handle
+    dealt = [0, 0]   # solves submitted to / collected from the pool so far: solve s runs on handle s % P, the oldest is collected first
+
+    def wait_oldest(c, through_pool):
+        # the oldest solve in flight: of the pool (it sits on handle c = ctx[collected % P]) or of handle c used alone
+        rc = pool.wait() if through_pool else c.opt.wait()
         sl = c.fifo.pop(0)
         if rc != api.OK:
             raise api.CilqrError(rc, "in bench step")
-        return sl, (c.opt.profile() if not args.no_profile else None)
+        if through_pool:
+            dealt[1] += 1
+        return sl, ((pool.profile() if through_pool else c.opt.profile()) if not args.no_profile else None)
 
     def finish(c, sl, p, timed):
         if timed and p is not None:
@@ -438,25 +446,31 @@ def main():
             last_gather.append(sl)
         c.free.append(sl)
 
-    def run_steps(n, timed, handles=None):
-        # a finished step is gathered AFTER the next one has been submitted (its buffers are a slot of their own), so the
-        # handle is never without work while the host packs and sends results
-        handles = handles or ctx
+    def run_steps(n, timed, alone=None):
+        # alone = None: the steps go to the POOL (cilqr_pool_submit / cilqr_pool_wait), at most P * D in flight;
+        # alone = a handle of the (then empty) pool: cilqr_submit / cilqr_wait on it, at most D in flight.
+        # A finished step is gathered AFTER the next one has been submitted (its buffers are a slot of their own), so no
+        # handle is without work while the host packs and sends results.
+        through_pool = alone is None
         for s_ in range(n):
-            c = handles[s_ % len(handles)]
-            done = wait_oldest(c) if len(c.fifo) == D else None
+            c = ctx[dealt[0] % P] if through_pool else alone       # the handle this step is dealt to
+            oldest = ctx[dealt[1] % P] if through_pool else alone
+            full = (dealt[0] - dealt[1] == P * D) if through_pool else (len(alone.fifo) == D)
+            done = (oldest, wait_oldest(oldest, through_pool)) if full else None
             sl = c.free.pop(0)
             sl.used = True
-            rc = c.opt.submit_raw(prob, sl.sol)
+            rc = pool.submit_raw(prob, sl.sol) if through_pool else c.opt.submit_raw(prob, sl.sol)
             if rc != api.OK:
                 raise api.CilqrError(rc, "in bench submit")
+            if through_pool:
+                dealt[0] += 1
             c.fifo.append(sl)
             if done is not None:
-                finish(c, done[0], done[1], timed)
-        for c in handles:
-            while c.fifo:
-                done = wait_oldest(c)
-                finish(c, done[0], done[1], timed)
+                finish(done[0], done[1][0], done[1][1], timed)
+        while (dealt[0] > dealt[1]) if through_pool else alone.fifo:
+            oldest = ctx[dealt[1] % P] if through_pool else alone
+            done = wait_oldest(oldest, through_pool)
+            finish(oldest, done[0], done[1], timed)
 
     def fence():
         if use_dist:
@@ -555,10 +569,10 @@ def main():
     # the same steps through ONE of the handles (two solves in flight on it): what a caller with one handle's memory gets
     one_handle = None
     if world == 1 and P > 1:
-        run_steps(min(args.warmup, 4), False, ctx[:1])
+        run_steps(min(args.warmup, 4), False, ctx[0])
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        run_steps(args.steps, False, ctx[:1])
+        run_steps(args.steps, False, ctx[0])
         torch.cuda.synchronize()
         t_one = (time.perf_counter() - t1) / args.steps
         one_handle = {"value": round(B / t_one, 1), "unit": "solves/s", "ms_per_step": round(t_one * 1e3, 3),
@@ -847,7 +861,8 @@ def main():
             os.write(real_stdout, (json.dumps(out) + "\n").encode())
         os._exit(0)
     for c in ctx:
-        c.opt.close()
+        c.opt.close()    # wrappers of the pool's handles: nothing destroyed here
+    pool.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -28,7 +28,7 @@ OPT_ROUND_GROUP = 7
 OPT_FINISH_THRESHOLD = 8
 OPT_EXACT_LANE_TIES = 9
 ST_RUNNING, ST_CONVERGED_ABS, ST_CONVERGED_REL, ST_GNORM, ST_UNSOLVED, ST_MAX_ITER, ST_NO_CORRIDOR = range(7)
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 T_GOALS, T_CORRIDOR, T_LANES, T_X, T_U, T_XCAND, T_UCAND, T_A, T_B, T_LX, T_LU, T_LXX, T_LUU, \
     T_KFB, T_KFF, T_DV, T_GNORM = range(17)
@@ -129,6 +129,8 @@ EXPORTS = [
     "cilqr_set_tracker_config",
     "cilqr_multi_create", "cilqr_multi_destroy", "cilqr_multi_solve", "cilqr_multi_set_option", "cilqr_multi_shards",
     "cilqr_multi_device_bytes",
+    "cilqr_pool_create", "cilqr_pool_destroy", "cilqr_pool_submit", "cilqr_pool_wait", "cilqr_pool_depth", "cilqr_pool_handle_at",
+    "cilqr_pool_set_option", "cilqr_pool_get_profile", "cilqr_pool_device_bytes",
     "cilqr_comm_unique_id", "cilqr_comm_create", "cilqr_comm_destroy", "cilqr_comm_info", "cilqr_gather_results",
 ]
 UNIQUE_ID_BYTES = 128
@@ -198,6 +200,19 @@ def lib():
         L.cilqr_multi_shards.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]
         L.cilqr_multi_device_bytes.argtypes = [C.c_void_p]
         L.cilqr_multi_device_bytes.restype = C.c_int64
+        L.cilqr_pool_create.argtypes = [C.POINTER(Config), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                        C.POINTER(C.c_void_p)]
+        L.cilqr_pool_destroy.argtypes = [C.c_void_p]
+        L.cilqr_pool_submit.argtypes = [C.c_void_p, C.POINTER(ProblemBatch), C.POINTER(SolutionBatch)]
+        L.cilqr_pool_wait.argtypes = [C.c_void_p]
+        L.cilqr_pool_depth.argtypes = [C.c_void_p]
+        L.cilqr_pool_depth.restype = C.c_int32
+        L.cilqr_pool_handle_at.argtypes = [C.c_void_p, C.c_int32]
+        L.cilqr_pool_handle_at.restype = C.c_void_p
+        L.cilqr_pool_set_option.argtypes = [C.c_void_p, C.c_int32, C.c_int64]
+        L.cilqr_pool_get_profile.argtypes = [C.c_void_p, C.POINTER(Profile)]
+        L.cilqr_pool_device_bytes.argtypes = [C.c_void_p]
+        L.cilqr_pool_device_bytes.restype = C.c_int64
         L.cilqr_comm_unique_id.argtypes = [C.c_void_p]
         L.cilqr_comm_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
         L.cilqr_comm_destroy.argtypes = [C.c_void_p]
@@ -230,25 +245,31 @@ class BatchIlqrOptimizer:
     """Batched drop-in of IlqrOptimizer: ``plan`` = Plan + cost() for B problems on one GPU."""
 
     def __init__(self, cfg: Config | None = None, n_steps: int = 50, device: int = 0,
-                 batch_capacity: int = 1, cmax: int = 16, max_lane_segments: int = 64):
+                 batch_capacity: int = 1, cmax: int = 16, max_lane_segments: int = 64, adopt=None):
+        """adopt: an existing cilqr_handle (HandlePool.handle_at) to wrap instead of creating one; never destroyed here."""
         self.cfg = cfg or default_config(n_steps)
         self.N = self.cfg.n_steps
         self.K = self.N + 1
         self.cmax = cmax
         self.capacity = batch_capacity
         self.L = lib()
-        self.h = C.c_void_p()
-        rc = self.L.cilqr_create(C.byref(self.cfg), device, batch_capacity, cmax, max_lane_segments,
-                                 C.byref(self.h))
-        if rc != OK:
+        self.owned = adopt is None
+        if adopt is not None:
+            self.h = C.c_void_p(adopt)
+        else:
             self.h = C.c_void_p()
-            raise CilqrError(rc, "in cilqr_create")
+            rc = self.L.cilqr_create(C.byref(self.cfg), device, batch_capacity, cmax, max_lane_segments,
+                                     C.byref(self.h))
+            if rc != OK:
+                self.h = C.c_void_p()
+                raise CilqrError(rc, "in cilqr_create")
         self.B = 0
         self.nl = self.nr = 0
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h.value:
-            self.L.cilqr_destroy(self.h)
+            if self.owned:
+                self.L.cilqr_destroy(self.h)
             self.h = C.c_void_p()
 
     def __del__(self):
@@ -538,6 +559,55 @@ def lane_constraints(boundary, segment_length: float = 5.0, is_left: bool = True
     if m < 0:
         raise CilqrError(m, "lane_constraints")
     return rows[:m].copy()
+
+
+class HandlePool:
+    """cilqr_pool_*: a stream of batches on ONE GPU through several handles dealt out round-robin (include/cilqr.h).
+    submit_raw() up to depth() solves, wait() collects the oldest; results bit-identical to BatchIlqrOptimizer."""
+
+    def __init__(self, cfg: "Config | None" = None, device: int = 0, handles: int = 3, batch_capacity: int = 1, cmax: int = 16,
+                 max_lane_segments: int = 64, n_steps: int = 50):
+        self.L = lib()
+        self.cfg = cfg if cfg is not None else default_config(n_steps)
+        self.K = self.cfg.n_steps + 1
+        self.h = C.c_void_p()
+        rc = self.L.cilqr_pool_create(C.byref(self.cfg), device, handles, batch_capacity, cmax, max_lane_segments, C.byref(self.h))
+        if rc != OK:
+            raise CilqrError(rc, "in cilqr_pool_create")
+
+    def close(self):
+        if self.h:
+            self.L.cilqr_pool_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def depth(self) -> int:
+        return int(self.L.cilqr_pool_depth(self.h))
+
+    def handle_at(self, k: int, **kw) -> "BatchIlqrOptimizer":
+        """handle k of the pool as a BatchIlqrOptimizer (not owned; valid while the pool lives and nothing is in flight on it)"""
+        h = self.L.cilqr_pool_handle_at(self.h, k)
+        if not h:
+            raise CilqrError(ERR_STATE, "in cilqr_pool_handle_at")
+        return BatchIlqrOptimizer(self.cfg, adopt=h, **kw)
+
+    def set_option(self, option: int, value: int):
+        rc = self.L.cilqr_pool_set_option(self.h, option, value)
+        if rc != OK:
+            raise CilqrError(rc, "in cilqr_pool_set_option")
+
+    def device_bytes(self) -> int:
+        return int(self.L.cilqr_pool_device_bytes(self.h))
+
+    def submit_raw(self, prob: ProblemBatch, sol: SolutionBatch) -> int:
+        return self.L.cilqr_pool_submit(self.h, C.byref(prob), C.byref(sol))
+
+    def wait(self) -> int:
+        return self.L.cilqr_pool_wait(self.h)
+
+    def profile(self) -> Profile:
+        p = Profile()
+        self.L.cilqr_pool_get_profile(self.h, C.byref(p))
+        return p
 
 
 class MultiDeviceOptimizer:

@@ -980,6 +980,53 @@ def test_nearest_lane_grid_equals_linear_scan():
     opt.close()
 
 
+def test_handle_pool_deals_batches_round_robin_bit_identically():
+    """cilqr_pool_*: three handles on one GPU, seven different batches submitted as a stream (up to depth = 6 in
+    flight, the oldest collected first).  Every batch comes back bit-identical to the synchronous call; a submit beyond
+    the depth and a wait on an empty pool are refused; destroy collects what is still in flight."""
+    torch = pytest.importorskip("torch")
+    sizes = [9000, 700, 8500, 100, 9000, 3000, 5000]
+    scenes = [scenario.generate("mix11", n, seed=300 + i) for i, n in enumerate(sizes)]
+    cfg = api.default_config(scenes[0]["n_steps"])
+    one = api.BatchIlqrOptimizer(cfg, batch_capacity=max(sizes), cmax=scenes[0]["cmax"], max_lane_segments=64)
+    sync = [one.plan(sc) for sc in scenes]
+    pool = api.HandlePool(cfg, device=0, handles=3, batch_capacity=max(sizes), cmax=scenes[0]["cmax"], max_lane_segments=64)
+    assert pool.depth() == 6 and pool.device_bytes() > 2 * api.BatchIlqrOptimizer.device_bytes(pool.handle_at(0))
+    K, M = cfg.n_steps + 1, cfg.max_iter
+    jobs = []
+    for sc in scenes:
+        B = sc["coarse"].shape[0]
+        keep = {k: np.ascontiguousarray(sc[k]) for k in ("start", "coarse", "corridor", "ccount", "left", "right")}
+        prob = one.make_problem(B, keep["start"].ctypes.data, keep["coarse"].ctypes.data, keep["corridor"].ctypes.data,
+                                keep["ccount"].ctypes.data, sc["cmax"], keep["left"].ctypes.data, keep["right"].ctypes.data,
+                                keep["left"].shape[0], keep["right"].shape[0], api.MEM_HOST)
+        bufs = (np.zeros((B, K, 10)), np.zeros((B, M + 1, 5)), np.zeros(B, np.int32), np.zeros(B, np.int32), np.zeros(B, np.int32))
+        sol = api.SolutionBatch(api.MEM_HOST, 0, bufs[0].ctypes.data, bufs[1].ctypes.data, bufs[2].ctypes.data,
+                                bufs[3].ctypes.data, bufs[4].ctypes.data, None, None)
+        jobs.append((keep, bufs, prob, sol))
+    assert pool.wait() == api.ERR_STATE                                   # nothing submitted
+    for j in jobs[:6]:
+        assert pool.submit_raw(j[2], j[3]) == api.OK
+    assert pool.submit_raw(jobs[6][2], jobs[6][3]) == api.ERR_STATE       # depth reached: collect first
+    assert pool.wait() == api.OK                                          # batch 0
+    assert pool.submit_raw(jobs[6][2], jobs[6][3]) == api.OK
+    assert pool.profile().iterations > 0
+    for _ in range(6):
+        assert pool.wait() == api.OK
+    assert pool.wait() == api.ERR_STATE
+    for i, (j, ref) in enumerate(zip(jobs, sync)):
+        for got, key in zip(j[1], ("traj", "cost_hist", "n_cost", "status", "n_iter")):
+            assert np.array_equal(got, ref[key]), (i, key)
+    # a pool destroyed with solves in flight waits for them (their arrays are still alive here)
+    for j in jobs[:4]:
+        j[1][0][...] = 0
+        assert pool.submit_raw(j[2], j[3]) == api.OK
+    pool.close()
+    for j, ref in zip(jobs[:4], sync):
+        assert np.array_equal(j[1][0], ref["traj"])
+    one.close()
+
+
 def test_exact_lane_ties_follow_the_reference_rule():
     """CILQR_OPT_EXACT_LANE_TIES: FindNeastLaneSegment (ilqr_optimizer.cc:605-618) compares DistanceTo values (hypot /
     |cross|, line_segment2d.cpp:61-75) with a strict '<', first index wins.  With the option on, the device search --

@@ -104,6 +104,20 @@ def test_multi_device_entry_points_reject_bad_arguments_without_a_gpu(built):
     assert L.cilqr_multi_device_bytes(None) == 0
 
 
+def test_pool_entry_points_reject_bad_arguments_without_a_gpu(built):
+    L = api.lib()
+    cfg = api.default_config(50)
+    h = C.c_void_p()
+    assert L.cilqr_pool_create(None, 0, 2, 8, 16, 64, C.byref(h)) == api.ERR_NULL
+    assert L.cilqr_pool_create(C.byref(cfg), 0, 2, 8, 16, 64, None) == api.ERR_NULL
+    assert L.cilqr_pool_create(C.byref(cfg), 0, 0, 8, 16, 64, C.byref(h)) == api.ERR_ARG     # no handles
+    assert L.cilqr_pool_create(C.byref(cfg), 0, 17, 8, 16, 64, C.byref(h)) == api.ERR_ARG    # more than 16
+    assert L.cilqr_pool_submit(None, None, None) == api.ERR_NULL
+    assert L.cilqr_pool_wait(None) == api.ERR_NULL
+    assert L.cilqr_pool_destroy(None) == api.ERR_NULL
+    assert L.cilqr_pool_depth(None) == 0 and L.cilqr_pool_device_bytes(None) == 0
+
+
 def test_errors_without_gpu(built):
     L = api.lib()
     assert L.cilqr_default_config(None, 50) == api.ERR_NULL
