@@ -785,8 +785,8 @@ def main():
                     orc.solve_batch(sl, ocfg_for(N), want_margin=False)
 
                 t_ac = time.perf_counter()
-                with ThreadPoolExecutor(nthr) as pool:
-                    list(pool.map(run_slice, idx))
+                with ThreadPoolExecutor(nthr) as tpool:
+                    list(tpool.map(run_slice, idx))
                 t_ac = time.perf_counter() - t_ac
                 cpu["all_cores"] = {"value": round(na / t_ac, 1), "unit": "solves/s", "threads": nthr,
                                     "sample": f"first {na} scenes, {per_thr} per thread, {t_ac:.1f} s wall; a Python thread pool over the C library "
