@@ -24,7 +24,7 @@ namespace cilqr {
 // generic path does not set the register budget of the common one.  Three waves per SIMD: the 5-disc cost function
 // fits 168 VGPRs (quad_core.hpp), and the attribute keeps the allocator from trading that for a shorter schedule.
 #ifndef CILQR_COST_OCC
-#define CILQR_COST_OCC 3
+#define CILQR_COST_OCC 4
 #endif
 #define CILQR_COST_ATTR __attribute__((amdgpu_waves_per_eu(CILQR_COST_OCC, CILQR_COST_OCC)))
 // ... and per tie rule (EX: CILQR_OPT_EXACT_LANE_TIES, see nearest_from_cell)
@@ -256,11 +256,10 @@ void launch_init_cost_commit(const DeviceState& s, int n, hipStream_t st) {
   hipLaunchKernelGGL(k_init_cost_commit, dim3((n + 255) / 256), dim3(256), 0, st, s, n);
 }
 
-#ifdef CILQR_QUAD_OCC
-#define CILQR_QUAD_ATTR __attribute__((amdgpu_waves_per_eu(CILQR_QUAD_OCC, CILQR_QUAD_OCC)))
-#else
-#define CILQR_QUAD_ATTR
+#ifndef CILQR_QUAD_OCC
+#define CILQR_QUAD_OCC 4
 #endif
+#define CILQR_QUAD_ATTR __attribute__((amdgpu_waves_per_eu(CILQR_QUAD_OCC, CILQR_QUAD_OCC)))
 template <int D, bool EX>
 __global__ __launch_bounds__(256) CILQR_QUAD_ATTR void k_quadratize(DeviceState s, const int* __restrict__ list, int n,
                                                     int only_upd) {

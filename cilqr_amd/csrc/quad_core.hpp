@@ -13,8 +13,14 @@ namespace cilqr {
 // corridor planes are read in chunks (all loads of a chunk in flight at once).  The cost function keeps its
 // chunks small: with two planes per chunk and the lane-grid cells fetched disc by disc it fits 168 VGPRs, i.e.
 // three waves per SIMD instead of two (+2 % solve throughput, measured); the quadratisation has the room for four.
-constexpr int kCostChunk = 2;
-constexpr int kQuadChunk = 4;
+#ifndef CILQR_COST_CHUNK
+#define CILQR_COST_CHUNK 2
+#endif
+#ifndef CILQR_QUAD_CHUNK
+#define CILQR_QUAD_CHUNK 2
+#endif
+constexpr int kCostChunk = CILQR_COST_CHUNK;
+constexpr int kQuadChunk = CILQR_QUAD_CHUNK;
 
 // lane tables -> LDS (call from every thread of the block, before any early exit)
 CILQR_DEV const double* stage_lanes(const DeviceState& s, double* lds) {
@@ -127,13 +133,18 @@ CILQR_DEV void knot_cost_core(const DeviceState& s, const double* __restrict__ l
   asm volatile("" :: "v"(jx), "v"(dyn.x), "v"(sn), "v"(pc.a[0]));
   CP_STAMP(2);   // operands arrived + J, bounds, sincos
 #endif
+  static_assert(D == 5, "the lane loop below selects among five disc offsets");
+  const double x0 = x[0], x1 = x[1];
   double px[D], py[D];
   BarGroup grp[D];
 #pragma unroll
   for (int j = 0; j < D; ++j) {
-    px[j] = x[0] + p.disc_off[j] * cs;                     // cc:564-565
-    py[j] = x[1] + p.disc_off[j] * sn;
+    px[j] = x0 + p.disc_off[j] * cs;                       // cc:564-565
+    py[j] = x1 + p.disc_off[j] * sn;
   }
+  // the partial sums that are complete leave now (eight registers less through the two loops below)
+  out[0] = make_double2(jx, ju);
+  out[stride] = dyn;
   // CorridorCost cc:553-581: planes outer (each read once), discs inner; one log for the knot
   for (int c0 = 0; c0 < cnt; c0 += C) {
     PlaneChunk<C> nx;
@@ -173,15 +184,20 @@ CILQR_DEV void knot_cost_core(const DeviceState& s, const double* __restrict__ l
 #ifdef CILQR_COST_PROFILE
     const unsigned long long cp_a = wall_clock64();
 #endif
-    const uint4 cl = lane_cell_fetch(s, 0, px[j], py[j]);
-    const uint4 cr = lane_cell_fetch(s, 1, px[j], py[j]);
+    // the disc's centre again from the state (the same expression as above, so the same bits) instead of px[j], py[j]:
+    // indexing the register arrays with the loop counter costs a chain of selects per access and keeps all ten
+    // values alive through the searches
+    const double doff = (j == 0) ? p.disc_off[0] : (j == 1) ? p.disc_off[1] : (j == 2) ? p.disc_off[2] : (j == 3) ? p.disc_off[3] : p.disc_off[4];
+    const double pxj = x0 + doff * cs, pyj = x1 + doff * sn;
+    const uint4 cl = lane_cell_fetch(s, 0, pxj, pyj);
+    const uint4 cr = lane_cell_fetch(s, 1, pxj, pyj);
 #ifdef CILQR_COST_PROFILE
     asm volatile("" :: "v"(cl.x), "v"(cr.x));
     const unsigned long long cp_b = wall_clock64();
 #endif
-    const double* L = lanes + nearest_from_cell<EX>(s, lanes, 0, cl, px[j], py[j]) * kLaneFields;
-    const double* Rr = lanes + (s.nl + nearest_from_cell<EX>(s, lanes, 1, cr, px[j], py[j])) * kLaneFields;
-    const double g[2] = {L[0] * px[j] + L[1] * py[j] - L[2], Rr[0] * px[j] + Rr[1] * py[j] - Rr[2]};
+    const double* L = lanes + nearest_from_cell<EX>(s, lanes, 0, cl, pxj, pyj) * kLaneFields;
+    const double* Rr = lanes + (s.nl + nearest_from_cell<EX>(s, lanes, 1, cr, pxj, pyj)) * kLaneFields;
+    const double g[2] = {L[0] * pxj + L[1] * pyj - L[2], Rr[0] * pxj + Rr[1] * pyj - Rr[2]};
     bar_accumulate(p, g, lall);
 #ifdef CILQR_COST_PROFILE
     asm volatile("" :: "v"(lall.prod));
@@ -195,8 +211,6 @@ CILQR_DEV void knot_cost_core(const DeviceState& s, const double* __restrict__ l
   CP_STAMP(4);   // lanes
   if ((threadIdx.x & 63) == 0) g_cost_prof[CP_WAVE * 8 + 7] = (cp_fetch << 32) | (cp_search & 0xffffffffull);   // cell words / searches
 #endif
-  out[0] = make_double2(jx, ju);
-  out[stride] = dyn;
   out[2 * stride] = make_double2(ccost, lcost);
 }
 
@@ -291,9 +305,16 @@ CILQR_DEV void plane_commit(Quad& q, double a, double b, const PlaneSums& m) {
   q.lx[2] += m.T1;
   const double aS = a * m.S0, bS = b * m.S0;
   const double h01 = aS * b, h02 = a * m.S1, h12 = b * m.S1;
+  // upper triangle only: the mirrored entries receive the same addends in the same order, so they are copies
+  // (quad_mirror, once per knot) -- three running sums less in registers
   q.h[0] += aS * a; q.h[1] += h01; q.h[2] += h02;
-  q.h[3] += h01; q.h[4] += bS * b; q.h[5] += h12;
-  q.h[6] += h02; q.h[7] += h12; q.h[8] += m.S2 - m.W;
+  q.h[4] += bS * b; q.h[5] += h12;
+  q.h[8] += m.S2 - m.W;
+}
+CILQR_DEV void quad_mirror(Quad& q) {
+  q.h[3] = q.h[1];
+  q.h[6] = q.h[2];
+  q.h[7] = q.h[5];
 }
 
 template <int D, bool EX = false>
@@ -351,6 +372,32 @@ CILQR_DEV void knot_quadratize(const DeviceState& s, const double* __restrict__ 
       q.huu[e] += c1l + c1h;
     }
   }
+  // What is complete at this point leaves now -- the dynamics' Jacobian (a function of x, u alone) and the entries
+  // the constraints below do not touch -- so that v, a, delta, the control and eight sums are dead through the two
+  // loops that follow (26 registers less where the pressure is highest; same values, same places as before).
+  if (term) {
+    double2* o = s.term + slot;
+    o[(size_t)Bc].y = q.lx[3];
+    o[(size_t)2 * Bc] = make_double2(q.lx[4], q.lx[5]);
+    o[(size_t)7 * Bc].y = q.hd[0];
+    o[(size_t)8 * Bc] = make_double2(q.hd[1], q.hd[2]);
+  } else {
+    DynJac J;
+    dynamics_jacobian(p, x, u, J);
+    double2* o = s.lin + (size_t)i * kLinPairs * Bc + slot;
+    o[(size_t)0 * Bc] = make_double2(J.a02, J.a03);
+    o[(size_t)1 * Bc] = make_double2(J.a04, J.a05);
+    o[(size_t)2 * Bc] = make_double2(J.a12, J.a13);
+    o[(size_t)3 * Bc] = make_double2(J.a14, J.a15);
+    o[(size_t)4 * Bc] = make_double2(J.a23, J.a24);
+    o[(size_t)5 * Bc] = make_double2(J.a25, J.b21);
+    o[(size_t)7 * Bc].y = q.lx[3];
+    o[(size_t)8 * Bc] = make_double2(q.lx[4], q.lx[5]);
+    o[(size_t)9 * Bc] = make_double2(q.lu[0], q.lu[1]);
+    o[(size_t)14 * Bc].y = q.hd[0];
+    o[(size_t)15 * Bc] = make_double2(q.hd[1], q.hd[2]);
+    o[(size_t)16 * Bc] = make_double2(q.huu[0], q.huu[1]);
+  }
   double sn, cs;
   lean_sincos(x[2], &sn, &cs);
   // corridor planes x discs (cc:690-727); planes outer (each read once), discs inner
@@ -395,39 +442,26 @@ CILQR_DEV void knot_quadratize(const DeviceState& s, const double* __restrict__ 
     plane_disc(p, Rr[0], Rr[1], Rr[2], px, py, lcj, lsj, mr);
     plane_commit(q, Rr[0], Rr[1], mr);
   }
+  quad_mirror(q);
   if (term) {
     double2* o = s.term + slot;
     o[0] = make_double2(q.lx[0], q.lx[1]);
-    o[(size_t)Bc] = make_double2(q.lx[2], q.lx[3]);
-    o[(size_t)2 * Bc] = make_double2(q.lx[4], q.lx[5]);
+    o[(size_t)Bc].x = q.lx[2];
     o[(size_t)3 * Bc] = make_double2(q.h[0], q.h[1]);
     o[(size_t)4 * Bc] = make_double2(q.h[2], q.h[3]);
     o[(size_t)5 * Bc] = make_double2(q.h[4], q.h[5]);
     o[(size_t)6 * Bc] = make_double2(q.h[6], q.h[7]);
-    o[(size_t)7 * Bc] = make_double2(q.h[8], q.hd[0]);
-    o[(size_t)8 * Bc] = make_double2(q.hd[1], q.hd[2]);
+    o[(size_t)7 * Bc].x = q.h[8];
     return;
   }
-  DynJac J;
-  dynamics_jacobian(p, x, u, J);
   double2* o = s.lin + (size_t)i * kLinPairs * Bc + slot;
-  o[(size_t)0 * Bc] = make_double2(J.a02, J.a03);
-  o[(size_t)1 * Bc] = make_double2(J.a04, J.a05);
-  o[(size_t)2 * Bc] = make_double2(J.a12, J.a13);
-  o[(size_t)3 * Bc] = make_double2(J.a14, J.a15);
-  o[(size_t)4 * Bc] = make_double2(J.a23, J.a24);
-  o[(size_t)5 * Bc] = make_double2(J.a25, J.b21);
   o[(size_t)6 * Bc] = make_double2(q.lx[0], q.lx[1]);
-  o[(size_t)7 * Bc] = make_double2(q.lx[2], q.lx[3]);
-  o[(size_t)8 * Bc] = make_double2(q.lx[4], q.lx[5]);
-  o[(size_t)9 * Bc] = make_double2(q.lu[0], q.lu[1]);
+  o[(size_t)7 * Bc].x = q.lx[2];
   o[(size_t)10 * Bc] = make_double2(q.h[0], q.h[1]);
   o[(size_t)11 * Bc] = make_double2(q.h[2], q.h[3]);
   o[(size_t)12 * Bc] = make_double2(q.h[4], q.h[5]);
   o[(size_t)13 * Bc] = make_double2(q.h[6], q.h[7]);
-  o[(size_t)14 * Bc] = make_double2(q.h[8], q.hd[0]);
-  o[(size_t)15 * Bc] = make_double2(q.hd[1], q.hd[2]);
-  o[(size_t)16 * Bc] = make_double2(q.huu[0], q.huu[1]);
+  o[(size_t)14 * Bc].x = q.h[8];
 }
 
 #ifdef CILQR_REF_ORDER
