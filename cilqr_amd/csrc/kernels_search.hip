@@ -15,8 +15,18 @@
 
 namespace cilqr {
 
+// One lane per rollout: given a wave per SIMD the compiler spends all 256 registers on unrolling and prefetching, and such a
+// wave then keeps two or three cost-kernel waves of another solve off its SIMD.  CILQR_ROLL_OCC > 0 caps the registers instead.
+#ifndef CILQR_ROLL_OCC
+#define CILQR_ROLL_OCC 0
+#endif
+#if CILQR_ROLL_OCC > 0
+#define CILQR_ROLL_ATTR __attribute__((amdgpu_waves_per_eu(CILQR_ROLL_OCC, CILQR_ROLL_OCC)))
+#else
+#define CILQR_ROLL_ATTR
+#endif
 // stage API: plain rollout of the listed slots with one alpha
-__global__ __launch_bounds__(64) void k_forward(DeviceState s, const int* __restrict__ list, int n,
+__global__ __launch_bounds__(64) CILQR_ROLL_ATTR void k_forward(DeviceState s, const int* __restrict__ list, int n,
                                                 double alpha, int skip_done) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
@@ -31,7 +41,7 @@ void launch_forward(const DeviceState& s, const int* list, int n, double alpha, 
 }
 
 // round 0 opener: gradient-norm exit (cc:235-241), else roll out alpha_0
-__global__ __launch_bounds__(64) void k_search_open(DeviceState s, int n) {
+__global__ __launch_bounds__(64) CILQR_ROLL_ATTR void k_search_open(DeviceState s, int n) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= active_count(s, n)) return;
   const int slot = s.act[j];
@@ -45,7 +55,7 @@ __global__ __launch_bounds__(64) void k_search_open(DeviceState s, int n) {
 
 // round r: total cost of the alpha_r candidate, acceptance test (cc:252-261); on rejection roll
 // out alpha_{r+1} and queue the slot for the next round.
-__global__ __launch_bounds__(64) void k_search_round(DeviceState s, int r, int n_max, int roll_next) {
+__global__ __launch_bounds__(64) CILQR_ROLL_ATTR void k_search_round(DeviceState s, int r, int n_max, int roll_next) {
   const int* __restrict__ list = (r == 0) ? s.act : s.pend + (size_t)r * s.Bcap;
   const int n = (r == 0) ? active_count(s, n_max) : min(s.counters[r], n_max);
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
@@ -78,7 +88,7 @@ __global__ __launch_bounds__(64) void k_search_round(DeviceState s, int r, int n
 // rollouts of a SPARSE list: eight consecutive lanes hold the remaining step sizes of one problem, so the nominal
 // trajectory and the gains of a step (11 pairs, the same for every step size) are read once per eight lanes
 // (see k_spec_cost_packed in kernels_quad.hip)
-__global__ __launch_bounds__(64) void k_spec_forward_packed(DeviceState s, const int* __restrict__ list,
+__global__ __launch_bounds__(64) CILQR_ROLL_ATTR void k_spec_forward_packed(DeviceState s, const int* __restrict__ list,
                                                             const int* __restrict__ n_ptr, int n_max, int r0) {
   const int n = n_ptr ? min(*n_ptr, n_max) : active_count(s, n_max);
   constexpr int per_block = 64 / 8;
@@ -90,7 +100,7 @@ __global__ __launch_bounds__(64) void k_spec_forward_packed(DeviceState s, const
   }
 }
 
-__global__ __launch_bounds__(64) void k_spec_forward(DeviceState s, const int* __restrict__ list,
+__global__ __launch_bounds__(64) CILQR_ROLL_ATTR void k_spec_forward(DeviceState s, const int* __restrict__ list,
                                                      const int* __restrict__ n_ptr, int n_max, int r0, int open) {
   const int n = n_ptr ? min(*n_ptr, n_max) : active_count(s, n_max);
   const int r = r0 + blockIdx.y;

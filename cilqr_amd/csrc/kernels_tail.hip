@@ -125,11 +125,14 @@ __device__ __attribute__((noinline)) void tail_backward(int off_T, int off_view)
 }
 
 // ... and so are the other three heavy phases (the lane tables sit at the start of the dynamic shared array)
+#ifndef CILQR_TAIL_AHEAD
+#define CILQR_TAIL_AHEAD 4
+#endif
 __device__ __attribute__((noinline)) void tail_forward(int off_view) {
   extern __shared__ double lds[];
   const DeviceState& t = *reinterpret_cast<const DeviceState*>(reinterpret_cast<const char*>(lds) + off_view);
   const int tid = (int)threadIdx.x;
-  forward_core<OutSpec, 4>(t, 0, kAlpha[tid], OutSpec{t, tid, 0});
+  forward_core<OutSpec, CILQR_TAIL_AHEAD>(t, 0, kAlpha[tid], OutSpec{t, tid, 0});
 }
 template <int D, bool EX>
 __device__ __attribute__((noinline)) void tail_quadratize(int off_view, int i) {

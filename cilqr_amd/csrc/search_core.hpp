@@ -34,7 +34,10 @@ struct OutSpec {
 };
 
 // what step i of a rollout reads: nominal state / control and the gains K_i, k_i
-constexpr int kFwdAhead = 4;
+#ifndef CILQR_ROLL_AHEAD
+#define CILQR_ROLL_AHEAD 4
+#endif
+constexpr int kFwdAhead = CILQR_ROLL_AHEAD;
 struct FwdStep {
   double2 x0, x1, x2, u, kk[kGainPairs];
 };
