@@ -21,8 +21,12 @@
 namespace cilqr {
 
 // The cost kernels exist per disc count: D = 5 (the reference's; unrolled) and D = 0 (any other count), so that the
-// generic path does not set the register budget of the common one.  Three waves per SIMD: the 5-disc cost function
-// fits 168 VGPRs (quad_core.hpp), and the attribute keeps the allocator from trading that for a shorter schedule.
+// generic path does not set the register budget of the common one.  Four waves per SIMD (128 VGPRs).  What made that
+// possible is a compiler switch as much as the code: this file is built with -mllvm -disable-machine-licm (Makefile,
+// QUADFLAGS).  With machine LICM on, the ~20 polynomial coefficients of sincos / log and the derived barrier constants
+// were materialised ONCE in VGPR pairs ahead of the block's problem loop and kept there through it -- 40-odd vector
+// registers holding uniform constants (the scalar file was full already), 168 VGPRs, three waves, and spills as soon as
+// a fourth was asked for.  Rematerialised at their uses they cost a v_mov pair each and no live range.
 #ifndef CILQR_COST_OCC
 #define CILQR_COST_OCC 4
 #endif

@@ -10,9 +10,10 @@
 
 namespace cilqr {
 
-// corridor planes are read in chunks (all loads of a chunk in flight at once).  The cost function keeps its
-// chunks small: with two planes per chunk and the lane-grid cells fetched disc by disc it fits 168 VGPRs, i.e.
-// three waves per SIMD instead of two (+2 % solve throughput, measured); the quadratisation has the room for four.
+// corridor planes are read in chunks (all loads of a chunk in flight at once).  Both kernels keep their chunks at two
+// planes: with that, the lane-grid cells fetched disc by disc, the disc centres recomputed in the lane loop and
+// finished outputs stored as soon as they are complete, the cost function needs 114-120 VGPRs and the quadratisation
+// 127 -- four waves per SIMD, no spills (kernels_quad.hip, Makefile: QUADFLAGS).  Three-plane chunks spill at that budget.
 #ifndef CILQR_COST_CHUNK
 #define CILQR_COST_CHUNK 2
 #endif
