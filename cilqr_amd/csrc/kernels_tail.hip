@@ -28,7 +28,10 @@
 
 namespace cilqr {
 
-constexpr int kTailThreads = 256;
+#ifndef CILQR_TAIL_THREADS
+#define CILQR_TAIL_THREADS 256
+#endif
+constexpr int kTailThreads = CILQR_TAIL_THREADS;
 constexpr int kTailChunk = 5;   // step sizes costed together: 5 x 51 knots = 255 items for 256 threads
 
 // byte offsets of the tensors inside one block's private arena
