@@ -291,6 +291,18 @@ def build_corridor_adapter_test(tmp_path):
     return exe
 
 
+def test_header_is_plain_c99_and_the_pool_calls_link(built, tmp_path):
+    """include/cilqr.h compiled as C99 (-pedantic -Werror) by gcc, linked against the C-ABI library alone; the program
+    (tests/cpp/pool_c99.c) walks the cilqr_pool_* argument checks, which need no GPU."""
+    exe = tmp_path / "pool_c99"
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "pool_c99.c"), "-o", str(exe),
+                           "-L" + os.path.dirname(api.LIB_PATH), "-lcilqr_hip", "-Wl,-rpath," + os.path.dirname(api.LIB_PATH),
+                           "-Wl,-rpath-link,/opt/rocm/lib"])
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "pool_c99 ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
 def test_corridor_adapter_compiles_as_cxx14_against_the_c_abi(built, tmp_path):
     """include/cilqr/corridor.hpp (the planning::Corridor call surface) builds with C++14 / g++ and
     links against the C-ABI library only."""
