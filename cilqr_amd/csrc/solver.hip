@@ -201,7 +201,10 @@ int do_load(cilqr_solver* h, const cilqr_problem_batch* in, cilqr_job_set& js, D
     const double margin = 60.0;  // rejected line-search candidates overshoot far off the road
     double w = (hi[0] - lo[0]) + 2 * margin, hgt = (hi[1] - lo[1]) + 2 * margin;
     if (!(w > 0.0) || !(hgt > 0.0) || !std::isfinite(w) || !std::isfinite(hgt)) return CILQR_ERR_ARG;
-    double cell = 1.0;
+#ifndef CILQR_GRID_MIN_CELL
+#define CILQR_GRID_MIN_CELL 1.0
+#endif
+    double cell = CILQR_GRID_MIN_CELL;
     while (std::ceil(w / cell) * std::ceil(hgt / cell) > (double)kGridMaxCells) cell *= 1.25;
     v->gx0 = lo[0] - margin;
     v->gy0 = lo[1] - margin;

@@ -38,7 +38,10 @@ constexpr int kNumAlpha = 11;
 constexpr int kMaxDiscs = 16;
 constexpr int kLaneFields = 11;  // a b c | sx sy | ux uy | len | ex ey | pad (an odd row stride: rows of different segments start in different LDS banks)
 constexpr int kGridCellBytes = 16;
-constexpr int kGridMaxCells = 1 << 16;  // per side
+#ifndef CILQR_GRID_CELLS_LOG2
+#define CILQR_GRID_CELLS_LOG2 16
+#endif
+constexpr int kGridMaxCells = 1 << CILQR_GRID_CELLS_LOG2;  // per side
 constexpr int kGridFullScan = 255;      // cell marker: too many candidates, scan every segment
 
 // pair rows of a step inside `lin`
