@@ -422,7 +422,8 @@ int64_t cilqr_multi_device_bytes(cilqr_multi_handle m);
  * bench workload (65536 problems per batch): 1.65-1.69 M solves/s with one handle, 1.83-1.93 M with three.
  * cilqr_pool_set_option: cilqr_set_option on every handle (nothing in flight); cilqr_pool_get_profile: of the solve
  * the last wait collected; cilqr_pool_destroy waits for whatever is still in flight.  Solves may also be submitted to a
- * handle of the pool directly (cilqr_pool_handle_at) as long as the pool itself is empty meanwhile. */
+ * handle of the pool directly (cilqr_pool_handle_at) as long as the pool itself is empty meanwhile.  Like a handle, a pool
+ * is driven by one host thread at a time (its handles run their own worker threads). */
 typedef struct cilqr_pool* cilqr_pool_handle;
 int cilqr_pool_create(const cilqr_config* cfg, int32_t device, int32_t n_handles, int32_t batch_capacity, int32_t cmax,
                       int32_t max_lane_segments, cilqr_pool_handle* out);
