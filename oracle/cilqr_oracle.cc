@@ -28,6 +28,7 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -961,6 +962,34 @@ int oracle_solve_batch(const oracle_config* c, int B, const double* start, const
   return oracle_solve_batch_trace(c, B, start, coarse, corridor, ccount, cmax, left, n_left, right, n_right,
                                   traj, cost_hist, n_cost, status, n_iter, min_margin, seconds, nullptr, nullptr,
                                   nullptr);
+}
+
+// The same loop over problems on `n_threads` host threads (contiguous slices, one Oracle each, no shared state): what the
+// box's cores give the reference's algorithm when a caller has many problems at once.  bench.py's cpu_baseline.all_cores.
+int oracle_solve_batch_threads(const oracle_config* c, int B, const double* start, const double* coarse,
+                               const double* corridor, const int* ccount, int cmax, const double* left, int n_left,
+                               const double* right, int n_right, double* traj, double* cost_hist, int* n_cost,
+                               int* status, int* n_iter, int n_threads, double* seconds) {
+  if (n_threads < 1) n_threads = 1;
+  if (n_threads > B) n_threads = B > 0 ? B : 1;
+  const int K = c->n_steps + 1, M = c->max_iter;
+  std::vector<int> rcs((size_t)n_threads, 0);
+  std::vector<std::thread> pool;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int t = 0; t < n_threads; ++t) {
+    const int b0 = (int)((long long)B * t / n_threads), b1 = (int)((long long)B * (t + 1) / n_threads);
+    pool.emplace_back([=, &rcs]() {
+      rcs[(size_t)t] = oracle_solve_batch(c, b1 - b0, start + (size_t)b0 * 4, coarse + (size_t)b0 * K * 6,
+                                          corridor + (size_t)b0 * K * cmax * 3, ccount + (size_t)b0 * K, cmax, left, n_left,
+                                          right, n_right, traj + (size_t)b0 * K * 10, cost_hist + (size_t)b0 * (M + 1) * 5,
+                                          n_cost + b0, status + b0, n_iter ? n_iter + b0 : nullptr, nullptr, nullptr);
+    });
+  }
+  for (std::thread& th : pool) th.join();
+  if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  for (int rc : rcs)
+    if (rc != 0) return rc;
+  return 0;
 }
 
 }  // extern "C"

@@ -307,6 +307,33 @@ def segment_distance(seg4, px, py) -> float:
     return lib().oracle_segment_distance(_p(seg4), C.c_double(px), C.c_double(py))
 
 
+def solve_batch_threads(scene: dict, cfg: "OracleConfig | None" = None, threads: int = 0):
+    """solve_batch on `threads` host threads inside the C library (0 = all cores): contiguous slices, one Oracle per thread.
+    Returns the same arrays as solve_batch (no margins / traces) and `seconds`, the wall time of the threaded loop."""
+    start, coarse = _f64(scene["start"]), _f64(scene["coarse"])
+    corridor = _f64(scene["corridor"])
+    ccount = np.ascontiguousarray(scene["ccount"], dtype=np.int32)
+    left, right = _f64(scene["left"]), _f64(scene["right"])
+    B, K = coarse.shape[0], coarse.shape[1]
+    cfg = cfg or default_config(K - 1)
+    assert cfg.n_steps == K - 1
+    M = cfg.max_iter
+    threads = threads or (os.cpu_count() or 1)
+    traj = np.zeros((B, K, 10))
+    hist = np.zeros((B, M + 1, 5))
+    n_cost, status, n_iter = np.zeros(B, np.int32), np.zeros(B, np.int32), np.zeros(B, np.int32)
+    sec = C.c_double(0.0)
+    L = lib()
+    L.oracle_solve_batch_threads.restype = C.c_int
+    rc = L.oracle_solve_batch_threads(C.byref(cfg), C.c_int(B), _p(start), _p(coarse), _p(corridor), _p(ccount),
+                                      C.c_int(corridor.shape[2]), _p(left), C.c_int(left.shape[0]), _p(right),
+                                      C.c_int(right.shape[0]), _p(traj), _p(hist), _p(n_cost), _p(status), _p(n_iter),
+                                      C.c_int(threads), C.byref(sec))
+    if rc != 0:
+        raise RuntimeError(f"oracle_solve_batch_threads: {rc}")
+    return dict(traj=traj, cost_hist=hist, n_cost=n_cost, status=status, n_iter=n_iter, seconds=sec.value, threads=threads)
+
+
 def solve_batch(scene: dict, cfg: OracleConfig | None = None, want_margin: bool = True, want_trace: bool = False,
                 want_times: bool = False):
     """Loop of independent Plan() calls over a problem-major scene dict (scenario.generate).

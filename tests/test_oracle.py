@@ -267,3 +267,15 @@ def test_oracle_reproduces_golden(path):
     # iter_trajs = init guess + accepted non-final iterates (cc:170,294)
     assert r["n_iter_trajs"] == int(g["st_n_iter_trajs"]) == r["n_cost"] - 1
     assert np.array_equal(r["iter_trajs"][0, :, 1:7], X)
+
+
+def test_threaded_batch_driver_equals_the_sequential_one():
+    """oracle_solve_batch_threads (bench.py's cpu_baseline.all_cores): contiguous slices on host threads, one solver object each;
+    every output array must equal the single-threaded loop's, for thread counts that divide the batch and that do not."""
+    from cilqr_amd import scenario
+    sc = scenario.generate("ped6", 37, seed=9)
+    ref = orc.solve_batch(sc, want_margin=False)
+    for threads in (1, 3, 8, 64):
+        got = orc.solve_batch_threads(sc, threads=threads)
+        for k in ("traj", "cost_hist", "n_cost", "status", "n_iter"):
+            assert np.array_equal(got[k], ref[k]), (threads, k)
