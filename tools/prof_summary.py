@@ -43,6 +43,8 @@ def main():
     ap.add_argument("path")
     ap.add_argument("--iters", default="")
     ap.add_argument("--solve", type=int, default=1, help="which solve (0-based) to print the timeline of")
+    ap.add_argument("--bench-json", default="", help="the JSON line bench.py printed in this capture: adds the backward launches of "
+                    "its TIMED REGION alone (the figure bench.py's roofline.avg_launch_ms must agree with)")
     a = ap.parse_args()
     rows = load(a.path)
     stats = {}
@@ -76,6 +78,21 @@ def main():
                 n, t, g = sizes[b]
                 print(f"  {b:8s} launches {n:5d}  avg {t / n / 1e3:8.1f} us  avg problems {g / n:9.0f}  "
                       f"algorithmic GB/s {(g / n) * (50 * 110 + 44) * 8 / (t / n):9.1f}")
+    if a.bench_json:
+        import json
+        rec = json.loads(open(a.bench_json).read().strip().splitlines()[-1])
+        steps, warm, roof = rec["steps"], rec["warmup"], rec["roofline"]
+        per_solve = roof["launches"] // steps          # backward launches of one solve (lockstep iterations)
+        skip = (2 + warm) * per_solve                   # the two calibration solves and the warm-up steps come first
+        bw = [(s_, e_) for name, s_, e_, *_ in rows if short(name) in ("k_backward", "k_backward_team", "k_backward_wave")]
+        win = bw[skip:skip + steps * per_solve]         # rows are sorted by start time; fences separate the regions
+        if len(win) == steps * per_solve:
+            avg = sum(e_ - s_ for s_, e_ in win) / len(win) / 1e6
+            print(f"\nbackward launches of bench.py's timed region alone ({steps} steps x {per_solve} launches, after {2 + warm} earlier solves; "
+                  f"the rows above also hold the calibration, warm-up, one-handle and sequential legs of the same process):\n"
+                  f"  launches {len(win)}  avg {avg * 1e3:.1f} us   -- bench.py roofline.avg_launch_ms (HIP events, same run): {roof['avg_launch_ms'] * 1e3:.1f} us")
+        else:
+            print(f"\n(timed-region window not found: {len(bw)} backward launches in the capture, expected at least {skip + steps * per_solve})")
     if not a.iters:
         return
     want = [int(x) for x in a.iters.split(",")]

@@ -15,7 +15,7 @@ mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$root"
 python bench.py > "$out/${tag}_bench.json" 2> "$out/bench.err"
 rocprofv3 --kernel-trace --stats -d "$out/kt3" -- python bench.py --cpu-sample 0 --no-latency > "$out/${tag}_bench_under_rocprofv3.json" 2> "$out/kt3.err"
-python tools/prof_summary.py "$out/kt3" > "$out/${tag}_kernel_stats_pipelined.txt" 2>&1
+python tools/prof_summary.py "$out/kt3" --bench-json "$out/${tag}_bench_under_rocprofv3.json" > "$out/${tag}_kernel_stats_pipelined.txt" 2>&1
 rocprofv3 --kernel-trace --stats -d "$out/kt1" -- python bench.py --steps 6 --warmup 2 --in-flight 1 --pipeline 1 --cpu-sample 0 --no-latency > "$out/${tag}_bench_pipeline1_under_rocprofv3.json" 2> "$out/kt1.err"
 { python tools/prof_summary.py "$out/kt1" --iters 1,2,5,10,20,40,80; python tools/phase_summary.py "$out/kt1"; } > "$out/${tag}_kernel_stats.txt" 2>&1
 targs=""
