@@ -283,6 +283,13 @@ __global__ __launch_bounds__(256) CILQR_QUAD_ATTR void k_quadratize(DeviceState 
 #endif
 }
 
+#ifdef CILQR_QUAD_PROFILE
+extern "C" void cilqr_debug_quad_profile(unsigned long long* out, int reset) {   // tuning build only, not part of the C-ABI
+  if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_quad_prof), sizeof(g_quad_prof));
+  if (reset) { void* p = nullptr; (void)hipGetSymbolAddress(&p, HIP_SYMBOL(g_quad_prof)); (void)hipMemset(p, 0, sizeof(g_quad_prof)); }
+}
+#endif
+
 void launch_quadratize(const DeviceState& s, const int* list, int n, int only_upd, hipStream_t st) {
   if (n == 0) return;
   dim3 g((n + 255) / 256, s.p.K);

@@ -318,8 +318,22 @@ CILQR_DEV void quad_mirror(Quad& q) {
   q.h[7] = q.h[5];
 }
 
+#ifdef CILQR_QUAD_PROFILE
+// Tuning build only (make OBJDIR=build/quadprof OUT=../lib/variants/libcilqr_hip_quadprof.so EXTRA=-DCILQR_QUAD_PROFILE;
+// tools/quad_phase_profile.py): wall-clock stamps (100 MHz) of the phases of a knot's quadratisation, one record per wave.
+constexpr int kQuadProfWaves = 1 << 16;
+__device__ unsigned long long g_quad_prof[kQuadProfWaves * 8];
+#define QP_WAVE ((int)(((blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (kQuadProfWaves - 1)))
+#define QP_STAMP(k) do { const unsigned long long n_ = wall_clock64(); if ((threadIdx.x & 63) == 0) g_quad_prof[QP_WAVE * 8 + (k)] = n_ - qp_t; qp_t = n_; } while (0)
+#else
+#define QP_STAMP(k)
+#endif
 template <int D, bool EX = false>
 CILQR_DEV void knot_quadratize(const DeviceState& s, const double* __restrict__ lanes, int buf, int i, int slot) {
+#ifdef CILQR_QUAD_PROFILE
+  unsigned long long qp_t = wall_clock64();
+  const unsigned long long qp_t0 = qp_t;
+#endif
   const Params& p = s.p;
   const int Bc = s.Bcap;
   const bool term = (i == p.N);
@@ -401,6 +415,10 @@ CILQR_DEV void knot_quadratize(const DeviceState& s, const double* __restrict__ 
   }
   double sn, cs;
   lean_sincos(x[2], &sn, &cs);
+#ifdef CILQR_QUAD_PROFILE
+  asm volatile("" :: "v"(sn), "v"(cs), "v"(pc.a[0]), "v"(q.lx[0]));
+  QP_STAMP(0);   // state, goals, first planes arrived; bounds, Jacobian, early stores, sincos
+#endif
   // corridor planes x discs (cc:690-727); planes outer (each read once), discs inner
   for (int c0 = 0; c0 < cnt; c0 += C) {
     PlaneChunk<C> nx;
@@ -425,6 +443,10 @@ CILQR_DEV void knot_quadratize(const DeviceState& s, const double* __restrict__ 
     }
     pc = nx;
   }
+#ifdef CILQR_QUAD_PROFILE
+  asm volatile("" :: "v"(q.h[0]), "v"(q.h[8]), "v"(q.lx[2]));
+  QP_STAMP(1);   // corridor
+#endif
   // nearest left / right lane plane, all discs (cc:729-769)
 #pragma unroll 1
   for (int j = 0; j < nd; ++j) {
@@ -443,6 +465,12 @@ CILQR_DEV void knot_quadratize(const DeviceState& s, const double* __restrict__ 
     plane_disc(p, Rr[0], Rr[1], Rr[2], px, py, lcj, lsj, mr);
     plane_commit(q, Rr[0], Rr[1], mr);
   }
+#ifdef CILQR_QUAD_PROFILE
+  asm volatile("" :: "v"(q.h[0]), "v"(q.h[8]), "v"(q.lx[2]));
+  QP_STAMP(2);   // lanes
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if ((threadIdx.x & 63) == 0) g_quad_prof[QP_WAVE * 8 + 5] = wall_clock64() - qp_t0;
+#endif
   quad_mirror(q);
   if (term) {
     double2* o = s.term + slot;
