@@ -8,15 +8,15 @@ Workload (config.workload): BASELINE.json configs[2] -- batch 65536 per GPU, 50-
 --gpus N every rank solves its own 65536 scenes (weak scaling, configs[3] at N=8) and the
 results are gathered to rank 0 with one RCCL gather per step inside the timed region.
 
-The K timed steps go round-robin through `--pipeline` = 3 solver handles, each with two solves in flight
+The K timed steps go round-robin through a pool of `--pipeline` = 2 solver handles (cilqr_pool_*), each with two solves in flight
 (cilqr_submit / cilqr_wait, `--in-flight 2`): a handle iterates the bulk of one step in its main arena while
 the last <= 8192 problems of its previous step -- the latency-bound part of a solve -- finish in its small
 finishing arena on a second stream (include/cilqr.h, CILQR_OPT_FINISH_THRESHOLD); and the first stages of
-the three handles, which drift apart by themselves, fill each other's gaps (a backward pass or a rollout is
+the handles, which drift apart by themselves, fill each other's gaps (a backward pass or a rollout is
 one lane per problem: a chain of N dependent steps that leaves most of the chip idle once the active set has
 shrunk, exactly where another handle's cost kernels fit).  Every step is a complete, independent solve of
 the batch; `value` = problems solved / wall time of the K steps.  `one_handle` reports the same steps
-through one handle (a third of the memory), `single_batch` the strictly sequential call.
+through one handle (half the memory), `single_batch` the strictly sequential call.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     backward-pass kernel, every launch of the timed region (time-weighted) and the launches
@@ -63,10 +63,15 @@ def parse_args(argv=None):
     ap.add_argument("--round-group", type=int, default=-1, help="CILQR_OPT_ROUND_GROUP value (tuning experiments)")
     ap.add_argument("--wave-threshold", type=int, default=-1, help="CILQR_OPT_WAVE_THRESHOLD value (tuning experiments)")
     ap.add_argument("--tail-threshold", type=int, default=-1, help="CILQR_OPT_TAIL_THRESHOLD value (tuning experiments; 0 = lockstep to the end)")
-    ap.add_argument("--pipeline", type=int, default=3,
+    ap.add_argument("--pipeline", type=int, default=2,
                     help="solver handles used round-robin in the timed region (each with its own arenas, streams and host threads): "
                          "the latency-bound launches of one handle's first stage run in the gaps of the others'; 1 = one handle "
                          "(also reported as `one_handle` when more are used)")
+    ap.add_argument("--torch-streams", action="store_true",
+                    help="give every handle a torch.cuda.Stream instead of the stream it created itself")
+    ap.add_argument("--stagger-ms", type=float, default=0.0,
+                    help="pause between the first submissions to the handles of an empty pool (inside the timed region): starts "
+                         "their first stages out of phase with each other")
     ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2],
                     help="solves in flight per handle (cilqr_submit / cilqr_wait): 2 = the stragglers of one solve finish in the "
                          "handle's finishing arena while the next solve is iterated in its main arena; 1 = one after the other")
@@ -382,8 +387,9 @@ def main():
     class Ctx:   # one handle of the pool: its stream, options and the result buffers of the solves it keeps in flight
         def __init__(self, k):
             self.opt = pool.handle_at(k, batch_capacity=B, cmax=cmax)
-            self.stream = torch.cuda.Stream()
-            self.opt.set_stream(self.stream.cuda_stream)
+            if args.torch_streams:   # a torch stream per handle instead of the handle's own (tuning experiments)
+                self.stream = torch.cuda.Stream()
+                self.opt.set_stream(self.stream.cuda_stream)
             o = self.opt
             if args.compact_percent >= 0:
                 o.set_option(api.OPT_COMPACTION, args.compact_percent)
@@ -464,6 +470,8 @@ def main():
                 raise api.CilqrError(rc, "in bench submit")
             if through_pool:
                 dealt[0] += 1
+                if args.stagger_ms > 0 and s_ + 1 < min(n, P) and dealt[0] - dealt[1] == s_ + 1:
+                    time.sleep(args.stagger_ms * 1e-3)   # the pool was empty when this region began: offset the handles' phases
             c.fifo.append(sl)
             if done is not None:
                 finish(done[0], done[1][0], done[1][1], timed)

@@ -295,7 +295,7 @@ def build_corridor_adapter_test(tmp_path):
 def test_bench_line_has_the_contract_fields_on_the_gpu():
     """`python bench.py` (small batch, a few steps) on the GPU box: ONE JSON line with the fields the driver reads -- metric,
     value, n_gpus, steps, ms_per_step, dtype, config.workload -- the roofline object (bound / achieved / peak / unit / frac /
-    traffic) and the cpu_baseline object (value / unit / cores / kind / sample); the timed steps went through the pool of three
+    traffic) and the cpu_baseline object (value / unit / cores / kind / sample); the timed steps went through the pool of two
     handles and every solve in flight returned the same bits."""
     bench = os.path.join(ROOT, "bench.py")
     r = subprocess.run([sys.executable, bench, "--batch", "2048", "--steps", "7", "--warmup", "2", "--no-traffic", "--no-latency",
@@ -305,7 +305,7 @@ def test_bench_line_has_the_contract_fields_on_the_gpu():
     assert rec["unit"] == "solves/s" and rec["value"] > 0 and rec["n_gpus"] == 1 and rec["steps"] == 7 and rec["warmup"] == 2
     assert rec["higher_is_better"] is True and rec["scaling"] == "weak" and rec["dtype"] == "f64" and rec["vs_baseline"] is None
     assert abs(rec["value"] - 2048 * 1e3 / rec["ms_per_step"]) <= 1e-3 * rec["value"]
-    assert "workload" in rec["config"] and rec["config"]["handles"] == 3 and rec["config"]["batches_in_flight"] == 6
+    assert "workload" in rec["config"] and rec["config"]["handles"] == 2 and rec["config"]["batches_in_flight"] == 4
     roof = rec["roofline"]
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
     assert 0.0 < roof["frac"] <= 1.0 and roof["achieved"] > 0 and "traffic" in roof

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Records the measurement set of one round on the GPU box into gpurun_out/<tag>/ :
-#   bench JSON of the default command; the same command under rocprofv3 --kernel-trace --stats, once as it is (three
+#   bench JSON of the default command; the same command under rocprofv3 --kernel-trace --stats, once as it is (two
 #   handles with two solves in flight each: what `value` is measured on) and once with --in-flight 1 (one batch at a time: per-kernel
 #   durations that other streams do not inflate, and the per-iteration timeline); PMC passes for the HBM traffic of the
 #   backward kernels (separate runs, counters only) on every bench workload; SQ counter passes over one solve for the
@@ -38,7 +38,8 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_
 done
 python tools/kernel_rooflines.py "$out" "$tag" > "$out/${tag}_kernel_rooflines.json" 2> "$out/kr.err"
 python bench.py --pipeline 1 --cpu-sample 0 --no-latency > "$out/${tag}_bench_one_handle.json" 2> "$out/h1.err"
-python bench.py --pipeline 2 --cpu-sample 0 --no-latency > "$out/${tag}_bench_two_handles.json" 2> "$out/h2.err"
+python bench.py --pipeline 3 --cpu-sample 0 --no-latency > "$out/${tag}_bench_three_handles.json" 2> "$out/h3.err"
+python bench.py --torch-streams --cpu-sample 0 --no-latency > "$out/${tag}_bench_torch_streams.json" 2> "$out/ts.err"
 python bench.py --steps 20 --warmup 5 --cpu-sample 0 --no-latency > "$out/${tag}_bench_steps20_warmup5.json" 2> "$out/s20.err"
 python bench.py --exact-lane-ties --cpu-sample 0 --no-latency > "$out/${tag}_bench_exact_lane_ties.json" 2> "$out/et.err"
 python bench.py --tail-threshold 0 --in-flight 1 --pipeline 1 --cpu-sample 0 > "$out/${tag}_bench_lockstep_only_pipeline1.json" 2> "$out/ls.err"
