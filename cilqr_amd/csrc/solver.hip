@@ -520,6 +520,7 @@ int cilqr_set_option(cilqr_handle h, int32_t option, int64_t value) {
     case CILQR_OPT_SPEC_THRESHOLD:
       if (value < 0) return CILQR_ERR_ARG;
       h->spec_threshold = (int)(value > h->ds.spec_cap ? h->ds.spec_cap : value);
+      h->spec_threshold_submit = h->spec_threshold;   // an explicit choice holds for both kinds of call
       return CILQR_OK;
     case CILQR_OPT_SEQ_ROUNDS:
       if (value < 1 || value > kNumAlpha) return CILQR_ERR_ARG;
@@ -625,6 +626,7 @@ static int solve_one(cilqr_solver* h, cilqr_job& j, const cilqr_problem_batch* i
 static int solve_sync(cilqr_solver* h, const cilqr_problem_batch* in, cilqr_solution_batch* out) {
   cilqr_job& j = h->jobs[0];
   j.set = 0;
+  j.spec_threshold = h->spec_threshold;
   j.st1 = h->stream;
   j.st2 = h->stream;
   return solve_groups(h, j, in, out);
@@ -892,7 +894,7 @@ int job_iterate(cilqr_solver* h, cilqr_job& j, int stage) {
     launch_backward(d, d.act, n_hint, nullptr, h->team_threshold, h->wave_threshold, st, eb0, eb1);    // cc:218
     if (j.tm.begin(2)) return CILQR_ERR_DEVICE;
     j.bwd_iter.push_back(it);
-    launch_linesearch(d, n_hint, h->spec_threshold, h->seq_rounds, h->round_group, st);  // cc:235-270
+    launch_linesearch(d, n_hint, j.spec_threshold, h->seq_rounds, h->round_group, st);  // cc:235-270
     launch_update(d, n_hint, st);                      // cc:272-308
     launch_export_done(d, n_hint, j.o_traj, st);       // cc:238,285,303,319
     if (j.o_it) launch_export_iter_traj(d, d.act, n_hint, j.o_it, j.out.max_iter_trajs, st);
@@ -1101,6 +1103,7 @@ int cilqr_submit(cilqr_handle h, const cilqr_problem_batch* in, cilqr_solution_b
   j.in = *in;
   j.out = *out;
   j.set = slot;
+  j.spec_threshold = h->spec_threshold_submit;
   j.st1 = h->stream;
   j.st2 = h->stream2;
   j.rc = CILQR_OK;

@@ -75,6 +75,7 @@ struct cilqr_job {
   cilqr_problem_batch in;
   cilqr_solution_batch out;
   int set = 0;
+  int spec_threshold = 0;   // the threshold of this solve (cilqr_solver::spec_threshold or spec_threshold_submit)
   int phase = 0;            // 0 free, 1 queued, 2 first stage, 3 waiting for the finishing stage, 4 finishing, 5 done
   int rc = CILQR_OK;
   hipStream_t st1 = nullptr, st2 = nullptr;
@@ -122,7 +123,11 @@ struct cilqr_solver {
   double* lambda_stage = nullptr;
   int B = 0;               // problems loaded
   int stage = 0;           // bit0 loaded, bit1 iterate, bit2 quadratized, bit3 gains
-  int spec_threshold = 8192;  // active sets up to this size evaluate all 11 step sizes at once
+  int spec_threshold = 8192;  // active sets up to this size evaluate all 11 step sizes at once (cilqr_solve_batch)
+  // ... and for solves submitted with cilqr_submit: other solves share the GPU then, and eleven candidates per problem
+  // where two or three would do is throughput taken from them (measured: pool of two 1.90 -> 1.98 M solves/s, one handle
+  // with two solves in flight 1.67 -> 1.72 M; the sequential call loses 1 % at 2048, hence the two defaults)
+  int spec_threshold_submit = 2048;
   int team_threshold = 4096;  // active sets up to this size run the backward pass with 8 lanes per problem
   int round_group = 2;        // step sizes costed per sequential round (1, 2 or 4)
   int wave_threshold = 1024;  // active sets up to this size run the backward pass with a wavefront per problem
