@@ -5,7 +5,7 @@
 // dependent steps that uses a fraction of the chip once the active set has shrunk -- exactly the room another solve's
 // cost kernels need.  A pool owns n handles on one device and deals the submitted batches out round-robin; the
 // handles' first stages drift apart by themselves and fill each other's gaps (measured on the bench workload, 65536
-// problems per batch: 1.65-1.69 M solves/s with one handle, 1.82-1.92 M with two, 1.83-1.94 M with three).
+// problems per batch: 1.69-1.72 M solves/s with one handle, 1.94-1.99 M with two, 1.97-2.00 M with three).
 // Results are the handle's own: bit-identical to cilqr_solve_batch.  Nothing here touches the device: the pool is
 // bookkeeping over cilqr_create / cilqr_submit / cilqr_wait.
 #include <hip/hip_runtime.h>

@@ -421,7 +421,7 @@ int64_t cilqr_multi_device_bytes(cilqr_multi_handle m);
  *     for (i = 0; i < depth; ++i) submit(batch[i]);   then   wait(); submit(next); wait(); submit(next); ...
  * The rules of cilqr_submit hold per solve (structs copied, arrays valid and distinct until the wait that collects them; a
  * submit beyond the depth returns CILQR_ERR_STATE).  Results are bit-identical to cilqr_solve_batch.  Measured on the
- * bench workload (65536 problems per batch): 1.65-1.69 M solves/s with one handle, 1.82-1.92 M with two, 1.83-1.94 M with three.
+ * bench workload (65536 problems per batch): 1.69-1.72 M solves/s with one handle, 1.94-1.99 M with two, 1.97-2.00 M with three.
  * cilqr_pool_set_option: cilqr_set_option on every handle (nothing in flight); cilqr_pool_get_profile: of the solve
  * the last wait collected; cilqr_pool_destroy waits for whatever is still in flight.  Solves may also be submitted to a
  * handle of the pool directly (cilqr_pool_handle_at) as long as the pool itself is empty meanwhile.  Like a handle, a pool
