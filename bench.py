@@ -75,7 +75,9 @@ def parse_args(argv=None):
     ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2],
                     help="solves in flight per handle (cilqr_submit / cilqr_wait): 2 = the stragglers of one solve finish in the "
                          "handle's finishing arena while the next solve is iterated in its main arena; 1 = one after the other")
-    ap.add_argument("--exact-lane-ties", action="store_true", help="CILQR_OPT_EXACT_LANE_TIES = 1 (the reference's tie rule in the nearest-segment search)")
+    ap.add_argument("--fast-lane-ties", action="store_true",
+                    help="CILQR_OPT_EXACT_LANE_TIES = 0: nearest lane segments by squared distances alone (the opt-in fast rule; the "
+                         "default is the reference's tie rule, ilqr_optimizer.cc:605-618)")
     ap.add_argument("--finish-threshold", type=int, default=-1, help="CILQR_OPT_FINISH_THRESHOLD value (tuning experiments)")
     ap.add_argument("--coarse", default="generator", choices=["generator", "dp"],
                     help="where the coarse trajectories come from: the generator's smooth best-clearance pick, or the DP coarse "
@@ -407,8 +409,8 @@ def main():
                 o.set_option(api.OPT_WAVE_THRESHOLD, args.wave_threshold)
             if args.finish_threshold >= 0:
                 o.set_option(api.OPT_FINISH_THRESHOLD, args.finish_threshold)
-            if args.exact_lane_ties:
-                o.set_option(api.OPT_EXACT_LANE_TIES, 1)
+            if args.fast_lane_ties:
+                o.set_option(api.OPT_EXACT_LANE_TIES, 0)
             self.slots = [Slot() for _ in range(D + 1)]   # D in flight + the one whose results are being gathered
             self.free = list(self.slots)
             self.fifo = []          # submitted, oldest first
@@ -836,7 +838,7 @@ def main():
                                    f"{spec.n_dynamic} moving + {spec.n_static} static vehicles), reference road, "
                                    f"seed {args.seed}",
                        "batch_per_gpu": B, "n_steps": N, "cmax": cmax, "batches_in_flight": P * D, "handles": P, "in_flight_per_handle": D,
-                       "exact_lane_ties": bool(args.exact_lane_ties),
+                       "exact_lane_ties": not args.fast_lane_ties,
                        "coarse_trajectories": ("DP coarse planner (cilqr_dp_plan) + cilqr_build_corridors" if dp_info else "scene generator"),
                        "dp_scene_source": dp_info,
                        "results_gather": "rccl" if use_dist else "none", "rccl_ranks": rccl_ranks},

@@ -362,6 +362,7 @@ int cilqr_create(const cilqr_config* cfg, int32_t device, int32_t batch_capacity
   DeviceState& d = h->ds;
   d.Bcap = Bc;
   d.cmax = cmax;
+  d.exact_ties = 1;   // CILQR_OPT_EXACT_LANE_TIES: the reference's tie rule (cc:605-618) is the default; twin / fin copy it below
   fill_params(*cfg, &d.p);
   {
     cilqr_tracker_config tc;

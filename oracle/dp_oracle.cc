@@ -790,4 +790,46 @@ void oracle_trajectory_cartesian(const double* rows, int n, double station, doub
   out2[1] = p.y();
 }
 
+// the header-only helpers of the reference the planner leans on, one by one (signatures of oracle/ref_shim.cc)
+double oracle_slerp(double a0, double t0, double a1, double t1, double t) { return math::slerp(a0, t0, a1, t1, t); }
+int oracle_lin_spaced(int n, double start, double end, double* out) {   // the three sizes of DpPlanner's constructor
+  if (n == 5) { const auto r = math::LinSpaced<5>(start, end); for (int i = 0; i < n; ++i) out[i] = r[i]; }
+  else if (n == 7) { const auto r = math::LinSpaced<7>(start, end); for (int i = 0; i < n; ++i) out[i] = r[i]; }
+  else if (n == 9) { const auto r = math::LinSpaced<9>(start, end); for (int i = 0; i < n; ++i) out[i] = r[i]; }
+  else return -1;
+  return n;
+}
+// the placement of a dynamic obstacle's body-frame vertex as oracle_dp_plan does it above (Pose::transform, pose.h:40-46)
+void oracle_pose_transform(double x, double y, double theta, double rx, double ry, double rtheta, double* out3) {
+  out3[0] = x + rx * cos(theta) - ry * sin(theta);
+  out3[1] = y + rx * sin(theta) + ry * cos(theta);
+  out3[2] = theta + rtheta;
+}
+// the two boxes of Environment::CheckOptimizationCollision as restated above (environment.cpp:92-104); layout of
+// ref_collision_boxes: xr yr xf yf | per box (f, r): centre, half extents, min/max x, min/max y, four corners
+void oracle_collision_boxes(double x, double y, double theta, double collision_buffer, double* out36) {
+  using math::Vec2d;
+  VehicleParam vehicle;
+  vehicle.Finish();
+  const Vec2d c0(-vehicle.radius - collision_buffer, -vehicle.radius - collision_buffer);
+  const Vec2d c1(vehicle.radius + collision_buffer, vehicle.radius + collision_buffer);
+  double xr, yr, xf, yf;
+  std::tie(xr, yr, xf, yf) = vehicle.GetDiscPositions(x, y, theta);
+  out36[0] = xr; out36[1] = yr; out36[2] = xf; out36[3] = yf;
+  const math::Box2d boxes[2] = {math::Box2d::FromAABox(c0, c1, Vec2d(xf, yf)), math::Box2d::FromAABox(c0, c1, Vec2d(xr, yr))};
+  for (int k = 0; k < 2; ++k) {
+    double* o = out36 + 4 + 16 * k;
+    const math::Box2d& b = boxes[k];
+    o[0] = b.center_.x(); o[1] = b.center_.y(); o[2] = b.half_length_; o[3] = b.half_width_;
+    o[4] = b.min_x(); o[5] = b.max_x(); o[6] = b.min_y(); o[7] = b.max_y();
+    for (int i = 0; i < 4; ++i) { o[8 + 2 * i] = b.corners()[i].x(); o[9 + 2 * i] = b.corners()[i].y(); }
+  }
+}
+// VehicleParam's derived members (vehicle_param.h:83-88) from the defaults: radius, f2x, r2x
+void oracle_vehicle_derived(double* out3) {
+  VehicleParam vehicle;
+  vehicle.Finish();
+  out3[0] = vehicle.radius; out3[1] = vehicle.f2x; out3[2] = vehicle.r2x;
+}
+
 }  // extern "C"

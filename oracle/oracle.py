@@ -63,6 +63,13 @@ def _pin_signatures(L, prefix):
     sig("trajectory_cartesian", None, [P, I, D, D, P])
     sig("tracker_evaluate_time", None, [P, I, D, P])
     sig("tracker_projection", None, [P, I, D, D, P])
+    sig("default", I, [C.c_char_p, C.POINTER(D)])
+    sig("slerp", D, [D, D, D, D, D])
+    sig("tracker_slerp", D, [D, D, D, D, D])
+    sig("lin_spaced", I, [I, D, D, P])
+    sig("pose_transform", None, [D, D, D, D, D, D, P])
+    sig("collision_boxes", None, [D, D, D, D, P])
+    sig("vehicle_derived", None, [P])
 
 
 def ref_lib():

@@ -382,6 +382,7 @@ int oracle_tracker_init_guess(const double* cfg, const double* start4, const dou
 
 
 /* test hooks with the signatures of oracle/ref_shim.cc (tests/test_reference_pins.py): the tracker's trajectory queries */
+double oracle_tracker_slerp(double a0, double t0, double a1, double t1, double t) { return slerp(a0, t0, a1, t1, t); }
 void oracle_tracker_evaluate_time(const double* rows, int n, double time, double* out9) {
   Follow f;
   f.tr.resize(n);

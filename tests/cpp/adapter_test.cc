@@ -1,7 +1,7 @@
 // Drives include/cilqr/ilqr_optimizer.hpp the way the reference's TrajectoryPlanner drives
-// planning::IlqrOptimizer (algorithm/planner/trajectory_planner.cpp:26,80-97), with minimal
-// stand-ins for the reference's own types (only the members the adapter touches; these are this
-// test's definitions, the reference headers are not copied).
+// planning::IlqrOptimizer (algorithm/planner/trajectory_planner.cpp:26,80-97).  The reference's types come from
+// tests/cpp/reference_types.hpp: its OWN headers with -DCILQR_TEST_REFERENCE_HEADERS (build container), minimal
+// stand-ins otherwise (GPU box).
 //
 //   adapter_test <scene.bin> <out.bin>
 // scene.bin: int32 K, cmax, nl, nr | start[4] | coarse[K][6] | counts[K] (int32) |
@@ -10,7 +10,13 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include "cilqr/ilqr_optimizer.hpp"
 #include "reference_types.hpp"
+
+namespace planning {
+using IlqrOptimizer = cilqr::IlqrOptimizerT<TrajectoryPoint, DiscretizedTrajectory, CorridorConstraints, LaneConstraints,
+                                            IlqrConfig, VehicleParam, Cost>;
+}
 
 template <class T>
 static bool rd(FILE* f, T* p, size_t n) { return std::fread(p, sizeof(T), n, f) == n; }
@@ -43,13 +49,13 @@ int main(int argc, char** argv) {
   for (int i = 0; i < K; ++i)
     for (int c = 0; c < counts[i]; ++c) {
       const double* p = &cor[((size_t)i * cmax + c) * 3];
-      corridor[i].push_back({p[0], p[1], p[2]});
+      corridor[i].push_back(Vector3d(p[0], p[1], p[2]));
     }
   auto lanes = [](const std::vector<double>& t, int n) {
     LaneConstraints out;
     for (int k = 0; k < n; ++k) {
       const double* r = &t[(size_t)k * 7];
-      out.push_back({Vector3{r[0], r[1], r[2]}, Segment{{r[3], r[4]}, {r[5], r[6]}}});
+      out.push_back({Vector3d(r[0], r[1], r[2]), math::LineSegment2d(math::Vec2d(r[3], r[4]), math::Vec2d(r[5], r[6]))});
     }
     return out;
   };

@@ -1,7 +1,7 @@
 // Drives include/cilqr/corridor.hpp the way the reference's TrajectoryPlanner drives
-// planning::Corridor (algorithm/ilqr/corridor.h:27-44), with minimal stand-ins for the reference's
-// own types (only the members the adapter touches; these are this test's definitions, the
-// reference headers are not copied).
+// planning::Corridor (algorithm/ilqr/corridor.h:27-44).  The reference's types come from tests/cpp/reference_types.hpp:
+// its OWN headers with -DCILQR_TEST_REFERENCE_HEADERS (build container), minimal stand-ins otherwise (GPU box);
+// Environment (environment.cpp needs ROS) is this test's own in both.
 //
 //   corridor_adapter_test <scene.bin> <out.bin>
 // scene.bin: int32 K, P, nlb, nrb | knots[K][4] (time, x, y, theta) | counts[K] (int32) |
@@ -17,45 +17,12 @@
 #include <vector>
 
 #include "cilqr/corridor.hpp"
+#include "reference_types.hpp"
 
 namespace planning {
 
-struct TrajectoryPoint {
-  double time = 0.0, x = 0.0, y = 0.0, theta = 0.0;
-};
-class DiscretizedTrajectory {
- public:
-  DiscretizedTrajectory() = default;
-  explicit DiscretizedTrajectory(const std::vector<TrajectoryPoint>& p) : pts_(p) {}
-  const std::vector<TrajectoryPoint>& trajectory() const { return pts_; }
-  bool empty() const { return pts_.empty(); }
-
- private:
-  std::vector<TrajectoryPoint> pts_;
-};
-struct Vec2d {
-  double x_, y_;
-  Vec2d(double x, double y) : x_(x), y_(y) {}
-  double x() const { return x_; }
-  double y() const { return y_; }
-};
-struct LineSegment2d {
-  Vec2d s, e;
-  LineSegment2d(const Vec2d& a, const Vec2d& b) : s(a), e(b) {}
-};
-struct Vector3d {
-  double v[3];
-  Vector3d(double a, double b, double c) : v{a, b, c} {}
-};
-struct Vector2d {
-  double v[2];
-  Vector2d(double a, double b) : v{a, b} {}
-};
-struct CorridorConfig {
-  bool is_multiple_sample = false;
-  double max_diff_x = 25.0, max_diff_y = 25.0, radius = 150.0, max_axis_x = 10.0, max_axis_y = 10.0;
-  double lane_segment_length = 5.0;
-};
+using math::LineSegment2d;
+using math::Vec2d;
 class Environment {
  public:
   std::vector<double> times;
@@ -133,7 +100,8 @@ int main(int argc, char** argv) {
   }
   auto dump_lane = [&](const Corridor::LaneConstraints& l) {
     for (const auto& e : l) {
-      const double row[7] = {e.first.v[0], e.first.v[1], e.first.v[2], e.second.s.x(), e.second.s.y(), e.second.e.x(), e.second.e.y()};
+      const double row[7] = {e.first.v[0], e.first.v[1], e.first.v[2], e.second.start().x(), e.second.start().y(),
+                             e.second.end().x(), e.second.end().y()};
       std::fwrite(row, sizeof(double), 7, o);
     }
   };

@@ -13,7 +13,13 @@
 #include <cstdlib>
 #include <numeric>
 
+#include "cilqr/ilqr_optimizer.hpp"
 #include "reference_types.hpp"
+
+namespace planning {
+using IlqrOptimizer = cilqr::IlqrOptimizerT<TrajectoryPoint, DiscretizedTrajectory, CorridorConstraints, LaneConstraints,
+                                            IlqrConfig, VehicleParam, Cost>;
+}
 
 template <class T>
 static bool rd(FILE* f, T* p, size_t n) { return std::fread(p, sizeof(T), n, f) == n; }
@@ -49,7 +55,7 @@ int main(int argc, char** argv) {
     LaneConstraints out;
     for (int k = 0; k < m; ++k) {
       const double* r = &t[(size_t)k * 7];
-      out.push_back({Vector3{r[0], r[1], r[2]}, Segment{{r[3], r[4]}, {r[5], r[6]}}});
+      out.push_back({Vector3d(r[0], r[1], r[2]), math::LineSegment2d(math::Vec2d(r[3], r[4]), math::Vec2d(r[5], r[6]))});
     }
     return out;
   };
@@ -77,7 +83,7 @@ int main(int argc, char** argv) {
       for (int i = 0; i < K; ++i)
         for (int c = 0; c < counts[(size_t)b * K + i]; ++c) {
           const double* p = &cor[(((size_t)b * K + i) * cmax + c) * 3];
-          corridor[i].push_back({p[0], p[1], p[2]});
+          corridor[i].push_back(Vector3d(p[0], p[1], p[2]));
         }
       DiscretizedTrajectory result;
       std::vector<DiscretizedTrajectory> iter_trajs;

@@ -27,9 +27,9 @@ def family_report(family, seed, nb, lib_path=None):
     sc = scenario.generate(family, nb, seed=seed, workers=8)
     cfg = api.default_config(sc["n_steps"])
     opt = api.BatchIlqrOptimizer(cfg, batch_capacity=nb, cmax=sc["cmax"])
-    exact = "--exact-lane-ties" in sys.argv
-    if exact:   # the reference's nearest-segment tie rule: the step replay then runs without the lane_tie excuse
-        opt.set_option(api.OPT_EXACT_LANE_TIES, 1)
+    exact = "--fast-lane-ties" not in sys.argv   # the library's default: the reference's nearest-segment tie rule
+    if not exact:   # the opt-in fast rule (squared distances only): the step replay then may use the lane_tie excuse
+        opt.set_option(api.OPT_EXACT_LANE_TIES, 0)
     t0 = time.time()
     gpu = opt.plan(sc, max_iter_trajs=48, alpha_trace=True)
     t_gpu = time.time() - t0
@@ -79,7 +79,7 @@ def build_report(n=1024, families=FAMILIES, with_reference_order=True):
     implementation with another libm; the product's share on top of it is what its re-associations add."""
     import torch  # noqa: F401  (one HIP runtime per process: torch's first)
     report = {"tolerance_whole_solves": 1e-4, "tolerance_steps": 1e-8, "problems_per_family": n,
-              "exact_lane_ties": "--exact-lane-ties" in sys.argv, "families": {}}
+              "exact_lane_ties": "--fast-lane-ties" not in sys.argv, "families": {}}
     for family, seed in families:
         report["families"][family] = family_report(family, seed, n)
     if with_reference_order:

@@ -1073,18 +1073,39 @@ def test_exact_lane_ties_follow_the_reference_rule():
 
 
 def test_exact_lane_ties_need_no_excuse():
-    """With CILQR_OPT_EXACT_LANE_TIES the step replay runs with the `lane_tie` excuse switched OFF: the zero-tolerance
-    configuration that iterates into the noise plateau (where iterates come to rest on tie strips), and a default run."""
+    """The library's DEFAULT is the reference's tie rule (CILQR_OPT_EXACT_LANE_TIES = 1, nothing set here): the step
+    replay runs with the `lane_tie` excuse switched OFF -- the zero-tolerance configuration that iterates into the noise
+    plateau (where iterates come to rest on tie strips), and a default run."""
     for over, n, frac in ((dict(rel_cost_tol=0.0, abs_cost_tol=0.0, max_iter=60), 48, 0.25), (dict(), 160, 0.02)):
         sc = scenario.generate("mix11", n, seed=77)
         cfg = api.default_config(sc["n_steps"], **over)
         opt = api.BatchIlqrOptimizer(cfg, batch_capacity=n, cmax=sc["cmax"])
-        opt.set_option(api.OPT_EXACT_LANE_TIES, 1)
         g = _plan(opt, sc)
         rep = assert_steps(g, sc, oracle_cfg_from(cfg), what=f"exact ties {over}", max_excused_frac=frac, allow_lane_tie=False)
         assert rep["lane_tie"] == 0
-        print(f"\nexact ties, {over}: steps {rep}")
+        # setting the option to 1 explicitly is the same solve, bit for bit
+        opt.set_option(api.OPT_EXACT_LANE_TIES, 1)
+        g1 = _plan(opt, sc)
+        for key in ("traj", "cost_hist", "status", "n_iter", "alpha_trace"):
+            assert np.array_equal(g[key], g1[key]), key
+        print(f"\nexact ties (default), {over}: steps {rep}")
         opt.close()
+
+
+def test_fast_lane_tie_rule_is_the_opt_in():
+    """CILQR_OPT_EXACT_LANE_TIES = 0: nearest segments by squared distances alone.  Same results as the default wherever
+    no iterate meets a tie strip; the step replay holds with the `lane_tie` excuse available (and only then may use it)."""
+    sc = scenario.generate("mix11", 160, seed=77)
+    cfg = api.default_config(sc["n_steps"])
+    opt = api.BatchIlqrOptimizer(cfg, batch_capacity=160, cmax=sc["cmax"])
+    g_ref = _plan(opt, sc)
+    opt.set_option(api.OPT_EXACT_LANE_TIES, 0)
+    g = _plan(opt, sc)
+    rep = assert_steps(g, sc, oracle_cfg_from(cfg), what="fast lane ties", allow_lane_tie=True)
+    same = int(np.sum([np.array_equal(g["traj"][b], g_ref["traj"][b]) for b in range(160)]))
+    print(f"\nfast tie rule: steps {rep}; {same} of 160 solves bit-identical to the default rule")
+    assert same >= 150
+    opt.close()
 
 
 def test_speculative_line_search_is_bit_identical_to_round_by_round(lockstep_only):

@@ -340,6 +340,155 @@ def test_barrier_oracle_equals_reference():
             assert _same_bits(o.barrier_hessian(g, dg, ddg), rh2), (g, n)
 
 
+# ------------------------------------------------------------------ configuration: the reference's own structs
+def _ref_default(key):
+    v = C.c_double()
+    assert REF.ref_default(key.encode(), C.byref(v)) == 1, f"oracle/ref_shim.cc does not know {key}"
+    return v.value
+
+
+# cilqr_config field -> member path in the reference's structs (planner_config.h:45-73, vehicle_param.h:26-64)
+_ILQR_KEYS = dict(num_of_disc="ilqr.num_of_disc", max_iter="ilqr.max_iter_num", safe_margin="ilqr.safe_margin",
+                  w_jerk="ilqr.weights.jerk", w_delta_rate="ilqr.weights.delta_rate", w_x="ilqr.weights.x_target",
+                  w_y="ilqr.weights.y_target", w_theta="ilqr.weights.theta", w_v="ilqr.weights.v", w_a="ilqr.weights.a",
+                  w_delta="ilqr.weights.delta", abs_cost_tol="ilqr.abs_cost_tol", rel_cost_tol="ilqr.rel_cost_tol",
+                  front_hang="vehicle.front_hang_length", wheel_base="vehicle.wheel_base", rear_hang="vehicle.rear_hang_length",
+                  width="vehicle.width", max_velocity="vehicle.max_velocity", min_acceleration="vehicle.min_acceleration",
+                  max_acceleration="vehicle.max_acceleration", jerk_min="vehicle.jerk_min", jerk_max="vehicle.jerk_max",
+                  delta_min="vehicle.delta_min", delta_max="vehicle.delta_max", delta_rate_min="vehicle.delta_rate_min",
+                  delta_rate_max="vehicle.delta_rate_max", dt="planner.delta_t")
+
+
+def test_default_configurations_equal_the_references_own_structs():
+    """Every default the C-ABI hands out (cilqr_default_config / _corridor_config / _tracker_config / _dp_config) and
+    every default the oracle starts from, against the reference's OWN IlqrConfig, Weights, VehicleParam, CorridorConfig,
+    TrackerConfig and PlannerConfig -- instantiated inside oracle/_ref from algorithm/params/planner_config.h:18-188 and
+    vehicle_param.h:21-95 (default member initialisers and VehicleParam's constructor), field by field, bit for bit.
+    The relaxed barrier's t = 5, epsilon = 0.01 (barrier_function.h:144-145) need Eigen to instantiate and stay literals."""
+    from cilqr_amd import api
+    # the solver: product and oracle
+    tf, dt = _ref_default("planner.tf"), _ref_default("planner.delta_t")
+    n_knots = int(np.floor(tf / dt + 1))                                  # ilqr_optimizer.cc:22 with the reference's horizon
+    assert n_knots == 81
+    c, o = api.default_config(n_knots - 1), orc.default_config(n_knots - 1)
+    for field, key in _ILQR_KEYS.items():
+        ref = _ref_default(key)
+        assert _same_bits(float(getattr(c, field)), ref), (field, key, getattr(c, field), ref)
+        assert _same_bits(float(getattr(o, field)), ref), ("oracle", field, key, getattr(o, field), ref)
+    assert set(_ILQR_KEYS) | {"n_steps", "init_guess", "barrier_t", "barrier_eps"} == {f for f, _ in api.Config._fields_}
+    assert c.init_guess == api.INIT_IQR and (c.barrier_t, c.barrier_eps) == (5.0, 0.01) == (o.barrier_t, o.barrier_eps)
+    # the corridor producer
+    cc = api.default_corridor_config()
+    for field in ("max_diff_x", "max_diff_y", "radius", "max_axis_x", "max_axis_y", "lane_segment_length", "is_multiple_sample"):
+        assert _same_bits(float(getattr(cc, field)), _ref_default("corridor." + field)), field
+    assert {f for f, _ in api.CorridorConfig._fields_} == {"max_diff_x", "max_diff_y", "radius", "max_axis_x", "max_axis_y",
+                                                            "lane_segment_length", "is_multiple_sample", "reserved0"}
+    for v, field in zip(orc.CORRIDOR_CFG, ("max_diff_x", "max_diff_y", "radius", "max_axis_x", "max_axis_y", "is_multiple_sample")):
+        assert _same_bits(float(v), _ref_default("corridor." + field)), ("oracle", field)
+    # the tracker: PlannerConfig::tracker_config and IlqrConfig::tracker_config carry the same defaults
+    tc = api.TrackerConfig()
+    api.lib().cilqr_default_tracker_config(C.byref(tc))
+    names = dict(weight_l="lateral.weight_l", weight_theta="lateral.weight_theta", weight_delta="lateral.weight_delta",
+                 weight_delta_rate="lateral.weight_delta_rate", preview_time="lateral.preview_time",
+                 weight_s="longitudinal.weight_s", weight_v="longitudinal.weight_v", weight_a="longitudinal.weight_a",
+                 weight_j="longitudinal.weight_j", sumulation_dt="sumulation_dt", dt="dt", tolerance="tolerance",
+                 max_num_iteration="max_num_iteration")
+    ocfg = dict(zip(orc.TRACKER_CFG_FIELDS, orc.TRACKER_CFG_DEFAULT))
+    for field, key in names.items():
+        for prefix in ("tracker.", "ilqr.tracker."):
+            ref = _ref_default(prefix + key)
+            assert _same_bits(float(getattr(tc, field)), ref), (field, prefix)
+            assert _same_bits(float(ocfg[field]), ref), ("oracle", field, prefix)
+    assert _ref_default("tracker.longitudinal.preview_time") == 0.0        # carried by neither: the reference never reads a non-zero value
+    for field in ("wheel_base", "delta_min", "delta_max", "delta_rate_min", "delta_rate_max", "jerk_min", "jerk_max",
+                  "min_acceleration", "max_acceleration"):
+        assert _same_bits(float(ocfg[field]), _ref_default("vehicle." + field)), ("oracle tracker", field)
+    # the DP coarse planner
+    dc = api.default_dp_config()
+    odp = dict(zip(orc.DP_CFG_FIELDS, orc.DP_CFG_DEFAULT))
+    for field, _ in api.DpConfig._fields_:
+        key = ("vehicle." if field in ("front_hang_length", "wheel_base", "rear_hang_length", "width", "max_velocity") else "planner.") + field
+        ref = _ref_default(key)
+        assert _same_bits(float(getattr(dc, field)), ref), (field, key)
+        assert _same_bits(float(odp[field]), ref), ("oracle", field, key)
+    # VehicleParam's constructor (vehicle_param.h:83-88): the collision discs of the DP
+    d3 = np.zeros(3)
+    orc.lib().oracle_vehicle_derived(_p(d3))
+    assert _same_bits(d3, [_ref_default("vehicle.radius"), _ref_default("vehicle.f2x"), _ref_default("vehicle.r2x")])
+
+
+def test_scene_generator_uses_the_references_vehicle_and_horizon():
+    """cilqr_amd/scenario.py (test / bench infrastructure) shrinks nothing itself, but its families quote the reference's
+    step and the demo horizon: dt and tf of PlannerConfig."""
+    sc = scenario.generate("demo80", 1, seed=1)
+    assert sc["n_steps"] + 1 == int(np.floor(_ref_default("planner.tf") / _ref_default("planner.delta_t") + 1))
+
+
+# ------------------------------------------------------------------ header-only helpers: slerp, LinSpaced, Pose, discs
+def test_slerp_equals_reference():
+    """math::slerp (math_utils.h:208-225), as the DP oracle and the tracker oracle restate it; the degenerate branch
+    (|t1 - t0| <= 1e-10), the +-pi wrap of the difference and arguments outside [t0, t1] included."""
+    L = orc.lib()
+    rng = np.random.default_rng(31)
+    n = 40000
+    a0, a1 = rng.uniform(-7, 7, n), rng.uniform(-7, 7, n)
+    a1[::5] = a0[::5] + rng.choice([np.pi, -np.pi, 2 * np.pi, 0.0], a0[::5].size) + rng.uniform(-1e-12, 1e-12, a0[::5].size)
+    t0 = rng.uniform(0, 50, n)
+    t1 = t0 + rng.uniform(0.01, 2.0, n)
+    t1[::11] = t0[::11] + rng.uniform(-2e-10, 2e-10, t0[::11].size)
+    t1[::13] = t0[::13]
+    t = t0 + rng.uniform(-0.3, 1.3, n) * (t1 - t0)
+    ref = np.array([REF.ref_slerp(*v) for v in zip(a0, t0, a1, t1, t)])
+    assert _same_bits(np.array([L.oracle_slerp(*v) for v in zip(a0, t0, a1, t1, t)]), ref)
+    assert _same_bits(np.array([L.oracle_tracker_slerp(*v) for v in zip(a0, t0, a1, t1, t)]), ref)
+
+
+def test_lin_spaced_equals_reference():
+    """math::LinSpaced<N> (math_utils.h:245-254) at the three sizes of DpPlanner's constructor (dp_planner.cpp:31-33), on the
+    reference's own arguments (tf / NT .. tf; 0 .. unit_time * max_velocity; 0 .. 1) and on random ones."""
+    L = orc.lib()
+    tf, vmax = _ref_default("planner.tf"), _ref_default("vehicle.max_velocity")
+    rng = np.random.default_rng(5)
+    cases = [(5, tf / 5, tf), (7, 0.0, tf / 5 * vmax), (9, 0.0, 1.0)]
+    cases += [(int(n), float(a), float(b)) for n, a, b in zip(rng.choice([5, 7, 9], 3000), rng.uniform(-30, 30, 3000), rng.uniform(-30, 200, 3000))]
+    for n, a, b in cases:
+        r, o = np.zeros(n), np.zeros(n)
+        assert REF.ref_lin_spaced(n, a, b, _p(r)) == n and L.oracle_lin_spaced(n, a, b, _p(o)) == n
+        assert _same_bits(o, r), (n, a, b)
+
+
+def test_pose_transform_equals_reference():
+    """Pose::transform (pose.h:40-46): body-frame polygon vertices placed along a dynamic obstacle's trajectory
+    (planning_node.cc:63-80) -- the oracle's scene builder, and the product's (cilqr_amd/scene_io.py uses numpy on the
+    same expression; include/cilqr/scene_file.hpp and dp_planner.hpp the C++ one)."""
+    L = orc.lib()
+    rng = np.random.default_rng(37)
+    n = 20000
+    args = np.stack([rng.uniform(-200, 200, n), rng.uniform(-200, 200, n), rng.uniform(-7, 7, n), rng.uniform(-3, 3, n),
+                     rng.uniform(-3, 3, n), np.zeros(n)], axis=1)
+    r, o = np.zeros(3), np.zeros(3)
+    for a in args:
+        REF.ref_pose_transform(*a, _p(r))
+        L.oracle_pose_transform(*a, _p(o))
+        assert _same_bits(o, r), a
+        x, y, th, rx, ry, _ = a
+        assert _same_bits(np.array([x + rx * np.cos(th) - ry * np.sin(th), y + rx * np.sin(th) + ry * np.cos(th)]), r[:2]), a
+
+
+def test_collision_boxes_of_the_dp_equal_reference():
+    """Environment::CheckOptimizationCollision (environment.cpp:92-104) builds two boxes per pose from
+    VehicleParam::GetDiscPositions (with its swapped result names), AABox2d::Shift and Box2d(AABox2d); the oracle's
+    restatement against the same statements run on the reference's own classes: disc centres, box centres, half extents,
+    min / max and corners, bit for bit."""
+    L = orc.lib()
+    rng = np.random.default_rng(41)
+    r, o = np.zeros(36), np.zeros(36)
+    for x, y, th in zip(rng.uniform(-300, 300, 20000), rng.uniform(-300, 300, 20000), rng.uniform(-7, 7, 20000)):
+        REF.ref_collision_boxes(x, y, th, 0.0, _p(r))
+        L.oracle_collision_boxes(x, y, th, 0.0, _p(o))
+        assert _same_bits(o, r), (x, y, th)
+
+
 # ------------------------------------------------------------------------------------------------- the device
 def _opt(sc):
     from cilqr_amd import api
@@ -360,11 +509,10 @@ def test_device_normalize_angle_equals_reference():
 
 @pytest.mark.gpu
 def test_device_nearest_lane_equals_reference_with_exact_ties():
-    """CILQR_OPT_EXACT_LANE_TIES: the device's nearest lane segment -- grid search and full scan -- is the one the
+    """CILQR_OPT_EXACT_LANE_TIES (default 1): the device's nearest lane segment -- grid search and full scan -- is the one the
     reference's own LineSegment2d::DistanceTo loop picks, on the tie strips too."""
     sc = scenario.generate("ped6", 4, seed=3)
-    api, opt = _opt(sc)
-    opt.set_option(api.OPT_EXACT_LANE_TIES, 1)
+    api, opt = _opt(sc)          # nothing set: the reference's tie rule is the library's default
     opt.stage_load(sc)
     pts = _tie_points(sc)
     gl, gr = opt.nearest_lane(pts, use_grid=True)

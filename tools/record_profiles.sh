@@ -41,7 +41,7 @@ python bench.py --pipeline 1 --cpu-sample 0 --no-latency > "$out/${tag}_bench_on
 python bench.py --pipeline 3 --cpu-sample 0 --no-latency > "$out/${tag}_bench_three_handles.json" 2> "$out/h3.err"
 python bench.py --torch-streams --cpu-sample 0 --no-latency > "$out/${tag}_bench_torch_streams.json" 2> "$out/ts.err"
 python bench.py --steps 20 --warmup 5 --cpu-sample 0 --no-latency > "$out/${tag}_bench_steps20_warmup5.json" 2> "$out/s20.err"
-python bench.py --exact-lane-ties --cpu-sample 0 --no-latency > "$out/${tag}_bench_exact_lane_ties.json" 2> "$out/et.err"
+python bench.py --fast-lane-ties --cpu-sample 0 --no-latency > "$out/${tag}_bench_fast_lane_ties.json" 2> "$out/et.err"
 python bench.py --tail-threshold 0 --in-flight 1 --pipeline 1 --cpu-sample 0 > "$out/${tag}_bench_lockstep_only_pipeline1.json" 2> "$out/ls.err"
 python bench.py --scene ped6 --batch 4096 --cpu-sample 0 > "$out/${tag}_bench_config1_ped6_b4096.json" 2> "$out/c1.err"
 python bench.py --scene dyn20 --cpu-sample 0 > "$out/${tag}_bench_config4_dyn20_n100.json" 2> "$out/c4.err"
