@@ -2,6 +2,15 @@
 //
 // Reference behaviour: IlqrOptimizer::Backward (algorithm/ilqr/ilqr_optimizer.cc:334-390) and
 // CalGradientNorm (cc:322-332); see kernels_backward.hip for the quirks that are kept.
+//
+// Compile-time switch CILQR_DV_EVAL ("hard parts"; the CPU checker the tests use carries the same switch):
+//   default ("lazy")        delta_V_ (cc:383-384) from Qu / Quu RE-EVALUATED on the Vx / Vxx that cc:379-381 have just
+//                           overwritten -- how Eigen's lazy `auto` expressions of cc:348-352 behave (read off Eigen's
+//                           expression semantics; not executable in this image, which has no Eigen);
+//   -DCILQR_DV_EVAL_EAGER   delta_V_ from the Qu / Quu the gains of the step were computed from.  TEST-ONLY build
+//                           (`make dveager` -> lib/libcilqr_hip_dveager.so, tests/test_gpu_parity.py): it is held
+//                           against the checker's eager variant, so both readings stay checked on the device.
+// All three mappings below (one lane, eight lanes, one wavefront per problem) honour it and stay bit-identical to each other.
 #pragma once
 #include "dev_model.hpp"
 
@@ -196,6 +205,11 @@ CILQR_DEV void backward_problem(const DeviceState& s, int slot, double lambda) {
 #pragma unroll
       for (int r = 0; r < 6; ++r) Vxx[r * 6 + c] = 0.5 * (Vxx[r * 6 + c] + Vxx[c * 6 + r]);
     // ---- delta_V_ with Qu / Quu re-evaluated on the NEW Vx / Vxx ----            cc:383-384
+#ifdef CILQR_DV_EVAL_EAGER
+    const double Qu0 = Qu[0], Qu1 = Qu[1];
+    dV0 += kc[0] * Qu0 + kc[1] * Qu1;
+    const double q00 = Quu[0], q01 = Quu[1], q10 = Quu[2], q11 = Quu[3];
+#else
     double BtV2[12], BtVB2[4], BtVx2[2];
     mt_x<2, 1, false>(B, Vx, BtVx2);
     const double Qu0 = lu[0] + BtVx2[0], Qu1 = lu[1] + BtVx2[1];
@@ -203,6 +217,7 @@ CILQR_DEV void backward_problem(const DeviceState& s, int slot, double lambda) {
     mt_x<2, 6, false>(B, Vxx, BtV2);
     x_m<2, 2, false>(BtV2, B, BtVB2);
     const double q00 = luu0 + BtVB2[0], q01 = BtVB2[1], q10 = BtVB2[2], q11 = luu1 + BtVB2[3];
+#endif
     const double hk0 = 0.5 * kc[0], hk1 = 0.5 * kc[1];
     const double r0 = hk0 * q00 + hk1 * q10, r1 = hk0 * q01 + hk1 * q11;
     dV1 += r0 * kc[0] + r1 * kc[1];
@@ -488,12 +503,18 @@ CILQR_DEV void backward_team_problem(const DeviceState& s, int slot, double lamb
     }
     // ---- delta_V_ with Qu / Quu re-evaluated on the NEW Vx / Vxx ----            cc:383-384
     {
+#ifdef CILQR_DV_EVAL_EAGER
+      const double Qu0 = Qu[0], Qu1 = Qu[1];
+      dV0 += kc[0] * Qu0 + kc[1] * Qu1;
+      const double q00 = Quu[0], q01 = Quu[1], q10 = Quu[2], q11 = Quu[3];
+#else
       const double BtVx2[2] = {B[6] * Vxa[3] + B[8] * Vxa[4], B[5] * Vxa[2] + B[11] * Vxa[5]};
       const double Qu0 = lu[0] + BtVx2[0], Qu1 = lu[1] + BtVx2[1];
       dV0 += kc[0] * Qu0 + kc[1] * Qu1;
       const double BtVB2[4] = {BtV0[3] * B[6] + BtV0[4] * B[8], BtV0[2] * B[5] + BtV0[5] * B[11],
                                Bt2_1[3] * B[6] + Bt2_1[4] * B[8], Bt2_1[2] * B[5] + Bt2_1[5] * B[11]};
       const double q00 = luu0 + BtVB2[0], q01 = BtVB2[1], q10 = BtVB2[2], q11 = luu1 + BtVB2[3];
+#endif
       const double hk0 = 0.5 * kc[0], hk1 = 0.5 * kc[1];
       const double r0 = hk0 * q00 + hk1 * q10, r1 = hk0 * q01 + hk1 * q11;
       dV1 += r0 * kc[0] + r1 * kc[1];
@@ -621,7 +642,7 @@ CILQR_DEV void backward_wave_problem(const DeviceState& s, int slot, double lamb
   double dV0 = 0.0, dV1 = 0.0, gsum = 0.0;
   double kp0 = 0.0, kp1 = 0.0, lup0 = 0.0, lup1 = 0.0, luup0 = 0.0, luup1 = 0.0;   // previous step: k, lu, luu
   // delta_V terms of the step whose B is in Bo, Qu / Quu on the current Vx / Vxx (cc:383-384)
-  auto delta_v = [&]() {
+  [[maybe_unused]] auto delta_v = [&]() {
     const double Qu0 = lup0 + L[oBtVx2], Qu1 = lup1 + L[oBtVx2 + 1];
     dV0 += kp0 * Qu0 + kp1 * Qu1;
     const double q00 = luup0 + L[oBtVB2], q01 = L[oBtVB2 + 1], q10 = L[oBtVB2 + 2], q11 = luup1 + L[oBtVB2 + 3];
@@ -659,7 +680,9 @@ CILQR_DEV void backward_wave_problem(const DeviceState& s, int slot, double lamb
       if (!mat && lane < 56) L[po2] = a;
     }
     sync();
+#ifndef CILQR_DV_EVAL_EAGER
     if (i < N - 1) delta_v();
+#endif
     if (i < 0) break;
     // ---- stage 3: Quu, Qu, inverse, k (every lane), K (lanes 36..47) ----
     const double lu0 = L[oLu], lu1 = L[oLu + 1], luu0 = L[oLuu], luu1 = L[oLuu + 1];
@@ -669,6 +692,14 @@ CILQR_DEV void backward_wave_problem(const DeviceState& s, int slot, double lamb
     const double invdet = 1.0 / (m00 * m11 - m10 * m01);                                           // cc:361-363
     const double n00 = -(m11 * invdet), n01 = -(-m01 * invdet), n10 = -(-m10 * invdet), n11 = -(m00 * invdet);
     const double kc0 = n00 * Qu[0] + n01 * Qu[1], kc1 = n10 * Qu[0] + n11 * Qu[1];                 // cc:366
+#ifdef CILQR_DV_EVAL_EAGER
+    {   // delta_V_ from the Qu / Quu the gains were computed from (see the switch at the top of this file)
+      dV0 += kc0 * Qu[0] + kc1 * Qu[1];
+      const double hk0 = 0.5 * kc0, hk1 = 0.5 * kc1;
+      const double r0 = hk0 * Quu[0] + hk1 * Quu[2], r1 = hk0 * Quu[1] + hk1 * Quu[3];
+      dV1 += r0 * kc0 + r1 * kc1;
+    }
+#endif
     {
       const double x0 = L[pq3], x1 = L[pq3 + 8];
       const double n0 = (q == 0) ? n00 : n10, n1 = (q == 0) ? n01 : n11;

@@ -11,13 +11,11 @@
  * ilqr_optimizer.cc, "vm" = algorithm/ilqr/vehicle_model.cc, "bf" = algorithm/ilqr/
  * barrier_function.h).  Plain arrays replace Eigen; the Eigen semantics reproduced by hand:
  *  - matrix products associate left to right ((A^T Vxx) A), each nested product is a temporary;
- *  - a dot product accumulates k = 0,1,2,... sequentially (Eigen's packet path; its scalar
- *    redux path sums as a tree -- which one the reference build used is unknowable here, the
- *    two differ by O(1 ulp));
+ *  - the order in which the six terms of a dot product are added: SWITCH CILQR_DOT_ORDER below;
  *  - `dst = xpr + product` evaluates the whole right side before writing dst (assume-aliasing);
  *  - 2x2 inverse is the closed form invdet = 1/(m00 m11 - m10 m01);
  *  - the lazy `auto` expressions of Backward (cc:348-363) are re-evaluated at every use, so the
- *    delta_V_ updates at cc:383-384 see the ALREADY UPDATED Vx/Vxx;
+ *    delta_V_ updates at cc:383-384 see the ALREADY UPDATED Vx/Vxx: SWITCH CILQR_DV_EVAL below;
  *  - cc:381 symmetrises Vxx in place without a temporary (column-major traversal);
  *  - iqr's R (cc:811-813) has indeterminate off-diagonals; 0 is used.
  */
@@ -67,11 +65,67 @@ struct Segment {
 
 struct Lane { double a, b, c; Segment seg; };
 
-// Small dense helpers, row-major, sequential accumulation over the inner index.
+// ---------------------------------------------------------------------------------------------------------------
+// Two assumptions about Eigen 3.4 that NOTHING in this image can check (no Eigen here), kept as switches.  Both have a
+// compile-time default (-DCILQR_DOT_ORDER=n, -DCILQR_DV_EVAL_EAGER) and a run-time override (oracle_set_semantics) so
+// that tests/semantics_report.py can run the variants side by side and count the solves each one moves.
+//
+// CILQR_DOT_ORDER -- how the six products of a 6-term dot product are added (2-term sums have one order):
+//   0 "sequential"   ((((t0+t1)+t2)+t3)+t4)+t5 everywhere.  This oracle's default since round 1.
+//   1 "eigen_redux"  (t0+(t1+t2)) + (t3+(t4+t5)) everywhere: a coefficient of a small fixed-size product is
+//                    (lhs.row(i).transpose().cwiseProduct(rhs.col(j))).sum() (Eigen/src/Core/ProductEvaluators.h,
+//                    product_evaluator<..LazyProduct..>::coeff), and sum() of a fixed-size expression unrolls through
+//                    redux_novec_unroller, which halves the range (Eigen/src/Core/Redux.h).  What an Eigen build
+//                    WITHOUT vectorisation (EIGEN_DONT_VECTORIZE, or a target without SIMD) computes.
+//   2 "eigen_sse2"   what the same headers do with 2-double packets (x86-64's baseline SSE2; also NEON), read off the
+//                    evaluator flags:
+//                      * lhs stored the other way round -- every `X.transpose() * Y` of Backward / iqr (A^T Vx, B^T Vx,
+//                        A^T Vxx, B^T Vxx, B^T P, A^T P): the product has no PacketAccessBit, each coefficient goes
+//                        through coeff(), and the redux itself is vectorised (both operands are contiguous columns):
+//                        packets p_j = (t_2j, t_2j+1), P = p0 + (p1 + p2), result = P[0] + P[1]
+//                        = (t0 + (t2 + t4)) + (t1 + (t3 + t5));
+//                      * lhs a column-major temporary or matrix -- (B^T Vxx) A, (B^T Vxx) B, (A^T Vxx) A, K (x - x_ref),
+//                        (A^T P)(A - B K) ...: CanVectorizeLhs, the assignment runs packet(row, col) =
+//                        etor_product_packet_impl: res = pmul(l0, r0); res = pmadd(l_k, r_k, res), k = 1..5, and pmadd
+//                        without FMA is padd(pmul(a, b), c): sequential.
+//                    Best reading of the default x86-64 -O2 build of CMakeLists.txt:9; not executable here.
+// The product kernels (cilqr_amd/csrc/backward_core.hpp) implement order 0.
+//
+// CILQR_DV_EVAL -- cc:348-352 declare Qu, Quu with `auto`: lazy expressions that hold references to Vx, Vxx.
+//   lazy  (default) cc:383-384 re-evaluate them AFTER cc:379-381 overwrote Vx, Vxx: delta_V_ uses the new value function
+//         (how Eigen's expression templates behave).
+//   eager delta_V_ uses the Qu, Quu that K and k were computed from (what the author most likely meant; what a
+//         compiler would do if `auto` were a Matrix).  -DCILQR_DV_EVAL_EAGER, also in backward_core.hpp.
+#ifndef CILQR_DOT_ORDER
+#define CILQR_DOT_ORDER 0
+#endif
+#ifdef CILQR_DV_EVAL_EAGER
+constexpr int kDvEagerDefault = 1;
+#else
+constexpr int kDvEagerDefault = 0;
+#endif
+int g_dot_order = CILQR_DOT_ORDER;   // written only by oracle_set_semantics, between solves
+int g_dv_eager = kDvEagerDefault;
+
+// sum of six products in the order `order` (0 sequential, 1 halving tree, 2 even/odd packets)
+inline double Sum6(const double* t, int order) {
+  if (order == 1) return (t[0] + (t[1] + t[2])) + (t[3] + (t[4] + t[5]));
+  if (order == 2) return (t[0] + (t[2] + t[4])) + (t[1] + (t[3] + t[5]));
+  return ((((t[0] + t[1]) + t[2]) + t[3]) + t[4]) + t[5];
+}
+// Small dense helpers, row-major.  MatMul: lhs as stored (Eigen: column-major temporary / matrix on the left);
+// MatTMul: lhs transposed (Eigen: X.transpose() * Y).  See CILQR_DOT_ORDER for what that decides.
 template <int R, int I, int C>
 inline void MatMul(const double* a, const double* b, double* out) {  // out[R][C] = a[R][I] b[I][C]
+  const int order = (I == 6) ? (g_dot_order == 1 ? 1 : 0) : 0;
   for (int r = 0; r < R; ++r)
     for (int c = 0; c < C; ++c) {
+      if (I == 6 && order != 0) {
+        double t[6];
+        for (int k = 0; k < 6; ++k) t[k] = a[r * I + (k % I)] * b[(k % I) * C + c];
+        out[r * C + c] = Sum6(t, order);
+        continue;
+      }
       double s = a[r * I + 0] * b[0 * C + c];
       for (int k = 1; k < I; ++k) s += a[r * I + k] * b[k * C + c];
       out[r * C + c] = s;
@@ -79,8 +133,15 @@ inline void MatMul(const double* a, const double* b, double* out) {  // out[R][C
 }
 template <int R, int I, int C>
 inline void MatTMul(const double* a, const double* b, double* out) {  // out[R][C] = a[I][R]^T b[I][C]
+  const int order = (I == 6) ? g_dot_order : 0;
   for (int r = 0; r < R; ++r)
     for (int c = 0; c < C; ++c) {
+      if (I == 6 && order != 0) {
+        double t[6];
+        for (int k = 0; k < 6; ++k) t[k] = a[(k % I) * R + r] * b[(k % I) * C + c];
+        out[r * C + c] = Sum6(t, order);
+        continue;
+      }
       double s = a[0 * R + r] * b[0 * C + c];
       for (int k = 1; k < I; ++k) s += a[k * R + r] * b[k * C + c];
       out[r * C + c] = s;
@@ -495,14 +556,19 @@ struct Oracle {
       // cc:381: in-place, column-major traversal, no temporary
       for (int c = 0; c < 6; ++c)
         for (int r = 0; r < 6; ++r) Vxx[r * 6 + c] = 0.5 * (Vxx[r * 6 + c] + Vxx[c * 6 + r]);
-      // cc:383-384: lazy Qu / Quu re-evaluated with the NEW Vx / Vxx
+      // cc:383-384: lazy Qu / Quu re-evaluated with the NEW Vx / Vxx (CILQR_DV_EVAL lazy; eager: the ones K, k came from)
       double BtV2[12], BtVB2[4], Quu2[4], BtVx2[2], Qu2[2];
-      MatTMul<2, 6, 1>(Bi, Vx, BtVx2);
-      for (int e = 0; e < 2; ++e) Qu2[e] = lu[i * 2 + e] + BtVx2[e];
+      if (g_dv_eager) {
+        for (int e = 0; e < 2; ++e) Qu2[e] = Qu[e];
+        for (int e = 0; e < 4; ++e) Quu2[e] = Quu[e];
+      } else {
+        MatTMul<2, 6, 1>(Bi, Vx, BtVx2);
+        for (int e = 0; e < 2; ++e) Qu2[e] = lu[i * 2 + e] + BtVx2[e];
+        MatTMul<2, 6, 6>(Bi, Vxx, BtV2);
+        MatMul<2, 6, 2>(BtV2, Bi, BtVB2);
+        for (int e = 0; e < 4; ++e) Quu2[e] = luu[i * 4 + e] + BtVB2[e];
+      }
       dV[0] += kc[0] * Qu2[0] + kc[1] * Qu2[1];
-      MatTMul<2, 6, 6>(Bi, Vxx, BtV2);
-      MatMul<2, 6, 2>(BtV2, Bi, BtVB2);
-      for (int e = 0; e < 4; ++e) Quu2[e] = luu[i * 4 + e] + BtVB2[e];
       const double hk[2] = {0.5 * kc[0], 0.5 * kc[1]};
       const double hkQ[2] = {hk[0] * Quu2[0] + hk[1] * Quu2[2], hk[0] * Quu2[1] + hk[1] * Quu2[3]};
       dV[1] += hkQ[0] * kc[0] + hkQ[1] * kc[1];
@@ -772,6 +838,23 @@ struct Oracle {
 }  // namespace
 
 extern "C" {
+
+/* dv_eval: 0 lazy, 1 eager; dot_order: 0 sequential, 1 eigen_redux, 2 eigen_sse2 (see the top of this file); a negative
+ * value leaves that switch alone.  Process-wide; call between solves only.  Returns dv_eval | dot_order << 8 as now set. */
+int oracle_set_semantics(int dv_eval, int dot_order) {
+  if (dv_eval == 0 || dv_eval == 1) g_dv_eager = dv_eval;
+  if (dot_order >= 0 && dot_order <= 2) g_dot_order = dot_order;
+  return g_dv_eager | (g_dot_order << 8);
+}
+
+/* test hook: one 6-term dot product through the helpers every matrix product of this file uses.  transposed_lhs = 1:
+ * the path of X.transpose() * Y (MatTMul), 0: plain lhs (MatMul); with the dot order currently set. */
+double oracle_dot6(const double* a, const double* b, int transposed_lhs) {
+  double out = 0.0;
+  if (transposed_lhs) MatTMul<1, 6, 1>(a, b, &out);
+  else MatMul<1, 6, 1>(a, b, &out);
+  return out;
+}
 
 void oracle_default_config(oracle_config* c, int n_steps) {
   c->n_steps = n_steps;

@@ -137,6 +137,14 @@ def lib():
     return _LIB
 
 
+def set_semantics(dv_eval: int = -1, dot_order: int = -1) -> int:
+    """The oracle's two switches for what cannot be checked against Eigen here (cilqr_oracle.cc, top): dv_eval 0 lazy /
+    1 eager, dot_order 0 sequential / 1 eigen_redux / 2 eigen_sse2; negative leaves a switch alone.  Process-wide."""
+    L = lib()
+    L.oracle_set_semantics.restype = C.c_int
+    return L.oracle_set_semantics(C.c_int(dv_eval), C.c_int(dot_order))
+
+
 def default_config(n_steps: int = 50, **over) -> OracleConfig:
     c = OracleConfig()
     lib().oracle_default_config(C.byref(c), C.c_int(n_steps))

@@ -331,13 +331,14 @@ def test_obstacles_to_trajectories_on_the_device(built):
 
 
 @pytest.mark.gpu
-def test_cpp_corridor_adapter_matches_oracle(built, tmp_path):
+@pytest.mark.parametrize("types", ["stand-ins", "reference headers"])
+def test_cpp_corridor_adapter_matches_oracle(built, tmp_path, types):
     """planning::Corridor-shaped C++ adapter (include/cilqr/corridor.hpp), one trajectory, host
     containers: half-planes and polygons against the oracle knot by knot, lane constraints equal
     to the oracle's, error paths of Corridor::Plan (corridor.cc:24-35), stored point lists."""
     import subprocess
     from test_host import build_corridor_adapter_test
-    exe = build_corridor_adapter_test(tmp_path)
+    exe = build_corridor_adapter_test(tmp_path, types)
     sc = scenario.generate("mix11", 3, seed=45, obstacle_points=True)
     b = 1
     K, P = sc["coarse"].shape[1], sc["obstacle_points"].shape[2]

@@ -152,27 +152,25 @@ def test_generator_with_dp_coarse_trajectories():
     assert np.abs(np.diff(kappa, axis=1)).max() > 0.02
 
 
-def build_planner_test(tmp_path):
-    exe = tmp_path / "planner_test"
-    cmd = ["g++", "-std=c++14", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
-           os.path.join(ROOT, "tests", "cpp", "planner_test.cc"), "-o", str(exe),
-           "-L" + os.path.dirname(api.LIB_PATH), "-lcilqr_hip", "-Wl,-rpath," + os.path.dirname(api.LIB_PATH),
-           "-Wl,-rpath-link,/opt/rocm/lib"]
-    subprocess.check_call(cmd)
-    return exe
+def build_planner_test(tmp_path, types="stand-ins"):
+    from test_host import build_cpp_test
+    return build_cpp_test("planner_test", tmp_path, types)
 
 
-def test_trajectory_planner_adapter_compiles_as_cxx14_against_the_c_abi(tmp_path):
+@pytest.mark.parametrize("types", ["stand-ins", "reference headers"])
+def test_trajectory_planner_adapter_compiles_as_cxx14_against_the_c_abi(tmp_path, types):
     """include/cilqr/trajectory_planner.hpp + dp_planner.hpp (the planning::DpPlanner / TrajectoryPlanner call
-    surfaces) build with C++14 / g++ against stand-ins of the reference's types and link against the C-ABI only."""
-    assert build_planner_test(tmp_path).exists()
+    surfaces) build with C++14 / g++ and link against the C-ABI only -- against stand-ins of the reference's types and
+    against its own headers (PlannerConfig, StartState, TrajectoryPoint, DiscretizedTrajectory, Polygon2d ...)."""
+    assert build_planner_test(tmp_path, types).exists()
 
 
 @pytest.mark.gpu
-def test_cpp_trajectory_planner_pipeline_matches_the_c_abi_stage_by_stage(tmp_path):
+@pytest.mark.parametrize("types", ["stand-ins", "reference headers"])
+def test_cpp_trajectory_planner_pipeline_matches_the_c_abi_stage_by_stage(tmp_path, types):
     """planning::TrajectoryPlanner-shaped C++ pipeline (DP -> Corridor -> IlqrOptimizer, include/cilqr/*.hpp) on scenes
     read from a .cqs file, against the same three stages driven one by one through the C-ABI from Python."""
-    exe = build_planner_test(tmp_path)
+    exe = build_planner_test(tmp_path, types)
     g = scenario.generate_dp("demo80", 4, seed=61, workers=4)
     path = tmp_path / "scenes.cqs"
     scene_io.save(str(path), g["scene_file"])

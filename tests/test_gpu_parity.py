@@ -18,6 +18,7 @@ from oracle import oracle as orc
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
 STAGE_TOL = 1e-9
 ITER_CAP = 48   # iterates kept per problem for the step-by-step replay (longer solves: decisions and costs only)
 
@@ -1108,6 +1109,24 @@ def test_fast_lane_tie_rule_is_the_opt_in():
     opt.close()
 
 
+def test_delta_v_evaluation_switch():
+    """whether cc:383-384 see the updated Vx / Vxx (lazy `auto`, the default in product and oracle) or
+    the ones the gains came from (eager) cannot be run against Eigen here, so BOTH readings stay built and checked: the
+    test-only library libcilqr_hip_dveager.so (-DCILQR_DV_EVAL_EAGER, cilqr_amd/csrc/backward_core.hpp) against the oracle's
+    eager variant, in a child process (a process holds one libcilqr_hip): tests/dv_eval_check.py."""
+    import json
+    import subprocess
+    import sys
+    lib = os.path.join(ROOT, "cilqr_amd", "lib", "libcilqr_hip_dveager.so")
+    assert os.path.exists(lib), f"{lib} is missing (make -C cilqr_amd/csrc dveager; __graft_entry__.build() does it)"
+    r = subprocess.run([sys.executable, os.path.join(HERE, "dv_eval_check.py")], env=dict(os.environ, CILQR_LIB=lib),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rep["ok"] and rep["steps"]["steps"] > 1000
+    print(f"\neager delta_V build: {rep}")
+
+
 def test_speculative_line_search_is_bit_identical_to_round_by_round(lockstep_only):
     """Small active sets evaluate all 11 step sizes at once; the first passing index must win exactly
     as in the sequential loop (ilqr_optimizer.cc:246-265), so both modes give the same bits."""
@@ -1168,11 +1187,13 @@ def test_tail_kernel_is_bit_identical_to_the_lockstep_loop(family, B, seed):
     opt.close()
 
 
-def test_cpp_adapter_plan_matches_oracle(tmp_path):
-    """planning::IlqrOptimizer-shaped C++ adapter (B = 1, host containers) end to end."""
+@pytest.mark.parametrize("types", ["stand-ins", "reference headers"])
+def test_cpp_adapter_plan_matches_oracle(tmp_path, types):
+    """planning::IlqrOptimizer-shaped C++ adapter (B = 1, host containers) end to end -- compiled against stand-ins for the
+    reference's types and against the reference's own headers (the binary built in the build container, oracle/_ref)."""
     import subprocess
     from test_host import build_adapter_test
-    exe = build_adapter_test(tmp_path)
+    exe = build_adapter_test(tmp_path, types)
     g = np.load(os.path.join(HERE, "golden", "mix11_n50.npz"))
     b = 1
     K, cmax = g["coarse"].shape[1], int(g["cmax"])

@@ -271,24 +271,41 @@ def test_bench_gpus_n_starts_n_ranks_by_itself():
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and r.stdout.strip() == ""
 
 
-def build_adapter_test(tmp_path):
-    exe = tmp_path / "adapter_test"
-    cmd = ["g++", "-std=c++14", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
-           os.path.join(ROOT, "tests", "cpp", "adapter_test.cc"), "-o", str(exe),
-           "-L" + os.path.dirname(api.LIB_PATH), "-lcilqr_hip", "-Wl,-rpath," + os.path.dirname(api.LIB_PATH),
-           "-Wl,-rpath-link,/opt/rocm/lib"]
-    subprocess.check_call(cmd)
+TYPES = ("stand-ins", "reference headers")
+
+
+def build_cpp_test(name, tmp_path, types="stand-ins"):
+    """One of the C++ programs under tests/cpp that drive the adapters of include/cilqr/*.hpp through the C-ABI.
+    types = "stand-ins": compiled here against tests/cpp/reference_types.hpp's minimal stand-ins for the reference's types;
+    types = "reference headers": the same program compiled against the REFERENCE'S OWN headers (TrajectoryPoint, StartState,
+    DiscretizedTrajectory, Vec2d, LineSegment2d, Polygon2d, IlqrConfig, Weights, CorridorConfig, PlannerConfig,
+    VehicleParam) and linked against its own objects -- oracle/Makefile target ref_typed_tests builds it into oracle/_ref/
+    where the reference tree exists (this container); on the GPU box the prebuilt binary that travelled is used."""
+    if types == "stand-ins":
+        exe = tmp_path / name
+        cmd = ["g++", "-std=c++14", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+               os.path.join(ROOT, "tests", "cpp", name + ".cc"), "-o", str(exe),
+               "-L" + os.path.dirname(api.LIB_PATH), "-lcilqr_hip", "-Wl,-rpath," + os.path.dirname(api.LIB_PATH),
+               "-Wl,-rpath-link,/opt/rocm/lib"]
+        subprocess.check_call(cmd)
+        return exe
+    import pathlib
+    exe = pathlib.Path(ROOT) / "oracle" / "_ref" / (name + "_reftypes")
+    if os.path.isdir("/root/reference/algorithm"):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "_ref/libcilqr_ref.so", f"_ref/{name}_reftypes"])
+    if not exe.exists():
+        pytest.skip(f"{exe} was not built (no reference tree here and nothing shipped)")
+    if not os.access(exe, os.X_OK):
+        os.chmod(exe, 0o755)
     return exe
 
 
-def build_corridor_adapter_test(tmp_path):
-    exe = tmp_path / "corridor_adapter_test"
-    cmd = ["g++", "-std=c++14", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
-           os.path.join(ROOT, "tests", "cpp", "corridor_adapter_test.cc"), "-o", str(exe),
-           "-L" + os.path.dirname(api.LIB_PATH), "-lcilqr_hip", "-Wl,-rpath," + os.path.dirname(api.LIB_PATH),
-           "-Wl,-rpath-link,/opt/rocm/lib"]
-    subprocess.check_call(cmd)
-    return exe
+def build_adapter_test(tmp_path, types="stand-ins"):
+    return build_cpp_test("adapter_test", tmp_path, types)
+
+
+def build_corridor_adapter_test(tmp_path, types="stand-ins"):
+    return build_cpp_test("corridor_adapter_test", tmp_path, types)
 
 
 @pytest.mark.gpu
@@ -327,16 +344,21 @@ def test_header_is_plain_c99_and_the_pool_calls_link(built, tmp_path):
     assert r.returncode == 0 and "pool_c99 ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
 
 
-def test_corridor_adapter_compiles_as_cxx14_against_the_c_abi(built, tmp_path):
+@pytest.mark.parametrize("types", TYPES)
+def test_corridor_adapter_compiles_as_cxx14_against_the_c_abi(built, tmp_path, types):
     """include/cilqr/corridor.hpp (the planning::Corridor call surface) builds with C++14 / g++ and
-    links against the C-ABI library only."""
-    assert build_corridor_adapter_test(tmp_path).exists()
+    links against the C-ABI library only -- with stand-ins for the reference's types and with the reference's own
+    headers (corridor.h:27-44's argument types: DiscretizedTrajectory, Vec2d, LineSegment2d, CorridorConfig)."""
+    assert build_corridor_adapter_test(tmp_path, types).exists()
 
 
-def test_cpp_adapter_compiles_as_cxx14_against_the_c_abi(built, tmp_path):
+@pytest.mark.parametrize("types", TYPES)
+def test_cpp_adapter_compiles_as_cxx14_against_the_c_abi(built, tmp_path, types):
     """The drop-in header (include/cilqr/ilqr_optimizer.hpp) must build with the reference's own
-    toolchain settings (C++14, g++, no HIP headers) and link against the C-ABI library only."""
-    exe = build_adapter_test(tmp_path)
+    toolchain settings (C++14, g++, no HIP headers) and link against the C-ABI library only -- with stand-ins and with
+    the reference's own TrajectoryPoint / DiscretizedTrajectory / LineSegment2d / IlqrConfig / VehicleParam, i.e. exactly
+    what trajectory_planner.cpp:26,80-97 hands to IlqrOptimizer (compiled here, not asserted)."""
+    exe = build_adapter_test(tmp_path, types)
     assert exe.exists()
     hdr = open(os.path.join(ROOT, "include", "cilqr.h")).read()
     includes = re.findall(r"#include\s+[<\"]([^>\"]+)", hdr)

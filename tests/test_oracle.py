@@ -1,5 +1,6 @@
 """CPU tests of the oracle (oracle/cilqr_oracle.cc) against independently restated formulas and
 the committed golden fixtures.  The reference has no tests; these follow SURVEY section 4."""
+import ctypes as C
 import glob
 import os
 
@@ -279,3 +280,59 @@ def test_threaded_batch_driver_equals_the_sequential_one():
         got = orc.solve_batch_threads(sc, threads=threads)
         for k in ("traj", "cost_hist", "n_cost", "status", "n_iter"):
             assert np.array_equal(got[k], ref[k]), (threads, k)
+
+
+# ---- the two unverifiable readings of Eigen's semantics, as switches (oracle/cilqr_oracle.cc, top) ----
+def test_dot_order_switch_adds_six_terms_in_the_documented_orders():
+    """CILQR_DOT_ORDER: 0 sequential; 1 eigen_redux = (t0+(t1+t2)) + (t3+(t4+t5)) on every product; 2 eigen_sse2 =
+    (t0+(t2+t4)) + (t1+(t3+t5)) for X.transpose() * Y and sequential for a plain left operand.  Python floats add in IEEE
+    double, so the three associations can be written down and compared bit for bit."""
+    L = orc.lib()
+    L.oracle_dot6.restype = C.c_double
+    L.oracle_dot6.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    rng = np.random.default_rng(17)
+    n_diff = 0
+    try:
+        for _ in range(2000):
+            a = rng.standard_normal(6) * 10.0 ** rng.integers(-3, 4, 6)
+            b = rng.standard_normal(6)
+            t = [float(x) * float(y) for x, y in zip(a, b)]
+            seq = ((((t[0] + t[1]) + t[2]) + t[3]) + t[4]) + t[5]
+            tree = (t[0] + (t[1] + t[2])) + (t[3] + (t[4] + t[5]))
+            pack = (t[0] + (t[2] + t[4])) + (t[1] + (t[3] + t[5]))
+            n_diff += (seq != tree) + (seq != pack)
+            for order, (plain, transposed) in {0: (seq, seq), 1: (tree, tree), 2: (seq, pack)}.items():
+                assert orc.set_semantics(-1, order) >> 8 == order
+                assert L.oracle_dot6(a.ctypes.data, b.ctypes.data, 0) == plain, order
+                assert L.oracle_dot6(a.ctypes.data, b.ctypes.data, 1) == transposed, order
+    finally:
+        assert orc.set_semantics(0, 0) == 0
+    assert n_diff > 1000          # the orders do round differently on such data
+
+
+def test_semantics_switches_move_only_what_they_should():
+    """dv_eval touches delta_V_ and nothing else of a backward pass; a dot order moves gains by rounding only; the defaults
+    (lazy, sequential) are what the golden fixtures were made with (test_oracle_reproduces_golden runs on them)."""
+    g = np.load(os.path.join(HERE, "golden", "mix11_n50.npz"))
+    o = orc.Oracle(n_steps=int(g["n_steps"]))
+    o.set_problem(g["start"][0], g["coarse"][0], g["corridor"][0], g["ccount"][0], g["left"], g["right"])
+    X, U = o.init_guess()
+    q = o.quadratize(X, U)
+    K0, k0, dV0 = o.backward(1.0, q)
+    try:
+        assert orc.set_semantics(1, -1) == 1
+        K1, k1, dV1 = o.backward(1.0, q)
+        assert np.array_equal(K0, K1) and np.array_equal(k0, k1)
+        assert np.all(np.abs(dV1 - dV0) > 1e-9 * np.abs(dV0))            # a different quantity, not a rounding
+        orc.set_semantics(0, -1)
+        for order in (1, 2):
+            orc.set_semantics(-1, order)
+            K2, k2, dV2 = o.backward(1.0, q)
+            assert not np.array_equal(K0, K2)
+            assert np.abs(K2 - K0).max() <= 1e-10 * np.abs(K0).max() and np.allclose(dV2, dV0, rtol=1e-9)
+            X2, _ = o.init_guess()
+            assert np.abs(X2 - X).max() < 1e-9
+    finally:
+        assert orc.set_semantics(0, 0) == 0
+    K3, k3, dV3 = o.backward(1.0, q)
+    assert np.array_equal(K3, K0) and np.array_equal(dV3, dV0)
