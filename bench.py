@@ -172,6 +172,12 @@ def measure_backward_traffic(args, problem_steps_per_solve):
             cmd = ["rocprofv3", "--pmc", c, "-d", d, "--", sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0",
                    "--in-flight", "1", "--pipeline", "1", "--cpu-sample", "0", "--no-latency", "--no-traffic", "--batch", str(args.batch),
                    "--scene", args.scene, "--seed", str(args.seed), "--coarse", args.coarse]
+            for flag, val in (("--compact-percent", args.compact_percent), ("--team-threshold", args.team_threshold),
+                              ("--wave-threshold", args.wave_threshold), ("--tail-threshold", args.tail_threshold)):
+                if val >= 0:      # what decides which backward kernel runs on which slots
+                    cmd += [flag, str(val)]
+            if args.fast_lane_ties:
+                cmd.append("--fast-lane-ties")
             env = dict(os.environ, TMPDIR="/tmp")
             for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
                 env.pop(k, None)
@@ -251,36 +257,91 @@ def plan_latency(scenario, families, n_scenes, seed, workers, batch=64):
 
 
 def dry_run(args, rank, world):
-    """Launch plumbing without a GPU (see --dry-run): the rendezvous, the rank census and the results gather of the
-    timed region, over gloo, on made-up results whose values encode (rank, problem)."""
+    """Launch plumbing without a GPU (see --dry-run): the rendezvous, the rank census and the per-step results gather of the
+    timed region -- the SAME GatherThread (cilqr_amd/distributed.py), fed `steps` made-up results per rank through recycled
+    slots -- over gloo.  Values encode (step, rank, problem); every problem has its own number of live Cost rows, so the
+    ragged part of the payload is exercised too.  Rank 0 checks every gathered step: rank r's block sits at offset r * B, in
+    problem order; steps arrive in the order they were put; the ragged rows unpack to the right problems."""
     import torch
     import torch.distributed as dist
-    from cilqr_amd.distributed import gather_results
+    from cilqr_amd.distributed import GatherThread
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     one = torch.ones(1, dtype=torch.int32)
     if world > 1:
         dist.all_reduce(one)
     ranks = int(one.item())
-    B, K, M = min(args.batch, 16), 6, 4
-    traj = torch.zeros((B, K, 10), dtype=torch.float64)
-    traj[:] = (rank * B + torch.arange(B, dtype=torch.float64))[:, None, None]
-    hist = torch.zeros((B, M + 1, 5), dtype=torch.float64)
-    nc = torch.full((B,), 2, dtype=torch.int32)
-    st = torch.full((B,), 1 + rank % 5, dtype=torch.int32)
-    order_ok = None
+    B, K, M = min(args.batch, 16), 6, 8
+    steps = max(1, min(args.steps, 6))
+    checks = {"rank_order": True, "step_order": True, "ragged_rows": True, "kappa_rebuilt": True}
+    seen = []
+
+    def make(step, slot):
+        pid = (rank * B + torch.arange(B, dtype=torch.float64))                 # global problem index
+        slot["traj"][:] = (1000.0 * step + pid)[:, None, None]
+        slot["traj"][:, :, 6] = 0.01 * (1 + rank)                                 # delta: kappa = tan(delta) / L is rebuilt on the root
+        slot["nc"][:] = (1 + (torch.arange(B) + rank + step) % M).to(torch.int32)  # live Cost rows: differ by problem, rank and step
+        slot["hist"][:] = -1.0
+        for b in range(B):
+            n = int(slot["nc"][b])
+            slot["hist"][b, :n, :] = (1000.0 * step + pid[b] + 0.001 * torch.arange(n, dtype=torch.float64))[:, None]
+        slot["st"][:] = 1 + (rank + step) % 5
+
+    def check(step, g):
+        n = world * B
+        want = 1000.0 * step + torch.arange(n, dtype=torch.float64)
+        checks["rank_order"] &= bool(torch.equal(g["traj"][:, 0, 1], want))       # column 1 (x) travels as it is
+        checks["kappa_rebuilt"] &= bool(torch.allclose(g["traj"][:, :, 7], torch.tan(g["traj"][:, :, 6]) / 1.0, rtol=0, atol=0)
+                                        and torch.equal(g["traj"][:, 1, 0], torch.full((n,), 0.1, dtype=torch.float64)))
+        nc = g["n_cost"].to(torch.int64)
+        r_ = torch.arange(n)
+        checks["ragged_rows"] &= bool(torch.equal(nc, 1 + (r_ % B + r_ // B + step) % M))
+        first = torch.cumsum(nc, 0) - nc
+        checks["ragged_rows"] &= bool(torch.equal(g["hist_rows"][first, 0], want) and g["hist_rows"].shape[0] == int(nc.sum())
+                                      and torch.equal(g["hist_rows"][first + nc - 1, 0], want + 0.001 * (nc - 1).to(torch.float64)))
+        checks["ragged_rows"] &= bool(torch.equal(g["status"], (1 + (r_ // B + step) % 5).to(g["status"].dtype)))
+
+    free = [dict(traj=torch.zeros((B, K, 10), dtype=torch.float64), hist=torch.zeros((B, M + 1, 5), dtype=torch.float64),
+                 nc=torch.zeros(B, dtype=torch.int32), st=torch.zeros(B, dtype=torch.int32)) for _ in range(2)]
+    import threading
+    cv = threading.Condition()
+    gt = None
+
+    def done(tag):
+        step, slot = tag
+        if rank == 0 and gt.last_tag is tag and gt.last is not None:
+            seen.append(step)
+            check(step, gt.last)
+        with cv:
+            free.append(slot)
+            cv.notify_all()
+
     if world > 1:
-        g = gather_results(traj, hist, nc, st, dst=0, densify=False)
-        if rank == 0:
-            order_ok = bool(torch.equal(g["traj"][:, 0, 0], torch.arange(world * B, dtype=torch.float64)))
+        gt = GatherThread(device=None, dst=0, derive=(0.1, 1.0), on_done=done)
+        for step in range(steps):
+            with cv:
+                while not free:
+                    cv.wait(60.0)
+                slot = free.pop(0)
+            make(step, slot)
+            gt.put((step, slot), slot["traj"], slot["hist"], slot["nc"], slot["st"])
+        gt.drain()
+        gt.close()
+        checks["step_order"] = (seen == list(range(steps))) if rank == 0 else True
         dist.barrier()
         dist.destroy_process_group()
     if ranks != world:
         raise SystemExit(f"bench.py: {ranks} ranks answered the all-reduce, WORLD_SIZE is {world}")
     if rank == 0:
+        ok = all(checks.values()) if world > 1 else None
         return {"metric": "CILQR solves/sec (dry run: launch plumbing only, nothing solved)", "value": None, "unit": "solves/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True, "ranks_reporting": ranks,
-                "gather_in_rank_order": order_ok, "spawned_by_bench": os.environ.get("CILQR_BENCH_SPAWNED") == "1"}
+                "gather_in_rank_order": (checks["rank_order"] if world > 1 else None), "gathers": len(seen),
+                "gathers_in_step_order": (checks["step_order"] if world > 1 else None),
+                "ragged_history_rows_ok": (checks["ragged_rows"] if world > 1 else None),
+                "time_and_kappa_rebuilt_on_root": (checks["kappa_rebuilt"] if world > 1 else None), "gather_checks_ok": ok,
+                "mode": "multi" if getattr(args, "multi", False) else "ranks",
+                "spawned_by_bench": os.environ.get("CILQR_BENCH_SPAWNED") == "1"}
     return None
 
 
@@ -331,7 +392,7 @@ def main():
             raise SystemExit(f"bench.py: {rccl_ranks} ranks answered the RCCL all-reduce, WORLD_SIZE is {world}")
 
     from cilqr_amd import api, scenario
-    from cilqr_amd.distributed import gather_results
+    from cilqr_amd.distributed import GatherThread
 
     spec = scenario.SPECS[args.scene]
     B, N, K, cmax = args.batch, spec.n_steps, spec.n_steps + 1, spec.cmax
@@ -411,7 +472,7 @@ def main():
                 o.set_option(api.OPT_FINISH_THRESHOLD, args.finish_threshold)
             if args.fast_lane_ties:
                 o.set_option(api.OPT_EXACT_LANE_TIES, 0)
-            self.slots = [Slot() for _ in range(D + 1)]   # D in flight + the one whose results are being gathered
+            self.slots = [Slot() for _ in range(D + (2 if use_dist else 1))]   # D in flight + the one(s) whose results are being gathered
             self.free = list(self.slots)
             self.fifo = []          # submitted, oldest first
             # the first slot doubles as the buffers of the synchronous calls below
@@ -427,6 +488,35 @@ def main():
 
     prof_acc = dict(bwd_ms=0.0, bwd_launches=0, bwd_steps=0, iters=0, full_ms=0.0, full_launches=0)
     last_gather = [None]   # [0]: result of the last gather; [-1]: the slot it gathered (when any)
+
+    # The per-step results gather (one collective per job, rank r's block after rank r-1's) runs on a thread and a
+    # stream of its own (cilqr_amd/distributed.py: GatherThread): packing, the length agreement (a host sync) and, on rank 0,
+    # unpacking world x the payload never hold the loop that keeps the handles fed.  Every rank gathers its finished steps in
+    # the order they finished, so the ranks' collectives pair up; a slot goes back to its handle's free list when its gather is done.
+    import threading
+    free_cv = threading.Condition()
+
+    def slot_gathered(tag):
+        c_, sl_ = tag
+        with free_cv:
+            c_.free.append(sl_)
+            free_cv.notify_all()
+
+    # 8 of the 10 trajectory columns travel (time and kappa are functions of the others)
+    gatherer = GatherThread(device=dev, dst=0, derive=(cfg.dt, cfg.wheel_base), on_done=slot_gathered) if use_dist else None
+
+    def take_free(c):
+        with free_cv:
+            while not c.free:
+                if not free_cv.wait(timeout=120.0):
+                    raise RuntimeError("bench.py: no result slot came back from the gather thread within 120 s")
+            return c.free.pop(0)
+
+    def drain_gathers():
+        if use_dist:
+            gatherer.drain()
+            if gatherer.last_tag is not None:
+                last_gather[:] = [gatherer.last, gatherer.last_tag[1]]
 
     dealt = [0, 0]   # solves submitted to / collected from the pool so far: solve s runs on handle s % P, the oldest is collected first
 
@@ -449,10 +539,9 @@ def main():
             prof_acc["full_ms"] += p.backward_full_ms
             prof_acc["full_launches"] += p.backward_full_launches
         if use_dist:
-            # 8 of the 10 trajectory columns travel (time and kappa are functions of the others)
-            last_gather[0] = gather_results(sl.traj, sl.hist, sl.nc, sl.st, dst=0, densify=False, derive=(cfg.dt, cfg.wheel_base))
-            last_gather.append(sl)
-        c.free.append(sl)
+            gatherer.put((c, sl), sl.traj, sl.hist, sl.nc, sl.st)      # the gather thread hands the slot back when the collective is done
+        else:
+            c.free.append(sl)
 
     def run_steps(n, timed, alone=None):
         # alone = None: the steps go to the POOL (cilqr_pool_submit / cilqr_pool_wait), at most P * D in flight;
@@ -465,7 +554,7 @@ def main():
             oldest = ctx[dealt[1] % P] if through_pool else alone
             full = (dealt[0] - dealt[1] == P * D) if through_pool else (len(alone.fifo) == D)
             done = (oldest, wait_oldest(oldest, through_pool)) if full else None
-            sl = c.free.pop(0)
+            sl = take_free(c)
             sl.used = True
             rc = pool.submit_raw(prob, sl.sol) if through_pool else c.opt.submit_raw(prob, sl.sol)
             if rc != api.OK:
@@ -481,6 +570,7 @@ def main():
             oldest = ctx[dealt[1] % P] if through_pool else alone
             done = wait_oldest(oldest, through_pool)
             finish(oldest, done[0], done[1], timed)
+        drain_gathers()      # a region ends when its last step's results are on rank 0
 
     def fence():
         if use_dist:
@@ -509,10 +599,13 @@ def main():
             c.opt.set_profiling(2)      # timed steps: events around the backward launches only (< 1 %)
     run_steps(args.warmup, False)
     fence()
+    if use_dist:
+        gatherer.reset_stats()
     t_start = time.perf_counter()
     run_steps(args.steps, True)
     fence()
     elapsed = time.perf_counter() - t_start
+    gather_timed = dict(busy_s=gatherer.busy_s, count=gatherer.count) if use_dist else None
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -696,46 +789,71 @@ def main():
             if rec is not None and "full_batch_launch" not in rec:
                 rec = None if not traffic else dict(rec, full_batch_launch={"hbm_bytes_per_problem_step": rec["hbm_bytes_per_problem_step_all_launches"]})
             real_all = rec["hbm_bytes_per_problem_step_all_launches"] * prof_acc["bwd_steps"] if rec else None
+            bps = rec["hbm_bytes_per_problem_step_all_launches"] if rec else None
+            gbs = lambda nbytes, t: nbytes / t / 1e9                                   # noqa: E731
+            # Contended figures: every backward launch of the TIMED region.  With P x D solves in flight a kernel's duration
+            # includes the time its CUs spent on the other streams' kernels.
+            contended = {"achieved": round(gbs(alg_bytes, t_all), 1),
+                         "frac": round(gbs(real_all, t_all) / HBM_PEAK_GBS, 4) if real_all else None,
+                         "frac_algorithmic": round(gbs(alg_bytes, t_all) / HBM_PEAK_GBS, 4),
+                         "avg_launch_ms": prof_acc["bwd_ms"] / prof_acc["bwd_launches"], "launches": prof_acc["bwd_launches"],
+                         "mean_problems_per_launch": n_act_sum / prof_acc["bwd_launches"], "batches_in_flight": P * D}
+            # The kernel's own figures: the same launches of ONE solve with nothing else on the GPU -- the calibration solve of
+            # this run (HIP events from the kernel's own start / end stamps on the solve's stream, one batch in flight).
+            # These are the top-level keys; the timed region's are the *_contended keys.
+            if single and single["bwd_ms"] > 0:
+                t1 = single["bwd_ms"] * 1e-3
+                n1 = single["bwd_launches"]
+                alg1 = single["bwd_problem_steps"] / N * per_problem
+                real1 = bps * single["bwd_problem_steps"] if bps else None
+                own = {"achieved": round(gbs(alg1, t1), 1), "frac": round(gbs(real1, t1) / HBM_PEAK_GBS, 4) if real1 else None,
+                       "frac_algorithmic": round(gbs(alg1, t1) / HBM_PEAK_GBS, 4), "avg_launch_ms": single["bwd_ms"] / n1,
+                       "launches": n1, "mean_problems_per_launch": single["bwd_problem_steps"] / N / n1,
+                       "traffic": (real1 / n1) if (traffic and real1) else None, "alg_per_launch": alg1 / n1,
+                       "real_per_launch": (real1 / n1) if real1 else None,
+                       "launch": "every backward launch of ONE solve of the batch with nothing else on the GPU (this run's calibration "
+                                 "solve: 65536 problems down to the tail threshold; launches of <= 4096 / <= 1024 problems run the 8-lanes / "
+                                 "wave-per-problem kernels and sit on the latency of N dependent steps; the last problems finish inside "
+                                 "k_tail), time-weighted: sum of bytes / sum of durations"}
+            else:
+                own = dict(contended, traffic=(real_all / prof_acc["bwd_launches"]) if (traffic and real_all) else None,
+                           alg_per_launch=alg_bytes / prof_acc["bwd_launches"],
+                           real_per_launch=(real_all / prof_acc["bwd_launches"]) if real_all else None,
+                           launch="every backward launch of the timed region (no calibration solve in this run), time-weighted")
+            full_alone_ms = single["bwd_full_ms"] if single else None
+            real_full = rec["full_batch_launch"]["hbm_bytes_per_problem_step"] * B * N if rec else None
             roof = {
                 "bound": "hbm", "kernel": "cilqr::k_backward (+ k_backward_team / k_backward_wave for launches of <= 4096 / <= 1024 problems)",
-                "launch": "every backward launch of the timed region, time-weighted (65536 problems down to the tail threshold; "
-                          "launches of <= 4096 / <= 1024 problems run the 8-lanes / wave-per-problem kernels and sit on the latency of "
-                          "N dependent steps; the last problems finish inside k_tail, not in backward launches).  With "
-                          "batches_in_flight > 1 the kernels of other batches share the GPU during these launches: see `uncontended`",
-                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(real_all / t_all / 1e9 / HBM_PEAK_GBS, 4) if real_all else None,
-                "frac_basis": "HBM bytes really moved (PMC-recorded bytes per problem-step x this run's problem-steps) / time / peak",
-                "frac_algorithmic": round(achieved / HBM_PEAK_GBS, 4),
-                # HBM bytes per launch (average over the backward launches of the timed region) from the PMC counters of this
-                # box, this workload; null when the counter passes could not run (then `frac` rests on traffic_recorded)
-                "traffic": (real_all / prof_acc["bwd_launches"]) if (traffic and real_all) else None,
+                "launch": own["launch"],
+                # achieved = ALGORITHMIC (dense, 880 B per problem-step + 352 B per problem) bytes / time
+                "achieved": own["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                # frac is quoted on the HBM bytes REALLY moved (PMC counters: FETCH_SIZE x 2 + WRITE_SIZE, separate passes), which
+                # is the stricter figure: the kernel stores 34 of the 96 scalars of a step (the rest are structural constants)
+                "frac": own["frac"],
+                "frac_basis": "HBM bytes really moved (PMC bytes per problem-step x problem-steps of these launches) / time / peak; "
+                              "frac_algorithmic = achieved / peak is the SURVEY 8(d) figure on dense bytes",
+                "frac_algorithmic": own["frac_algorithmic"],
+                "frac_full_batch": (round(gbs(real_full, full_alone_ms * 1e-3) / HBM_PEAK_GBS, 4) if (real_full and full_alone_ms) else None),
+                "frac_full_batch_algorithmic": (round(gbs(B * per_problem, full_alone_ms * 1e-3) / HBM_PEAK_GBS, 4) if full_alone_ms else None),
+                "frac_contended": contended["frac"], "frac_contended_algorithmic": contended["frac_algorithmic"],
+                "bytes_per_problem_step": round(bps, 1) if bps else None,
+                "bytes_per_problem_step_full_batch_launch": (round(rec["full_batch_launch"]["hbm_bytes_per_problem_step"], 1) if rec else None),
+                "bytes_per_problem_step_minimum": api.REAL_BYTES_PER_STEP,
+                "bytes_per_problem_step_algorithmic": api.DENSE_DOUBLES_PER_STEP * 8,
+                # HBM bytes per launch from the PMC counters of THIS run (null when the counter passes could not run; frac then
+                # rests on the bytes recorded under profiles/, see traffic_recorded)
+                "traffic": own["traffic"],
+                "algorithmic_bytes_per_launch": own["alg_per_launch"],
+                "avg_launch_ms": own["avg_launch_ms"], "launches": own["launches"],
+                "mean_problems_per_launch": own["mean_problems_per_launch"],
+                "full_batch_avg_launch_ms": full_alone_ms,
+                "avg_launch_ms_contended": contended["avg_launch_ms"], "launches_contended": contended["launches"],
+                "batches_in_flight_contended": P * D,
                 "traffic_measured": traffic,
-                "traffic_recorded": ({"bytes_per_launch": real_all / prof_acc["bwd_launches"],
-                                      "bytes_per_problem_step": rec["hbm_bytes_per_problem_step_all_launches"],
+                "traffic_recorded": ({"bytes_per_launch": own["real_per_launch"], "bytes_per_problem_step": bps,
                                       "source": os.path.relpath(args.traffic_file, ROOT)} if (rec and not traffic) else None),
-                "algorithmic_bytes_per_launch": alg_bytes / prof_acc["bwd_launches"],
-                "avg_launch_ms": prof_acc["bwd_ms"] / prof_acc["bwd_launches"],
-                "launches": prof_acc["bwd_launches"],
-                "mean_problems_per_launch": n_act_sum / prof_acc["bwd_launches"],
-                "batches_in_flight": P * D,
+                "contended": contended,
             }
-            if single and single["bwd_ms"] > 0:
-                # the same launches with nothing else on the GPU: the calibration solve (HIP events around every
-                # backward launch, one batch in flight).  In the timed region P batches share the GPU and a kernel's
-                # duration includes the time its CUs spent on other streams' kernels.
-                t1 = single["bwd_ms"] * 1e-3
-                alg1 = single["bwd_problem_steps"] / N * per_problem
-                real1 = rec["hbm_bytes_per_problem_step_all_launches"] * single["bwd_problem_steps"] if rec else None
-                roof["uncontended"] = {
-                    "what": "all backward launches of ONE solve alone on the GPU (calibration step, HIP events)",
-                    "achieved": round(alg1 / t1 / 1e9, 1),
-                    "frac": round(real1 / t1 / 1e9 / HBM_PEAK_GBS, 4) if real1 else None,
-                    "frac_algorithmic": round(alg1 / t1 / 1e9 / HBM_PEAK_GBS, 4),
-                    "avg_launch_ms": single["bwd_ms"] / single["bwd_launches"], "launches": single["bwd_launches"],
-                    "full_batch_frac": (round(rec["full_batch_launch"]["hbm_bytes_per_problem_step"] * B * N / (single["bwd_full_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-                                        if rec and single["bwd_full_ms"] else None),
-                    "full_batch_avg_launch_ms": single["bwd_full_ms"],
-                }
             try:   # fp64-issue / stall record of the other kernels (rocprofv3 PMC, tools/kernel_rooflines.py): recorded, not measured here
                 with open(os.path.join(ROOT, "profiles", "r03_kernel_rooflines.json")) as f:
                     kr = json.load(f)
@@ -750,17 +868,19 @@ def main():
             if prof_acc["full_launches"] > 0:
                 t_full = prof_acc["full_ms"] / prof_acc["full_launches"] * 1e-3
                 fb = B * per_problem / t_full / 1e9
-                real_full = rec["full_batch_launch"]["hbm_bytes_per_problem_step"] * B * N if rec else None
                 roof["full_batch"] = {
                     "kernel": "cilqr::k_backward", "launch": f"all {B} problems of the batch (one launch per solve)",
-                    "achieved": round(fb, 1), "frac": round(real_full / t_full / 1e9 / HBM_PEAK_GBS, 4) if real_full else None,
-                    "frac_algorithmic": round(fb / HBM_PEAK_GBS, 4),
-                    "traffic_recorded_bytes_per_launch": real_full,
-                    "algorithmic_bytes_per_launch": B * per_problem, "avg_launch_ms": t_full * 1e3,
-                    "avg_launch_ms_alone": single["bwd_full_ms"] if single else None,
-                    "launches": prof_acc["full_launches"],
-                    "note": "avg_launch_ms: HIP events in the timed region, where other batches' kernels share the GPU; "
-                            "avg_launch_ms_alone: the same launch with nothing else in flight (calibration step)",
+                    "achieved_alone": (round(gbs(B * per_problem, full_alone_ms * 1e-3), 1) if full_alone_ms else None),
+                    "frac_alone": roof["frac_full_batch"], "frac_algorithmic_alone": roof["frac_full_batch_algorithmic"],
+                    "avg_launch_ms_alone": full_alone_ms,
+                    "achieved_contended": round(fb, 1),
+                    "frac_contended": round(real_full / t_full / 1e9 / HBM_PEAK_GBS, 4) if real_full else None,
+                    "frac_algorithmic_contended": round(fb / HBM_PEAK_GBS, 4),
+                    "traffic_bytes_per_launch": real_full,
+                    "algorithmic_bytes_per_launch": B * per_problem, "avg_launch_ms_contended": t_full * 1e3,
+                    "launches_contended": prof_acc["full_launches"],
+                    "note": "alone: the launch with nothing else in flight (calibration step); contended: HIP events in the timed "
+                            "region, where other batches' kernels share the GPU",
                 }
         cpu = None
         if args.cpu_sample > 0 and world == 1:   # rank 0 at N = 1 only
@@ -850,6 +970,10 @@ def main():
             "one_handle": one_handle,
             "results_identical_across_solves_in_flight": same,
             "c_abi_gather": cabi,
+            "results_gather_thread": ({"gathers": gather_timed["count"],
+                                       "busy_ms_per_gather": round(1e3 * gather_timed["busy_s"] / max(1, gather_timed["count"]), 3),
+                                       "note": "rank 0's gather thread (own stream): pack, agree on the ragged length, RCCL gather, unpack "
+                                               "world x the payload; overlapped with the next steps' solves"} if use_dist else None),
             "end_to_end": end_to_end,
             # drop-in latency (never `value`): Plan through the C++ adapter with a batch of one, and small host batches
             "latency": ({fam: ({k: v for k, v in rec.items() if k != "_scene"} if isinstance(rec, dict) else rec)

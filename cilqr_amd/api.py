@@ -36,6 +36,7 @@ T_GOALS, T_CORRIDOR, T_LANES, T_X, T_U, T_XCAND, T_UCAND, T_A, T_B, T_LX, T_LU, 
 # dense fp64 scalars moved per problem-step / per problem by the backward pass
 DENSE_DOUBLES_PER_STEP = 110
 DENSE_DOUBLES_TERMINAL = 44
+REAL_BYTES_PER_STEP = (18 + 7) * 16   # what k_backward really moves per problem-step: 17 pairs of `lin` + 1 of U in, 7 pairs of gains out
 
 
 class Config(C.Structure):

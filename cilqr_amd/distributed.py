@@ -102,3 +102,122 @@ def gather_results(traj, cost_hist, n_cost, status, dst: int = 0, densify: bool 
         hists.append(dense)
     out["cost_hist"] = torch.cat(hists)
     return out
+
+
+class GatherThread:
+    """The per-job results gather of a rank, off the thread that keeps the solver fed.
+
+    A job's results are complete when its wait returns; packing them, agreeing on the ragged length (a host
+    synchronisation), the collective and -- on the root -- unpacking world x the payload then run here, on a thread and (on a
+    GPU) a stream of their own, while the caller submits the next jobs.  Every rank must `put` its finished jobs in the same
+    order: the ranks' collectives pair up by position in that order.  `on_done(tag)` is called after the gather of `tag`
+    (hand the result buffers back to whoever reuses them).  `drain()` blocks until everything put so far is gathered and
+    re-raises the first error of the thread; call it before any collective of the caller's own."""
+
+    def __init__(self, device=None, dst=0, derive=None, on_done=None, gather_fn=None):
+        """gather_fn(traj, hist, nc, st) -> result replaces the torch.distributed gather (bench.py --multi: the ranks are
+        threads of one process and results travel by peer copies, see PeerGather)."""
+        import queue
+        import threading
+        self.device, self.dst, self.derive, self.on_done = device, dst, derive, on_done
+        self.gather_fn = gather_fn or (lambda t, h, n, s: gather_results(t, h, n, s, dst=self.dst, densify=False, derive=self.derive))
+        self.q = queue.Queue()
+        self.error = None
+        self.busy_s = 0.0
+        self.count = 0
+        self.last = None        # result of the last gather (root) / None (other ranks)
+        self.last_tag = None
+        self.thread = threading.Thread(target=self._run, daemon=True)
+        self.thread.start()
+
+    def _run(self):
+        import time
+        stream = None
+        if self.device is not None:
+            import torch
+            torch.cuda.set_device(self.device)
+            stream = torch.cuda.Stream(device=self.device)
+        while True:
+            item = self.q.get()
+            if item is None:
+                self.q.task_done()
+                return
+            tag, traj, hist, nc, st = item
+            t0 = time.perf_counter()
+            try:
+                if self.error is None:
+                    if stream is not None:
+                        import torch
+                        with torch.cuda.stream(stream):
+                            res = self.gather_fn(traj, hist, nc, st)
+                        stream.synchronize()
+                    else:
+                        res = self.gather_fn(traj, hist, nc, st)
+                    self.last, self.last_tag = res, tag
+            except Exception as e:   # noqa: BLE001  (kept for drain(); the tags keep coming back so nothing deadlocks)
+                self.error = e
+            self.busy_s += time.perf_counter() - t0
+            self.count += 1
+            if self.on_done is not None:
+                self.on_done(tag)
+            self.q.task_done()
+
+    def put(self, tag, traj, hist, nc, st):
+        self.q.put((tag, traj, hist, nc, st))
+
+    def drain(self):
+        self.q.join()
+        if self.error is not None:
+            raise self.error
+
+    def reset_stats(self):
+        self.busy_s, self.count = 0.0, 0
+
+    def close(self):
+        self.q.put(None)
+        self.thread.join(30.0)
+
+
+class PeerGather:
+    """Results of N GPUs driven by ONE process (bench.py --multi; the reference's caller is one process, planning_node.cc:9-31)
+    brought to the root device without a process group: rank r -- a thread -- copies its block into rows [r B, (r + 1) B) of
+    tensors that live on the root device (peer-to-peer copies over xGMI: torch's cross-device copy_), the 8 independent
+    trajectory columns, the first max(n_cost) Cost rows, n_cost, status; the root rebuilds time and kappa as gather_results
+    does.  Same order rule as the collective: every rank gathers its jobs in the order they finished."""
+
+    def __init__(self, world, B, K, M, root_device=None, derive=(0.1, 1.0), dtype=None):
+        import threading
+        import torch
+        self.world, self.B, self.K, self.derive = world, B, K, derive
+        kw = dict(device=root_device) if root_device is not None else {}
+        self.traj = torch.zeros((world * B, K, 10), dtype=torch.float64, **kw)
+        self.hist = torch.zeros((world * B, M + 1, 5), dtype=torch.float64, **kw)
+        self.nc = torch.zeros(world * B, dtype=torch.int32, **kw)
+        self.st = torch.zeros(world * B, dtype=torch.int32, **kw)
+        self.barrier = threading.Barrier(world)
+
+    def gather_fn(self, rank):
+        import torch
+
+        def fn(traj, hist, nc, st):
+            lo, hi = rank * self.B, (rank + 1) * self.B
+            cols = [1, 2, 3, 4, 5, 6, 8, 9]
+            self.traj[lo:hi, :, cols] = traj[:, :, cols].to(self.traj.device, non_blocking=True)
+            h = int(nc.max().item()) if self.B > 0 else 0
+            self.hist[lo:hi, :h] = hist[:, :h].to(self.hist.device, non_blocking=True)
+            self.nc[lo:hi] = nc.to(self.nc.device, non_blocking=True)
+            self.st[lo:hi] = st.to(self.st.device, non_blocking=True)
+            if traj.is_cuda:
+                torch.cuda.current_stream().synchronize()
+            self.barrier.wait()          # every rank's block of this job has landed
+            res = None
+            if rank == 0:
+                dt_, wb_ = self.derive
+                self.traj[:, :, 0] = torch.arange(self.K, dtype=torch.float64, device=self.traj.device)[None, :] * dt_
+                self.traj[:, :, 7] = torch.tan(self.traj[:, :, 6]) / wb_
+                if self.traj.is_cuda:
+                    torch.cuda.current_stream().synchronize()
+                res = {"traj": self.traj, "cost_hist": self.hist, "n_cost": self.nc, "status": self.st}
+            self.barrier.wait()          # the root has read / rebuilt before the next job overwrites the rows
+            return res
+        return fn

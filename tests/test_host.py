@@ -326,6 +326,14 @@ def test_bench_line_has_the_contract_fields_on_the_gpu():
     roof = rec["roofline"]
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
     assert 0.0 < roof["frac"] <= 1.0 and roof["achieved"] > 0 and "traffic" in roof
+    # the kernel's own numbers are flat keys of the line (the driver's parser keeps one level): one solve alone on the GPU at
+    # the top, the whole batch in one launch, the timed region with four solves in flight, and the bytes behind them
+    for key in ("frac_algorithmic", "frac_full_batch", "frac_contended", "bytes_per_problem_step", "bytes_per_problem_step_minimum",
+                "avg_launch_ms", "avg_launch_ms_contended", "launches", "launches_contended", "full_batch_avg_launch_ms"):
+        assert isinstance(roof[key], (int, float)) and roof[key] > 0, key
+    assert roof["frac_contended"] <= roof["frac"] * 1.25 and roof["bytes_per_problem_step_minimum"] == 400
+    assert abs(roof["achieved"] - roof["algorithmic_bytes_per_launch"] / (roof["avg_launch_ms"] * 1e-3) / 1e9) <= 0.01 * roof["achieved"]
+    assert roof["launches_contended"] >= 7 * roof["launches"] * 0.5
     cpu = rec["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] == 1 and cpu["value"] > 0 and cpu["unit"] == "solves/s" and "sample" in cpu
     assert rec["results_identical_across_solves_in_flight"] is True

@@ -22,7 +22,9 @@ def entry(fetch_txt, write_txt, bench_json):
     B = b["config"]["batch_per_gpu"]
     rf = b["roofline"]
     # the capture holds `solves` identical solves of the same batch (calibration, single-batch timing, the timed step)
-    n_act_sum = solves * rf["mean_problems_per_launch"] * rf["launches"] / b["steps"]
+    # roofline.launches / mean_problems_per_launch describe ONE solve (round 4 on; earlier records: the whole timed region)
+    per_solve = rf["mean_problems_per_launch"] * rf["launches"] / (1 if "launches_contended" in rf else b["steps"])
+    n_act_sum = solves * per_solve
     hbm = fs * 1024 * 2 + ws * 1024
     return {
         "command": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) -- python bench.py --steps 1 --warmup 0 --in-flight 1 --cpu-sample 0 [--scene ...]",

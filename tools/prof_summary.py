@@ -82,15 +82,22 @@ def main():
         import json
         rec = json.loads(open(a.bench_json).read().strip().splitlines()[-1])
         steps, warm, roof = rec["steps"], rec["warmup"], rec["roofline"]
-        per_solve = roof["launches"] // steps          # backward launches of one solve (lockstep iterations)
+        new_layout = "launches_contended" in roof      # round 4 on: top-level keys = ONE solve alone, *_contended = the timed region
+        per_solve = roof["launches"] if new_layout else roof["launches"] // steps   # backward launches of one solve (lockstep iterations)
         skip = (2 + warm) * per_solve                   # the two calibration solves and the warm-up steps come first
         bw = [(s_, e_) for name, s_, e_, *_ in rows if short(name) in ("k_backward", "k_backward_team", "k_backward_wave")]
         win = bw[skip:skip + steps * per_solve]         # rows are sorted by start time; fences separate the regions
         if len(win) == steps * per_solve:
             avg = sum(e_ - s_ for s_, e_ in win) / len(win) / 1e6
+            hip_ms = roof["avg_launch_ms_contended"] if new_layout else roof["avg_launch_ms"]
             print(f"\nbackward launches of bench.py's timed region alone ({steps} steps x {per_solve} launches, after {2 + warm} earlier solves; "
                   f"the rows above also hold the calibration, warm-up, one-handle and sequential legs of the same process):\n"
-                  f"  launches {len(win)}  avg {avg * 1e3:.1f} us   -- bench.py roofline.avg_launch_ms (HIP events, same run): {roof['avg_launch_ms'] * 1e3:.1f} us")
+                  f"  launches {len(win)}  avg {avg * 1e3:.1f} us   -- bench.py roofline.avg_launch_ms_contended (HIP events, same run): {hip_ms * 1e3:.1f} us")
+            if new_layout:
+                cal = bw[per_solve:2 * per_solve]        # the calibration solve: second solve of the process, alone on the GPU
+                avg1 = sum(e_ - s_ for s_, e_ in cal) / len(cal) / 1e6
+                print(f"backward launches of the calibration solve (one solve alone on the GPU, {len(cal)} launches):\n"
+                      f"  avg {avg1 * 1e3:.1f} us   -- bench.py roofline.avg_launch_ms (HIP events, same run): {roof['avg_launch_ms'] * 1e3:.1f} us")
         else:
             print(f"\n(timed-region window not found: {len(bw)} backward launches in the capture, expected at least {skip + steps * per_solve})")
     if not a.iters:
