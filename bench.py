@@ -92,6 +92,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-latency", action="store_true",
                     help="skip the drop-in latency section (planning::IlqrOptimizer::Plan with a batch of one, C++ program under tests/cpp)")
     ap.add_argument("--latency-scenes", type=int, default=256, help="scenes per family for the latency section")
+    ap.add_argument("--multi", action="store_true",
+                    help="ONE process drives the N GPUs of --gpus (the reference's caller is one process, planning_node.cc:9-31): "
+                         "a thread per GPU with its own pool of handles and device-resident inputs, no process group, no RCCL; "
+                         "results reach GPU 0 by peer copies over xGMI.  The second path next to one process per GPU")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch plumbing only, on CPU: the ranks rendezvous over gloo, exchange made-up results through the same "
                          "gather and rank 0 prints a line with \"dry_run\": true and no value (tests/test_host.py)")
@@ -345,10 +349,37 @@ def dry_run(args, rank, world):
     return None
 
 
+class ThreadComm:
+    """--multi: the N "ranks" are threads of one process.  barrier() / max_over_ranks() stand for the process group's."""
+
+    def __init__(self, world):
+        import threading
+        self.world = world
+        self.bar = threading.Barrier(world)
+        self.vals = [0.0] * world
+        self.peer = None          # PeerGather, made by rank 0
+        self.failed = None
+
+    def barrier(self):
+        self.bar.wait(timeout=600.0)
+
+    def max_over_ranks(self, rank, v):
+        self.vals[rank] = v
+        self.barrier()
+        m = max(self.vals)
+        self.barrier()
+        return m
+
+
 def main():
     args = parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.multi:
+        if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != 1:
+            raise SystemExit("bench.py: --multi is ONE process for all GPUs; it was started under a launcher with "
+                             f"WORLD_SIZE={os.environ['WORLD_SIZE']}")
+        return main_multi(args)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         return spawn_ranks(args)       # no launcher: be the launcher
 
@@ -356,10 +387,6 @@ def main():
     # (RCCL's version banner, for one) is sent to stderr
     real_stdout = os.dup(1)
     os.dup2(2, 1)
-
-    import torch
-    import torch.distributed as dist
-
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -370,15 +397,136 @@ def main():
         if rank == 0:
             os.write(real_stdout, (json.dumps(rec) + "\n").encode())
         return
+    run(args, rank, local_rank, world, None, real_stdout)
+
+
+def main_multi(args):
+    """One process, a thread per GPU (see --multi).  CILQR_BENCH_MULTI_DEVICES="0,0" maps the ranks onto listed devices
+    (rehearsal on a 1-GPU box: two "GPUs" that are the same one)."""
+    import threading
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    world = args.gpus
+    comm = ThreadComm(world)
+    if args.dry_run:
+        rec = dry_run_multi(args, comm)
+        os.write(real_stdout, (json.dumps(rec) + "\n").encode())
+        return
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU path exists)")
+    devices = [int(x) for x in os.environ.get("CILQR_BENCH_MULTI_DEVICES", ",".join(str(i) for i in range(world))).split(",")]
+    if len(devices) != world or max(devices) >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py --multi: {world} GPUs asked for, devices {devices}, {torch.cuda.device_count()} visible")
+    errors = []
+
+    def worker(r):
+        try:
+            run(args, r, devices[r], world, comm, real_stdout)
+        except BaseException as e:   # noqa: BLE001
+            errors.append((r, e))
+            comm.bar.abort()         # the other threads leave their barriers with an error instead of waiting forever
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        for r, e in errors:
+            sys.stderr.write(f"bench.py --multi: rank {r}: {e!r}\n")
+        raise SystemExit(1)
+
+
+def dry_run_multi(args, comm):
+    """--multi --dry-run: the thread plumbing without a GPU -- N threads, the barrier, the max over ranks and the per-step
+    PeerGather (CPU tensors), checked on rank 0 like dry_run()."""
+    import threading
+    import torch
+    from cilqr_amd.distributed import GatherThread, PeerGather
+    world = comm.world
+    B, K, M = min(args.batch, 16), 6, 8
+    steps = max(1, min(args.steps, 6))
+    ok = {"rank_order": True, "rows": True, "steps": []}
+    errors = []
+
+    def check_on_root(g):      # between the barriers of PeerGather: the root tensors hold exactly this job
+        step = len(ok["steps"])
+        n = world * B
+        want = 1000.0 * step + torch.arange(n, dtype=torch.float64)
+        ok["rank_order"] &= bool(torch.equal(g["traj"][:, 0, 1], want))
+        r_ = torch.arange(n)
+        nc = g["n_cost"].to(torch.int64)
+        ok["rows"] &= bool(torch.equal(nc, 1 + (r_ % B + r_ // B + step) % M)
+                           and torch.equal(g["cost_hist"][r_, nc - 1, 0], want)
+                           and torch.equal(g["traj"][:, 1, 0], torch.full((n,), 0.1, dtype=torch.float64))
+                           and torch.equal(g["status"], (1 + (r_ // B + step) % 5).to(g["status"].dtype)))
+        ok["steps"].append(step)
+
+    peer = PeerGather(world, B, K, M, root_device=None, derive=(0.1, 1.0), on_root=check_on_root)
+
+    def worker(rank):
+        try:
+            free = [dict(traj=torch.zeros((B, K, 10), dtype=torch.float64), hist=torch.zeros((B, M + 1, 5), dtype=torch.float64),
+                         nc=torch.zeros(B, dtype=torch.int32), st=torch.zeros(B, dtype=torch.int32)) for _ in range(2)]
+            cv = threading.Condition()
+
+            def done(tag):
+                step, slot = tag
+                with cv:
+                    free.append(slot)
+                    cv.notify_all()
+
+            gt = GatherThread(device=None, on_done=done, gather_fn=peer.gather_fn(rank))
+            for step in range(steps):
+                with cv:
+                    while not free:
+                        cv.wait(60.0)
+                    slot = free.pop(0)
+                pid = rank * B + torch.arange(B, dtype=torch.float64)
+                slot["traj"][:] = (1000.0 * step + pid)[:, None, None]
+                slot["traj"][:, :, 6] = 0.01 * (1 + rank)
+                slot["nc"][:] = (1 + (torch.arange(B) + rank + step) % M).to(torch.int32)
+                slot["hist"][:] = (1000.0 * step + pid)[:, None, None]
+                slot["st"][:] = 1 + (rank + step) % 5
+                gt.put((step, slot), slot["traj"], slot["hist"], slot["nc"], slot["st"])
+            gt.drain()
+            gt.close()
+            comm.max_over_ranks(rank, float(rank))
+        except BaseException as e:   # noqa: BLE001
+            errors.append((rank, e))
+            comm.bar.abort()
+            peer.barrier.abort()
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise SystemExit(f"bench.py --multi --dry-run: {errors[0]!r}")
+    good = ok["rank_order"] and ok["rows"] and ok["steps"] == list(range(steps)) and max(comm.vals) == world - 1
+    return {"metric": "CILQR solves/sec (dry run: launch plumbing only, nothing solved)", "value": None, "unit": "solves/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True, "ranks_reporting": world,
+            "gather_in_rank_order": ok["rank_order"], "gathers": len(ok["steps"]), "gathers_in_step_order": ok["steps"] == list(range(steps)),
+            "ragged_history_rows_ok": ok["rows"], "gather_checks_ok": good, "mode": "multi", "spawned_by_bench": False}
+
+
+def run(args, rank, local_rank, world, comm, real_stdout):
+    """One rank: a process under a launcher (comm is None: torch.distributed over RCCL when world > 1) or a thread of --multi
+    (comm: ThreadComm)."""
+    import torch
+    import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path exists)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # CILQR_BENCH_FORCE_DIST=1 exercises the RCCL path (process group, all-reduce, gather) even
     # with a single rank -- the only way to smoke-test it on a 1-GPU box
-    use_dist = world > 1 or os.environ.get("CILQR_BENCH_FORCE_DIST") == "1"
+    use_rccl = comm is None and (world > 1 or os.environ.get("CILQR_BENCH_FORCE_DIST") == "1")
+    use_dist = use_rccl or comm is not None        # results are gathered to rank 0 after every step
     rccl_ranks = 0
-    if use_dist:
+    if use_rccl:
         # keep RCCL's log lines off stdout (rank 0 prints exactly one JSON line there, last)
         os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -392,7 +540,7 @@ def main():
             raise SystemExit(f"bench.py: {rccl_ranks} ranks answered the RCCL all-reduce, WORLD_SIZE is {world}")
 
     from cilqr_amd import api, scenario
-    from cilqr_amd.distributed import GatherThread
+    from cilqr_amd.distributed import GatherThread, PeerGather
 
     spec = scenario.SPECS[args.scene]
     B, N, K, cmax = args.batch, spec.n_steps, spec.n_steps + 1, spec.cmax
@@ -503,7 +651,14 @@ def main():
             free_cv.notify_all()
 
     # 8 of the 10 trajectory columns travel (time and kappa are functions of the others)
-    gatherer = GatherThread(device=dev, dst=0, derive=(cfg.dt, cfg.wheel_base), on_done=slot_gathered) if use_dist else None
+    gatherer = None
+    if use_rccl:
+        gatherer = GatherThread(device=dev, dst=0, derive=(cfg.dt, cfg.wheel_base), on_done=slot_gathered)
+    elif comm is not None:      # --multi: peer copies into tensors on rank 0's device
+        if rank == 0:
+            comm.peer = PeerGather(world, B, K, M, root_device=dev, derive=(cfg.dt, cfg.wheel_base))
+        comm.barrier()
+        gatherer = GatherThread(device=dev, on_done=slot_gathered, gather_fn=comm.peer.gather_fn(rank))
 
     def take_free(c):
         with free_cv:
@@ -573,8 +728,11 @@ def main():
         drain_gathers()      # a region ends when its last step's results are on rank 0
 
     def fence():
-        if use_dist:
+        if use_rccl:
             dist.barrier()
+        elif comm is not None:
+            torch.cuda.synchronize()
+            comm.barrier()
         torch.cuda.synchronize()
 
     # One step alone on one handle, with HIP events around every phase of every lockstep iteration:
@@ -606,16 +764,18 @@ def main():
     fence()
     elapsed = time.perf_counter() - t_start
     gather_timed = dict(busy_s=gatherer.busy_s, count=gatherer.count) if use_dist else None
-    if use_dist:
+    if use_rccl:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    elif comm is not None:
+        elapsed = comm.max_over_ranks(rank, elapsed)
 
     # Extra (never `value`): the same gather through the C-ABI (cilqr_comm_* / cilqr_gather_results: librccl
     # called directly, no PyTorch), checked against the torch.distributed gather of the timed region.  Guarded
     # by a watchdog: a multi-rank send / recv cannot be rehearsed on a 1-GPU box.
     cabi = None
-    if use_dist:
+    if use_rccl:
         import threading
         res = {}
 
@@ -961,7 +1121,8 @@ def main():
                        "exact_lane_ties": not args.fast_lane_ties,
                        "coarse_trajectories": ("DP coarse planner (cilqr_dp_plan) + cilqr_build_corridors" if dp_info else "scene generator"),
                        "dp_scene_source": dp_info,
-                       "results_gather": "rccl" if use_dist else "none", "rccl_ranks": rccl_ranks},
+                       "results_gather": ("rccl" if use_rccl else "peer copies (one process, --multi)" if comm is not None else "none"),
+                       "rccl_ranks": rccl_ranks, "processes": 1 if comm is not None else world},
             "roofline": roof,
             "cpu_baseline": cpu,
             "single_batch": ({"value": round(B / seq, 1), "unit": "solves/s", "ms_per_step": round(seq * 1e3, 3),
@@ -997,9 +1158,13 @@ def main():
     for c in ctx:
         c.opt.close()    # wrappers of the pool's handles: nothing destroyed here
     pool.close()
-    if use_dist:
+    if gatherer is not None:
+        gatherer.close()
+    if use_rccl:
         dist.barrier()
         dist.destroy_process_group()
+    elif comm is not None:
+        comm.barrier()
     if rank == 0:
         try:  # flush what native libraries left in the C stdio buffer (to stderr), then the JSON line
             import ctypes

@@ -279,6 +279,13 @@ class BatchIlqrOptimizer:
         except Exception:
             pass
 
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
     # ---- raw-pointer interface (device or host memory) ----
     def make_problem(self, B, start, coarse, corridor, ccount, cmax, left, right, n_left, n_right,
                      memory) -> ProblemBatch:
@@ -572,14 +579,33 @@ class HandlePool:
         self.cfg = cfg if cfg is not None else default_config(n_steps)
         self.K = self.cfg.n_steps + 1
         self.h = C.c_void_p()
+        self._adopted = []
         rc = self.L.cilqr_pool_create(C.byref(self.cfg), device, handles, batch_capacity, cmax, max_lane_segments, C.byref(self.h))
         if rc != OK:
+            self.h = C.c_void_p()
             raise CilqrError(rc, "in cilqr_pool_create")
 
     def close(self):
-        if self.h:
+        """Destroys the pool (n_handles x the device memory of one handle) and invalidates the wrappers handle_at() gave out."""
+        if getattr(self, "h", None) is not None and self.h.value:
+            for w in self._adopted:
+                w.h = C.c_void_p()       # the handle dies with the pool: a stale wrapper must not touch it
+            self._adopted = []
             self.L.cilqr_pool_destroy(self.h)
             self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
     def depth(self) -> int:
         return int(self.L.cilqr_pool_depth(self.h))
@@ -589,7 +615,9 @@ class HandlePool:
         h = self.L.cilqr_pool_handle_at(self.h, k)
         if not h:
             raise CilqrError(ERR_STATE, "in cilqr_pool_handle_at")
-        return BatchIlqrOptimizer(self.cfg, adopt=h, **kw)
+        w = BatchIlqrOptimizer(self.cfg, adopt=h, **kw)
+        self._adopted.append(w)
+        return w
 
     def set_option(self, option: int, value: int):
         rc = self.L.cilqr_pool_set_option(self.h, option, value)
@@ -606,8 +634,11 @@ class HandlePool:
         return self.L.cilqr_pool_wait(self.h)
 
     def profile(self) -> Profile:
+        """of the solve the last wait() collected (CilqrError ERR_STATE before the first wait)"""
         p = Profile()
-        self.L.cilqr_pool_get_profile(self.h, C.byref(p))
+        rc = self.L.cilqr_pool_get_profile(self.h, C.byref(p))
+        if rc != OK:
+            raise CilqrError(rc, "in cilqr_pool_get_profile")
         return p
 
 
@@ -627,12 +658,26 @@ class MultiDeviceOptimizer:
         rc = self.L.cilqr_multi_create(C.byref(self.cfg), self.devices.ctypes.data, len(self.devices), batch_capacity, cmax,
                                        max_lane_segments, C.byref(self.h))
         if rc != OK:
+            self.h = C.c_void_p()
             raise CilqrError(rc, "in cilqr_multi_create")
 
     def close(self):
-        if self.h:
+        if getattr(self, "h", None) is not None and self.h.value:
             self.L.cilqr_multi_destroy(self.h)
             self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
     def set_option(self, option: int, value: int):
         rc = self.L.cilqr_multi_set_option(self.h, option, value)

@@ -22,6 +22,9 @@
 //   only if none: alpha_5..9, then alpha_10 | the winner becomes the iterate | update_state | exports.
 // The first passing list index wins whatever the evaluation order (cc:246-265), so evaluating the candidates in
 // chunks of five and stopping at the first chunk with a winner gives the sequential loop's answer.
+#include <algorithm>
+#include <mutex>
+
 #include "backward_core.hpp"
 #include "quad_core.hpp"
 #include "search_core.hpp"
@@ -370,8 +373,29 @@ void launch_tail(const DeviceState& g, void* workspace, int n_max, double* traj,
   a.max_iter = max_iter_dev;
   const size_t lane_d = (size_t)((g.nl + g.nr) * kLaneFields + 1) / 2 * 2;
   const size_t fixed = ((lane_d + wave::kDoubles + kNumAlpha * 5) * sizeof(double) + 16 * sizeof(int) + sizeof(DeviceState) + 31) / 16 * 16;
-  // tensors into LDS by priority until the workgroup's share (one workgroup per CU: 160 KiB less a margin) is used up
-  const size_t budget = (size_t)160 * 1024 - 2048 - fixed;
+  // Dynamic shared memory beyond the default has to be asked for, once per kernel and device; what the device grants
+  // (160 KiB per workgroup on gfx950, 64 KiB on older CDNA) sizes the budget below.  One-time, guarded: several handles'
+  // worker threads come through here.
+  struct DeviceLds { std::once_flag once; size_t bytes = 0; };
+  static DeviceLds lds_of[64];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  DeviceLds& dl = lds_of[dev & 63];
+  std::call_once(dl.once, [&] {
+    int max_lds = 0;
+    if (hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || max_lds <= 0) max_lds = 64 * 1024;
+    const void* fns[] = {reinterpret_cast<const void*>(&k_tail<5, false>), reinterpret_cast<const void*>(&k_tail<5, true>),
+                         reinterpret_cast<const void*>(&k_tail<0, false>), reinterpret_cast<const void*>(&k_tail<0, true>)};
+    bool ok = true;
+    for (const void* f : fns) ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) == hipSuccess;
+    if (!ok) {            // keep to what needs no permission; the tensors that do not fit stay in the global-memory arena
+      (void)hipGetLastError();
+      max_lds = std::min(max_lds, 64 * 1024);
+    }
+    dl.bytes = (size_t)max_lds;
+  });
+  // tensors into LDS by priority until the workgroup's share (one workgroup per CU: all of its LDS less a margin) is used up
+  const size_t budget = dl.bytes > fixed + 2048 ? dl.bytes - 2048 - fixed : 0;
   const size_t K = g.p.K, N = g.p.N;
   struct Item { size_t TailLayout::*field; size_t bytes; };
   const Item items[] = {
@@ -390,17 +414,6 @@ void launch_tail(const DeviceState& g, void* workspace, int n_max, double* traj,
   }
   a.lds_base = (int)fixed;
   const size_t lds = fixed + used;
-  static bool attr_done[64] = {};   // dynamic shared memory beyond 64 KiB has to be asked for, once per kernel and device
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  bool& attr_set = attr_done[dev & 63];
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tail<5, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tail<5, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tail<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tail<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
   if (g.p.num_of_disc == 5) {
     if (g.exact_ties) hipLaunchKernelGGL((k_tail<5, true>), dim3(n_max), dim3(kTailThreads), lds, st, g, a, n_max);
     else hipLaunchKernelGGL((k_tail<5, false>), dim3(n_max), dim3(kTailThreads), lds, st, g, a, n_max);

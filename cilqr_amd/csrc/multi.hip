@@ -37,6 +37,7 @@ int cilqr_multi_create(const cilqr_config* cfg, const int32_t* devices, int32_t 
   if (cfg == nullptr || devices == nullptr || out == nullptr) return CILQR_ERR_NULL;
   *out = nullptr;
   if (n_devices < 1 || batch_capacity < n_devices) return CILQR_ERR_ARG;
+  cilqr_device_guard keep_callers_device;
   cilqr_multi* m = new (std::nothrow) cilqr_multi();
   if (m == nullptr) return CILQR_ERR_DEVICE;
   m->capacity = batch_capacity;
@@ -52,12 +53,21 @@ int cilqr_multi_create(const cilqr_config* cfg, const int32_t* devices, int32_t 
     m->shard.push_back(h);
     m->device.push_back(devices[k]);
   }
+  // A shard is submitted through cilqr_submit, whose default speculation threshold (2048) is the one tuned for several
+  // solves SHARING a GPU.  A device listed once is its shard's alone: those shards take the threshold of the synchronous
+  // call (8192, ~1 % faster there).  A device listed several times does share, and keeps the default.
+  for (int k = 0; k < n_devices; ++k) {
+    int listed = 0;
+    for (int q = 0; q < n_devices; ++q) listed += devices[q] == devices[k];
+    m->shard[(size_t)k]->alone_on_device = (listed == 1);
+  }
   *out = m;
   return CILQR_OK;
 }
 
 int cilqr_multi_destroy(cilqr_multi_handle m) {
   if (m == nullptr) return CILQR_ERR_NULL;
+  cilqr_device_guard keep_callers_device;
   for (cilqr_handle h : m->shard) (void)cilqr_destroy(h);
   delete m;
   return CILQR_OK;

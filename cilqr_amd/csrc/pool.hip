@@ -28,6 +28,7 @@ int cilqr_pool_create(const cilqr_config* cfg, int32_t device, int32_t n_handles
   if (cfg == nullptr || out == nullptr) return CILQR_ERR_NULL;
   *out = nullptr;
   if (n_handles < 1 || n_handles > 16) return CILQR_ERR_ARG;
+  cilqr_device_guard keep_callers_device;
   cilqr_pool* p = new (std::nothrow) cilqr_pool();
   if (p == nullptr) return CILQR_ERR_DEVICE;
   for (int k = 0; k < n_handles; ++k) {
@@ -45,6 +46,7 @@ int cilqr_pool_create(const cilqr_config* cfg, int32_t device, int32_t n_handles
 
 int cilqr_pool_destroy(cilqr_pool_handle p) {
   if (p == nullptr) return CILQR_ERR_NULL;
+  cilqr_device_guard keep_callers_device;
   while (p->collected < p->submitted) (void)cilqr_pool_wait(p);   // nothing is left running on arrays the caller frees next
   for (cilqr_handle h : p->handle) (void)cilqr_destroy(h);
   delete p;

@@ -630,15 +630,14 @@ static int solve_sync(cilqr_solver* h, const cilqr_problem_batch* in, cilqr_solu
   j.spec_threshold = h->spec_threshold;
   j.st1 = h->stream;
   j.st2 = h->stream;
-  return solve_groups(h, j, in, out);
+  const int rc = solve_groups(h, j, in, out);
+  std::lock_guard<std::mutex> lk(h->mu);
+  h->prof = j.prof;
+  return rc;
 }
 
 static int solve_groups(cilqr_solver* h, cilqr_job& j, const cilqr_problem_batch* in, cilqr_solution_batch* out) {
-  if (in == nullptr || in->n_lane_groups <= 1) {
-    const int rc = solve_one(h, j, in, out);
-    h->prof = j.prof;
-    return rc;
-  }
+  if (in == nullptr || in->n_lane_groups <= 1) return solve_one(h, j, in, out);   // j.prof: published by the caller's thread
   // problems grouped by lane table: one solve per group on contiguous sub-ranges of every array
   if (in->lane_group_start == nullptr || in->lane_group_left == nullptr || in->lane_group_right == nullptr ||
       in->left_lane == nullptr || in->right_lane == nullptr)
@@ -689,7 +688,6 @@ static int solve_groups(cilqr_solver* h, cilqr_job& j, const cilqr_problem_batch
     rrow += (size_t)in->lane_group_right[g];
   }
   j.prof = acc;
-  h->prof = acc;
   return CILQR_OK;
 }
 
@@ -1053,6 +1051,7 @@ void worker1_main(cilqr_solver* h) {
     }
     lk.lock();
     j.rc = rc;
+    if (rc != CILQR_OK) std::snprintf(j.err_text, sizeof(j.err_text), "%s", g_last_hip_error);
     j.phase = to_stage2 ? 3 : 5;
     h->cv.notify_all();
   }
@@ -1081,6 +1080,7 @@ void worker2_main(cilqr_solver* h) {
     release_fin(h, j);
     lk.lock();
     j.rc = rc;
+    if (rc != CILQR_OK) std::snprintf(j.err_text, sizeof(j.err_text), "%s", g_last_hip_error);
     j.phase = 5;
     h->cv.notify_all();
   }
@@ -1104,10 +1104,11 @@ int cilqr_submit(cilqr_handle h, const cilqr_problem_batch* in, cilqr_solution_b
   j.in = *in;
   j.out = *out;
   j.set = slot;
-  j.spec_threshold = h->spec_threshold_submit;
+  j.spec_threshold = h->alone_on_device ? h->spec_threshold : h->spec_threshold_submit;
   j.st1 = h->stream;
   j.st2 = h->stream2;
   j.rc = CILQR_OK;
+  j.err_text[0] = 0;
   j.phase = 1;
   h->job_count += 1;
   h->cv.notify_all();
@@ -1122,6 +1123,7 @@ int cilqr_wait(cilqr_handle h) {
   h->cv.wait(lk, [&] { return j.phase == 5; });
   const int rc = j.rc;
   h->prof = j.prof;
+  if (rc != CILQR_OK) std::snprintf(g_last_hip_error, sizeof(g_last_hip_error), "%s", j.err_text);   // the caller's cilqr_error_string
   j.phase = 0;
   h->job_head = (h->job_head + 1) % 2;
   h->job_count -= 1;

@@ -27,6 +27,16 @@ extern thread_local char g_last_hip_error[256];
 
 struct cilqr_comm;   // comm.hip: RCCL communicator + staging of cilqr_gather_results
 
+// Entry points that create or destroy handles on SEVERAL devices (cilqr_multi_*, cilqr_pool_*) leave the calling thread's
+// current HIP device as they found it.
+struct cilqr_device_guard {
+  int dev = -1;
+  cilqr_device_guard() { if (hipGetDevice(&dev) != hipSuccess) dev = -1; }
+  ~cilqr_device_guard() { if (dev >= 0) (void)hipSetDevice(dev); }
+  cilqr_device_guard(const cilqr_device_guard&) = delete;
+  cilqr_device_guard& operator=(const cilqr_device_guard&) = delete;
+};
+
 // What ONE solve in flight owns besides the arenas: the tensors indexed by PROBLEM (they outlive the hand-over of
 // the survivors to the finishing arena and are read by the final export), the lane tables it was loaded with,
 // its host-visible iteration counters and its events.  A handle has two of these, so that the finishing stage of
@@ -78,6 +88,7 @@ struct cilqr_job {
   int spec_threshold = 0;   // the threshold of this solve (cilqr_solver::spec_threshold or spec_threshold_submit)
   int phase = 0;            // 0 free, 1 queued, 2 first stage, 3 waiting for the finishing stage, 4 finishing, 5 done
   int rc = CILQR_OK;
+  char err_text[256] = "";  // what the worker thread's g_last_hip_error held when rc was set (that variable is thread-local)
   hipStream_t st1 = nullptr, st2 = nullptr;
   cilqr::DeviceState gmain;   // main arena with this job's problem-indexed tensors and lane tables
   cilqr::DeviceState d, o;    // the arena the active problems live in, and its twin
@@ -128,6 +139,7 @@ struct cilqr_solver {
   // where two or three would do is throughput taken from them (measured: pool of two 1.90 -> 1.98 M solves/s, one handle
   // with two solves in flight 1.67 -> 1.72 M; the sequential call loses 1 % at 2048, hence the two defaults)
   int spec_threshold_submit = 2048;
+  bool alone_on_device = false;   // a shard of cilqr_multi_*: its device is the caller's alone, submitted solves take spec_threshold
   int team_threshold = 4096;  // active sets up to this size run the backward pass with 8 lanes per problem
   int round_group = 2;        // step sizes costed per sequential round (1, 2 or 4)
   int wave_threshold = 1024;  // active sets up to this size run the backward pass with a wavefront per problem

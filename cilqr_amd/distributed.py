@@ -185,7 +185,9 @@ class PeerGather:
     trajectory columns, the first max(n_cost) Cost rows, n_cost, status; the root rebuilds time and kappa as gather_results
     does.  Same order rule as the collective: every rank gathers its jobs in the order they finished."""
 
-    def __init__(self, world, B, K, M, root_device=None, derive=(0.1, 1.0), dtype=None):
+    def __init__(self, world, B, K, M, root_device=None, derive=(0.1, 1.0), on_root=None):
+        """on_root(result): called on the root between the arrival of every rank's block and the release of the rows for the
+        next job -- the only window in which the root tensors hold exactly one job (the returned dict aliases them)."""
         import threading
         import torch
         self.world, self.B, self.K, self.derive = world, B, K, derive
@@ -195,6 +197,7 @@ class PeerGather:
         self.nc = torch.zeros(world * B, dtype=torch.int32, **kw)
         self.st = torch.zeros(world * B, dtype=torch.int32, **kw)
         self.barrier = threading.Barrier(world)
+        self.on_root = on_root
 
     def gather_fn(self, rank):
         import torch
@@ -218,6 +221,8 @@ class PeerGather:
                 if self.traj.is_cuda:
                     torch.cuda.current_stream().synchronize()
                 res = {"traj": self.traj, "cost_hist": self.hist, "n_cost": self.nc, "status": self.st}
+                if self.on_root is not None:
+                    self.on_root(res)
             self.barrier.wait()          # the root has read / rebuilt before the next job overwrites the rows
             return res
         return fn

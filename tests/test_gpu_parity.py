@@ -1109,6 +1109,39 @@ def test_fast_lane_tie_rule_is_the_opt_in():
     opt.close()
 
 
+def test_iter_trajs_beyond_the_count_are_unspecified_on_every_path():
+    """include/cilqr.h: entries of iter_trajs at or beyond n_iter_trajs[b] are UNSPECIFIED -- small host batches copy out
+    only the iterates that exist (whatever the caller's buffer held stays behind them), large host batches and device
+    outputs deliver the whole block.  Pinned here for both host paths: the entries below the count are identical whichever
+    path produced them, and a caller that pre-fills its buffer finds the fill value (small path) or anything (large path)
+    behind them -- never something to rely on.  INTEGRATION.md section 3 says the same."""
+    sc = scenario.generate("mix11", 300, seed=31)
+    K, cap = sc["n_steps"] + 1, 12
+    opt = _opt(sc)
+
+    def solve(n, fill):
+        sub = {k: (v[:n] if isinstance(v, np.ndarray) and v.shape[:1] == (300,) else v) for k, v in sc.items()}
+        prob, keep = opt._host_problem(sub)
+        M = opt.cfg.max_iter
+        traj, hist = np.zeros((n, K, 10)), np.zeros((n, M + 1, 5))
+        nc, st, ni, nit = (np.zeros(n, np.int32) for _ in range(4))
+        it = np.full((n, cap, K, 10), fill)
+        sol = api.SolutionBatch(api.MEM_HOST, cap, traj.ctypes.data, hist.ctypes.data, nc.ctypes.data, st.ctypes.data,
+                                ni.ctypes.data, it.ctypes.data, nit.ctypes.data, None)
+        assert opt.solve_raw(prob, sol) == api.OK
+        del keep
+        return it, nit, traj
+
+    small_it, small_n, small_traj = solve(3, -7.5)          # a few problems from host arrays: the packed small-transfer path
+    big_it, big_n, big_traj = solve(300, -7.5)              # the staged path
+    assert np.array_equal(small_n, big_n[:3]) and np.array_equal(small_traj, big_traj[:3])
+    for b in range(3):
+        n = min(int(small_n[b]), cap)
+        assert n >= 1 and np.array_equal(small_it[b, :n], big_it[b, :n])          # what exists is the same on both paths
+        assert np.all(small_it[b, n:] == -7.5)                                     # small path: the caller's bytes stay
+    opt.close()
+
+
 def test_delta_v_evaluation_switch():
     """whether cc:383-384 see the updated Vx / Vxx (lazy `auto`, the default in product and oracle) or
     the ones the gains came from (eager) cannot be run against Eigen here, so BOTH readings stay built and checked: the

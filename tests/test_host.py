@@ -271,6 +271,61 @@ def test_bench_gpus_n_starts_n_ranks_by_itself():
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and r.stdout.strip() == ""
 
 
+def test_bench_rehearses_configs3_at_eight_ranks_without_a_gpu():
+    """BASELINE configs[3] (8 x 65536, results gathered to rank 0) as far as a box without GPUs allows: `bench.py --gpus 8
+    --dry-run` starts EIGHT ranks -- by itself and under the driver's launcher -- which rendezvous over gloo and push made-up
+    results of several steps through the SAME gather thread the timed region uses (cilqr_amd/distributed.py: GatherThread):
+    rank r's block at offset r * B, steps in order, ragged Cost rows, time / kappa rebuilt on the root; ONE JSON line with
+    n_gpus 8.  The one-process form (`--multi`: a thread per GPU, peer copies instead of a collective) prints the same line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    bench = os.path.join(ROOT, "bench.py")
+    runs = {
+        "spawned": [sys.executable, bench, "--gpus", "8", "--dry-run", "--steps", "5"],
+        "launcher": [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                     "--master-port", "29541", bench, "--gpus", "8", "--steps", "5", "--warmup", "2", "--dry-run"],
+        "multi": [sys.executable, bench, "--gpus", "8", "--multi", "--dry-run", "--steps", "5"],
+    }
+    for name, cmd in runs.items():
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (name, r.stderr[-2000:])
+        rec = _one_json_line(r.stdout)
+        assert rec["n_gpus"] == 8 and rec["ranks_reporting"] == 8 and rec["dry_run"] is True and rec["value"] is None, (name, rec)
+        assert rec["gathers"] == 5 and rec["gather_in_rank_order"] is True and rec["gathers_in_step_order"] is True, (name, rec)
+        assert rec["ragged_history_rows_ok"] is True and rec["gather_checks_ok"] is True, (name, rec)
+        assert rec["mode"] == ("multi" if name == "multi" else "ranks") and rec["spawned_by_bench"] is (name == "spawned")
+    # mismatches are errors, never a smaller run: the launcher started 2 ranks for --gpus 8; --multi under a launcher
+    r = subprocess.run([sys.executable, bench, "--gpus", "8", "--dry-run"], env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr and r.stdout.strip() == ""
+    r = subprocess.run([sys.executable, bench, "--gpus", "8", "--multi", "--dry-run"], env=dict(env, WORLD_SIZE="8", RANK="0", LOCAL_RANK="0"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "--multi is ONE process" in r.stderr and r.stdout.strip() == ""
+
+
+@pytest.mark.gpu
+def test_bench_distributed_paths_on_one_gpu():
+    """What a 1-GPU box can run of the N > 1 paths, with real solves: (a) CILQR_BENCH_FORCE_DIST=1 -- the RCCL process group, the
+    rank census, the per-step gather through the gather thread and cilqr_gather_results, all with one rank; (b) --multi with
+    both "GPUs" mapped onto device 0: two threads, two pools, peer-copy gather.  Each prints one line; (b) reports n_gpus 2."""
+    bench = os.path.join(ROOT, "bench.py")
+    common = ["--batch", "2048", "--steps", "6", "--warmup", "2", "--no-traffic", "--no-latency", "--cpu-sample", "0", "--cpu-configs", "0"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, bench] + common, env=dict(env, CILQR_BENCH_FORCE_DIST="1", MASTER_PORT="29551"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = _one_json_line(r.stdout)
+    assert rec["n_gpus"] == 1 and rec["config"]["results_gather"] == "rccl" and rec["config"]["rccl_ranks"] == 1
+    assert rec["results_gather_thread"]["gathers"] == 6 and rec["c_abi_gather"]["ok"] is True
+    assert rec["c_abi_gather"]["identical_to_torch_gather"] is True and rec["c_abi_gather"]["rank0_block_identical_to_local"] is True
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--multi"] + common, env=dict(env, CILQR_BENCH_MULTI_DEVICES="0,0"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = _one_json_line(r.stdout)
+    assert rec["n_gpus"] == 2 and rec["config"]["processes"] == 1 and rec["config"]["results_gather"].startswith("peer copies")
+    assert rec["results_gather_thread"]["gathers"] == 6 and rec["value"] > 0
+    assert abs(rec["value"] - 2 * 2048 * 1e3 / rec["ms_per_step"]) <= 1e-3 * rec["value"]
+
+
 TYPES = ("stand-ins", "reference headers")
 
 
