@@ -1015,11 +1015,13 @@ def run(args, rank, local_rank, world, comm, real_stdout):
                 "contended": contended,
             }
             try:   # fp64-issue / stall record of the other kernels (rocprofv3 PMC, tools/kernel_rooflines.py): recorded, not measured here
-                with open(os.path.join(ROOT, "profiles", "r03_kernel_rooflines.json")) as f:
+                import glob as _glob
+                kr_path = sorted(_glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_kernel_rooflines.json")))[-1]   # the latest round's record
+                with open(kr_path) as f:
                     kr = json.load(f)
                 if args.scene == "mix11" and N == 50 and B == 65536:
                     roof["other_kernels_recorded"] = {
-                        "source": "profiles/r03_kernel_rooflines.json (separate rocprofv3 --pmc passes of this workload, one batch in flight)",
+                        "source": f"profiles/{os.path.basename(kr_path)} (separate rocprofv3 --pmc passes of this workload, one batch in flight)",
                         "kernels": {k: {f: v[f] for f in ("ms_per_solve", "bound", "valu_issue_frac", "hbm_frac", "wait_share", "valu_per_wave") if f in v}
                                     for k, v in kr["kernels"].items()
                                     if k.split("<")[0] in ("k_round_cost", "k_spec_cost", "k_spec_cost_packed", "k_quadratize", "k_multi_forward_packed", "k_multi_forward", "k_tail")}}

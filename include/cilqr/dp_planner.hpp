@@ -435,94 +435,19 @@ class DpPlanner {
     for (int t = 0; t < kDpNT; ++t) nseg_[t] = CountSegmentPoints(t);
   }
 
-  // false = no collision-free path (min cost >= dp_w_obstacle); `result` is filled either way, as in the reference
+  // false = no collision-free path (min cost >= dp_w_obstacle); `result` is filled either way, as in the reference.
+  // Three passes over the lattice: relax every layer from the one before (Relax), pick the cheapest leaf and walk the
+  // parent links back (Backtrack), sample the chosen polyline at the knot times and profile it (Sample).
   bool Plan(double start_x, double start_y, double start_theta, std::vector<CoarsePoint>* result) {
-    const ReferenceLine& ref = env_->reference();
-    const DpPoint2 sl = ref.GetProjection(start_x, start_y);
-    start_s_ = sl.x;
-    start_l_ = sl.y;
     (void)start_theta;
-    for (auto& layer : cells_)
-      for (auto& row : layer)
-        for (auto& c : row) c = Cell();
-    for (int i = 0; i < kDpNS; ++i)                                                    // first layer, cpp:155-161
-      for (int j = 0; j < kDpNL; ++j) {
-        const auto tup = GetCost(-1, -1, -1, 0, i, j);
-        cells_[0][i][j].current_s = tup.first;
-        cells_[0][i][j].cost = tup.second;
-      }
-    for (int i = 0; i < kDpNT - 1; ++i)                                                // cpp:164-184
-      for (int j = 0; j < kDpNS; ++j)
-        for (int k = 0; k < kDpNL; ++k)
-          for (int m = 0; m < kDpNS; ++m)
-            for (int n = 0; n < kDpNL; ++n) {
-              const auto tup = GetCost(i, j, k, i + 1, m, n);
-              const double cur_cost = cells_[i][j][k].cost + tup.second;
-              if (cur_cost < cells_[i + 1][m][n].cost) {
-                Cell& c = cells_[i + 1][m][n];
-                c.cost = cur_cost;
-                c.current_s = tup.first;
-                c.parent_s = j;
-                c.parent_l = k;
-                c.lat_valid = false;
-              }
-            }
-    double min_cost = std::numeric_limits<double>::max();                              // cpp:187-198
-    int min_s = 0, min_l = 0;
-    for (int i = 0; i < kDpNS; ++i)
-      for (int j = 0; j < kDpNL; ++j)
-        if (cells_[kDpNT - 1][i][j].cost < min_cost) {
-          min_s = i;
-          min_l = j;
-          min_cost = cells_[kDpNT - 1][i][j].cost;
-        }
-    struct Way {
-      int s, l;
-      Cell cell;
-    };
-    Way way[kDpNT];
-    for (int i = kDpNT - 1; i >= 0; --i) {                                             // cpp:203-208
-      way[i] = Way{min_s, min_l, cells_[i][min_s][min_l]};
-      min_s = way[i].cell.parent_s;   // every cell of a layer >= 1 has a parent (the first candidate always improves
-      min_l = way[i].cell.parent_l;   // on the initial cost), so the indices stay valid down to layer 0
-    }
-    // interpolation, cpp:217-244
-    const size_t n_data = (size_t)(cfg_.tf / cfg_.delta_t + 1);
-    std::vector<CoarsePoint> data(n_data);
-    double last_l = start_l_, last_s = start_s_;
-    std::vector<std::pair<double, double>> xy_points;
-    size_t n = 0;
-    for (int i = 0; i < kDpNT; ++i) {
-      const double parent_s = i > 0 ? way[i - 1].cell.current_s : start_s_;
-      const std::vector<DpPoint2> segment = InterpolateLinearly(parent_s, way[i].cell.parent_l, i, way[i].s, way[i].l);
-      for (size_t j = 0; j < segment.size(); ++j) {
-        const double dl = segment[j].y - last_l;
-        const double ds = std::max(segment[j].x - last_s, dp_detail::kDpEps);
-        last_l = segment[j].y;
-        last_s = segment[j].x;
-        const DpPoint2 xy = ref.GetCartesian(segment[j].x, segment[j].y);
-        const RefPoint tp = ref.EvaluateStation(segment[j].x);
-        if (n < n_data) {
-          data[n].time = cfg_.delta_t * n;
-          data[n].s = segment[j].x;
-          data[n].x = xy.x;
-          data[n].y = xy.y;
-          data[n].theta = tp.theta + std::atan((dl / ds) / (1 - tp.kappa * segment[j].y));
-        }
-        xy_points.emplace_back(xy.x, xy.y);
-        ++n;
-      }
-    }
-    std::vector<double> headings, acc_s, speeds, accels, kappas;
-    ComputePathProfile(cfg_.delta_t, xy_points, &headings, &acc_s, &speeds, &accels, &kappas);
-    for (size_t i = 0; i < xy_points.size() && i < n_data; ++i) {                      // cpp:253-275
-      data[i].kappa = kappas[i];
-      data[i].delta = std::atan(data[i].kappa * cfg_.wheel_base);
-      data[i].velocity = speeds[i];
-      data[i].a = accels[i];
-    }
-    *result = std::move(data);
-    return min_cost < cfg_.dp_w_obstacle;
+    const DpPoint2 origin = env_->reference().GetProjection(start_x, start_y);
+    start_s_ = origin.x;
+    start_l_ = origin.y;
+    Relax();
+    Node chosen[kDpNT];
+    const double best = Backtrack(chosen);
+    Sample(chosen, result);
+    return best < cfg_.dp_w_obstacle;
   }
 
   int segment_points(int layer) const { return nseg_[layer]; }
@@ -532,8 +457,20 @@ class DpPlanner {
     double cost = std::numeric_limits<double>::max();
     double current_s = std::numeric_limits<double>::min();
     int parent_s = -1, parent_l = -1;
-    double lat = 0.0;       // GetLateralOffset(current_s, own lateral index), cached
-    bool lat_valid = false;
+  };
+  struct Node {   // a cell on the chosen path
+    int s, l;
+    Cell cell;
+  };
+  // What a transition needs to know about the cell it starts from -- the same for all kDpNS x kDpNL children, so it is
+  // worked out once per parent instead of once per (parent, child) pair.  No parent (first layer): the start state.
+  struct Origin {
+    int layer = -1, l_index = -1;   // l_index: lateral sample of the parent, -1 = start state
+    double s = 0, l = 0;            // where the new segment starts: the parent's station and lateral offset
+    double before_s = 0, before_l = 0;   // where the parent's own segment started (its parent, or the start state)
+    double tail_s = 0, tail_l = 0;  // last sampled point of the parent's own segment: the heading of the first new point hangs on it
+    double time = 0;                // time of the parent's layer
+    double cost = 0;                // accumulated cost of the parent
   };
 
   int CountSegmentPoints(int cur_t) const {   // the counting loop of InterpolateLinearly, cpp:287-299
@@ -548,117 +485,197 @@ class DpPlanner {
     return nseg;
   }
 
-  double GetLateralOffset(double s, int l_ind) const {   // dp_planner.h:84-92
+  double LateralAt(double s, int l_ind) const {   // dp_planner.h:84-92
     if (l_ind == kDpNL - 1) return 0.0;
     const RefPoint ref = env_->reference().EvaluateStation(s);
     const double lb = -ref.right_bound + safe_margin_;
     const double ub = ref.left_bound - safe_margin_;
     return lb + (ub - lb) * lateral_[l_ind];
   }
-  double CellLateral(int t, int s, int l) {
-    Cell& c = cells_[t][s][l];
-    if (!c.lat_valid) {
-      c.lat = GetLateralOffset(c.current_s, l);
-      c.lat_valid = true;
+
+  Origin StartOrigin() const {
+    Origin o;
+    o.s = o.before_s = o.tail_s = start_s_;
+    o.l = o.before_l = o.tail_l = start_l_;
+    return o;
+  }
+  // cell (t, si, li) as the origin of the next layer's transitions (cpp:45-61 and cpp:92-105 for one parent)
+  Origin OriginOf(int t, int si, int li) const {
+    const Cell& cell = cells_[t][si][li];
+    Origin o;
+    o.layer = t;
+    o.l_index = li;
+    o.cost = cell.cost;
+    o.time = time_[t];
+    o.s = cell.current_s;
+    o.l = LateralAt(o.s, li);
+    o.before_s = start_s_;
+    o.before_l = start_l_;
+    if (t >= 1) {
+      o.before_s = cells_[t - 1][cell.parent_s][cell.parent_l].current_s;
+      o.before_l = LateralAt(o.before_s, cell.parent_l);
     }
-    return c.lat;
+    // the parent's own segment ran from (before_s, before_l) to (before_s + station, its lateral there) in nseg_[t] samples;
+    // its last sample is one step short of the end
+    const int n_own = nseg_[t];
+    const double end_s = o.before_s + station_[si];
+    const double end_l = LateralAt(end_s, li);
+    const double step_s = station_[si] / n_own;
+    const double step_l = (end_l - o.before_l) / n_own;
+    o.tail_s = o.before_s + (n_own - 1) * step_s;
+    o.tail_l = o.before_l + (n_own - 1) * step_l;
+    return o;
   }
 
-  // start of a segment: the parent's (station, lateral), or the start state when there is no parent
-  void SegmentStart(double parent_s, int parent_l_ind, double* p_s, double* p_l) const {
-    *p_l = start_l_;
-    *p_s = start_s_;
-    if (parent_l_ind >= 0) {
-      *p_s = parent_s;
-      *p_l = GetLateralOffset(*p_s, parent_l_ind);
-    }
-  }
-
-  std::vector<DpPoint2> InterpolateLinearly(double parent_s, int parent_l_ind, int cur_t, int cur_s_ind,
-                                            int cur_l_ind) const {   // cpp:283-320
-    const int nseg = nseg_[cur_t];
-    std::vector<DpPoint2> result(nseg);
-    double p_s, p_l;
-    SegmentStart(parent_s, parent_l_ind, &p_s, &p_l);
-    const double cur_s = p_s + station_[cur_s_ind];
-    const double cur_l = GetLateralOffset(cur_s, cur_l_ind);
-    const double s_step = station_[cur_s_ind] / nseg;
-    const double l_step = (cur_l - p_l) / nseg;
-    for (int i = 0; i < nseg; ++i) result[i] = DpPoint2{p_s + i * s_step, p_l + i * l_step};
-    return result;
-  }
-
-  double GetCollisionCost(int pt, int ps, int pl, int ct, int cs, int cl) {   // cpp:44-86
+  // Does the sampled segment from `from` to (end_s, end_l) leave the road or hit something (cpp:63-85)?
+  bool SegmentBlocked(const Origin& from, int layer, int si, double end_l) const {
     const ReferenceLine& ref = env_->reference();
-    double parent_s = start_s_, grandparent_s = start_s_;
-    double last_l = start_l_, last_s = start_s_;
-    if (pt >= 0) {
-      const Cell& cell = cells_[pt][ps][pl];
-      parent_s = cell.current_s;
-      if (pt > 0) grandparent_s = cells_[pt - 1][cell.parent_s][cell.parent_l].current_s;
-      // last point of the parent's own segment, InterpolateLinearly(grandparent_s, cell.parent_l, pt, ps, pl).back()
-      const int nprev = nseg_[pt];
-      double g_s, g_l;
-      SegmentStart(grandparent_s, cell.parent_l, &g_s, &g_l);
-      const double prev_cur_s = g_s + station_[ps];
-      const double prev_cur_l = GetLateralOffset(prev_cur_s, pl);
-      const double s_step = station_[ps] / nprev;
-      const double l_step = (prev_cur_l - g_l) / nprev;
-      last_s = g_s + (nprev - 1) * s_step;
-      last_l = g_l + (nprev - 1) * l_step;
+    const int n = nseg_[layer];
+    const double step_s = station_[si] / n;
+    const double step_l = (end_l - from.l) / n;
+    double seen_s = from.tail_s, seen_l = from.tail_l;
+    for (int i = 0; i < n; ++i) {
+      const double at_s = from.s + i * step_s, at_l = from.l + i * step_l;
+      const double rise = at_l - seen_l;
+      const double run = std::max(at_s - seen_s, dp_detail::kDpEps);
+      seen_l = at_l;
+      seen_s = at_s;
+      const RefPoint r = ref.EvaluateStation(at_s);
+      const double lo = std::min(0.0, -r.right_bound + safe_margin_);
+      const double hi = std::max(0.0, r.left_bound - safe_margin_);
+      if (at_l < lo - dp_detail::kDpEps || at_l > hi + dp_detail::kDpEps) return true;
+      // GetCartesian(at_s, at_l) evaluates the same station: same RefPoint
+      const double cx = r.x - at_l * std::sin(r.theta), cy = r.y + at_l * std::cos(r.theta);
+      const double heading = r.theta + std::atan((rise / run) / (1 - r.kappa * at_l));
+      const double when = from.time + i * (unit_time_ / n);
+      if (env_->CheckOptimizationCollision(when, cx, cy, heading)) return true;
     }
-    const std::vector<DpPoint2> path = InterpolateLinearly(parent_s, pl, ct, cs, cl);
-    const int nseg = (int)path.size();
-    for (int i = 0; i < nseg; ++i) {
-      const DpPoint2& pt_ = path[i];
-      const double dl = pt_.y - last_l;
-      const double ds = std::max(pt_.x - last_s, dp_detail::kDpEps);
-      last_l = pt_.y;
-      last_s = pt_.x;
-      const RefPoint r = ref.EvaluateStation(pt_.x);
-      const double lb = std::min(0.0, -r.right_bound + safe_margin_);
-      const double ub = std::max(0.0, r.left_bound - safe_margin_);
-      if (pt_.y < lb - dp_detail::kDpEps || pt_.y > ub + dp_detail::kDpEps) return cfg_.dp_w_obstacle;
-      // GetCartesian(pt.x, pt.y) evaluates the same station: same RefPoint
-      const double cx = r.x - pt_.y * std::sin(r.theta), cy = r.y + pt_.y * std::cos(r.theta);
-      const double heading = r.theta + std::atan((dl / ds) / (1 - r.kappa * pt_.y));
-      const double parent_time = pt < 0 ? 0.0 : time_[pt];
-      const double time = parent_time + i * (unit_time_ / nseg);
-      if (env_->CheckOptimizationCollision(time, cx, cy, heading)) return cfg_.dp_w_obstacle;
-    }
-    return 0.0;
+    return false;
   }
 
-  std::pair<double, double> GetCost(int pt, int ps, int pl, int ct, int cs, int cl) {   // cpp:88-133
-    double parent_s = start_s_, grandparent_s = start_s_;
-    double parent_l = start_l_, grandparent_l = start_l_;
-    if (pt >= 0) {
-      const Cell& cell = cells_[pt][ps][pl];
-      parent_s = cell.current_s;
-      parent_l = CellLateral(pt, ps, pl);
-      if (pt >= 1) {
-        grandparent_s = cells_[pt - 1][cell.parent_s][cell.parent_l].current_s;
-        grandparent_l = CellLateral(pt - 1, cell.parent_s, cell.parent_l);
+  // cost of going from `from` to sample (si, li) of `layer`, and the station reached (cpp:88-133).  The five smoothness
+  // terms keep the reference's order of summation (the sum decides ties between parents).
+  double Transition(const Origin& from, int layer, int si, int li, double* reached_s) const {
+    const double to_s = from.s + station_[si];
+    const double to_l = LateralAt(to_s, li);
+    *reached_s = to_s;
+    if (SegmentBlocked(from, layer, si, to_l)) return cfg_.dp_w_obstacle;
+    const double advance = to_s - from.s, advance_before = from.s - from.before_s;
+    const double shift = to_l - from.l, shift_before = from.l - from.before_l;
+    const double off_centre = std::fabs(to_l);
+    const double slope = std::fabs(from.l - to_l) / (station_[si] + dp_detail::kDpEps);
+    const double lateral_rate_jump = std::fabs(shift - shift_before) / unit_time_;
+    const double speed_error = std::fabs(advance / unit_time_ - cfg_.dp_nominal_velocity);
+    const double speed_jump = std::fabs((advance - advance_before) / unit_time_);
+    return (cfg_.dp_w_lateral * off_centre + cfg_.dp_w_lateral_change * slope + cfg_.dp_w_lateral_velocity_change * lateral_rate_jump +
+            cfg_.dp_w_longitudinal_velocity_bias * speed_error + cfg_.dp_w_longitudinal_velocity_change * speed_jump);
+  }
+
+  // all children of one origin; a child keeps the first parent that reaches it most cheaply (strict <, cpp:176-178)
+  void Expand(const Origin& from, int layer, int parent_s, int parent_l) {
+    for (int si = 0; si < kDpNS; ++si)
+      for (int li = 0; li < kDpNL; ++li) {
+        double reached = 0.0;
+        const double step_cost = Transition(from, layer, si, li, &reached);
+        Cell& child = cells_[layer][si][li];
+        if (from.layer < 0) {           // first layer: assigned, not compared (cpp:155-161)
+          child.current_s = reached;
+          child.cost = step_cost;
+          continue;
+        }
+        const double total = from.cost + step_cost;
+        if (total < child.cost) {
+          child.cost = total;
+          child.current_s = reached;
+          child.parent_s = parent_s;
+          child.parent_l = parent_l;
+        }
+      }
+  }
+
+  void Relax() {                         // cpp:144-184
+    for (auto& layer : cells_)
+      for (auto& row : layer)
+        for (auto& c : row) c = Cell();
+    Expand(StartOrigin(), 0, -1, -1);
+    for (int t = 0; t + 1 < kDpNT; ++t)
+      for (int si = 0; si < kDpNS; ++si)
+        for (int li = 0; li < kDpNL; ++li) Expand(OriginOf(t, si, li), t + 1, si, li);
+  }
+
+  // cheapest cell of the last layer (first one on ties, cpp:187-198) and its ancestors; returns its cost
+  double Backtrack(Node* chosen) const {
+    double best = std::numeric_limits<double>::max();
+    int at_s = 0, at_l = 0;
+    for (int si = 0; si < kDpNS; ++si)
+      for (int li = 0; li < kDpNL; ++li)
+        if (cells_[kDpNT - 1][si][li].cost < best) {
+          at_s = si;
+          at_l = li;
+          best = cells_[kDpNT - 1][si][li].cost;
+        }
+    for (int t = kDpNT - 1; t >= 0; --t) {   // every cell of a layer >= 1 has a parent (its first candidate always improves
+      chosen[t] = Node{at_s, at_l, cells_[t][at_s][at_l]};   // on the initial cost), so the indices stay valid down to layer 0
+      at_s = chosen[t].cell.parent_s;
+      at_l = chosen[t].cell.parent_l;
+    }
+    return best;
+  }
+
+  // the samples of one segment of the chosen path (cpp:283-320)
+  std::vector<DpPoint2> SegmentSamples(double from_s, int from_l_index, int layer, int si, int li) const {
+    const int n = nseg_[layer];
+    std::vector<DpPoint2> pts(n);
+    double p_s = start_s_, p_l = start_l_;
+    if (from_l_index >= 0) {
+      p_s = from_s;
+      p_l = LateralAt(p_s, from_l_index);
+    }
+    const double end_s = p_s + station_[si];
+    const double end_l = LateralAt(end_s, li);
+    const double step_s = station_[si] / n;
+    const double step_l = (end_l - p_l) / n;
+    for (int i = 0; i < n; ++i) pts[i] = DpPoint2{p_s + i * step_s, p_l + i * step_l};
+    return pts;
+  }
+
+  // knots of the coarse trajectory along the chosen path, then speed / acceleration / curvature from the points (cpp:217-275)
+  void Sample(const Node* chosen, std::vector<CoarsePoint>* result) const {
+    const ReferenceLine& ref = env_->reference();
+    const size_t n_knots = (size_t)(cfg_.tf / cfg_.delta_t + 1);
+    std::vector<CoarsePoint> knots(n_knots);
+    std::vector<std::pair<double, double>> xy;
+    double seen_l = start_l_, seen_s = start_s_;
+    size_t k = 0;
+    for (int t = 0; t < kDpNT; ++t) {
+      const double from_s = t > 0 ? chosen[t - 1].cell.current_s : start_s_;
+      for (const DpPoint2& q : SegmentSamples(from_s, chosen[t].cell.parent_l, t, chosen[t].s, chosen[t].l)) {
+        const double rise = q.y - seen_l;
+        const double run = std::max(q.x - seen_s, dp_detail::kDpEps);
+        seen_l = q.y;
+        seen_s = q.x;
+        const DpPoint2 p = ref.GetCartesian(q.x, q.y);
+        const RefPoint r = ref.EvaluateStation(q.x);
+        if (k < n_knots) {
+          knots[k].time = cfg_.delta_t * k;
+          knots[k].s = q.x;
+          knots[k].x = p.x;
+          knots[k].y = p.y;
+          knots[k].theta = r.theta + std::atan((rise / run) / (1 - r.kappa * q.y));
+        }
+        xy.emplace_back(p.x, p.y);
+        ++k;
       }
     }
-    const double cur_s = parent_s + station_[cs];
-    const double cur_l = GetLateralOffset(cur_s, cl);
-    const double ds1 = cur_s - parent_s;
-    const double dl1 = cur_l - parent_l;
-    const double ds0 = parent_s - grandparent_s;
-    const double dl0 = parent_l - grandparent_l;
-    const double cost_obstacle = GetCollisionCost(pt, ps, pl, ct, cs, cl);
-    if (cost_obstacle >= cfg_.dp_w_obstacle) return std::make_pair(cur_s, cfg_.dp_w_obstacle);
-    const double cost_lateral = std::fabs(cur_l);
-    const double cost_lateral_change = std::fabs(parent_l - cur_l) / (station_[cs] + dp_detail::kDpEps);
-    const double cost_lateral_change_t = std::fabs(dl1 - dl0) / unit_time_;
-    const double cost_longitudinal_velocity = std::fabs(ds1 / unit_time_ - cfg_.dp_nominal_velocity);
-    const double cost_longitudinal_velocity_change = std::fabs((ds1 - ds0) / unit_time_);
-    const double delta_cost = (cfg_.dp_w_lateral * cost_lateral + cfg_.dp_w_lateral_change * cost_lateral_change +
-                               cfg_.dp_w_lateral_velocity_change * cost_lateral_change_t +
-                               cfg_.dp_w_longitudinal_velocity_bias * cost_longitudinal_velocity +
-                               cfg_.dp_w_longitudinal_velocity_change * cost_longitudinal_velocity_change);
-    return std::make_pair(cur_s, delta_cost);
+    std::vector<double> headings, stations, speeds, accels, kappas;
+    ComputePathProfile(cfg_.delta_t, xy, &headings, &stations, &speeds, &accels, &kappas);
+    for (size_t i = 0; i < xy.size() && i < n_knots; ++i) {
+      knots[i].kappa = kappas[i];
+      knots[i].delta = std::atan(knots[i].kappa * cfg_.wheel_base);
+      knots[i].velocity = speeds[i];
+      knots[i].a = accels[i];
+    }
+    *result = std::move(knots);
   }
 
   const DpEnvironment* env_;

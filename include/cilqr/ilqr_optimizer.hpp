@@ -38,6 +38,7 @@
 #define CILQR_ILQR_OPTIMIZER_HPP_
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -120,6 +121,7 @@ class IlqrOptimizerT {
       std::fprintf(stderr, "ilqr input coarse_traj error\n");                      // cc:75-78
       return false;
     }
+    const auto t_enter = std::chrono::steady_clock::now();
     const int K = num_of_knots_;
     int cmax = 1;
     for (size_t i = 0; i < corridor.size(); ++i) cmax = std::max<int>(cmax, static_cast<int>(corridor[i].size()));
@@ -187,7 +189,9 @@ class IlqrOptimizerT {
     out.iter_trajs = iters.data();
     out.n_iter_trajs = &n_it;
     out.alpha_trace = nullptr;
+    const auto t_call = std::chrono::steady_clock::now();
     const int rc = cilqr_solve_batch(handle_, &in, &out);
+    const auto t_back = std::chrono::steady_clock::now();
     if (rc != CILQR_OK) {
       std::fprintf(stderr, "cilqr_solve_batch failed: %s\n", cilqr_error_string(rc));
       return false;
@@ -204,6 +208,10 @@ class IlqrOptimizerT {
     for (int t = 0; t < n_it && t < max_it; ++t)
       iter_trajs->emplace_back(ToTrajectory(&iters[static_cast<size_t>(t) * K * CILQR_TRAJ_FIELDS], K));
     *opt_trajectory = ToTrajectory(traj.data(), K);
+    const auto t_leave = std::chrono::steady_clock::now();
+    timing_.flatten_ms = std::chrono::duration<double, std::milli>(t_call - t_enter).count();
+    timing_.solve_ms = std::chrono::duration<double, std::milli>(t_back - t_call).count();
+    timing_.unflatten_ms = std::chrono::duration<double, std::milli>(t_leave - t_back).count();
     return true;
   }
 
@@ -211,6 +219,15 @@ class IlqrOptimizerT {
 
   // not in the reference: CILQR_ST_* of the last Plan
   int status() const { return status_; }
+  // not in the reference (measurement plumbing, tests/cpp/latency_bench.cc): where the last successful Plan spent its wall
+  // time on the host side of the C-ABI, and the handle behind this object (cilqr_set_profiling / cilqr_get_profile)
+  struct PlanTiming {
+    double flatten_ms = 0.0;     // reference containers -> problem-major arrays (+ the handle, on the first call)
+    double solve_ms = 0.0;       // cilqr_solve_batch: transfers, kernels, launch gaps
+    double unflatten_ms = 0.0;   // arrays -> DiscretizedTrajectory / Cost objects
+  };
+  const PlanTiming& last_timing() const { return timing_; }
+  cilqr_handle native_handle() const { return handle_; }
 
  private:
   static DiscretizedTrajectory ToTrajectory(const double* t, int K) {               // cc:771-791
@@ -286,6 +303,7 @@ class IlqrOptimizerT {
   int status_ = 0;
   std::vector<Cost> cost_;
   std::vector<double> traj_buf_, hist_buf_, iters_buf_;
+  PlanTiming timing_;
 };
 
 }  // namespace cilqr

@@ -65,10 +65,15 @@ int main(int argc, char** argv) {
   IlqrOptimizer opt(config, vehicle, 0.1 * (K - 1), 0.1);     // trajectory_planner.cpp:26
 
   // ---- Plan, one scene per call ----
+  // pass 0: the first calls create the handle and load code objects (untimed); pass 1: the timed calls; pass 2: the same
+  // calls once more with the library's phase profiling on (HIP events around every phase: adds a little, so not the
+  // timed pass) -- where a batch-of-one call spends its time
   std::vector<double> t_plan, iters;
+  struct Phases { double wall = 0, flatten = 0, solve = 0, unflatten = 0, dev_span = 0, tail = 0, other = 0, lockstep = 0, iters = 0; int n = 0; } ph;
   int failed = 0;
-  for (int pass = 0; pass < 2; ++pass) {    // pass 0: the first calls create the handle and load code objects (untimed)
+  for (int pass = 0; pass < 3; ++pass) {
     const int m = pass == 0 ? std::min(n, 8) : n;
+    if (pass == 2 && opt.native_handle() != nullptr) cilqr_set_profiling(opt.native_handle(), 1);
     for (int b = 0; b < m; ++b) {
       TrajectoryPoint st;
       st.x = start[(size_t)b * 4]; st.y = start[(size_t)b * 4 + 1]; st.theta = start[(size_t)b * 4 + 2]; st.velocity = start[(size_t)b * 4 + 3];
@@ -95,8 +100,18 @@ int main(int argc, char** argv) {
         iters.push_back((double)opt.cost().size() - 1.0);
         if (!ok || result.empty()) ++failed;
       }
+      if (pass == 2 && ok) {
+        cilqr_profile pr;
+        if (cilqr_get_profile(opt.native_handle(), &pr) == CILQR_OK) {
+          ph.wall += std::chrono::duration<double, std::milli>(t1 - t0).count();
+          ph.flatten += opt.last_timing().flatten_ms; ph.solve += opt.last_timing().solve_ms; ph.unflatten += opt.last_timing().unflatten_ms;
+          ph.dev_span += pr.total_ms; ph.tail += pr.tail_ms; ph.other += pr.other_ms;
+          ph.lockstep += pr.quadratize_ms + pr.backward_ms + pr.linesearch_ms; ph.iters += pr.iterations; ph.n += 1;
+        }
+      }
     }
   }
+  if (opt.native_handle() != nullptr) cilqr_set_profiling(opt.native_handle(), 0);
 
   // ---- cilqr_solve_batch, `batch` scenes per call, host arrays ----
   std::vector<double> t_batch;
@@ -129,6 +144,17 @@ int main(int argc, char** argv) {
   std::printf("{\"scenes\": %d, \"n_steps\": %d, \"plan_failed\": %d, \"mean_accepted_iterations\": %.2f, ", n, K - 1, failed,
               std::accumulate(iters.begin(), iters.end(), 0.0) / std::max<size_t>(1, iters.size()));
   stats(t_plan, "plan_b1");
+  if (ph.n > 0) {
+    const double k = 1.0 / ph.n;
+    // iterations of Optimize() per call: all of them run inside the tail kernel for a batch of one (one workgroup, all
+    // remaining iterations in one launch); load / init guess / first cost / export are `load_initguess_export_ms`
+    std::printf(", \"plan_b1_phases\": {\"calls\": %d, \"wall_ms\": %.4f, \"flatten_ms\": %.4f, \"solve_call_ms\": %.4f, \"unflatten_ms\": %.4f, "
+                "\"device_span_ms\": %.4f, \"tail_kernel_ms\": %.4f, \"load_initguess_export_ms\": %.4f, \"lockstep_ms\": %.4f, "
+                "\"host_transfers_and_launch_gaps_ms\": %.4f, \"iterations\": %.2f, \"tail_us_per_iteration\": %.1f, "
+                "\"note\": \"means over the calls of an extra pass with HIP events around every phase (not the timed pass)\"}",
+                ph.n, ph.wall * k, ph.flatten * k, ph.solve * k, ph.unflatten * k, ph.dev_span * k, ph.tail * k, ph.other * k, ph.lockstep * k,
+                (ph.solve - ph.dev_span) * k, ph.iters * k, ph.iters > 0 ? 1e3 * ph.tail / ph.iters : 0.0);
+  }
   if (!t_batch.empty()) {
     std::printf(", \"batch\": %d, ", batch);
     stats(t_batch, "solve_batch");

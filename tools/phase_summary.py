@@ -14,8 +14,12 @@ def main():
         path = glob.glob(os.path.join(path, "**", "*.db"), recursive=True)[0]
     c = sqlite3.connect(path)
     rows = c.execute("select name, start, end, grid_x from kernels order by start").fetchall()
-    names = [r[0].split("(")[0].replace("void ", "").replace("cilqr::", "") for r in rows]
+    # kernel names as rocprofv3 records them carry the template arguments (k_quadratize<5, true>): cut them off
+    names = [r[0].split("(")[0].replace("void ", "").replace("cilqr::", "").split("<")[0] for r in rows]
     starts = [i for i, n in enumerate(names) if n == "k_load_corridor"]
+    if solve >= len(starts):
+        print(f"(no solve {solve} in this capture: {len(starts)} solves found)")
+        return
     lo = starts[solve]
     hi = starts[solve + 1] if solve + 1 < len(starts) else len(rows)
     its, cur = [], []
@@ -26,6 +30,9 @@ def main():
             cur = []
         cur.append((n, r[1], r[2], r[3]))
     its.append(cur)
+    if len(its) < 2 or not its[0]:
+        print(f"(solve {solve}: no lockstep iteration found among {hi - lo} kernels -- kernel names changed?)")
+        return
     t0 = its[0][0][1]
     print(f"prologue {(its[1][0][1] - t0) / 1e6:.2f} ms; {len(its) - 1} iterations; total {(its[-1][-1][2] - t0) / 1e6:.2f} ms")
     bounds = [1, 5, 10, 18, 30, 50, 200]

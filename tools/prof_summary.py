@@ -103,7 +103,7 @@ def main():
     if not a.iters:
         return
     want = [int(x) for x in a.iters.split(",")]
-    names = [short(r[0]) for r in rows]
+    names = [short(r[0]).split("<")[0] for r in rows]          # k_quadratize<5, true> -> k_quadratize
     starts = [i for i, n in enumerate(names) if n == "k_load_corridor"]
     if a.solve >= len(starts):
         return

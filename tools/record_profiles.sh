@@ -8,7 +8,7 @@
 #   usage (through gpurun): bash tools/record_profiles.sh r02
 # then copy gpurun_out/<tag>/*.{json,txt} into profiles/ (see DESIGN.md "Measurement").
 set -u
-tag=${1:-r03}
+tag=${1:-r04}
 root=$(cd "$(dirname "$0")/.." && pwd)
 out=$root/gpurun_out/$tag
 mkdir -p "$out"
@@ -37,9 +37,11 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_
   python tools/pmc_summary.py "$out/pmc_all_$i" > "$out/${tag}_pmc_all_kernels_$i.txt" 2>&1
 done
 python tools/kernel_rooflines.py "$out" "$tag" > "$out/${tag}_kernel_rooflines.json" 2> "$out/kr.err"
+CILQR_BENCH_FORCE_DIST=1 python bench.py --cpu-sample 0 --no-latency > "$out/${tag}_bench_force_dist.json" 2> "$out/fd.err"
+CILQR_BENCH_MULTI_DEVICES=0,0 python bench.py --gpus 2 --multi --cpu-sample 0 --no-latency > "$out/${tag}_bench_multi_two_shards_one_gpu.json" 2> "$out/mu.err"
+python tools/mall_probe.py > "$out/${tag}_mall_probe.json" 2> "$out/mall.err"
 python bench.py --pipeline 1 --cpu-sample 0 --no-latency > "$out/${tag}_bench_one_handle.json" 2> "$out/h1.err"
 python bench.py --pipeline 3 --cpu-sample 0 --no-latency > "$out/${tag}_bench_three_handles.json" 2> "$out/h3.err"
-python bench.py --torch-streams --cpu-sample 0 --no-latency > "$out/${tag}_bench_torch_streams.json" 2> "$out/ts.err"
 python bench.py --steps 20 --warmup 5 --cpu-sample 0 --no-latency > "$out/${tag}_bench_steps20_warmup5.json" 2> "$out/s20.err"
 python bench.py --fast-lane-ties --cpu-sample 0 --no-latency > "$out/${tag}_bench_fast_lane_ties.json" 2> "$out/et.err"
 python bench.py --tail-threshold 0 --in-flight 1 --pipeline 1 --cpu-sample 0 > "$out/${tag}_bench_lockstep_only_pipeline1.json" 2> "$out/ls.err"
@@ -50,6 +52,8 @@ python bench.py --coarse dp --cpu-sample 0 > "$out/${tag}_bench_dp_coarse.json" 
 python bench.py --scene demo80 --coarse dp --cpu-sample 0 > "$out/${tag}_bench_dp_coarse_demo80.json" 2> "$out/dp80.err"
 python bench.py --end-to-end --cpu-sample 0 > "$out/${tag}_bench_end_to_end.json" 2> "$out/e2e.err"
 python tools/pcie_rate.py > "$out/${tag}_pcie_inclusive.json" 2> "$out/pcie.err"
+python tests/parity_report.py 8192 > "$out/${tag}_parity_report_8192.json" 2> "$out/pr8.err"
+python tests/parity_report.py 4096 --fast-lane-ties --plain > "$out/${tag}_parity_report_4096_fast_lane_ties.json" 2> "$out/pr4.err"
 # the raw captures stay on the box: only summaries travel back (gpurun_out/ is capped at 64 MiB)
 rm -rf "$out"/kt3 "$out"/kt1 "$out"/pmc_*_FETCH_SIZE "$out"/pmc_*_WRITE_SIZE "$out"/pmc_all_[0-9]
 du -sh "$out"; ls -la "$out"; tail -3 "$out"/*.err
