@@ -86,9 +86,10 @@ CILQR_DEV void backward_problem(const DeviceState& s, int slot, double lambda) {
   const Params& p = s.p;
   const int Bc = s.Bcap, N = p.N;
   const double dt = p.dt;
+  const int sp = scratch_index(s, slot);   // where this slot's lin / term / gains live this iteration
   double Vx[6], Vxx[36];
   {
-    const double2* t = s.term + slot;
+    const double2* t = s.term + sp;
     const double2 t0 = t[0], t1 = t[(size_t)Bc], t2 = t[(size_t)2 * Bc], t3 = t[(size_t)3 * Bc],
                   t4 = t[(size_t)4 * Bc], t5 = t[(size_t)5 * Bc], t6 = t[(size_t)6 * Bc],
                   t7 = t[(size_t)7 * Bc], t8 = t[(size_t)8 * Bc];
@@ -107,7 +108,7 @@ CILQR_DEV void backward_problem(const DeviceState& s, int slot, double lambda) {
   double2 w[kLinPairs], wn[kLinPairs];
   double2 uu, uun;
   {
-    const double2* q = s.lin + (size_t)(N - 1) * kLinPairs * Bc + slot;
+    const double2* q = s.lin + (size_t)(N - 1) * kLinPairs * Bc + sp;
 #pragma unroll
     for (int r = 0; r < kLinPairs; ++r) w[r] = q[(size_t)r * Bc];
     uu = s.U[((size_t)buf * N + (N - 1)) * Bc + slot];
@@ -115,7 +116,7 @@ CILQR_DEV void backward_problem(const DeviceState& s, int slot, double lambda) {
   for (int i = N - 1; i >= 0; --i) {
     {
       const int ip = (i > 0) ? i - 1 : 0;
-      const double2* q = s.lin + (size_t)ip * kLinPairs * Bc + slot;
+      const double2* q = s.lin + (size_t)ip * kLinPairs * Bc + sp;
 #pragma unroll
       for (int r = 0; r < kLinPairs; ++r) wn[r] = q[(size_t)r * Bc];
       uun = s.U[((size_t)buf * N + ip) * Bc + slot];
@@ -159,7 +160,7 @@ CILQR_DEV void backward_problem(const DeviceState& s, int slot, double lambda) {
     kc[0] = n00 * Qu[0] + n01 * Qu[1];                                              // cc:366
     kc[1] = n10 * Qu[0] + n11 * Qu[1];
     if (kStore) {
-      double2* g = s.gains + (size_t)i * kGainPairs * Bc + slot;
+      double2* g = s.gains + (size_t)i * kGainPairs * Bc + sp;
 #pragma unroll
       for (int r = 0; r < 6; ++r) g[(size_t)r * Bc] = make_double2(Kc[2 * r], Kc[2 * r + 1]);
       g[(size_t)6 * Bc] = make_double2(kc[0], kc[1]);
@@ -264,13 +265,7 @@ constexpr int oVx = 102;           // Vx
 struct BlockSync {
   CILQR_DEV void operator()() const { __syncthreads(); }
 };
-struct WaveSync {
-  CILQR_DEV void operator()() const {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  }
-};
+// WaveSync: dev_model.hpp
 
 // cl: lane within the team (0..7); T: the team's kStride doubles of LDS; live: stores enabled
 template <class Sync>
@@ -287,10 +282,11 @@ CILQR_DEV void backward_team_problem(const DeviceState& s, int slot, double lamb
   auto sel6 = [&](double v0, double v1, double v2, double v3, double v4, double v5) {
     return c0 ? v0 : c1 ? v1 : c2 ? v2 : c3 ? v3 : c4 ? v4 : v5;
   };
+  const int sp = scratch_index(s, slot);   // where this slot's lin / term / gains live this iteration
   // terminal value function: column c of Vxx, entry c of Vx
   double V[6], vx;
   {
-    const double2* t = s.term + slot;
+    const double2* t = s.term + sp;
     const double2 t0 = t[0], t1 = t[(size_t)Bc], t2 = t[(size_t)2 * Bc], t3 = t[(size_t)3 * Bc],
                   t4 = t[(size_t)4 * Bc], t5 = t[(size_t)5 * Bc], t6 = t[(size_t)6 * Bc],
                   t7 = t[(size_t)7 * Bc], t8 = t[(size_t)8 * Bc];
@@ -328,10 +324,10 @@ CILQR_DEV void backward_team_problem(const DeviceState& s, int slot, double lamb
     double2 wa[6], lu, luu, u;     // wa: the pairs that hold A (and B(2,1)): A^T x needs all of A
   };
   auto load_step = [&](int i, StepIn& o) {
-    const double* q = reinterpret_cast<const double*>(s.lin + (size_t)i * kLinPairs * Bc + slot);
+    const double* q = reinterpret_cast<const double*>(s.lin + (size_t)i * kLinPairs * Bc + sp);
     o.a0 = q[o_a0]; o.a1 = q[o_a1]; o.a2 = q[o_a2]; o.lx = q[o_lx];
     o.h0 = q[o_h0]; o.h1 = q[o_h1]; o.h2 = q[o_h2];
-    const double2* q2 = s.lin + (size_t)i * kLinPairs * Bc + slot;
+    const double2* q2 = s.lin + (size_t)i * kLinPairs * Bc + sp;
 #pragma unroll
     for (int r = 0; r < 6; ++r) o.wa[r] = q2[(size_t)r * Bc];
     o.lu = q2[(size_t)9 * Bc]; o.luu = q2[(size_t)16 * Bc];
@@ -430,7 +426,7 @@ CILQR_DEV void backward_team_problem(const DeviceState& s, int slot, double lamb
       Qa[e] = T[oQux + e];
     }
     if (live) {   // gains: lane r < 6 stores pair r of (K row 0 | K row 1), lane 6 stores k
-      double2* g = s.gains + (size_t)i * kGainPairs * Bc + slot;
+      double2* g = s.gains + (size_t)i * kGainPairs * Bc + sp;
       if (cl < 6) g[(size_t)cl * Bc] = make_double2(Ka[2 * cl], Ka[2 * cl + 1]);
       else if (cl == 6) g[(size_t)6 * Bc] = make_double2(kc[0], kc[1]);
     }
@@ -563,6 +559,7 @@ CILQR_DEV void backward_wave_problem(const DeviceState& s, int slot, double lamb
   const int Bc = s.Bcap, N = p.N;
   const double dt = p.dt;
   const int buf = s.cur[slot];
+  const int sp = scratch_index(s, slot);   // where this slot's lin / term / gains live this iteration
   // the pointers as locals: when the state is a large by-value copy (kernels_tail.hip) its fields live in scratch
   const double2* __restrict__ lin_p = s.lin;
   const double2* __restrict__ u_p = s.U;
@@ -612,7 +609,7 @@ CILQR_DEV void backward_wave_problem(const DeviceState& s, int slot, double lamb
   if (lane < 16) { L[oQux + lane] = 0.0; L[oK + lane] = 0.0; }
   sync();
   if (lane < 9) {
-    const double2 t = s.term[(size_t)lane * Bc + slot];
+    const double2 t = s.term[(size_t)lane * Bc + sp];
     // pairs 0..2: Vx; 3..8: (h00,h01) (h02,h10) (h11,h12) (h20,h21) (h22,h33) (h44,h55) of Vxx
     constexpr int px[9] = {oVx + 0, oVx + 2, oVx + 4, oV + 0, oV + 2, oV + 7, oV + 12, oV + 14, oV + 28};
     constexpr int py[9] = {oVx + 1, oVx + 3, oVx + 5, oV + 1, oV + 6, oV + 8, oV + 13, oV + 21, oV + 35};
@@ -629,7 +626,7 @@ CILQR_DEV void backward_wave_problem(const DeviceState& s, int slot, double lamb
     if (lane < 18) { in0 = t0[lane]; in1 = t1[lane]; }
   }
   auto fetch = [&](int i) -> double2 {
-    if (lane < kLinPairs) return lin_p[((size_t)i * kLinPairs + lane) * Bc + slot];
+    if (lane < kLinPairs) return lin_p[((size_t)i * kLinPairs + lane) * Bc + sp];
     if (lane == kLinPairs) return u_p[((size_t)buf * N + i) * Bc + slot];
     return make_double2(0.0, 0.0);
   };
@@ -721,7 +718,7 @@ CILQR_DEV void backward_wave_problem(const DeviceState& s, int slot, double lamb
       } else {
         g2 = make_double2(kc0, kc1);
       }
-      gains_p[((size_t)i * kGainPairs + lane) * Bc + slot] = g2;
+      gains_p[((size_t)i * kGainPairs + lane) * Bc + sp] = g2;
     }
     // ---- stage 4: new Vxx (unsymmetrised) and new Vx ----
     double own;

@@ -290,12 +290,15 @@ CILQR_DEV double segment_dist2(const double* __restrict__ r, double px, double p
   return (len <= kMathEps || proj <= 0.0) ? d_start : (proj >= len ? d_end : d_perp);
 }
 
-// segment_dist2 that also reports WHERE the distance was taken: the offset from the end point used (ox, oy), NaN for
-// the foot of the perpendicular.  Two candidates with the same offset are the same distance in any arithmetic (the
-// shared end point of consecutive segments: the wedge outside every joint) -- no tie to re-examine.
-CILQR_DEV double segment_dist2_where(const double* __restrict__ r, double px, double py, double* ox, double* oy) {
-  double sx = r[3], sy = r[4], ux = r[5], uy = r[6], len = r[7], ex = r[8], ey = r[9];
-  asm volatile("" : "+v"(sx), "+v"(sy), "+v"(ux), "+v"(uy), "+v"(len), "+v"(ex), "+v"(ey));
+// segment_dist2 that also reports WHERE the distance was taken, as a code: the identity of the end point used (row field
+// 10 carries two int32: ids of the segment's start and end point, equal for points with bitwise equal coordinates --
+// k_load_lanes), or a code of its own for the foot of the perpendicular.  Two candidates with the same code measure
+// to the same point: the same distance in any arithmetic (the shared end point of consecutive segments: the wedge
+// outside every joint) -- no tie to re-examine.
+constexpr int kPerpCode = 0x10000;   // + segment index; end-point ids are < 2 * CILQR_MAX_LANE_SEGMENTS
+CILQR_DEV double segment_dist2_code(const double* __restrict__ r, int seg, double px, double py, int* code) {
+  double sx = r[3], sy = r[4], ux = r[5], uy = r[6], len = r[7], ex = r[8], ey = r[9], ids = r[10];
+  asm volatile("" : "+v"(sx), "+v"(sy), "+v"(ux), "+v"(uy), "+v"(len), "+v"(ex), "+v"(ey), "+v"(ids));
   const double x0 = px - sx, y0 = py - sy;
   double d_start = x0 * x0 + y0 * y0;
   const double proj = x0 * ux + y0 * uy;
@@ -305,9 +308,8 @@ CILQR_DEV double segment_dist2_where(const double* __restrict__ r, double px, do
   double d_perp = c * c;
   asm volatile("" : "+v"(d_start), "+v"(d_end), "+v"(d_perp));
   const bool at_start = (len <= kMathEps || proj <= 0.0), at_end = proj >= len;
-  const double nan = __builtin_nan("");
-  *ox = at_start ? x0 : (at_end ? x1 : nan);
-  *oy = at_start ? y0 : (at_end ? y1 : nan);
+  const long long both = __double_as_longlong(ids);
+  *code = at_start ? (int)(both & 0xffffffffll) : (at_end ? (int)(both >> 32) : kPerpCode + seg);
   return at_start ? d_start : (at_end ? d_end : d_perp);
 }
 
@@ -386,17 +388,16 @@ CILQR_DEV int nearest_segment_scan(const double* __restrict__ tab, int n, double
   double best = DBL_MAX;
   int bi = 0;
   bool suspect = false;
-  double box = 0.0, boy = 0.0;
+  int bcode = -1;
 #pragma unroll 1
   for (int s = 0; s < n; ++s) {
-    double ox = 0.0, oy = 0.0;
-    const double d2 = exact ? segment_dist2_where(tab + s * kLaneFields, px, py, &ox, &oy) : segment_dist2(tab + s * kLaneFields, px, py);
-    if (exact) suspect |= near_tie(d2, best) && !(ox == box && oy == boy);
+    int code = -2;
+    const double d2 = exact ? segment_dist2_code(tab + s * kLaneFields, s, px, py, &code) : segment_dist2(tab + s * kLaneFields, px, py);
+    if (exact) suspect |= near_tie(d2, best) && code != bcode;
     if (d2 < best) {
       best = d2;
       bi = s;
-      box = ox;
-      boy = oy;
+      bcode = code;
     }
   }
   if (exact && suspect) bi = nearest_by_reference_distance(tab, n, make_uint4(0u, 0u, 0u, 0u), 0, px, py);
@@ -430,7 +431,7 @@ CILQR_DEV int nearest_from_cell(const DeviceState& s, const double* __restrict__
   double best = DBL_MAX;
   int bi = 0;
   bool suspect = false;
-  double box = 0.0, boy = 0.0;   // EX: where the best distance was taken (segment_dist2_where)
+  int bcode = -1;                // EX: where the best distance was taken (segment_dist2_code)
   // Compact loop (not unrolled: this function is inlined at every disc of three kernels and an
   // unrolled 15-way test made them instruction-cache bound).  The trip count is the longest list
   // of the wave, tested with a ballot, so the loop is a scalar branch around straight-line
@@ -443,12 +444,11 @@ CILQR_DEV int nearest_from_cell(const DeviceState& s, const double* __restrict__
     double d2;
     bool take;
     if constexpr (exact) {
-      double ox, oy;
-      d2 = segment_dist2_where(tab + seg * kLaneFields, px, py, &ox, &oy);
-      suspect |= (k <= cnt) && near_tie(d2, best) && !(ox == box && oy == boy);
+      int code;
+      d2 = segment_dist2_code(tab + seg * kLaneFields, seg, px, py, &code);
+      suspect |= (k <= cnt) && near_tie(d2, best) && code != bcode;
       take = (k <= cnt) && (d2 < best);
-      box = take ? ox : box;
-      boy = take ? oy : boy;
+      bcode = take ? code : bcode;
     } else {
       d2 = segment_dist2(tab + seg * kLaneFields, px, py);
       take = (k <= cnt) && (d2 < best);
@@ -467,6 +467,18 @@ CILQR_DEV int nearest_segment(const DeviceState& s, const double* __restrict__ l
                               double py) {
   return nearest_from_cell<EX>(s, lanes, side, lane_cell_fetch(s, side, px, py), px, py);
 }
+
+// LDS exchange among the lanes of ONE wavefront (the wave-per-problem kernels): no s_barrier, only ordering
+struct WaveSync {
+  CILQR_DEV void operator()() const {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+};
+
+// where the per-iteration scratch of a slot (lin, term, gains) lives: see DeviceState::posn
+CILQR_DEV int scratch_index(const DeviceState& s, int slot) { return s.posn ? s.posn[slot] : slot; }
 
 // number of list entries a kernel of the solve loop has to process (see DeviceState::n_dev)
 CILQR_DEV int active_count(const DeviceState& s, int n_host) {

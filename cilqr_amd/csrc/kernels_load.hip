@@ -4,6 +4,8 @@
 //   TransformGoals cc:141-152, ShrinkConstraints cc:438-473, NormalizeHalfPlane cc:475-495,
 //   iqr (init guess) cc:793-842, TransformToTrajectory cc:771-791,
 //   OpenLoopRollout algorithm/slover/ilqr.h:363-370.
+#include <cstdlib>
+
 #include "dev_model.hpp"
 
 namespace cilqr {
@@ -75,6 +77,7 @@ __global__ __launch_bounds__(256) void k_load_goals(DeviceState s, int B, Proble
     s.status[slot] = 0;
     s.n_cost[slot] = 0;
     s.upd[slot] = 1;
+    if (s.posn) s.posn[slot] = slot;      // the first active list is the identity
     s.acc_idx[slot] = -1;
     s.cur[slot] = 0;
     s.n_iter_trajs[slot] = 0;
@@ -116,6 +119,22 @@ __global__ void k_load_lanes(DeviceState s, const double* __restrict__ raw) {
   o[6] = (len <= kMathEps) ? 0.0 : dy / len;
   o[7] = len;
   o[8] = ex; o[9] = ey;
+  // identities of the two end points within this side's table: the smallest index (start of segment k = 2k, its end =
+  // 2k + 1) of a point with bitwise equal coordinates.  Consecutive segments of a polyline share a point, hence an id;
+  // the exact-tie rule of the nearest-segment search compares these instead of coordinates (dev_model.hpp).
+  const int first = (t < s.nl) ? 0 : s.nl, n_side = (t < s.nl) ? s.nl : s.nr;
+  auto same = [](double ax, double ay, double bx, double by) {
+    return __double_as_longlong(ax) == __double_as_longlong(bx) && __double_as_longlong(ay) == __double_as_longlong(by);
+  };
+  int sid = 2 * (t - first), eid = 2 * (t - first) + 1;
+  for (int k = n_side - 1; k >= 0; --k) {           // downwards: the smallest matching index is written last
+    const double* q = raw + (first + k) * 7;
+    if (same(q[5], q[6], sx, sy)) sid = min(sid, 2 * k + 1);
+    if (same(q[3], q[4], sx, sy)) sid = min(sid, 2 * k);
+    if (same(q[5], q[6], ex, ey)) eid = min(eid, 2 * k + 1);
+    if (same(q[3], q[4], ex, ey)) eid = min(eid, 2 * k);
+  }
+  o[10] = __longlong_as_double((long long)(unsigned)sid | ((long long)eid << 32));
 }
 
 // Candidate sets of the lane grid.  For a square with centre q and half-diagonal r, any point p of
@@ -395,8 +414,175 @@ __global__ __launch_bounds__(64) void k_init_guess(DeviceState s, int B) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same init guess with ONE WAVEFRONT per problem, for small batches (the reference's own call is a batch of one,
+// trajectory_planner.cpp:79-89): with one lane per problem a step of the LQR sweep is ~1300 fp64 instructions in a row
+// on one lane (2.2 us; 0.185 ms of a 1.7 ms Plan were this kernel).  Here the Jacobians at the goals -- which do not
+// depend on the sweep -- are evaluated for all steps side by side first, and every lane owns one output element of
+// every stage of the sweep: B^T P | A^T P, then M | (B^T P) A, then K, then A - B K, then the new P; each element is the
+// SAME dense 6-term dot product, k = 0..5 in order, that k_init_guess writes out (the exact zeros and ones of A and B
+// included), so the two kernels agree bit for bit (tests/test_gpu_parity.py).  The clamped closed-loop rollout stays
+// one dependent chain (lane 0), with the gains read back from LDS instead of global memory.
+// LDS: jac [N][12] | A 36 | B 12 | P 36 | BtP 12 | AtP 36 | M 4 | BtPA 12 | K 12 | AmBK 36 | Kall [N][12]
+// ---------------------------------------------------------------------------------------------
+constexpr int kIgFixed = 36 + 12 + 36 + 12 + 36 + 4 + 12 + 12 + 36;
+__global__ __launch_bounds__(64) void k_init_guess_wave(DeviceState s, int B) {
+  extern __shared__ double ig_lds[];
+  const int slot = blockIdx.x;
+  if (slot >= B) return;
+  const int lane = threadIdx.x;
+  const Params& p = s.p;
+  const int N = p.N, Bc = s.Bcap;
+  const double dt = p.dt;
+  const WaveSync sync{};
+  double* jac = ig_lds;
+  double* A = jac + (size_t)N * 12;
+  double* Bm = A + 36;
+  double* P = Bm + 12;
+  double* BtP = P + 36;
+  double* AtP = BtP + 12;
+  double* M = AtP + 36;
+  double* BtPA = M + 4;
+  double* Kg = BtPA + 12;
+  double* AmBK = Kg + 12;
+  double* Kall = AmBK + 36;
+  const double Qd[6] = {0.001, 0.001, 0.001, 0.001, 0.01, 0.005};  // cc:801-807
+  const double R0 = 0.2, R1 = 0.05;                                // cc:811-813 (off-diagonals: 0)
+  const double zero_u[2] = {0.0, 0.0};
+  // ---- all Jacobians at the goals (vm:21-86), a step per lane ----
+  for (int i = lane; i < N; i += 64) {
+    double g[6];
+    const double2* gp = s.goals + (size_t)i * 3 * Bc + slot;
+    const double2 g0 = gp[0], g1 = gp[(size_t)Bc], g2 = gp[(size_t)2 * Bc];
+    g[0] = g0.x; g[1] = g0.y; g[2] = g1.x; g[3] = g1.y; g[4] = g2.x; g[5] = g2.y;
+    DynJac J;
+    dynamics_jacobian(p, g, zero_u, J);
+    double* o = jac + (size_t)i * 12;
+    o[0] = J.a02; o[1] = J.a03; o[2] = J.a04; o[3] = J.a05; o[4] = J.a12; o[5] = J.a13; o[6] = J.a14; o[7] = J.a15;
+    o[8] = J.a23; o[9] = J.a24; o[10] = J.a25; o[11] = J.b21;
+  }
+  if (lane < 36) P[lane] = (lane / 6 == lane % 6) ? Qd[lane / 6] : 0.0;
+  // where a lane's entry of the dense A / B comes from: the Jacobian record (>= 0), or a constant
+  int a_src = -1;
+  double a_const = 0.0;
+  if (lane < 36) {
+    const int r = lane / 6, c = lane % 6;
+    if (r == c) a_const = 1.0;
+    else if (r == 0 && c >= 2) a_src = c - 2;
+    else if (r == 1 && c >= 2) a_src = 4 + c - 2;
+    else if (r == 2 && c >= 3) a_src = 8 + c - 3;
+    else if (r == 3 && c == 4) a_const = dt;
+  } else if (lane < 48) {
+    const int e = lane - 36;   // B[k][q] at k * 2 + q
+    if (e == 2 * 2 + 1) a_src = 11;
+    else if (e == 3 * 2 + 0) a_const = 0.5 * dt * dt;
+    else if (e == 4 * 2 + 0 || e == 5 * 2 + 1) a_const = dt;
+  }
+  // stage roles
+  const int r6 = (lane < 36) ? lane / 6 : 0, c6 = (lane < 36) ? lane % 6 : 0;
+  const bool s2_btp = lane >= 36 && lane < 48;           // B^T P (q, c)
+  const int q2 = s2_btp ? (lane - 36) / 6 : 0, c2 = s2_btp ? (lane - 36) % 6 : 0;
+  const bool s3_m = lane < 4, s3_bpa = lane >= 4 && lane < 16;
+  const int m_r = lane >> 1, m_c = lane & 1, b_r = s3_bpa ? (lane - 4) / 6 : 0, b_c = s3_bpa ? (lane - 4) % 6 : 0;
+  const int k_r = (lane < 12) ? lane / 6 : 0, k_c = (lane < 12) ? lane % 6 : 0;
+  sync();
+  for (int i = N - 1; i >= 0; --i) {
+    // ---- dense A, B of this step ----
+    if (lane < 36) A[lane] = (a_src >= 0) ? jac[(size_t)i * 12 + a_src] : a_const;
+    else if (lane < 48) Bm[lane - 36] = (a_src >= 0) ? jac[(size_t)i * 12 + a_src] : a_const;
+    sync();
+    // ---- A^T P (36 lanes) | B^T P (12 lanes) ----
+    if (lane < 36) {
+      double acc = A[0 * 6 + r6] * P[0 * 6 + c6];
+#pragma unroll
+      for (int k = 1; k < 6; ++k) acc += A[k * 6 + r6] * P[k * 6 + c6];
+      AtP[r6 * 6 + c6] = acc;
+    } else if (s2_btp) {
+      double acc = Bm[0 * 2 + q2] * P[0 * 6 + c2];
+#pragma unroll
+      for (int k = 1; k < 6; ++k) acc += Bm[k * 2 + q2] * P[k * 6 + c2];
+      BtP[q2 * 6 + c2] = acc;
+    }
+    sync();
+    // ---- M = R + (B^T P) B (4 lanes) | (B^T P) A (12 lanes) ----
+    if (s3_m) {
+      double acc = BtP[m_r * 6 + 0] * Bm[0 * 2 + m_c];
+#pragma unroll
+      for (int k = 1; k < 6; ++k) acc += BtP[m_r * 6 + k] * Bm[k * 2 + m_c];
+      M[lane] = ((lane == 0) ? R0 : (lane == 3) ? R1 : 0.0) + acc;
+    } else if (s3_bpa) {
+      double acc = BtP[b_r * 6 + 0] * A[0 * 6 + b_c];
+#pragma unroll
+      for (int k = 1; k < 6; ++k) acc += BtP[b_r * 6 + k] * A[k * 6 + b_c];
+      BtPA[b_r * 6 + b_c] = acc;
+    }
+    sync();
+    // ---- K = M^-1 (B^T P A), closed-form inverse (cc:822) ----
+    if (lane < 12) {
+      const double invdet = 1.0 / (M[0] * M[3] - M[2] * M[1]);
+      const double inv[4] = {M[3] * invdet, -M[1] * invdet, -M[2] * invdet, M[0] * invdet};
+      const double kv = inv[k_r * 2 + 0] * BtPA[k_c] + inv[k_r * 2 + 1] * BtPA[6 + k_c];
+      Kg[lane] = kv;
+      Kall[(size_t)i * 12 + lane] = kv;
+    }
+    sync();
+    if (lane < 6) s.gains[((size_t)i * kGainPairs + lane) * Bc + slot] = make_double2(Kg[2 * lane], Kg[2 * lane + 1]);
+    // ---- A - B K ----
+    if (lane < 36) AmBK[lane] = A[lane] - (Bm[r6 * 2 + 0] * Kg[c6] + Bm[r6 * 2 + 1] * Kg[6 + c6]);
+    sync();
+    // ---- P = Q + (A^T P)(A - B K)     cc:823 ----
+    if (lane < 36) {
+      double acc = AtP[r6 * 6 + 0] * AmBK[0 * 6 + c6];
+#pragma unroll
+      for (int k = 1; k < 6; ++k) acc += AtP[r6 * 6 + k] * AmBK[k * 6 + c6];
+      P[lane] = ((r6 == c6) ? Qd[r6] : 0.0) + acc;
+    }
+    sync();
+  }
+  if (lane != 0) return;
+  // closed-loop rollout with clamped controls   cc:830-841
+  double x[6];
+  {
+    const double2* gp = s.goals + slot;
+    const double2 g0 = gp[0], g1 = gp[(size_t)Bc], g2 = gp[(size_t)2 * Bc];
+    x[0] = g0.x; x[1] = g0.y; x[2] = g1.x; x[3] = g1.y; x[4] = g2.x; x[5] = g2.y;
+  }
+  store_x(s, 0, 0, slot, x);
+  for (int i = 0; i < N; ++i) {
+    const double2* gp = s.goals + (size_t)i * 3 * Bc + slot;
+    const double2 g0 = gp[0], g1 = gp[(size_t)Bc], g2 = gp[(size_t)2 * Bc];
+    const double dx[6] = {x[0] - g0.x, x[1] - g0.y, x[2] - g1.x, x[3] - g1.y, x[4] - g2.x, x[5] - g2.y};
+    const double* kp = Kall + (size_t)i * 12;
+    double u[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      double acc = (-kp[r * 6 + 0]) * dx[0];
+#pragma unroll
+      for (int k = 1; k < 6; ++k) acc += (-kp[r * 6 + k]) * dx[k];
+      u[r] = acc;
+    }
+    u[0] = fmin(p.jerk_max, fmax(u[0], p.jerk_min));
+    u[1] = fmin(p.delta_rate_max, fmax(u[1], p.delta_rate_min));
+    store_u(s, 0, i, slot, u);
+    dynamics(p, x, u, x);
+    store_x(s, 0, i + 1, slot, x);
+  }
+}
+
+// Batches up to this size give every problem a wavefront (4096 problems are 4 waves per SIMD of ~0.1 ms each; the one-lane
+// kernel needs 0.185 ms whatever the batch, and wins from there on).  CILQR_INIT_GUESS_WAVE=0 / 1: never / always (tests).
+constexpr int kInitGuessWaveMax = 4096;
 void launch_init_guess(const DeviceState& s, int B, hipStream_t st) {
-  hipLaunchKernelGGL(k_init_guess, dim3((B + 63) / 64), dim3(64), 0, st, s, B);
+  static const int forced = [] {
+    const char* e = std::getenv("CILQR_INIT_GUESS_WAVE");
+    return e ? std::atoi(e) : -1;
+  }();
+  const size_t lds = ((size_t)s.p.N * 24 + kIgFixed) * sizeof(double);
+  const bool wave = forced >= 0 ? forced != 0 : B <= kInitGuessWaveMax;
+  if (wave && lds <= 64 * 1024)
+    hipLaunchKernelGGL(k_init_guess_wave, dim3(B), dim3(64), lds, st, s, B);
+  else
+    hipLaunchKernelGGL(k_init_guess, dim3((B + 63) / 64), dim3(64), 0, st, s, B);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -532,6 +718,7 @@ __global__ __launch_bounds__(256) void k_compact(DeviceState a, DeviceState b, i
     b.emit[j] = 0;
     b.done_now[j] = 0;
     b.act[j] = j;
+    if (b.posn) b.posn[j] = j;
   }
 }
 void launch_compact(const DeviceState& src, const DeviceState& dst, int n_max, hipStream_t st) {
@@ -632,10 +819,10 @@ __global__ void k_expand(DeviceState s, int B, int tensor, double* __restrict__ 
   const bool term = (i == N);
   double2 w[kLinPairs];
   if (!term) {
-    const double2* q = s.lin + (size_t)i * kLinPairs * Bc + slot;
+    const double2* q = s.lin + (size_t)i * kLinPairs * Bc + scratch_index(s, slot);
     for (int r = 0; r < kLinPairs; ++r) w[r] = q[(size_t)r * Bc];
   } else {
-    const double2* q = s.term + slot;
+    const double2* q = s.term + scratch_index(s, slot);
     for (int r = 0; r < 3; ++r) w[kRowLx + r] = q[(size_t)r * Bc];
     for (int r = 0; r < 6; ++r) w[kRowH + r] = q[(size_t)(3 + r) * Bc];
   }
@@ -686,7 +873,7 @@ __global__ void k_expand(DeviceState s, int B, int tensor, double* __restrict__ 
     }
     case 13: {  // K [B][N][2][6]
       if (term) return;
-      const double2* g = s.gains + (size_t)i * kGainPairs * Bc + slot;
+      const double2* g = s.gains + (size_t)i * kGainPairs * Bc + scratch_index(s, slot);
       double* o = dst + ((size_t)slot * N + i) * 12;
       for (int r = 0; r < 6; ++r) {
         const double2 v = g[(size_t)r * Bc];
@@ -696,7 +883,7 @@ __global__ void k_expand(DeviceState s, int B, int tensor, double* __restrict__ 
     }
     case 14: {  // k [B][N][2]
       if (term) return;
-      const double2 v = s.gains[((size_t)i * kGainPairs + 6) * Bc + slot];
+      const double2 v = s.gains[((size_t)i * kGainPairs + 6) * Bc + scratch_index(s, slot)];
       double* o = dst + ((size_t)slot * N + i) * 2;
       o[0] = v.x; o[1] = v.y;
       break;

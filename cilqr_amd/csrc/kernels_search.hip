@@ -454,6 +454,7 @@ CILQR_DEV void update_problem(const DeviceState& s, int j) {
   if (!update_state(s, s, slot)) {
     const int pos = atomicAdd(s.n_next, 1);
     s.act_next[pos] = slot;
+    if (s.posn) s.posn[slot] = pos;       // where the next iteration's lin / term / gains of this slot will live
   }
 }
 __global__ __launch_bounds__(256) void k_update(DeviceState s, int n) {

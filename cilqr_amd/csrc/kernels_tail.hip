@@ -118,6 +118,7 @@ CILQR_DEV DeviceState tail_view(const DeviceState& g, const TailArgs& a, int blk
   t.emit = q + 5;
   t.part = nullptr;    // the tail costs candidates only (parts)
   t.n_dev = nullptr;
+  t.posn = nullptr;    // one problem, slot 0: its scratch is at position 0
   return t;
 }
 

@@ -391,7 +391,7 @@ CILQR_DEV void knot_quadratize(const DeviceState& s, const double* __restrict__ 
   // the constraints below do not touch -- so that v, a, delta, the control and eight sums are dead through the two
   // loops that follow (26 registers less where the pressure is highest; same values, same places as before).
   if (term) {
-    double2* o = s.term + slot;
+    double2* o = s.term + scratch_index(s, slot);
     o[(size_t)Bc].y = q.lx[3];
     o[(size_t)2 * Bc] = make_double2(q.lx[4], q.lx[5]);
     o[(size_t)7 * Bc].y = q.hd[0];
@@ -399,7 +399,7 @@ CILQR_DEV void knot_quadratize(const DeviceState& s, const double* __restrict__ 
   } else {
     DynJac J;
     dynamics_jacobian(p, x, u, J);
-    double2* o = s.lin + (size_t)i * kLinPairs * Bc + slot;
+    double2* o = s.lin + (size_t)i * kLinPairs * Bc + scratch_index(s, slot);
     o[(size_t)0 * Bc] = make_double2(J.a02, J.a03);
     o[(size_t)1 * Bc] = make_double2(J.a04, J.a05);
     o[(size_t)2 * Bc] = make_double2(J.a12, J.a13);
@@ -473,7 +473,7 @@ CILQR_DEV void knot_quadratize(const DeviceState& s, const double* __restrict__ 
 #endif
   quad_mirror(q);
   if (term) {
-    double2* o = s.term + slot;
+    double2* o = s.term + scratch_index(s, slot);
     o[0] = make_double2(q.lx[0], q.lx[1]);
     o[(size_t)Bc].x = q.lx[2];
     o[(size_t)3 * Bc] = make_double2(q.h[0], q.h[1]);
@@ -483,7 +483,7 @@ CILQR_DEV void knot_quadratize(const DeviceState& s, const double* __restrict__ 
     o[(size_t)7 * Bc].x = q.h[8];
     return;
   }
-  double2* o = s.lin + (size_t)i * kLinPairs * Bc + slot;
+  double2* o = s.lin + (size_t)i * kLinPairs * Bc + scratch_index(s, slot);
   o[(size_t)6 * Bc] = make_double2(q.lx[0], q.lx[1]);
   o[(size_t)7 * Bc].x = q.lx[2];
   o[(size_t)10 * Bc] = make_double2(q.h[0], q.h[1]);
@@ -505,7 +505,7 @@ CILQR_DEV void knot_quadratize_ref(const DeviceState& s, int buf, int i, int slo
   Quad q;
   reforder::knot_quadratize(s, i, slot, x, u, q.lx, q.lu, q.h, q.hd, q.huu);
   if (term) {
-    double2* o = s.term + slot;
+    double2* o = s.term + scratch_index(s, slot);
     o[0] = make_double2(q.lx[0], q.lx[1]);
     o[(size_t)Bc] = make_double2(q.lx[2], q.lx[3]);
     o[(size_t)2 * Bc] = make_double2(q.lx[4], q.lx[5]);
@@ -519,7 +519,7 @@ CILQR_DEV void knot_quadratize_ref(const DeviceState& s, int buf, int i, int slo
   }
   DynJac J;
   dynamics_jacobian(p, x, u, J);
-  double2* o = s.lin + (size_t)i * kLinPairs * Bc + slot;
+  double2* o = s.lin + (size_t)i * kLinPairs * Bc + scratch_index(s, slot);
   o[(size_t)0 * Bc] = make_double2(J.a02, J.a03);
   o[(size_t)1 * Bc] = make_double2(J.a04, J.a05);
   o[(size_t)2 * Bc] = make_double2(J.a12, J.a13);

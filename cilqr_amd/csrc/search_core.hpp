@@ -41,12 +41,13 @@ constexpr int kFwdAhead = CILQR_ROLL_AHEAD;
 struct FwdStep {
   double2 x0, x1, x2, u, kk[kGainPairs];
 };
-CILQR_DEV void load_fwd_step(const DeviceState& s, int buf, int i, int slot, FwdStep& f) {
+// sp: scratch_index(s, slot), where the slot's gains live this iteration (looked up once per rollout by the caller)
+CILQR_DEV void load_fwd_step(const DeviceState& s, int buf, int i, int slot, int sp, FwdStep& f) {
   const int Bc = s.Bcap;
   const double2* b = s.X + ((size_t)buf * s.p.K + i) * 3 * Bc + slot;
   f.x0 = b[0]; f.x1 = b[(size_t)Bc]; f.x2 = b[(size_t)2 * Bc];
   f.u = s.U[((size_t)buf * s.p.N + i) * Bc + slot];
-  const double2* g = s.gains + (size_t)i * kGainPairs * Bc + slot;
+  const double2* g = s.gains + (size_t)i * kGainPairs * Bc + sp;
 #pragma unroll
   for (int r = 0; r < kGainPairs; ++r) f.kk[r] = g[(size_t)r * Bc];
 }
@@ -59,6 +60,7 @@ CILQR_DEV void forward_core(const DeviceState& s, int slot, double alpha, const 
   const Params& p = s.p;
   const int Bc = s.Bcap, N = p.N;
   const int buf = s.cur[slot];
+  const int sp = scratch_index(s, slot);
   double x[6];
   {
     const double2* gp = s.goals + slot;
@@ -72,14 +74,14 @@ CILQR_DEV void forward_core(const DeviceState& s, int slot, double alpha, const 
   FwdStep pf[kAhead];
 #pragma unroll
   for (int d = 0; d < kAhead; ++d)
-    if (d < N) load_fwd_step(s, buf, d, slot, pf[d]);
+    if (d < N) load_fwd_step(s, buf, d, slot, sp, pf[d]);
   for (int i0 = 0; i0 < N; i0 += kAhead) {
 #pragma unroll
     for (int d = 0; d < kAhead; ++d) {
       const int i = i0 + d;
       if (i < N) {
         const FwdStep c = pf[d];
-        if (i + kAhead < N) load_fwd_step(s, buf, i + kAhead, slot, pf[d]);
+        if (i + kAhead < N) load_fwd_step(s, buf, i + kAhead, slot, sp, pf[d]);
         const double xs[6] = {c.x0.x, c.x0.y, c.x1.x, c.x1.y, c.x2.x, c.x2.y};
         const double us[2] = {c.u.x, c.u.y};
         double dx[6];
@@ -118,6 +120,7 @@ CILQR_DEV void forward_multi(const DeviceState& s, int slot, int j) {
   const Params& p = s.p;
   const int Bc = s.Bcap, N = p.N;
   const int buf = s.cur[slot];
+  const int sp = scratch_index(s, slot);
   double x[G][6];
   {
     const double2* gp = s.goals + slot;
@@ -131,14 +134,14 @@ CILQR_DEV void forward_multi(const DeviceState& s, int slot, int j) {
   FwdStep pf[kFwdAhead];
 #pragma unroll
   for (int d = 0; d < kFwdAhead; ++d)
-    if (d < N) load_fwd_step(s, buf, d, slot, pf[d]);
+    if (d < N) load_fwd_step(s, buf, d, slot, sp, pf[d]);
   for (int i0 = 0; i0 < N; i0 += kFwdAhead) {
 #pragma unroll
     for (int d = 0; d < kFwdAhead; ++d) {
       const int i = i0 + d;
       if (i < N) {
         const FwdStep c = pf[d];
-        if (i + kFwdAhead < N) load_fwd_step(s, buf, i + kFwdAhead, slot, pf[d]);
+        if (i + kFwdAhead < N) load_fwd_step(s, buf, i + kFwdAhead, slot, sp, pf[d]);
         const double xs[6] = {c.x0.x, c.x0.y, c.x1.x, c.x1.y, c.x2.x, c.x2.y};
         const double us[2] = {c.u.x, c.u.y};
 #pragma unroll

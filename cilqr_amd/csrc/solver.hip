@@ -384,7 +384,7 @@ int cilqr_create(const cilqr_config* cfg, int32_t device, int32_t batch_capacity
     ALLOCM(ccnt, K * cap);
     ALLOCM(lambda, cap); ALLOCM(dlambda, cap); ALLOCM(cost_old, cap); ALLOCM(dcost, cap);
     ALLOCM(upd, cap); ALLOCM(acc_idx, cap); ALLOCM(emit, cap); ALLOCM(pid, cap); ALLOCM(done_now, cap);
-    ALLOCM(act, cap); ALLOCM(act_next, cap);
+    ALLOCM(act, cap); ALLOCM(act_next, cap); ALLOCM(posn, cap);
 #undef ALLOCM
   };
   // per-iteration scratch of an arena (shared with its twin)
@@ -712,7 +712,7 @@ DeviceState twin_of(const DeviceState& own, const DeviceState& tw) {
   t.X = tw.X; t.U = tw.U; t.cur = tw.cur; t.goals = tw.goals; t.cor = tw.cor; t.ccnt = tw.ccnt;
   t.lambda = tw.lambda; t.dlambda = tw.dlambda; t.cost_old = tw.cost_old; t.dcost = tw.dcost;
   t.upd = tw.upd; t.acc_idx = tw.acc_idx; t.emit = tw.emit; t.pid = tw.pid; t.done_now = tw.done_now;
-  t.act = tw.act; t.act_next = tw.act_next;
+  t.act = tw.act; t.act_next = tw.act_next; t.posn = tw.posn;
   return t;
 }
 
@@ -887,7 +887,10 @@ int job_iterate(cilqr_solver* h, cilqr_job& j, int stage) {
       break;
     }
     if (j.tm.begin(0)) return CILQR_ERR_DEVICE;
-    launch_quadratize(d, d.act, n_hint, 1, st);        // cc:203-214
+    // every active problem is linearised every iteration: the rows of `lin` belong to POSITIONS of this iteration's active
+    // list (DeviceState::posn), so a problem whose line search was rejected (1.3 % of the iterations; cc:296-308 keeps its
+    // linearisation) computes the same numbers again instead of finding them at last iteration's position
+    launch_quadratize(d, d.act, n_hint, 0, st);        // cc:203-214
     hipEvent_t eb0, eb1;
     if (j.tm.end() || j.tm.pair(1, &eb0, &eb1)) return CILQR_ERR_DEVICE;
     launch_backward(d, d.act, n_hint, nullptr, h->team_threshold, h->wave_threshold, st, eb0, eb1);    // cc:218

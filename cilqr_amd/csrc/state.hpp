@@ -108,9 +108,14 @@ struct DeviceState {
   unsigned char* lgrid;  // [2 sides][gnx*gny][kGridCellBytes]: count | up to 15 segment indices
   double gx0, gy0, ginv_h;
   int gnx, gny;
+  // lin / term / gains are per-ITERATION scratch (written by the quadratisation, read by the backward pass, whose gains
+  // the rollouts read): a slot's rows live at its POSITION in the iteration's active list (posn), not at the slot, so
+  // that the three big streams of an iteration stay dense while the slots thin out between two re-packings
+  // (dev_model.hpp: scratch_index).  posn == nullptr (stage API views, the tail kernel's private view): position = slot.
   double2* lin;    // [N][17][Bcap]
   double2* term;   // [9][Bcap]
   double2* gains;  // [N][7][Bcap]
+  int* posn;       // [Bcap] slot -> position in the current active list (k_load_goals: identity; k_update; k_compact: identity)
   double* dV;      // [2][Bcap]
   double* gnorm;   // [Bcap]
   double2* part;   // [K][3][Bcap]

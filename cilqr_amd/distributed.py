@@ -67,33 +67,36 @@ def gather_results(traj, cost_hist, n_cost, status, dst: int = 0, densify: bool 
     pad = torch.zeros((R - rows.shape[0], C), dtype=cost_hist.dtype, device=cost_hist.device)
     packed = torch.cat([traj.reshape(-1), rows.reshape(-1), pad.reshape(-1),
                         n_cost.to(torch.float64), status.to(torch.float64)])
+    n_traj, n_rows = B * K * F, R * C
     if rank == dst:
-        parts = [torch.empty_like(packed) for _ in range(world)]
+        # the ranks' blocks land side by side in ONE buffer (the gather list are its rows): no concatenation pass on the root
+        buf = torch.empty((world, packed.numel()), dtype=packed.dtype, device=packed.device)
+        parts = list(buf.unbind(0))
         dist.gather(packed, parts, dst=dst)
     else:
         dist.gather(packed, None, dst=dst)
         return None
-    n_traj, n_rows = B * K * F, R * C
-    trajs, ncs, sts, hists = [], [], [], []
-    for p in parts:
-        trajs.append(p[:n_traj].reshape(B, K, F))
-        ncs.append(p[n_traj + n_rows:n_traj + n_rows + B].to(n_cost.dtype))
-        sts.append(p[n_traj + n_rows + B:].to(status.dtype))
-    all_traj = torch.cat(trajs)
+    ncs = [p[n_traj + n_rows:n_traj + n_rows + B].to(n_cost.dtype) for p in parts]
+    sts = [p[n_traj + n_rows + B:].to(status.dtype) for p in parts]
+    trav = buf[:, :n_traj].reshape(world, B, K, F)                 # a view: only the rank dimension is strided
     if derive is not None:
+        # 8 travelling columns -> the 10 of a trajectory point, written once into the final tensor
         dt_, wb_ = derive
-        full = torch.empty((all_traj.shape[0], K, full_F), dtype=all_traj.dtype, device=all_traj.device)
-        full[:, :, 1:7] = all_traj[:, :, 0:6]
-        full[:, :, 8:10] = all_traj[:, :, 6:8]
-        full[:, :, 0] = torch.arange(K, dtype=all_traj.dtype, device=all_traj.device)[None, :] * dt_
-        full[:, :, 7] = torch.tan(all_traj[:, :, 5]) / wb_
-        all_traj = full
+        full = torch.empty((world, B, K, full_F), dtype=trav.dtype, device=trav.device)
+        full[..., 1:7] = trav[..., 0:6]
+        full[..., 8:10] = trav[..., 6:8]
+        full[..., 0] = torch.arange(K, dtype=trav.dtype, device=trav.device)[None, None, :] * dt_
+        full[..., 7] = torch.tan(trav[..., 5]) / wb_
+        all_traj = full.reshape(world * B, K, full_F)
+    else:
+        all_traj = trav.reshape(world * B, K, F)                    # one copy (the rank dimension is strided in the buffer)
     out = {"traj": all_traj, "n_cost": torch.cat(ncs), "status": torch.cat(sts)}
     if not densify:
         out["hist_rows"] = torch.cat([p[n_traj:n_traj + int(c.to(torch.int64).sum().item()) * C].reshape(-1, C)
                                       for p, c in zip(parts, ncs)])
         return out
     H = int(max(int(c.max().item()) for c in ncs)) if B > 0 else 0
+    hists = []
     for p, c in zip(parts, ncs):
         c64 = c.to(torch.int64)
         dense = torch.zeros((B, H, C), dtype=cost_hist.dtype, device=cost_hist.device)

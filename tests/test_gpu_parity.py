@@ -114,6 +114,38 @@ def test_stage_parity(family, B, seed):
     opt.close()
 
 
+@pytest.mark.parametrize("family", ["mix11", "dyn20"])
+def test_wave_init_guess_is_bit_identical_to_the_lane_kernel(family):
+    """Small batches build the init guess (iqr, ilqr_optimizer.cc:793-842) with a wavefront per problem (k_init_guess_wave:
+    Jacobians of all steps side by side, one output element of the LQR sweep per lane), large ones with a lane per problem.
+    The same scenes must come out with the same bits from both -- states, controls and the whole solve that starts there."""
+    n_small, n_big = 96, 4200                      # launch_init_guess switches kernels above 4096 problems
+    base = scenario.generate(family, n_small, seed=71)
+    rep = (n_big + n_small - 1) // n_small
+    big = {k: (np.tile(v, (rep,) + (1,) * (v.ndim - 1))[:n_big] if isinstance(v, np.ndarray) and v.shape[:1] == (n_small,) else v)
+           for k, v in base.items()}
+    small_opt = _opt(base)
+    small_opt.stage_load(base)
+    small_opt.stage_init_guess()
+    Xs, Us = small_opt.read(api.T_X), small_opt.read(api.T_U)
+    big_opt = _opt(big)
+    big_opt.stage_load(big)
+    big_opt.stage_init_guess()
+    Xb, Ub = big_opt.read(api.T_X), big_opt.read(api.T_U)
+    assert np.array_equal(Xs, Xb[:n_small]) and np.array_equal(Us, Ub[:n_small])
+    assert np.array_equal(Xb[:n_small], Xb[n_small:2 * n_small])          # and the position in the batch does not matter
+    o = orc.Oracle(oracle_cfg_from(small_opt.cfg))
+    for b in range(0, n_small, 7):
+        assert o.set_problem(base["start"][b], base["coarse"][b], base["corridor"][b], base["ccount"][b], base["left"], base["right"]) == 0
+        oX, oU = o.init_guess()
+        assert rel_err(Xs[b], oX) < STAGE_TOL and rel_err(Us[b], oU, 1e-3) < STAGE_TOL
+    a, b_ = small_opt.plan(base), big_opt.plan(big)
+    for k in ("traj", "cost_hist", "n_cost", "status", "n_iter"):
+        assert np.array_equal(a[k], b_[k][:n_small]), k
+    small_opt.close()
+    big_opt.close()
+
+
 def test_open_loop_rollout():
     rng = np.random.default_rng(5)
     B, N = 70, 50
