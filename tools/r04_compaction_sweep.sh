@@ -5,17 +5,17 @@
 # alone, the sequential solve and the pooled throughput.   usage (through gpurun): bash tools/r04_compaction_sweep.sh
 set -u
 root=$(cd "$(dirname "$0")/.." && pwd)
-out=$root/gpurun_out/r04_compaction
+out=$root/gpurun_out/${OUTDIR:-r04_compaction}
 mkdir -p "$out"
 cd "$root"
-for p in 75 85 92 100; do
+for p in ${PERCENTS:-75 85 92 100}; do
   python bench.py --compact-percent $p --cpu-sample 0 --no-latency > "$out/compact_$p.json" 2> "$out/compact_$p.err"
 done
 python - "$out" <<'PY'
 import json, sys, glob, os
 out = sys.argv[1]
 print("percent  value  single_batch  one_handle  bytes/problem-step  frac  frac_alg  frac_full  avg_launch_ms  bwd_ms/solve  other_ms/solve")
-for p in (75, 85, 92, 100):
+for p in [int(x) for x in os.environ.get("PERCENTS", "75 85 92 100").split()]:
     try:
         d = json.load(open(os.path.join(out, f"compact_{p}.json")))
     except Exception as e:
