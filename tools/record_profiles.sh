@@ -16,14 +16,17 @@ cd /tmp && export TMPDIR=/tmp && cd "$root"
 python bench.py > "$out/${tag}_bench.json" 2> "$out/bench.err"
 rocprofv3 --kernel-trace --stats -d "$out/kt3" -- python bench.py --cpu-sample 0 --no-latency > "$out/${tag}_bench_under_rocprofv3.json" 2> "$out/kt3.err"
 python tools/prof_summary.py "$out/kt3" --bench-json "$out/${tag}_bench_under_rocprofv3.json" > "$out/${tag}_kernel_stats_pipelined.txt" 2>&1
+rm -rf "$out/kt3"   # raw captures go as soon as they are summarised: a call that is cut off must not leave them for the merge (64 MiB cap)
 rocprofv3 --kernel-trace --stats -d "$out/kt1" -- python bench.py --steps 6 --warmup 2 --in-flight 1 --pipeline 1 --cpu-sample 0 --no-latency > "$out/${tag}_bench_pipeline1_under_rocprofv3.json" 2> "$out/kt1.err"
 { python tools/prof_summary.py "$out/kt1" --iters 1,2,5,10,20,40,80; python tools/phase_summary.py "$out/kt1"; } > "$out/${tag}_kernel_stats.txt" 2>&1
+rm -rf "$out/kt1"
 targs=""
 for wl in "mix11:50:" "dyn20:100:--scene dyn20" "dyn20x:100:--scene dyn20x"; do
   IFS=: read -r name n extra <<< "$wl"
   for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $c -d "$out/pmc_${name}_$c" -- python bench.py --steps 1 --warmup 0 --in-flight 1 --pipeline 1 --cpu-sample 0 --no-latency $extra > "$out/pmc_${name}_$c.json" 2> "$out/pmc_${name}_$c.err"
     python tools/pmc_kernel.py "$out/pmc_${name}_$c" k_backward > "$out/${tag}_pmc_backward_${name}_$c.txt" 2>&1
+    rm -rf "$out/pmc_${name}_$c"
   done
   targs="$targs ${name}_n${n} $out/${tag}_pmc_backward_${name}_FETCH_SIZE.txt $out/${tag}_pmc_backward_${name}_WRITE_SIZE.txt $out/pmc_${name}_FETCH_SIZE.json"
 done
@@ -35,6 +38,7 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_
   i=$((i+1))
   rocprofv3 --pmc $set -d "$out/pmc_all_$i" -- python bench.py --steps 1 --warmup 0 --in-flight 1 --pipeline 1 --cpu-sample 0 --no-latency > "$out/pmc_all_$i.json" 2> "$out/pmc_all_$i.err"
   python tools/pmc_summary.py "$out/pmc_all_$i" > "$out/${tag}_pmc_all_kernels_$i.txt" 2>&1
+  rm -rf "$out/pmc_all_$i"
 done
 python tools/kernel_rooflines.py "$out" "$tag" > "$out/${tag}_kernel_rooflines.json" 2> "$out/kr.err"
 CILQR_BENCH_FORCE_DIST=1 python bench.py --cpu-sample 0 --no-latency > "$out/${tag}_bench_force_dist.json" 2> "$out/fd.err"
