@@ -549,43 +549,80 @@ constexpr int oA = 0, oB = 36, oBo = 48, oV = 60, oVx = 96, oAtV = 102, oBtV = 1
               oBtVx = 168, oBtVx2 = 170, oQux = 172, oBtVB = 188, oBtVB2 = 192, oK = 196, oVn = 212, oLx = 248,
               oLu = 254, oLuu = 256, oU = 258, oH = 260, oDummy = 296, kDoubles = 304;
 // Qux and K are [2][8]: columns 0..5, column 6 = (Qu | k) so that the new Vx is the "seventh column" of the Vxx update
+// Behind the stage operands: one row per step (and one spare) of what delta_V and the gradient norm need from it --
+// (B^T Vx)(2) and (B^T Vxx B)(4) on the UPDATED value function, k (2).  Their sums are taken after the recursion (below).
+constexpr int kDefer = 8, oD = kDoubles;
+__host__ __device__ constexpr size_t lds_doubles(int N) { return (size_t)kDoubles + (size_t)(N + 1) * kDefer; }
 }  // namespace wave
 
-template <class Sync>
+// Solo: the problem is alone in its arena (capacity 1, slot 0, position 0 -- the tail kernel's private view): every
+// stride is a compile-time constant.  L: wave::lds_doubles(N) doubles of LDS.
+// InLds (with Solo): lin, term, gains, U, dV and gnorm of the view are in LDS (dev_model.hpp: assume_lds).
+#ifdef CILQR_BWD_STAGE_PROFILE   // tuning build: cycles per stage of the wave form, printed by lane 0 of block 0
+#define BSP_DECL long long bsp_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long bsp_t = __builtin_readcyclecounter();
+#define BSP(k) do { const long long n_ = __builtin_readcyclecounter(); bsp_[k] += n_ - bsp_t; bsp_t = n_; } while (0)
+#else
+#define BSP_DECL
+#define BSP(k)
+#endif
+template <class Sync, bool Solo = false, bool InLds = false>
 CILQR_DEV void backward_wave_problem(const DeviceState& s, int slot, double lambda, int lane,
                                      double* __restrict__ L, const Sync& sync) {
   using namespace wave;
   const Params& p = s.p;
-  const int Bc = s.Bcap, N = p.N;
+  const size_t Bc = Solo ? (size_t)1 : (size_t)s.Bcap;
+  const int N = p.N;
   const double dt = p.dt;
   const int buf = s.cur[slot];
-  const int sp = scratch_index(s, slot);   // where this slot's lin / term / gains live this iteration
+  const int sp = Solo ? 0 : scratch_index(s, slot);   // where this slot's lin / term / gains live this iteration
   // the pointers as locals: when the state is a large by-value copy (kernels_tail.hip) its fields live in scratch
-  const double2* __restrict__ lin_p = s.lin;
-  const double2* __restrict__ u_p = s.U;
-  double2* __restrict__ gains_p = s.gains;
+  const double2* __restrict__ lin_p = s.lin + sp;
+  const double2* __restrict__ u_p = s.U + (size_t)buf * N * Bc + slot;
+  double2* __restrict__ gains_p = s.gains + sp;
+  const double2* __restrict__ term_p = s.term + sp;
+  double* __restrict__ dV_p = s.dV;
+  double* __restrict__ gnorm_p = s.gnorm;
+  assume_lds<InLds>(lin_p);
+  assume_lds<InLds>(u_p);
+  assume_lds<InLds>(gains_p);
+  assume_lds<InLds>(term_p);
+  assume_lds<InLds>(dV_p);
+  assume_lds<InLds>(gnorm_p);
   // ---- per-lane roles ----
   const bool mat = lane < 36, row2 = lane >= 36 && lane < 48, vec = lane >= 48 && lane < 54;
   const int r = mat ? lane / 6 : (vec ? lane - 48 : 0);
   const int c = mat ? lane % 6 : (row2 ? (lane - 36) % 6 : (lane >= 58 ? lane - 58 : 0));
   const int q = row2 ? (lane - 36) / 6 : ((lane >= 54 && lane < 58) ? (lane & 1) : 0);
-  // stage 1: sum_k M[pm1 + k sm1] * X[px1 + k sx1] -> L[po1]
-  int pm1, sm1, px1, sx1, po1;
+  // stage 1: sum_k M[pm1 + k sm1] * X[px1 + k sx1] -> L[po1]; the lanes that evaluate a DEFERRED quantity (B^T Vx on the
+  // updated value function: lanes 56, 57) write into the row of the step it belongs to, d1 doubles further every step
+  int pm1, sm1, px1, sx1, po1, d1 = 0;
   if (mat)            { pm1 = oA + r;  sm1 = 6; px1 = oV + c; sx1 = 6; po1 = oAtV + r * 6 + c; }
   else if (row2)      { pm1 = oB + q;  sm1 = 2; px1 = oV + c; sx1 = 6; po1 = oBtV + q * 6 + c; }
   else if (vec)       { pm1 = oA + r;  sm1 = 6; px1 = oVx;    sx1 = 1; po1 = oAtVx + r; }
   else if (lane < 56) { pm1 = oB + q;  sm1 = 2; px1 = oVx;    sx1 = 1; po1 = oBtVx + q; }
+#ifdef CILQR_DV_EVAL_EAGER   // the rows keep the step's OWN Qu / Quu (lane 0, stage 3); these lanes' results go unused
   else if (lane < 58) { pm1 = oBo + q; sm1 = 2; px1 = oVx;    sx1 = 1; po1 = oBtVx2 + q; }
+#else
+  else if (lane < 58) { pm1 = oBo + q; sm1 = 2; px1 = oVx;    sx1 = 1; po1 = oD + q; d1 = kDefer; }
+#endif
   else                { pm1 = oBo + 1; sm1 = 2; px1 = oV + c; sx1 = 6; po1 = oBtV2 + 6 + c; }
-  // stage 2: sum_k X[px2 + k] * M[pm2 + k sm2] -> L[po2] (matrix lanes keep the result)
-  int px2, pm2, sm2, po2;
+  // stage 2: sum_k X[px2 + k] * M[pm2 + k sm2] -> L[po2] (matrix lanes keep the result); lanes 52..55: deferred (B^T Vxx B)
+  int px2, pm2, sm2, po2, d2 = 0;
   if (mat)            { px2 = oAtV + r * 6; pm2 = oA + c; sm2 = 6; po2 = oDummy; }
   else if (row2)      { px2 = oBtV + q * 6; pm2 = oA + c; sm2 = 6; po2 = oQux + q * 8 + c; }
   else if (lane < 52) { const int a = (lane - 48) >> 1, b = (lane - 48) & 1;
                         px2 = oBtV + a * 6; pm2 = oB + b; sm2 = 2; po2 = oBtVB + a * 2 + b; }
+#ifdef CILQR_DV_EVAL_EAGER
   else if (lane < 56) { const int a = (lane - 52) >> 1, b = (lane - 52) & 1;
                         px2 = (a == 0) ? oBtV : oBtV2 + 6; pm2 = oBo + b; sm2 = 2; po2 = oBtVB2 + a * 2 + b; }
+#else
+  else if (lane < 56) { const int a = (lane - 52) >> 1, b = (lane - 52) & 1;
+                        px2 = (a == 0) ? oBtV : oBtV2 + 6; pm2 = oBo + b; sm2 = 2; po2 = oD + 2 + a * 2 + b; d2 = kDefer; }
+#endif
   else                { px2 = oBtV; pm2 = oB; sm2 = 2; po2 = oDummy + 1 + (lane & 3); }
+  // the quantities evaluated while step i runs belong to step i + 1 (its B is in Bo): row i + 1, starting at row N (spare)
+  po1 += d1 * N;
+  po2 += d2 * N;
   // stage 3: K(q, c) (lanes 36..47), the others write to the dummy cell
   const int pk3 = row2 ? oK + q * 8 + c : oDummy + 5;
   const int pq3 = row2 ? oQux + c : oQux;          // Qux(0, c), Qux(1, c) = +8
@@ -609,7 +646,7 @@ CILQR_DEV void backward_wave_problem(const DeviceState& s, int slot, double lamb
   if (lane < 16) { L[oQux + lane] = 0.0; L[oK + lane] = 0.0; }
   sync();
   if (lane < 9) {
-    const double2 t = s.term[(size_t)lane * Bc + sp];
+    const double2 t = term_p[(size_t)lane * Bc];
     // pairs 0..2: Vx; 3..8: (h00,h01) (h02,h10) (h11,h12) (h20,h21) (h22,h33) (h44,h55) of Vxx
     constexpr int px[9] = {oVx + 0, oVx + 2, oVx + 4, oV + 0, oV + 2, oV + 7, oV + 12, oV + 14, oV + 28};
     constexpr int py[9] = {oVx + 1, oVx + 3, oVx + 5, oV + 1, oV + 6, oV + 8, oV + 13, oV + 21, oV + 35};
@@ -625,9 +662,11 @@ CILQR_DEV void backward_wave_problem(const DeviceState& s, int slot, double lamb
                             oH + 1, oH + 6, oH + 8, oH + 13, oH + 21, oH + 35, oLuu + 1, oU + 1};
     if (lane < 18) { in0 = t0[lane]; in1 = t1[lane]; }
   }
+  // one pair per lane and step: pair `lane` of the step's 17, lane 17 the control
+  const double2* __restrict__ fp = (lane < kLinPairs) ? lin_p + (size_t)lane * Bc : u_p;
+  const size_t fstride = (lane < kLinPairs) ? (size_t)kLinPairs * Bc : Bc;
   auto fetch = [&](int i) -> double2 {
-    if (lane < kLinPairs) return lin_p[((size_t)i * kLinPairs + lane) * Bc + sp];
-    if (lane == kLinPairs) return u_p[((size_t)buf * N + i) * Bc + slot];
+    if (lane <= kLinPairs) return fp[(size_t)i * fstride];
     return make_double2(0.0, 0.0);
   };
   // operands of the next kWaveAhead steps in flight (one pair per lane and step): a step is ~0.9 us of arithmetic,
@@ -636,27 +675,20 @@ CILQR_DEV void backward_wave_problem(const DeviceState& s, int slot, double lamb
   double2 pre[kWaveAhead];
 #pragma unroll
   for (int d = 0; d < kWaveAhead; ++d) pre[d] = fetch(N - 1 - d >= 0 ? N - 1 - d : 0);
-  double dV0 = 0.0, dV1 = 0.0, gsum = 0.0;
-  double kp0 = 0.0, kp1 = 0.0, lup0 = 0.0, lup1 = 0.0, luup0 = 0.0, luup1 = 0.0;   // previous step: k, lu, luu
-  // delta_V terms of the step whose B is in Bo, Qu / Quu on the current Vx / Vxx (cc:383-384)
-  [[maybe_unused]] auto delta_v = [&]() {
-    const double Qu0 = lup0 + L[oBtVx2], Qu1 = lup1 + L[oBtVx2 + 1];
-    dV0 += kp0 * Qu0 + kp1 * Qu1;
-    const double q00 = luup0 + L[oBtVB2], q01 = L[oBtVB2 + 1], q10 = L[oBtVB2 + 2], q11 = luup1 + L[oBtVB2 + 3];
-    const double hk0 = 0.5 * kp0, hk1 = 0.5 * kp1;
-    const double r0 = hk0 * q00 + hk1 * q10, r1 = hk0 * q01 + hk1 * q11;
-    dV1 += r0 * kp0 + r1 * kp1;
-  };
+  BSP_DECL
+  double b21_prev = dt;   // lane 5: B(2,1) of the step before (moves to Bo when the next one arrives); first: unused
   for (int i = N - 1; i >= -1; --i) {
-    // inputs of step i; step -1 only finishes delta_V of step 0.  The previous B(2,1) moves to Bo first -- by the lane
-    // that overwrites B(2,1) (lane 5), so the move needs no exchange of its own (every reader of the old Bo is at least
-    // one exchange behind)
-    if (lane == 5) L[oBo + 5] = L[oB + 5];
+    // inputs of step i; step -1 only finishes the deferred quantities of step 0.  The previous B(2,1) moves to Bo first --
+    // by the lane that overwrites B(2,1) (lane 5, from its own register: no round trip through LDS), so the move needs no
+    // exchange of its own (every reader of the old Bo is at least one exchange behind)
+    if (lane == 5 && i < N - 1) L[oBo + 5] = b21_prev;
     if (i >= 0 && lane <= kLinPairs) { L[in0] = pre[0].x; L[in1] = pre[0].y; }
+    b21_prev = pre[0].y;
 #pragma unroll
     for (int d = 0; d + 1 < kWaveAhead; ++d) pre[d] = pre[d + 1];
     if (i - kWaveAhead >= 0) pre[kWaveAhead - 1] = fetch(i - kWaveAhead);
     sync();
+    BSP(0);
     // ---- stage 1 ----
     double res1;
     {
@@ -667,6 +699,7 @@ CILQR_DEV void backward_wave_problem(const DeviceState& s, int slot, double lamb
       L[po1] = a;
     }
     sync();
+    BSP(1);
     // ---- stage 2 ----
     double res2;
     {
@@ -676,10 +709,10 @@ CILQR_DEV void backward_wave_problem(const DeviceState& s, int slot, double lamb
       res2 = a;
       if (!mat && lane < 56) L[po2] = a;
     }
+    po1 -= d1;
+    po2 -= d2;
     sync();
-#ifndef CILQR_DV_EVAL_EAGER
-    if (i < N - 1) delta_v();
-#endif
+    BSP(2);
     if (i < 0) break;
     // ---- stage 3: Quu, Qu, inverse, k (every lane), K (lanes 36..47) ----
     const double lu0 = L[oLu], lu1 = L[oLu + 1], luu0 = L[oLuu], luu1 = L[oLuu + 1];
@@ -689,26 +722,23 @@ CILQR_DEV void backward_wave_problem(const DeviceState& s, int slot, double lamb
     const double invdet = 1.0 / (m00 * m11 - m10 * m01);                                           // cc:361-363
     const double n00 = -(m11 * invdet), n01 = -(-m01 * invdet), n10 = -(-m10 * invdet), n11 = -(m00 * invdet);
     const double kc0 = n00 * Qu[0] + n01 * Qu[1], kc1 = n10 * Qu[0] + n11 * Qu[1];                 // cc:366
-#ifdef CILQR_DV_EVAL_EAGER
-    {   // delta_V_ from the Qu / Quu the gains were computed from (see the switch at the top of this file)
-      dV0 += kc0 * Qu[0] + kc1 * Qu[1];
-      const double hk0 = 0.5 * kc0, hk1 = 0.5 * kc1;
-      const double r0 = hk0 * Quu[0] + hk1 * Quu[2], r1 = hk0 * Quu[1] + hk1 * Quu[3];
-      dV1 += r0 * kc0 + r1 * kc1;
-    }
-#endif
     {
       const double x0 = L[pq3], x1 = L[pq3 + 8];
       const double n0 = (q == 0) ? n00 : n10, n1 = (q == 0) ? n01 : n11;
       const double kq = n0 * x0 + n1 * x1;                                                         // cc:365
       if (row2) L[pk3] = kq;
     }
-    if (lane == 0) { L[oK + 6] = kc0; L[oK + 14] = kc1; L[oQux + 6] = Qu[0]; L[oQux + 14] = Qu[1]; }
-    {  // CalGradientNorm term, cc:328-329
-      const double v0 = fabs(kc0) / (fabs(L[oU]) + 1), v1 = fabs(kc1) / (fabs(L[oU + 1]) + 1);
-      gsum += (v0 > v1 ? v0 : v1);
+    if (lane == 0) {
+      L[oK + 6] = kc0; L[oK + 14] = kc1; L[oQux + 6] = Qu[0]; L[oQux + 14] = Qu[1];
+      double* D = L + oD + i * kDefer;
+      D[6] = kc0; D[7] = kc1;
+#ifdef CILQR_DV_EVAL_EAGER
+      // delta_V_ from the Qu / Quu the gains were computed from (see the switch at the top of this file)
+      D[0] = Qu[0]; D[1] = Qu[1]; D[2] = Quu[0]; D[3] = Quu[1]; D[4] = Quu[2]; D[5] = Quu[3];
+#endif
     }
     sync();
+    BSP(3);
     // gains: lanes 0..5 store pair r of (K row 0 | K row 1), lane 6 stores k
     if (lane < 7) {
       double2 g2;
@@ -718,7 +748,7 @@ CILQR_DEV void backward_wave_problem(const DeviceState& s, int slot, double lamb
       } else {
         g2 = make_double2(kc0, kc1);
       }
-      gains_p[((size_t)i * kGainPairs + lane) * Bc + sp] = g2;
+      gains_p[((size_t)i * kGainPairs + lane) * Bc] = g2;
     }
     // ---- stage 4: new Vxx (unsymmetrised) and new Vx ----
     double own;
@@ -734,6 +764,7 @@ CILQR_DEV void backward_wave_problem(const DeviceState& s, int slot, double lamb
       if (mat || vec) L[po4] = own;
     }
     sync();
+    BSP(4);
     // ---- stage 5: in-place symmetrisation, column-major order (cc:381) ----
     if (mat) {
       const double o_cr = L[psym];
@@ -741,13 +772,55 @@ CILQR_DEV void backward_wave_problem(const DeviceState& s, int slot, double lamb
       const double upper = 0.5 * (own + 0.5 * (o_cr + own));
       L[oV + r * 6 + c] = (r < c) ? upper : lower;
     }
-    kp0 = kc0; kp1 = kc1; lup0 = lu0; lup1 = lu1; luup0 = luu0; luup1 = luu1;
+    BSP(5);
   }
+  // ---- delta_V_ (cc:383-384) and the gradient norm (cc:328-329), after the recursion ----
+  // Their per-step terms do not feed the recursion; evaluated inside it they were ~50 instructions of every lane's step
+  // (two IEEE divisions among them).  Here the steps' terms are evaluated side by side, a step per lane, from the rows kept
+  // above -- Qu / Quu of a step on the UPDATED Vx / Vxx (lazy reading; the eager build keeps the step's own) -- and then
+  // summed by one lane in the recursion's order, i = N-1 .. 0: the same operations on the same operands in the same order.
+  for (int j = lane; j < N; j += 64) {
+    double* D = L + oD + j * kDefer;
+    const double k0 = D[6], k1 = D[7];
+    const double2 luj = lin_p[((size_t)j * kLinPairs + kRowLu) * Bc], luuj = lin_p[((size_t)j * kLinPairs + kRowLuu) * Bc];
+    const double2 uj = u_p[(size_t)j * Bc];
+#ifdef CILQR_DV_EVAL_EAGER
+    const double Qu0 = D[0], Qu1 = D[1];
+    const double q00 = D[2], q01 = D[3], q10 = D[4], q11 = D[5];
+    (void)luj; (void)luuj;
+#else
+    const double Qu0 = luj.x + D[0], Qu1 = luj.y + D[1];
+    const double q00 = luuj.x + D[2], q01 = D[3], q10 = D[4], q11 = luuj.y + D[5];
+#endif
+    const double t0 = k0 * Qu0 + k1 * Qu1;
+    const double hk0 = 0.5 * k0, hk1 = 0.5 * k1;
+    const double r0 = hk0 * q00 + hk1 * q10, r1 = hk0 * q01 + hk1 * q11;
+    const double t1 = r0 * k0 + r1 * k1;
+    const double v0 = fabs(k0) / (fabs(uj.x) + 1), v1 = fabs(k1) / (fabs(uj.y) + 1);
+    D[0] = t0;
+    D[1] = t1;
+    D[2] = (v0 > v1 ? v0 : v1);
+  }
+  sync();
   if (lane == 0) {
-    s.dV[slot] = dV0;
-    s.dV[(size_t)Bc + slot] = dV1;
-    s.gnorm[slot] = gsum / N;
+    double dV0 = 0.0, dV1 = 0.0, gsum = 0.0;
+#pragma unroll 5
+    for (int i = N - 1; i >= 0; --i) {
+      const double* D = L + oD + i * kDefer;
+      dV0 += D[0];
+      dV1 += D[1];
+      gsum += D[2];
+    }
+    dV_p[slot] = dV0;
+    dV_p[Bc + slot] = dV1;
+    gnorm_p[slot] = gsum / N;
   }
+#ifdef CILQR_BWD_STAGE_PROFILE
+  BSP(6);
+  if (lane == 0 && blockIdx.x == 0)
+    printf("bwd wave cycles/step: inputs %lld st1 %lld st2 %lld st3 %lld st4 %lld st5 %lld | after the loop %lld\n", bsp_[0] / N, bsp_[1] / N,
+           bsp_[2] / N, bsp_[3] / N, bsp_[4] / N, bsp_[5] / N, bsp_[6]);
+#endif
 }
 
 }  // namespace cilqr

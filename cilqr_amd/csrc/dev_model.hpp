@@ -197,10 +197,37 @@ CILQR_DEV void bar_coefs(const Params& p, double g, double& jc, double& c1, doub
 }
 
 // ---- continuous dynamics f(x,u), vehicle_model.cc:123-138 ----
-CILQR_DEV void dyn_continuous(const Params& p, const double* s, const double* u, double* r) {
-  const double theta = normalize_angle(s[2]);
+// The three scalars of the parameter block a dynamics step reads, as a value: a rollout keeps them in registers for its N
+// steps (where the state is a view in LDS -- kernels_tail.hip -- every store through a generic pointer may alias the
+// block, and its fields would be fetched again after each one).
+struct DynP {
+  double dt, wheel_base, inv_wheel_base;
+};
+CILQR_DEV DynP dyn_params(const Params& p) { return DynP{p.dt, p.wheel_base, p.inv_wheel_base}; }
+
+// NormalizeAngle without its rare branch.  Every angle a rollout wraps lies within (-3 pi, 3 pi) -- the states are wrapped
+// after every step -- and takes one of the three short, exact paths of normalize_angle; written as selects those are a
+// straight line of five instructions.  The fmod branch (and with it three levels of exec-mask bookkeeping per call, seven
+// calls per rollout step) moves out of the way: `rare` is raised instead, and the caller repeats the step with the complete
+// function if any lane of the wave raised it.  Same operations on the same operands wherever `rare` stays false.
+CILQR_DEV double normalize_angle_common(double angle, bool& rare) {
+  const double t = angle + kPi;
+  rare |= !(t > -kTwoPi && t < 2.0 * kTwoPi);   // outside the short paths (or NaN)
+  double r = (t >= kTwoPi) ? t - kTwoPi : t;    // exact (Sterbenz)
+  r = (r < 0.0) ? r + kTwoPi : r;
+  return r - kPi;
+}
+template <bool Common>
+CILQR_DEV double wrap_angle(double a, bool& rare) {
+  if constexpr (Common) return normalize_angle_common(a, rare);
+  else return normalize_angle(a);
+}
+
+template <bool Common>
+CILQR_DEV void dyn_continuous(const DynP& p, const double* s, const double* u, double* r, bool& rare) {
+  const double theta = wrap_angle<Common>(s[2], rare);
   const double v = s[3];
-  const double delta = normalize_angle(s[5]);
+  const double delta = wrap_angle<Common>(s[5], rare);
   double sn, cs;
   lean_sincos(theta, &sn, &cs);
   r[0] = v * cs;
@@ -212,20 +239,72 @@ CILQR_DEV void dyn_continuous(const Params& p, const double* s, const double* u,
 }
 
 // ---- RK2 midpoint step, vehicle_model.cc:88-121 ----
-CILQR_DEV void dynamics(const Params& p, const double* s, const double* u, double* out) {
+template <bool Common>
+CILQR_DEV void dynamics_body(const DynP& p, const double* s, const double* u, double* o, bool& rare) {
   double k1[6], mid[6], k2[6];
-  dyn_continuous(p, s, u, k1);
+  dyn_continuous<Common>(p, s, u, k1, rare);
   const double h = 0.5 * p.dt;
 #pragma unroll
   for (int i = 0; i < 6; ++i) mid[i] = s[i] + h * k1[i];
-  dyn_continuous(p, mid, u, k2);
-  double o[6];
+  dyn_continuous<Common>(p, mid, u, k2, rare);
 #pragma unroll
   for (int i = 0; i < 6; ++i) o[i] = s[i] + p.dt * k2[i];
-  o[2] = normalize_angle(o[2]);
-  o[5] = normalize_angle(o[5]);
+  o[2] = wrap_angle<Common>(o[2], rare);
+  o[5] = wrap_angle<Common>(o[5], rare);
+}
+// The complete step, out of line: only a wave in which some lane left the short paths ever comes here (never, on any
+// scene of the test and bench sets), so its code -- the fmod loops of six angle wraps -- stays out of the callers' loops.
+struct StepResult {
+  double x[6];
+  double u1;
+};
+__device__ __attribute__((noinline)) StepResult dynamics_exact(DynP p, double x0, double x1, double x2, double x3, double x4, double x5,
+                                                              double u0, double u1_raw, int wrap_u1) {
+  const double s[6] = {x0, x1, x2, x3, x4, x5};
+  double u[2] = {u0, wrap_u1 ? normalize_angle(u1_raw) : u1_raw};
+  bool unused = false;
+  StepResult r;
+  dynamics_body<false>(p, s, u, r.x, unused);
+  r.u1 = u[1];
+  return r;
+}
+// One step: the straight-line form first, the complete one again if a lane of the wave left the short paths (the lanes
+// that did not would compute the same bits again, so only those that did are rewritten).  `out` may be `s`.
+CILQR_DEV void dynamics(const DynP& p, const double* s, const double* u, double* out) {
+  bool rare = false;
+  double o[6];
+  dynamics_body<true>(p, s, u, o, rare);
+  if (__builtin_amdgcn_ballot_w64(rare) != 0) {
+    if (rare) {
+      const StepResult r = dynamics_exact(p, s[0], s[1], s[2], s[3], s[4], s[5], u[0], u[1], 0);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) o[i] = r.x[i];
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 6; ++i) out[i] = o[i];
+}
+CILQR_DEV void dynamics(const Params& p, const double* s, const double* u, double* out) {
+  dynamics(dyn_params(p), s, u, out);
+}
+// A closed-loop rollout step (Forward, cc:407-410): delta_rate wrapped (cc:408), then the dynamics; u[1] is replaced by its
+// wrapped value, `xn` may be `x`.  One test for the rare path covers both.
+CILQR_DEV void closed_loop_step(const DynP& p, const double* x, double* u, double* xn) {
+  bool rare = false;
+  const double u1_raw = u[1];
+  u[1] = normalize_angle_common(u1_raw, rare);
+  double o[6];
+  dynamics_body<true>(p, x, u, o, rare);
+  if (__builtin_amdgcn_ballot_w64(rare) != 0) {
+    if (rare) {
+      const StepResult r = dynamics_exact(p, x[0], x[1], x[2], x[3], x[4], x[5], u[0], u1_raw, 1);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) o[i] = r.x[i];
+      u[1] = r.u1;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) xn[i] = o[i];
 }
 
 // ---- analytic Jacobian of the midpoint map, vehicle_model.cc:21-86 ----
@@ -476,6 +555,19 @@ struct WaveSync {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
 };
+
+// The tail kernel's view keeps a problem's tensors in LDS as far as they fit; the device functions reach them through the
+// generic pointers of DeviceState (flat_load / flat_store: every access waits for the address check and shares a counter
+// with the real LDS traffic).  Where a launch KNOWS that the tensors a phase touches are in LDS it says so, and the
+// compiler's address-space inference turns the accesses behind the pointer into ds_read / ds_write.
+template <bool InLds, class T>
+CILQR_DEV void assume_lds(T* ptr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (InLds) __builtin_assume(__builtin_amdgcn_is_shared((const void*)ptr));
+#else
+  (void)ptr;
+#endif
+}
 
 // where the per-iteration scratch of a slot (lin, term, gains) lives: see DeviceState::posn
 CILQR_DEV int scratch_index(const DeviceState& s, int slot) { return s.posn ? s.posn[slot] : slot; }

@@ -43,16 +43,9 @@ __global__ __launch_bounds__(64, 1) void k_backward(DeviceState s, const int* __
   backward_problem<true>(s, slot, lambda);
 }
 
-// one wavefront per problem (backward_core.hpp: backward_wave_problem)
-__global__ __launch_bounds__(64) void k_backward_wave(DeviceState s, const int* __restrict__ list, int n,
-                                                      const double* __restrict__ lambda_override) {
-  __shared__ double lds[wave::kDoubles];
-  const int j = blockIdx.x;
-  if (j >= active_count(s, n)) return;
-  const int slot = list ? list[j] : j;
-  const double lambda = lambda_override ? lambda_override[slot] : s.lambda[slot];
-  backward_wave_problem(s, slot, lambda, (int)threadIdx.x, lds, WaveSync{});
-}
+// one wavefront per problem: kernels_backward_wave.hip (a file of its own: it is scheduled for ILP, this one is not)
+bool launch_backward_wave(const DeviceState& s, const int* list, int n, const double* lambda_override, hipStream_t st,
+                          hipEvent_t ev_start, hipEvent_t ev_stop);
 
 // wave_threshold: active sets up to this size give every problem a wavefront; team_threshold: up to this size,
 // eight lanes; larger ones, one lane (the HBM-bound form)
@@ -61,9 +54,9 @@ void launch_backward(const DeviceState& s, const int* list, int n, const double*
   if (n == 0) return;
   // ev_start / ev_stop (profiling): the kernel's OWN start and end (dispatch timestamps, what rocprofv3 reports) --
   // events recorded around the launch would also count the time the dispatch waits for CUs that other streams hold
-  if (n <= wave_threshold)
-    hipExtLaunchKernelGGL(k_backward_wave, dim3(n), dim3(64), 0, st, ev_start, ev_stop, 0, s, list, n, lambda_override);
-  else if (n <= team_threshold)
+  if (n <= wave_threshold && launch_backward_wave(s, list, n, lambda_override, st, ev_start, ev_stop))
+    return;
+  if (n <= team_threshold)
     hipExtLaunchKernelGGL(k_backward_team, dim3((n + 7) / 8), dim3(64), 0, st, ev_start, ev_stop, 0, s, list, n, lambda_override);
   else
     hipExtLaunchKernelGGL(k_backward, dim3((n + 63) / 64), dim3(64), 0, st, ev_start, ev_stop, 0, s, list, n, lambda_override);

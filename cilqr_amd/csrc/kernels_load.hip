@@ -249,6 +249,15 @@ __global__ void k_device_math(int fn, int n, const double* __restrict__ in, doub
   const double x = in[t];
   double sn, cs;
   lean_sincos(x, &sn, &cs);
+  if (fn == 10) {   // NormalizeAngle as the rollouts take it: the straight-line form, the complete one if any lane of the wave needs it
+    bool rare = false;
+    double r = normalize_angle_common(x, rare);
+    if (__builtin_amdgcn_ballot_w64(rare) != 0) {
+      if (rare) r = normalize_angle(x);
+    }
+    out[t] = r;
+    return;
+  }
   out[t] = (fn == 0) ? log_pos(x, 0) : (fn == 1) ? fast_rcp(x)
          : (fn == 2) ? log_pos(__builtin_amdgcn_frexp_mant(x), __builtin_amdgcn_frexp_exp(x))
          : (fn == 3) ? sn : (fn == 4) ? cs : (fn == 5) ? lean_tan(x) : (fn == 6) ? normalize_angle(x)

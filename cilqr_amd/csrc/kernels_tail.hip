@@ -23,6 +23,7 @@
 // The first passing list index wins whatever the evaluation order (cc:246-265), so evaluating the candidates in
 // chunks of five and stopping at the first chunk with a winner gives the sequential loop's answer.
 #include <algorithm>
+#include <cstdlib>
 #include <mutex>
 
 #include "backward_core.hpp"
@@ -51,6 +52,12 @@ struct TailArgs {
   double* iter_trajs;
   int it_cap;
   int* max_iter;   // host-visible: largest iteration count a problem of the tail reached
+  int bwd_in_lds;  // lin, term, gains, U and the scalars are in LDS: the backward pass runs on ds_* instructions
+  int fwd_in_lds;  // X, U, gains, goals, Xs, Us are: so do the rollouts
+  int quad_in_lds; // X, U, goals, cor, ccnt, lin, term
+  int quad_scr;    // >= 0: the quadratisation runs in its split form, with its per-plane sums at this byte offset of the
+                   // block's LDS (the candidates' rows -- parts, Xs, Us -- which are dead until the line search); -1: one lane per knot
+  int cost_in_lds; // Xs, Us, parts, goals, cor, ccnt
 };
 
 static TailLayout tail_layout(const DeviceState& s) {
@@ -125,42 +132,69 @@ CILQR_DEV DeviceState tail_view(const DeviceState& g, const TailArgs& a, int blk
 // The backward phase as a function of its own: inlined, its loop inherits the scalar-register pressure of the whole
 // kernel (exec masks of its lane roles spilled to vector lanes: 57 v_readlane per step); called, it is allocated
 // on its own.  LDS is reached through the kernel's dynamic shared array, so the accesses stay ds_* instructions.
+// InLds: every tensor the phase touches lives in LDS (TailArgs::bwd_in_lds / fwd_in_lds; the usual case: horizons up to ~100)
+template <bool InLds>
 __device__ __attribute__((noinline)) void tail_backward(int off_T, int off_view) {
   extern __shared__ double lds[];
   const DeviceState& t = *reinterpret_cast<const DeviceState*>(reinterpret_cast<const char*>(lds) + off_view);
-  backward_wave_problem(t, 0, t.lambda[0], (int)threadIdx.x, lds + off_T, WaveSync{});
+  backward_wave_problem<WaveSync, true, InLds>(t, 0, t.lambda[0], (int)threadIdx.x, lds + off_T, WaveSync{});
 }
 
 // ... and so are the other three heavy phases (the lane tables sit at the start of the dynamic shared array)
 #ifndef CILQR_TAIL_AHEAD
 #define CILQR_TAIL_AHEAD 4
 #endif
+template <bool InLds>
 __device__ __attribute__((noinline)) void tail_forward(int off_view) {
   extern __shared__ double lds[];
   const DeviceState& t = *reinterpret_cast<const DeviceState*>(reinterpret_cast<const char*>(lds) + off_view);
   const int tid = (int)threadIdx.x;
-  forward_core<OutSpec, CILQR_TAIL_AHEAD>(t, 0, kAlpha[tid], OutSpec{t, tid, 0});
+  // operands in LDS are a short round trip away: one step ahead is enough (and a quarter of the registers)
+  forward_core<OutSpecSolo<InLds>, InLds ? 1 : CILQR_TAIL_AHEAD, true, InLds>(t, 0, kAlpha[tid], OutSpecSolo<InLds>(t, tid));
 }
-template <int D, bool EX>
+template <int D, bool EX, bool InLds>
 __device__ __attribute__((noinline)) void tail_quadratize(int off_view, int i) {
   extern __shared__ double lds[];
   const DeviceState& t = *reinterpret_cast<const DeviceState*>(reinterpret_cast<const char*>(lds) + off_view);
-  knot_quadratize<D, EX>(t, lds, t.cur[0], i, 0);
+  knot_quadratize<D, EX, InLds>(t, lds, t.cur[0], i, 0);
 }
-template <int D, bool EX>
+// The split form (quad_core.hpp: knot_plane_items / knot_commit_items): kQuadParts lanes share a knot's planes, then one lane
+// adds their sums up in order while another evaluates the part that depends on the knot's state and control alone.
+constexpr int kQuadParts = 4;
+template <bool EX>
+__device__ __attribute__((noinline)) void tail_quad_items(int off_view, int off_scr, int i, int part) {
+  extern __shared__ double lds[];
+  const DeviceState& t = *reinterpret_cast<const DeviceState*>(reinterpret_cast<const char*>(lds) + off_view);
+  knot_plane_items<EX, true>(t, lds, t.cur[0], i, part, kQuadParts, reinterpret_cast<double*>(reinterpret_cast<char*>(lds) + off_scr));
+}
+__device__ __attribute__((noinline)) void tail_quad_commit(int off_view, int off_scr, int i) {
+  extern __shared__ double lds[];
+  const DeviceState& t = *reinterpret_cast<const DeviceState*>(reinterpret_cast<const char*>(lds) + off_view);
+  knot_commit_items<true>(t, t.cur[0], i, reinterpret_cast<const double*>(reinterpret_cast<const char*>(lds) + off_scr));
+}
+template <bool EX>
+__device__ __attribute__((noinline)) void tail_quad_first_part(int off_view, int i) {
+  extern __shared__ double lds[];
+  const DeviceState& t = *reinterpret_cast<const DeviceState*>(reinterpret_cast<const char*>(lds) + off_view);
+  knot_quadratize<5, EX, true, true>(t, lds, t.cur[0], i, 0);
+}
+template <int D, bool EX, bool InLds>
 __device__ __attribute__((noinline)) void tail_knot_cost(int off_view, int r, int i) {
   extern __shared__ double lds[];
   const DeviceState& t = *reinterpret_cast<const DeviceState*>(reinterpret_cast<const char*>(lds) + off_view);
   const int K = t.p.K, N = t.p.N;
   const double2* xb = t.Xs + ((size_t)r * K + i) * 3;
+  assume_lds<InLds>(xb);
   const double2 p0 = xb[0], p1 = xb[1], p2 = xb[2];
   const double x[6] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y};
   double u[2] = {0.0, 0.0};
   if (i < N) {
-    const double2 q = t.Us[(size_t)r * N + i];
+    const double2* ub = t.Us + (size_t)r * N + i;
+    assume_lds<InLds>(ub);
+    const double2 q = *ub;
     u[0] = q.x; u[1] = q.y;
   }
-  knot_cost<D, EX>(t, lds, i, 0, x, u, t.parts + ((size_t)r * K + i) * kPartPairs, 1);
+  knot_cost<D, EX, InLds>(t, lds, i, 0, x, u, t.parts + ((size_t)r * K + i) * kPartPairs, 1);
 }
 
 #ifdef CILQR_TAIL_PROFILE
@@ -184,7 +218,7 @@ __global__ __launch_bounds__(kTailThreads) CILQR_TAIL_ATTR void k_tail(DeviceSta
   const int tid = threadIdx.x;
   (void)stage_lanes(g, lds);   // lane tables -> the start of the dynamic shared array (read by the phase functions)
   double* T = lds + ((g.nl + g.nr) * kLaneFields + 1) / 2 * 2;   // operands of the backward pass
-  double* tot = T + wave::kDoubles;                              // [11][5] candidate totals
+  double* tot = T + wave::lds_doubles(g.p.N);                    // [11][5] candidate totals
   int* flag = reinterpret_cast<int*>(tot + kNumAlpha * 5);       // [0] leaves before the search [1] accepted index [2] done
   // The view sits in LDS, not in registers: its ~70 uniform fields on top of the kernel's own would spill the scalar
   // registers into vector lanes (385 spills, 159 v_readlane per backward step measured: +60 % on that phase).
@@ -239,12 +273,25 @@ __global__ __launch_bounds__(kTailThreads) CILQR_TAIL_ATTR void k_tail(DeviceSta
   for (;;) {
     TP(7);
     if (t.upd[0]) {                                                        // cc:203-214
-      for (int i = tid; i < K; i += kTailThreads) tail_quadratize<D, EX>(off_view, i);
+      if (D == 5 && a.quad_scr >= 0) {
+        const int off_scr = a.lds_base + a.quad_scr;
+        for (int w = tid; w < K * kQuadParts; w += kTailThreads) tail_quad_items<EX>(off_view, off_scr, w / kQuadParts, w % kQuadParts);
+        __syncthreads();
+        // even waves add the planes' sums up, odd waves evaluate the state-only part: different SIMDs, disjoint outputs
+        const int wv = tid >> 6;
+        for (int i = (wv >> 1) * 64 + (tid & 63); i < K; i += kTailThreads / 2) {
+          if (wv & 1) tail_quad_first_part<EX>(off_view, i);
+          else tail_quad_commit(off_view, off_scr, i);
+        }
+      } else if (a.quad_in_lds) { for (int i = tid; i < K; i += kTailThreads) tail_quadratize<D, EX, true>(off_view, i); }
+      else { for (int i = tid; i < K; i += kTailThreads) tail_quadratize<D, EX, false>(off_view, i); }
     }
     __syncthreads();
     TP(0);
-    if (tid < 64)                                                          // cc:218 (wave 0)
-      tail_backward((int)(T - lds), off_view);
+    if (tid < 64) {                                                        // cc:218 (wave 0)
+      if (a.bwd_in_lds) tail_backward<true>((int)(T - lds), off_view);
+      else tail_backward<false>((int)(T - lds), off_view);
+    }
     __syncthreads();
     TP(1);
     if (tid == 0) {                                                        // cc:235-241
@@ -255,7 +302,10 @@ __global__ __launch_bounds__(kTailThreads) CILQR_TAIL_ATTR void k_tail(DeviceSta
     }
     __syncthreads();
     if (!flag[0]) {
-      if (tid < kNumAlpha) tail_forward(off_view);                         // cc:246-250, all step sizes
+      if (tid < kNumAlpha) {                                               // cc:246-250, all step sizes
+        if (a.fwd_in_lds) tail_forward<true>(off_view);
+        else tail_forward<false>(off_view);
+      }
       __syncthreads();
       TP(2);
       int acc = -1;
@@ -263,7 +313,8 @@ __global__ __launch_bounds__(kTailThreads) CILQR_TAIL_ATTR void k_tail(DeviceSta
         const int nr = min(kTailChunk, kNumAlpha - r0);
         for (int e = tid; e < nr * K; e += kTailThreads) {
           const int rr = e / K, i = e - rr * K, r = r0 + rr;
-          tail_knot_cost<D, EX>(off_view, r, i);
+          if (a.cost_in_lds) tail_knot_cost<D, EX, true>(off_view, r, i);
+          else tail_knot_cost<D, EX, false>(off_view, r, i);
         }
         __syncthreads();
         TP(3);
@@ -361,6 +412,13 @@ __global__ __launch_bounds__(kTailThreads) CILQR_TAIL_ATTR void k_tail(DeviceSta
   }
 }
 
+static size_t tail_fixed_lds(const DeviceState& g) {
+  const size_t lane_d = (size_t)((g.nl + g.nr) * kLaneFields + 1) / 2 * 2;
+  return ((lane_d + wave::lds_doubles(g.p.N) + kNumAlpha * 5) * sizeof(double) + 16 * sizeof(int) + sizeof(DeviceState) + 31) / 16 * 16;
+}
+// lane tables + the backward pass's operands and per-step rows + the view: within the 64 KiB no attribute has to grant
+bool tail_supported(const DeviceState& g) { return tail_fixed_lds(g) <= 62 * 1024; }
+
 // g.act / g.n_dev: the active list the tail takes over (n_max bounds its length and sizes the grid)
 void launch_tail(const DeviceState& g, void* workspace, int n_max, double* traj, double* iter_trajs,
                  int max_iter_trajs, int* max_iter_dev, hipStream_t st) {
@@ -372,8 +430,7 @@ void launch_tail(const DeviceState& g, void* workspace, int n_max, double* traj,
   a.iter_trajs = iter_trajs;
   a.it_cap = max_iter_trajs;
   a.max_iter = max_iter_dev;
-  const size_t lane_d = (size_t)((g.nl + g.nr) * kLaneFields + 1) / 2 * 2;
-  const size_t fixed = ((lane_d + wave::kDoubles + kNumAlpha * 5) * sizeof(double) + 16 * sizeof(int) + sizeof(DeviceState) + 31) / 16 * 16;
+  const size_t fixed = tail_fixed_lds(g);
   // Dynamic shared memory beyond the default has to be asked for, once per kernel and device; what the device grants
   // (160 KiB per workgroup on gfx950, 64 KiB on older CDNA) sizes the budget below.  One-time, guarded: several handles'
   // worker threads come through here.
@@ -414,6 +471,27 @@ void launch_tail(const DeviceState& g, void* workspace, int n_max, double* traj,
     else a.S.*(it.field) = kNotInLds;
   }
   a.lds_base = (int)fixed;
+  auto in_lds = [&](size_t TailLayout::*f) { return a.S.*f != kNotInLds; };
+  a.bwd_in_lds = in_lds(&TailLayout::lin) && in_lds(&TailLayout::term) && in_lds(&TailLayout::gains) && in_lds(&TailLayout::U) &&
+                 in_lds(&TailLayout::dbl);
+  a.fwd_in_lds = in_lds(&TailLayout::X) && in_lds(&TailLayout::U) && in_lds(&TailLayout::gains) && in_lds(&TailLayout::goals) &&
+                 in_lds(&TailLayout::Xs) && in_lds(&TailLayout::Us);
+  a.quad_in_lds = in_lds(&TailLayout::X) && in_lds(&TailLayout::U) && in_lds(&TailLayout::goals) && in_lds(&TailLayout::cor) &&
+                  in_lds(&TailLayout::ccnt) && in_lds(&TailLayout::lin) && in_lds(&TailLayout::term);
+  a.cost_in_lds = in_lds(&TailLayout::Xs) && in_lds(&TailLayout::Us) && in_lds(&TailLayout::parts) && in_lds(&TailLayout::goals) &&
+                  in_lds(&TailLayout::cor) && in_lds(&TailLayout::ccnt);
+  {  // split quadratisation: needs its tensors and the (then idle) candidate rows in LDS, the latter in one piece
+    auto al = [](size_t b) { return (b + 15) / 16 * 16; };
+    const size_t b_parts = al((size_t)kNumAlpha * K * kPartPairs * sizeof(double2)), b_xs = al((size_t)kNumAlpha * K * 3 * sizeof(double2)),
+                 b_us = al((size_t)kNumAlpha * N * sizeof(double2));
+    const bool one_piece = in_lds(&TailLayout::parts) && in_lds(&TailLayout::Xs) && in_lds(&TailLayout::Us) &&
+                           a.S.Xs == a.S.parts + b_parts && a.S.Us == a.S.Xs + b_xs;
+    const size_t need = K * (size_t)quad_split_doubles(g.cmax) * sizeof(double);
+    const char* env = std::getenv("CILQR_TAIL_QUAD_SPLIT");   // "0": one lane per knot (A/B measurements; both forms are tested)
+    const bool off = env && env[0] == '0';
+    a.quad_scr = (!off && g.p.num_of_disc == 5 && a.quad_in_lds && one_piece && need <= b_parts + b_xs + b_us && kTailThreads == 256)
+                     ? (int)a.S.parts : -1;
+  }
   const size_t lds = fixed + used;
   if (g.p.num_of_disc == 5) {
     if (g.exact_ties) hipLaunchKernelGGL((k_tail<5, true>), dim3(n_max), dim3(kTailThreads), lds, st, g, a, n_max);

@@ -106,7 +106,8 @@ __device__ unsigned long long g_cost_prof[kCostProfWaves * 8];
 #else
 #define CP_STAMP(k)
 #endif
-template <int D, bool EX>
+// InLds: goals, cor, ccnt of the view and `out` are in LDS (the tail kernel; dev_model.hpp: assume_lds)
+template <int D, bool EX, bool InLds = false>
 CILQR_DEV void knot_cost_core(const DeviceState& s, const double* __restrict__ lanes, int i, int slot,
                               const double* x, const double* u, double2* __restrict__ out, size_t stride) {
   constexpr int C = kCostChunk;
@@ -116,12 +117,17 @@ CILQR_DEV void knot_cost_core(const DeviceState& s, const double* __restrict__ l
   const Params& p = s.p;
   const int Bc = s.Bcap;
   const double2* gp = s.goals + (size_t)i * 3 * Bc + slot;
+  assume_lds<InLds>(gp);
   const double2 g0 = gp[0];
   const double gth = gp[(size_t)Bc].x;
   const double* __restrict__ cor = s.cor + (size_t)i * s.cmax * 3 * Bc + slot;
+  assume_lds<InLds>(cor);
+  assume_lds<InLds>(out);
   PlaneChunk<C> pc;
   load_first_chunk(cor, Bc, s.cmax, pc);
-  const int cnt = s.ccnt[(size_t)i * Bc + slot];
+  const int* cntp = s.ccnt + (size_t)i * Bc + slot;
+  assume_lds<InLds>(cntp);
+  const int cnt = *cntp;
   mask_first_chunk(cnt, pc);
   // JCost cc:501-513
   const double ex = x[0] - g0.x, ey = x[1] - g0.y, eth = x[2] - gth;
@@ -254,10 +260,10 @@ CILQR_DEV void knot_cost_generic(const DeviceState& s, const double* __restrict_
 }
 
 // D = 5: the reference's disc count, unrolled (knot_cost_core); D = 0: any other count
-template <int D, bool EX = false>
+template <int D, bool EX = false, bool InLds = false>
 CILQR_DEV void knot_cost(const DeviceState& s, const double* __restrict__ lanes, int i, int slot,
                          const double* x, const double* u, double2* __restrict__ out, size_t stride) {
-  if constexpr (D == 5) knot_cost_core<5, EX>(s, lanes, i, slot, x, u, out, stride);
+  if constexpr (D == 5) knot_cost_core<5, EX, InLds>(s, lanes, i, slot, x, u, out, stride);
   else knot_cost_generic<EX>(s, lanes, i, slot, x, u, out, stride);
 }
 
@@ -328,7 +334,11 @@ __device__ unsigned long long g_quad_prof[kQuadProfWaves * 8];
 #else
 #define QP_STAMP(k)
 #endif
-template <int D, bool EX = false>
+// InLds: X, U, goals, cor, ccnt, lin, term of the view are in LDS (the tail kernel; dev_model.hpp: assume_lds)
+// OnlyFirstPart: stop after the part that is a function of the knot's state and control alone -- the bounds' barriers,
+// the dynamics' Jacobian and the entries of lx / lu / lxx / luu no corridor or lane plane touches (the tail kernel's
+// split quadratisation evaluates the planes on other lanes: knot_plane_items / knot_commit_items below).
+template <int D, bool EX = false, bool InLds = false, bool OnlyFirstPart = false>
 CILQR_DEV void knot_quadratize(const DeviceState& s, const double* __restrict__ lanes, int buf, int i, int slot) {
 #ifdef CILQR_QUAD_PROFILE
   unsigned long long qp_t = wall_clock64();
@@ -339,16 +349,30 @@ CILQR_DEV void knot_quadratize(const DeviceState& s, const double* __restrict__ 
   const bool term = (i == p.N);
   const int nd = (D > 0) ? D : p.num_of_disc;
   double x[6], u[2] = {0.0, 0.0};
-  load_x(s, buf, i, slot, x);
-  if (!term) load_u(s, buf, i, slot, u);
+  {
+    const double2* xb = s.X + ((size_t)buf * p.K + i) * 3 * Bc + slot;
+    assume_lds<InLds>(xb);
+    const double2 p0 = xb[0], p1 = xb[(size_t)Bc], p2 = xb[(size_t)2 * Bc];
+    x[0] = p0.x; x[1] = p0.y; x[2] = p1.x; x[3] = p1.y; x[4] = p2.x; x[5] = p2.y;
+    if (!term) {
+      const double2* ub = s.U + ((size_t)buf * p.N + i) * Bc + slot;
+      assume_lds<InLds>(ub);
+      const double2 uq = *ub;
+      u[0] = uq.x; u[1] = uq.y;
+    }
+  }
   const double2* gp = s.goals + (size_t)i * 3 * Bc + slot;
+  assume_lds<InLds>(gp);
   const double2 g0 = gp[0];
   const double gth = gp[(size_t)Bc].x;
   const double* __restrict__ cor = s.cor + (size_t)i * s.cmax * 3 * Bc + slot;
+  assume_lds<InLds>(cor);
   constexpr int C = kQuadChunk;
   PlaneChunk<C> pc;
   load_first_chunk(cor, Bc, s.cmax, pc);
-  const int cnt = s.ccnt[(size_t)i * Bc + slot];
+  const int* cntp = s.ccnt + (size_t)i * Bc + slot;
+  assume_lds<InLds>(cntp);
+  const int cnt = *cntp;
   mask_first_chunk(cnt, pc);
   Quad q;
   q.lx[0] = 2.0 * p.w_x * (x[0] - g0.x);           // cc:623-628
@@ -392,6 +416,7 @@ CILQR_DEV void knot_quadratize(const DeviceState& s, const double* __restrict__ 
   // loops that follow (26 registers less where the pressure is highest; same values, same places as before).
   if (term) {
     double2* o = s.term + scratch_index(s, slot);
+    assume_lds<InLds>(o);
     o[(size_t)Bc].y = q.lx[3];
     o[(size_t)2 * Bc] = make_double2(q.lx[4], q.lx[5]);
     o[(size_t)7 * Bc].y = q.hd[0];
@@ -400,6 +425,7 @@ CILQR_DEV void knot_quadratize(const DeviceState& s, const double* __restrict__ 
     DynJac J;
     dynamics_jacobian(p, x, u, J);
     double2* o = s.lin + (size_t)i * kLinPairs * Bc + scratch_index(s, slot);
+    assume_lds<InLds>(o);
     o[(size_t)0 * Bc] = make_double2(J.a02, J.a03);
     o[(size_t)1 * Bc] = make_double2(J.a04, J.a05);
     o[(size_t)2 * Bc] = make_double2(J.a12, J.a13);
@@ -413,6 +439,7 @@ CILQR_DEV void knot_quadratize(const DeviceState& s, const double* __restrict__ 
     o[(size_t)15 * Bc] = make_double2(q.hd[1], q.hd[2]);
     o[(size_t)16 * Bc] = make_double2(q.huu[0], q.huu[1]);
   }
+  if constexpr (OnlyFirstPart) return;
   double sn, cs;
   lean_sincos(x[2], &sn, &cs);
 #ifdef CILQR_QUAD_PROFILE
@@ -474,6 +501,7 @@ CILQR_DEV void knot_quadratize(const DeviceState& s, const double* __restrict__ 
   quad_mirror(q);
   if (term) {
     double2* o = s.term + scratch_index(s, slot);
+    assume_lds<InLds>(o);
     o[0] = make_double2(q.lx[0], q.lx[1]);
     o[(size_t)Bc].x = q.lx[2];
     o[(size_t)3 * Bc] = make_double2(q.h[0], q.h[1]);
@@ -484,6 +512,7 @@ CILQR_DEV void knot_quadratize(const DeviceState& s, const double* __restrict__ 
     return;
   }
   double2* o = s.lin + (size_t)i * kLinPairs * Bc + scratch_index(s, slot);
+  assume_lds<InLds>(o);
   o[(size_t)6 * Bc] = make_double2(q.lx[0], q.lx[1]);
   o[(size_t)7 * Bc].x = q.lx[2];
   o[(size_t)10 * Bc] = make_double2(q.h[0], q.h[1]);
@@ -491,6 +520,139 @@ CILQR_DEV void knot_quadratize(const DeviceState& s, const double* __restrict__ 
   o[(size_t)12 * Bc] = make_double2(q.h[4], q.h[5]);
   o[(size_t)13 * Bc] = make_double2(q.h[6], q.h[7]);
   o[(size_t)14 * Bc].x = q.h[8];
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same quadratisation with a knot's planes spread over lanes (the tail kernel: one problem, a workgroup, and a
+// dependent chain of ~5300 instructions per knot if one lane does it all).  What a plane contributes is its five sums
+// over the discs (plane_disc) -- independent of every other plane -- followed by a handful of additions into the knot's
+// lx / lxx in plane order (plane_commit).  knot_plane_items evaluates the sums of the planes (and of the nearest lane
+// planes of the discs) that lane `part` of `parts` owns and leaves them in `scr`; knot_commit_items, one lane per knot,
+// adds them up in the order knot_quadratize does: corridor planes 0, 1, ..., then disc 0 left, disc 0 right, disc 1
+// left, ...  Same operations on the same operands in the same order: bit-identical to knot_quadratize (tested).
+// Problem alone in its arena (capacity 1, slot 0), D = 5.  scr: quad_split_doubles(cmax) doubles per knot.
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int quad_split_planes(int cmax) { return (cmax + kQuadChunk - 1) / kQuadChunk * kQuadChunk; }
+__host__ __device__ constexpr int quad_split_doubles(int cmax) { return quad_split_planes(cmax) * 5 + 2 * 5 * 7; }
+template <bool EX, bool InLds>
+CILQR_DEV void knot_plane_items(const DeviceState& s, const double* __restrict__ lanes, int buf, int i, int part, int parts,
+                                double* __restrict__ scr) {
+  const Params& p = s.p;
+  const double2* xb = s.X + ((size_t)buf * p.K + i) * 3;
+  assume_lds<InLds>(xb);
+  const double2 p0 = xb[0];
+  const double x0 = p0.x, x1 = p0.y, th = xb[1].x;
+  const double* __restrict__ cor = s.cor + (size_t)i * s.cmax * 3;
+  assume_lds<InLds>(cor);
+  const int* cntp = s.ccnt + i;
+  assume_lds<InLds>(cntp);
+  const int cnt = *cntp;
+  // knot_quadratize walks the planes in chunks of kQuadChunk and fills the last chunk up with (0, 0, 1) planes
+  const int padded = (cnt + kQuadChunk - 1) / kQuadChunk * kQuadChunk;
+  double sn, cs;
+  lean_sincos(th, &sn, &cs);
+  double* __restrict__ o = scr + (size_t)i * quad_split_doubles(s.cmax);
+  for (int k = part; k < padded; k += parts) {
+    const bool live = k < cnt;
+    const double* q = cor + (size_t)(live ? k : 0) * 3;
+    const double qa = q[0], qb = q[1], qc = q[2];
+    const double a = live ? qa : 0.0, b = live ? qb : 0.0, c = live ? qc : 1.0;
+    PlaneSums m;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const double lc = p.disc_off[j] * cs, ls = p.disc_off[j] * sn;
+      plane_disc(p, a, b, c, x0 + lc, x1 + ls, lc, ls, m);
+    }
+    double* w = o + k * 5;
+    w[0] = m.T0; w[1] = m.T1; w[2] = m.S0; w[3] = m.S1; w[4] = m.S2 - m.W;
+  }
+  double* __restrict__ ol = o + quad_split_planes(s.cmax) * 5;
+#pragma unroll 1
+  for (int e = part; e < 10; e += parts) {
+    const int j = e >> 1, side = e & 1;
+    const double doff = (j == 0) ? p.disc_off[0] : (j == 1) ? p.disc_off[1] : (j == 2) ? p.disc_off[2] : (j == 3) ? p.disc_off[3] : p.disc_off[4];
+    const double lcj = doff * cs, lsj = doff * sn;
+    const double px = x0 + lcj, py = x1 + lsj;
+    const double* L = lanes + ((side ? s.nl : 0) + nearest_segment<EX>(s, lanes, side, px, py)) * kLaneFields;
+    const double la = L[0], lb = L[1];
+    PlaneSums m;
+    plane_disc(p, la, lb, L[2], px, py, lcj, lsj, m);
+    double* w = ol + e * 7;
+    w[0] = m.T0; w[1] = m.T1; w[2] = m.S0; w[3] = m.S1; w[4] = m.S2 - m.W; w[5] = la; w[6] = lb;
+  }
+}
+// plane_commit from the stored sums (d = S2 - W)
+CILQR_DEV void plane_commit_sums(Quad& q, double a, double b, double T0, double T1, double S0, double S1, double d) {
+  q.lx[0] += a * T0;
+  q.lx[1] += b * T0;
+  q.lx[2] += T1;
+  const double aS = a * S0, bS = b * S0;
+  const double h01 = aS * b, h02 = a * S1, h12 = b * S1;
+  q.h[0] += aS * a; q.h[1] += h01; q.h[2] += h02;
+  q.h[4] += bS * b; q.h[5] += h12;
+  q.h[8] += d;
+}
+template <bool InLds>
+CILQR_DEV void knot_commit_items(const DeviceState& s, int buf, int i, const double* __restrict__ scr) {
+  const Params& p = s.p;
+  const bool term = (i == p.N);
+  const double2* xb = s.X + ((size_t)buf * p.K + i) * 3;
+  assume_lds<InLds>(xb);
+  const double2 p0 = xb[0];
+  const double th = xb[1].x;
+  const double2* gp = s.goals + (size_t)i * 3;
+  assume_lds<InLds>(gp);
+  const double2 g0 = gp[0];
+  const double gth = gp[1].x;
+  const double* __restrict__ cor = s.cor + (size_t)i * s.cmax * 3;
+  assume_lds<InLds>(cor);
+  const int* cntp = s.ccnt + i;
+  assume_lds<InLds>(cntp);
+  const int cnt = *cntp;
+  const int padded = (cnt + kQuadChunk - 1) / kQuadChunk * kQuadChunk;
+  Quad q;
+  q.lx[0] = 2.0 * p.w_x * (p0.x - g0.x);           // cc:623-628
+  q.lx[1] = 2.0 * p.w_y * (p0.y - g0.y);
+  q.lx[2] = 2.0 * p.w_theta * (th - gth);
+#pragma unroll
+  for (int e = 0; e < 9; ++e) q.h[e] = 0.0;
+  q.h[0] = 2.0 * p.w_x; q.h[4] = 2.0 * p.w_y; q.h[8] = 2.0 * p.w_theta;   // cc:642-647
+  const double* __restrict__ o = scr + (size_t)i * quad_split_doubles(s.cmax);
+  for (int k = 0; k < padded; ++k) {
+    const bool live = k < cnt;
+    const double* qq = cor + (size_t)(live ? k : 0) * 3;
+    const double qa = qq[0], qb = qq[1];
+    const double* w = o + k * 5;
+    plane_commit_sums(q, live ? qa : 0.0, live ? qb : 0.0, w[0], w[1], w[2], w[3], w[4]);
+  }
+  const double* __restrict__ ol = o + quad_split_planes(s.cmax) * 5;
+#pragma unroll 2
+  for (int e = 0; e < 10; ++e) {
+    const double* w = ol + e * 7;
+    plane_commit_sums(q, w[5], w[6], w[0], w[1], w[2], w[3], w[4]);
+  }
+  quad_mirror(q);
+  if (term) {
+    double2* t = s.term;
+    assume_lds<InLds>(t);
+    t[0] = make_double2(q.lx[0], q.lx[1]);
+    t[1].x = q.lx[2];
+    t[3] = make_double2(q.h[0], q.h[1]);
+    t[4] = make_double2(q.h[2], q.h[3]);
+    t[5] = make_double2(q.h[4], q.h[5]);
+    t[6] = make_double2(q.h[6], q.h[7]);
+    t[7].x = q.h[8];
+    return;
+  }
+  double2* t = s.lin + (size_t)i * kLinPairs;
+  assume_lds<InLds>(t);
+  t[6] = make_double2(q.lx[0], q.lx[1]);
+  t[7].x = q.lx[2];
+  t[10] = make_double2(q.h[0], q.h[1]);
+  t[11] = make_double2(q.h[2], q.h[3]);
+  t[12] = make_double2(q.h[4], q.h[5]);
+  t[13] = make_double2(q.h[6], q.h[7]);
+  t[14].x = q.h[8];
 }
 
 #ifdef CILQR_REF_ORDER

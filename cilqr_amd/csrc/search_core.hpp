@@ -33,6 +33,25 @@ struct OutSpec {
   }
 };
 
+// the same for a problem that is alone in its arena (the tail kernel's private view: capacity 1, list position 0): the
+// candidate's rows are contiguous, so a store is a pointer plus a compile-time offset
+template <bool InLds>
+struct OutSpecSolo {
+  double2* xs;   // Xs + r K 3
+  double2* us;   // Us + r N
+  CILQR_DEV OutSpecSolo(const DeviceState& s, int r) : xs(s.Xs + (size_t)r * s.p.K * 3), us(s.Us + (size_t)r * s.p.N) {
+    assume_lds<InLds>(xs);
+    assume_lds<InLds>(us);
+  }
+  CILQR_DEV void x(int i, const double* v) const {
+    double2* b = xs + (size_t)i * 3;
+    b[0] = make_double2(v[0], v[1]);
+    b[1] = make_double2(v[2], v[3]);
+    b[2] = make_double2(v[4], v[5]);
+  }
+  CILQR_DEV void u(int i, const double* v) const { us[i] = make_double2(v[0], v[1]); }
+};
+
 // what step i of a rollout reads: nominal state / control and the gains K_i, k_i
 #ifndef CILQR_ROLL_AHEAD
 #define CILQR_ROLL_AHEAD 4
@@ -41,32 +60,47 @@ constexpr int kFwdAhead = CILQR_ROLL_AHEAD;
 struct FwdStep {
   double2 x0, x1, x2, u, kk[kGainPairs];
 };
-// sp: scratch_index(s, slot), where the slot's gains live this iteration (looked up once per rollout by the caller)
-CILQR_DEV void load_fwd_step(const DeviceState& s, int buf, int i, int slot, int sp, FwdStep& f) {
-  const int Bc = s.Bcap;
-  const double2* b = s.X + ((size_t)buf * s.p.K + i) * 3 * Bc + slot;
-  f.x0 = b[0]; f.x1 = b[(size_t)Bc]; f.x2 = b[(size_t)2 * Bc];
-  f.u = s.U[((size_t)buf * s.p.N + i) * Bc + slot];
-  const double2* g = s.gains + (size_t)i * kGainPairs * Bc + sp;
+// the tensors a rollout reads, as locals (a view in LDS -- kernels_tail.hip -- would be read again after every store)
+struct FwdSrc {
+  const double2* X;      // nominal states of the current iterate: X + buf K 3 Bc + slot
+  const double2* U;      // U + buf N Bc + slot
+  const double2* gains;  // gains + sp (sp: scratch_index(s, slot), where the slot's gains live this iteration)
+  size_t Bc;
+};
+CILQR_DEV FwdSrc fwd_source(const DeviceState& s, int buf, int slot, int sp, size_t Bc) {
+  return FwdSrc{s.X + (size_t)buf * s.p.K * 3 * Bc + slot, s.U + (size_t)buf * s.p.N * Bc + slot, s.gains + sp, Bc};
+}
+CILQR_DEV void load_fwd_step(const FwdSrc& q, int i, FwdStep& f) {
+  const double2* b = q.X + (size_t)i * 3 * q.Bc;
+  f.x0 = b[0]; f.x1 = b[q.Bc]; f.x2 = b[2 * q.Bc];
+  f.u = q.U[(size_t)i * q.Bc];
+  const double2* g = q.gains + (size_t)i * kGainPairs * q.Bc;
 #pragma unroll
-  for (int r = 0; r < kGainPairs; ++r) f.kk[r] = g[(size_t)r * Bc];
+  for (int r = 0; r < kGainPairs; ++r) f.kk[r] = g[(size_t)r * q.Bc];
 }
 
 // roll the closed-loop policy out from goals_[0] (cc:392-415).  kAhead: steps whose operands are requested ahead of
 // the arithmetic -- 4 where a lane is alone on its SIMD (176 VGPRs of loads in flight), 1 where several waves per
-// SIMD hide each other's latency instead.
-template <class Out, int kAhead = kFwdAhead>
+// SIMD hide each other's latency instead.  Solo: the problem is alone in its arena (capacity 1, slot 0, position 0:
+// kernels_tail.hip) -- every stride is a compile-time constant and a step's operands are a pointer bump away.
+// InLds (with Solo): X, U, gains, goals of the view are in LDS (dev_model.hpp: assume_lds; Out says the same of its rows).
+template <class Out, int kAhead = kFwdAhead, bool Solo = false, bool InLds = false>
 CILQR_DEV void forward_core(const DeviceState& s, int slot, double alpha, const Out& out) {
-  const Params& p = s.p;
-  const int Bc = s.Bcap, N = p.N;
+  const DynP p = dyn_params(s.p);
+  const size_t Bc = Solo ? (size_t)1 : (size_t)s.Bcap;
+  const int N = s.p.N;
   const int buf = s.cur[slot];
-  const int sp = scratch_index(s, slot);
+  const int sp = Solo ? 0 : scratch_index(s, slot);
   double x[6];
   {
     const double2* gp = s.goals + slot;
-    const double2 g0 = gp[0], g1 = gp[(size_t)Bc], g2 = gp[(size_t)2 * Bc];
+    const double2 g0 = gp[0], g1 = gp[Bc], g2 = gp[2 * Bc];
     x[0] = g0.x; x[1] = g0.y; x[2] = g1.x; x[3] = g1.y; x[4] = g2.x; x[5] = g2.y;
   }
+  const FwdSrc src = fwd_source(s, buf, slot, sp, Bc);
+  assume_lds<InLds>(src.X);
+  assume_lds<InLds>(src.U);
+  assume_lds<InLds>(src.gains);
   out.x(0, x);
   // The nominal (xs, us) and the gains of a step do not depend on the rollout, and one lane's step
   // is short (~0.5 us of arithmetic) against the latency of a load that misses L2 (the gains were
@@ -74,14 +108,14 @@ CILQR_DEV void forward_core(const DeviceState& s, int slot, double alpha, const 
   FwdStep pf[kAhead];
 #pragma unroll
   for (int d = 0; d < kAhead; ++d)
-    if (d < N) load_fwd_step(s, buf, d, slot, sp, pf[d]);
+    if (d < N) load_fwd_step(src, d, pf[d]);
   for (int i0 = 0; i0 < N; i0 += kAhead) {
 #pragma unroll
     for (int d = 0; d < kAhead; ++d) {
       const int i = i0 + d;
       if (i < N) {
         const FwdStep c = pf[d];
-        if (i + kAhead < N) load_fwd_step(s, buf, i + kAhead, slot, sp, pf[d]);
+        if (i + kAhead < N) load_fwd_step(src, i + kAhead, pf[d]);
         const double xs[6] = {c.x0.x, c.x0.y, c.x1.x, c.x1.y, c.x2.x, c.x2.y};
         const double us[2] = {c.u.x, c.u.y};
         double dx[6];
@@ -99,9 +133,8 @@ CILQR_DEV void forward_core(const DeviceState& s, int slot, double alpha, const 
           const double kff = (r == 0) ? c.kk[6].x : c.kk[6].y;
           u[r] = (us[r] + acc) + alpha * kff;                           // cc:407
         }
-        u[1] = normalize_angle(u[1]);                                     // cc:408
+        closed_loop_step(p, x, u, x);                                     // cc:408-410
         out.u(i, u);
-        dynamics(p, x, u, x);
         out.x(i + 1, x);
       }
     }
@@ -117,10 +150,11 @@ CILQR_DEV void forward_problem(const DeviceState& s, int slot, double alpha) {
 // per rollout as forward_core.
 template <int G>
 CILQR_DEV void forward_multi(const DeviceState& s, int slot, int j) {
-  const Params& p = s.p;
-  const int Bc = s.Bcap, N = p.N;
+  const DynP p = dyn_params(s.p);
+  const int Bc = s.Bcap, N = s.p.N;
   const int buf = s.cur[slot];
   const int sp = scratch_index(s, slot);
+  const FwdSrc src = fwd_source(s, buf, slot, sp, (size_t)Bc);
   double x[G][6];
   {
     const double2* gp = s.goals + slot;
@@ -134,14 +168,14 @@ CILQR_DEV void forward_multi(const DeviceState& s, int slot, int j) {
   FwdStep pf[kFwdAhead];
 #pragma unroll
   for (int d = 0; d < kFwdAhead; ++d)
-    if (d < N) load_fwd_step(s, buf, d, slot, sp, pf[d]);
+    if (d < N) load_fwd_step(src, d, pf[d]);
   for (int i0 = 0; i0 < N; i0 += kFwdAhead) {
 #pragma unroll
     for (int d = 0; d < kFwdAhead; ++d) {
       const int i = i0 + d;
       if (i < N) {
         const FwdStep c = pf[d];
-        if (i + kFwdAhead < N) load_fwd_step(s, buf, i + kFwdAhead, slot, sp, pf[d]);
+        if (i + kFwdAhead < N) load_fwd_step(src, i + kFwdAhead, pf[d]);
         const double xs[6] = {c.x0.x, c.x0.y, c.x1.x, c.x1.y, c.x2.x, c.x2.y};
         const double us[2] = {c.u.x, c.u.y};
 #pragma unroll
@@ -161,10 +195,9 @@ CILQR_DEV void forward_multi(const DeviceState& s, int slot, int j) {
             const double kff = (q == 0) ? c.kk[6].x : c.kk[6].y;
             u[q] = (us[q] + acc) + kAlpha[r] * kff;                         // cc:407
           }
-          u[1] = normalize_angle(u[1]);                                     // cc:408
+          closed_loop_step(p, x[r], u, x[r]);                               // cc:408-410
           const OutSpec out{s, r, j};
           out.u(i, u);
-          dynamics(p, x[r], u, x[r]);
           out.x(i + 1, x[r]);
         }
       }

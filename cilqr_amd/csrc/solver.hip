@@ -824,7 +824,8 @@ int job_iterate(cilqr_solver* h, cilqr_job& j, int stage) {
 #ifdef CILQR_REF_ORDER
   const int tail_threshold = 0;   // the test-only build re-evaluates whole trajectories in the reference's order
 #else
-  const int tail_threshold = h->tail_threshold;
+  // (a horizon whose per-step rows no longer fit beside the tail kernel's fixed LDS block stays in the lockstep loop)
+  const int tail_threshold = tail_supported(d) ? h->tail_threshold : 0;
 #endif
   int& it = j.it;
   int& n_hint = j.n_hint;
@@ -1456,7 +1457,7 @@ int cilqr_lane_constraints(const double* boundary, int32_t n, double segment_len
 
 int cilqr_device_math(cilqr_handle h, int32_t fn, int32_t n, const double* in, double* out) {
   if (h == nullptr || in == nullptr || out == nullptr) return CILQR_ERR_NULL;
-  if (n <= 0 || fn < 0 || fn > 9) return CILQR_ERR_ARG;
+  if (n <= 0 || fn < 0 || fn > 10) return CILQR_ERR_ARG;
   HIP_TRY(hipSetDevice(h->device));
   double* d = nullptr;
   if (hipMalloc(reinterpret_cast<void**>(&d), (size_t)n * 16) != hipSuccess) return CILQR_ERR_DEVICE;

@@ -210,6 +210,7 @@ void launch_linesearch(const DeviceState& s, int n_act, int spec_threshold, int 
 void launch_init_counters(const DeviceState& s, int first_n, hipStream_t st);
 // kernels_tail.hip: one workgroup per problem finishes every problem of the active list (all remaining iterations)
 size_t tail_workspace_bytes(const DeviceState& s);   // private arena of one problem
+bool tail_supported(const DeviceState& s);           // the kernel's fixed LDS block fits what every device grants
 void launch_tail(const DeviceState& s, void* workspace, int n_max, double* traj, double* iter_trajs,
                  int max_iter_trajs, int* max_iter_dev, hipStream_t st);
 void launch_update(const DeviceState& s, int n_act, hipStream_t st);

@@ -346,7 +346,9 @@ int cilqr_lane_constraints(const double* boundary, int32_t n, double segment_len
  * fn 2: log(x) with mantissa and exponent handed over separately (the long-product path);
  * fn 3 / 4 / 5: sin / cos / tan(x) for |x| <= 1e5;  fn 6: NormalizeAngle(x) (math_utils.cpp:53-59);
  * fn 7 / 8: the device library's cos / sin as the corridor producer uses them for the box corners (corridor.cc:96-99);
- * fn 9: hypot(x, 1) by the libm-identical routine of the lane search and the constraint normalisation. */
+ * fn 9: hypot(x, 1) by the libm-identical routine of the lane search and the constraint normalisation;
+ * fn 10: NormalizeAngle(x) as the rollouts evaluate it (short paths as one straight line; the complete function for the
+ *        wavefront when a lane's argument lies outside (-3 pi, 3 pi)) -- the same bits as fn 6 on every input. */
 int cilqr_device_math(cilqr_handle h, int32_t fn, int32_t n, const double* in, double* out);
 
 /* X[b][0] = x0[b]; X[b][i+1] = Dynamics(X[b][i], U[b][i]).  x0 [B][6], U [B][N][2], X [B][K][6] */

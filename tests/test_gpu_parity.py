@@ -157,6 +157,18 @@ def test_open_loop_rollout():
     o = orc.Oracle(n_steps=N)
     for b in range(B):
         assert rel_err(X[b], o.open_loop_rollout(x0[b], U[b])) < 1e-11
+    # a step's angle wraps take a straight-line form unless some lane of the wavefront leaves (-3 pi, 3 pi), in which case
+    # the wavefront repeats the step with the complete function (dev_model.hpp: dynamics): start states whose heading and
+    # steering angle are several turns off the principal range, on every third problem, exercise that path next to lanes
+    # that stay on the short one
+    x02 = x0.copy()
+    x02[::3, 2] += 2.0 * np.pi * rng.integers(2, 9, len(x02[::3])) * rng.choice([-1.0, 1.0], len(x02[::3]))
+    x02[::3, 5] += 2.0 * np.pi * rng.integers(2, 9, len(x02[::3])) * rng.choice([-1.0, 1.0], len(x02[::3]))
+    X2 = opt.open_loop_rollout(x02, U)
+    keep = np.ones(B, bool); keep[::3] = False
+    assert np.array_equal(X2[keep], X[keep])
+    for b in range(0, B, 3):
+        assert rel_err(X2[b], o.open_loop_rollout(x02[b], U[b])) < 1e-11
     opt.close()
 
 
@@ -849,6 +861,14 @@ def test_normalize_angle_is_the_reference_expression_bit_for_bit():
     got = opt.device_math(6, x)
     assert np.array_equal(got, ref), (x[got != ref][:5], got[got != ref][:5], ref[got != ref][:5])
     assert ((got >= -np.pi) & (got <= np.pi)).all()
+    # the form the rollouts use (short paths as a straight line, the complete function for a wavefront in which a lane
+    # leaves them): the same bits, whether the rare arguments sit alone in their wavefront, mixed with common ones, or absent
+    for xs in (x, rng.permutation(x), x[:200000], np.concatenate([[np.nan, np.inf, -np.inf], x[:61]])):
+        a = np.fmod(xs + np.pi, 2.0 * np.pi)
+        with np.errstate(invalid="ignore"):
+            ref = np.where(a < 0.0, a + 2.0 * np.pi, a) - np.pi
+        got = opt.device_math(10, xs)
+        assert np.array_equal(got, ref, equal_nan=True), (xs[got != ref][:5], got[got != ref][:5], ref[got != ref][:5])
     opt.close()
 
 
