@@ -60,6 +60,11 @@ struct TailArgs {
   int cost_in_lds; // Xs, Us, parts, goals, cor, ccnt
 };
 
+// Plane capacity of the view's corridor tensor.  A knot's planes are read by the lane that owns the knot (quadratisation,
+// knot costs): with the batch's capacity as the stride -- 16 planes x 3 doubles = 96 dwords -- the 64 lanes of a wave fall
+// into TWO bank pairs of LDS (96 i mod 64), every plane load a 32-way conflict; an odd capacity spreads them over all banks.
+__host__ __device__ constexpr int tail_cmax(int cmax) { return cmax | 1; }
+
 static TailLayout tail_layout(const DeviceState& s) {
   const size_t K = s.p.K, N = s.p.N;
   TailLayout L;
@@ -72,7 +77,7 @@ static TailLayout tail_layout(const DeviceState& s) {
   L.X = take(2 * K * 3 * sizeof(double2));
   L.U = take(2 * N * sizeof(double2));
   L.goals = take(K * 3 * sizeof(double2));
-  L.cor = take(K * s.cmax * 3 * sizeof(double));
+  L.cor = take(K * tail_cmax(s.cmax) * 3 * sizeof(double));
   L.ccnt = take(K * sizeof(int));
   L.lin = take(N * kLinPairs * sizeof(double2));
   L.term = take(kTermPairs * sizeof(double2));
@@ -96,6 +101,7 @@ CILQR_DEV DeviceState tail_view(const DeviceState& g, const TailArgs& a, int blk
   auto at = [&](size_t in_arena, size_t in_lds) -> char* { return in_lds != kNotInLds ? lds_block + in_lds : p + in_arena; };
   t.Bcap = 1;
   t.spec_cap = 1;
+  t.cmax = tail_cmax(g.cmax);
   t.X = reinterpret_cast<double2*>(at(a.L.X, a.S.X));
   t.U = reinterpret_cast<double2*>(at(a.L.U, a.S.U));
   t.goals = reinterpret_cast<double2*>(at(a.L.goals, a.S.goals));
@@ -162,15 +168,17 @@ __device__ __attribute__((noinline)) void tail_quadratize(int off_view, int i) {
 // adds their sums up in order while another evaluates the part that depends on the knot's state and control alone.
 constexpr int kQuadParts = 4;
 template <bool EX>
-__device__ __attribute__((noinline)) void tail_quad_items(int off_view, int off_scr, int i, int part) {
+__device__ __attribute__((noinline)) void tail_quad_items(int off_view, int off_scr, int cap, int i, int part) {
   extern __shared__ double lds[];
   const DeviceState& t = *reinterpret_cast<const DeviceState*>(reinterpret_cast<const char*>(lds) + off_view);
-  knot_plane_items<EX, true>(t, lds, t.cur[0], i, part, kQuadParts, reinterpret_cast<double*>(reinterpret_cast<char*>(lds) + off_scr));
+  knot_plane_items<EX, true>(t, lds, t.cur[0], i, part, kQuadParts, reinterpret_cast<double*>(reinterpret_cast<char*>(lds) + off_scr), cap,
+                             quad_split_stride(cap));
 }
-__device__ __attribute__((noinline)) void tail_quad_commit(int off_view, int off_scr, int i) {
+__device__ __attribute__((noinline)) void tail_quad_commit(int off_view, int off_scr, int cap, int i) {
   extern __shared__ double lds[];
   const DeviceState& t = *reinterpret_cast<const DeviceState*>(reinterpret_cast<const char*>(lds) + off_view);
-  knot_commit_items<true>(t, t.cur[0], i, reinterpret_cast<const double*>(reinterpret_cast<const char*>(lds) + off_scr));
+  knot_commit_items<true>(t, t.cur[0], i, reinterpret_cast<const double*>(reinterpret_cast<const char*>(lds) + off_scr), cap,
+                          quad_split_stride(cap));
 }
 template <bool EX>
 __device__ __attribute__((noinline)) void tail_quad_first_part(int off_view, int i) {
@@ -249,10 +257,10 @@ __global__ __launch_bounds__(kTailThreads) CILQR_TAIL_ATTR void k_tail(DeviceSta
       t.goals[i * 3 + 2] = gg[2 * Bc];
       t.ccnt[i] = g.ccnt[(size_t)i * Bc + src];
     }
-    const int rows = g.cmax * 3;
+    const int rows = g.cmax * 3, rows_t = tail_cmax(g.cmax) * 3;
     for (int e = tid; e < K * rows; e += kTailThreads) {
       const int i = e / rows, r = e - i * rows;
-      if (r < g.ccnt[(size_t)i * Bc + src] * 3) t.cor[e] = g.cor[((size_t)i * rows + r) * Bc + src];
+      if (r < g.ccnt[(size_t)i * Bc + src] * 3) t.cor[i * rows_t + r] = g.cor[((size_t)i * rows + r) * Bc + src];
     }
     if (tid == 0) {
       t.cur[0] = 0;
@@ -274,14 +282,14 @@ __global__ __launch_bounds__(kTailThreads) CILQR_TAIL_ATTR void k_tail(DeviceSta
     TP(7);
     if (t.upd[0]) {                                                        // cc:203-214
       if (D == 5 && a.quad_scr >= 0) {
-        const int off_scr = a.lds_base + a.quad_scr;
-        for (int w = tid; w < K * kQuadParts; w += kTailThreads) tail_quad_items<EX>(off_view, off_scr, w / kQuadParts, w % kQuadParts);
+        const int off_scr = a.lds_base + a.quad_scr, cap = quad_split_planes(g.cmax);   // the batch's plane capacity, not the view's padded one
+        for (int w = tid; w < K * kQuadParts; w += kTailThreads) tail_quad_items<EX>(off_view, off_scr, cap, w / kQuadParts, w % kQuadParts);
         __syncthreads();
         // even waves add the planes' sums up, odd waves evaluate the state-only part: different SIMDs, disjoint outputs
         const int wv = tid >> 6;
         for (int i = (wv >> 1) * 64 + (tid & 63); i < K; i += kTailThreads / 2) {
           if (wv & 1) tail_quad_first_part<EX>(off_view, i);
-          else tail_quad_commit(off_view, off_scr, i);
+          else tail_quad_commit(off_view, off_scr, cap, i);
         }
       } else if (a.quad_in_lds) { for (int i = tid; i < K; i += kTailThreads) tail_quadratize<D, EX, true>(off_view, i); }
       else { for (int i = tid; i < K; i += kTailThreads) tail_quadratize<D, EX, false>(off_view, i); }
@@ -462,7 +470,7 @@ void launch_tail(const DeviceState& g, void* workspace, int n_max, double* traj,
       {&TailLayout::X, 2 * K * 3 * sizeof(double2)}, {&TailLayout::U, 2 * N * sizeof(double2)},
       {&TailLayout::lin, N * kLinPairs * sizeof(double2)}, {&TailLayout::parts, (size_t)kNumAlpha * K * kPartPairs * sizeof(double2)},
       {&TailLayout::Xs, (size_t)kNumAlpha * K * 3 * sizeof(double2)}, {&TailLayout::Us, (size_t)kNumAlpha * N * sizeof(double2)},
-      {&TailLayout::goals, K * 3 * sizeof(double2)}, {&TailLayout::ccnt, K * sizeof(int)}, {&TailLayout::cor, K * g.cmax * 3 * sizeof(double)}};
+      {&TailLayout::goals, K * 3 * sizeof(double2)}, {&TailLayout::ccnt, K * sizeof(int)}, {&TailLayout::cor, K * tail_cmax(g.cmax) * 3 * sizeof(double)}};
   size_t used = 0;
   a.S = a.L;
   for (const Item& it : items) {

@@ -530,13 +530,16 @@ CILQR_DEV void knot_quadratize(const DeviceState& s, const double* __restrict__ 
 // planes of the discs) that lane `part` of `parts` owns and leaves them in `scr`; knot_commit_items, one lane per knot,
 // adds them up in the order knot_quadratize does: corridor planes 0, 1, ..., then disc 0 left, disc 0 right, disc 1
 // left, ...  Same operations on the same operands in the same order: bit-identical to knot_quadratize (tested).
-// Problem alone in its arena (capacity 1, slot 0), D = 5.  scr: quad_split_doubles(cmax) doubles per knot.
+// Problem alone in its arena (capacity 1, slot 0), D = 5.  scr: quad_split_doubles(cmax) doubles per knot, cmax = the batch's.
 // ---------------------------------------------------------------------------------------------
 __host__ __device__ constexpr int quad_split_planes(int cmax) { return (cmax + kQuadChunk - 1) / kQuadChunk * kQuadChunk; }
-__host__ __device__ constexpr int quad_split_doubles(int cmax) { return quad_split_planes(cmax) * 5 + 2 * 5 * 7; }
+// (an odd count: the committing lanes, one per knot, then read their rows from different LDS banks)
+__host__ __device__ constexpr int quad_split_stride(int cap) { return (cap * 5 + 2 * 5 * 7) | 1; }   // cap = quad_split_planes(cmax)
+__host__ __device__ constexpr int quad_split_doubles(int cmax) { return quad_split_stride(quad_split_planes(cmax)); }
+// cap: quad_split_planes of the batch's plane capacity (rows of a knot's corridor block in scr); stride: quad_split_doubles of it
 template <bool EX, bool InLds>
 CILQR_DEV void knot_plane_items(const DeviceState& s, const double* __restrict__ lanes, int buf, int i, int part, int parts,
-                                double* __restrict__ scr) {
+                                double* __restrict__ scr, int cap, int stride) {
   const Params& p = s.p;
   const double2* xb = s.X + ((size_t)buf * p.K + i) * 3;
   assume_lds<InLds>(xb);
@@ -551,7 +554,7 @@ CILQR_DEV void knot_plane_items(const DeviceState& s, const double* __restrict__
   const int padded = (cnt + kQuadChunk - 1) / kQuadChunk * kQuadChunk;
   double sn, cs;
   lean_sincos(th, &sn, &cs);
-  double* __restrict__ o = scr + (size_t)i * quad_split_doubles(s.cmax);
+  double* __restrict__ o = scr + (size_t)i * stride;
   for (int k = part; k < padded; k += parts) {
     const bool live = k < cnt;
     const double* q = cor + (size_t)(live ? k : 0) * 3;
@@ -566,7 +569,7 @@ CILQR_DEV void knot_plane_items(const DeviceState& s, const double* __restrict__
     double* w = o + k * 5;
     w[0] = m.T0; w[1] = m.T1; w[2] = m.S0; w[3] = m.S1; w[4] = m.S2 - m.W;
   }
-  double* __restrict__ ol = o + quad_split_planes(s.cmax) * 5;
+  double* __restrict__ ol = o + cap * 5;
 #pragma unroll 1
   for (int e = part; e < 10; e += parts) {
     const int j = e >> 1, side = e & 1;
@@ -593,7 +596,7 @@ CILQR_DEV void plane_commit_sums(Quad& q, double a, double b, double T0, double 
   q.h[8] += d;
 }
 template <bool InLds>
-CILQR_DEV void knot_commit_items(const DeviceState& s, int buf, int i, const double* __restrict__ scr) {
+CILQR_DEV void knot_commit_items(const DeviceState& s, int buf, int i, const double* __restrict__ scr, int cap, int stride) {
   const Params& p = s.p;
   const bool term = (i == p.N);
   const double2* xb = s.X + ((size_t)buf * p.K + i) * 3;
@@ -617,7 +620,7 @@ CILQR_DEV void knot_commit_items(const DeviceState& s, int buf, int i, const dou
 #pragma unroll
   for (int e = 0; e < 9; ++e) q.h[e] = 0.0;
   q.h[0] = 2.0 * p.w_x; q.h[4] = 2.0 * p.w_y; q.h[8] = 2.0 * p.w_theta;   // cc:642-647
-  const double* __restrict__ o = scr + (size_t)i * quad_split_doubles(s.cmax);
+  const double* __restrict__ o = scr + (size_t)i * stride;
   for (int k = 0; k < padded; ++k) {
     const bool live = k < cnt;
     const double* qq = cor + (size_t)(live ? k : 0) * 3;
@@ -625,7 +628,7 @@ CILQR_DEV void knot_commit_items(const DeviceState& s, int buf, int i, const dou
     const double* w = o + k * 5;
     plane_commit_sums(q, live ? qa : 0.0, live ? qb : 0.0, w[0], w[1], w[2], w[3], w[4]);
   }
-  const double* __restrict__ ol = o + quad_split_planes(s.cmax) * 5;
+  const double* __restrict__ ol = o + cap * 5;
 #pragma unroll 2
   for (int e = 0; e < 10; ++e) {
     const double* w = ol + e * 7;
