@@ -212,9 +212,14 @@ CILQR_DEV DynP dyn_params(const Params& p) { return DynP{p.dt, p.wheel_base, p.i
 // function if any lane of the wave raised it.  Same operations on the same operands wherever `rare` stays false.
 CILQR_DEV double normalize_angle_common(double angle, bool& rare) {
   const double t = angle + kPi;
-  rare |= !(t > -kTwoPi && t < 2.0 * kTwoPi);   // outside the short paths (or NaN)
-  double r = (t >= kTwoPi) ? t - kTwoPi : t;    // exact (Sterbenz)
-  r = (r < 0.0) ? r + kTwoPi : r;
+  // |angle| < 9.4 puts t inside (-2 pi, 4 pi) with room to spare: one compare instead of the two ends (NaN: rare)
+  rare |= !(fabs(angle) < 9.4);
+  // t - k 2 pi with k = 1 for t >= 2 pi, -1 for t < 0, else 0: k 2 pi is exact, so the fused form rounds once, exactly as the
+  // subtraction / addition of the corresponding short path of normalize_angle does (and leaves t alone for k = 0)
+  unsigned hi = (t < 0.0) ? 0xBFF00000u : 0u;
+  hi = (t >= kTwoPi) ? 0x3FF00000u : hi;
+  const double k = __hiloint2double((int)hi, 0);
+  const double r = fma(-k, kTwoPi, t);
   return r - kPi;
 }
 template <bool Common>
