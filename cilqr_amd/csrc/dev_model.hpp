@@ -294,7 +294,21 @@ CILQR_DEV void dynamics(const Params& p, const double* s, const double* u, doubl
 }
 // A closed-loop rollout step (Forward, cc:407-410): delta_rate wrapped (cc:408), then the dynamics; u[1] is replaced by its
 // wrapped value, `xn` may be `x`.  One test for the rare path covers both.
+// Straight = false: the step as a chain of complete NormalizeAngle calls (branches).  The rollout kernels of the lockstep
+// loop use that form: their waves share a SIMD with others, the untaken branches are nearly free there, and the out-of-line
+// call of the straight form costs them scalar-register spills (measured, r04 log 11: bulk rollout launch 139 us branchy,
+// 148 us straight with the exact step inlined, 161 us straight with the call).  Same bits either way.
+template <bool Straight = true>
 CILQR_DEV void closed_loop_step(const DynP& p, const double* x, double* u, double* xn) {
+  if constexpr (!Straight) {
+    bool unused = false;
+    u[1] = normalize_angle(u[1]);
+    double o[6];
+    dynamics_body<false>(p, x, u, o, unused);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) xn[i] = o[i];
+    return;
+  }
   bool rare = false;
   const double u1_raw = u[1];
   u[1] = normalize_angle_common(u1_raw, rare);

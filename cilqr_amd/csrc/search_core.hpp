@@ -133,7 +133,9 @@ CILQR_DEV void forward_core(const DeviceState& s, int slot, double alpha, const 
           const double kff = (r == 0) ? c.kk[6].x : c.kk[6].y;
           u[r] = (us[r] + acc) + alpha * kff;                           // cc:407
         }
-        closed_loop_step(p, x, u, x);                                     // cc:408-410
+        // the straight-line step where a wavefront is alone with its chain (the tail kernel), the branchy one where several
+        // waves per SIMD fill each other's gaps (the lockstep rollout kernels: 139 against 161 us per bulk launch, r04 log 11)
+        closed_loop_step<Solo>(p, x, u, x);                               // cc:408-410
         out.u(i, u);
         out.x(i + 1, x);
       }
@@ -195,7 +197,7 @@ CILQR_DEV void forward_multi(const DeviceState& s, int slot, int j) {
             const double kff = (q == 0) ? c.kk[6].x : c.kk[6].y;
             u[q] = (us[q] + acc) + kAlpha[r] * kff;                         // cc:407
           }
-          closed_loop_step(p, x[r], u, x[r]);                               // cc:408-410
+          closed_loop_step<false>(p, x[r], u, x[r]);                        // cc:408-410
           const OutSpec out{s, r, j};
           out.u(i, u);
           out.x(i + 1, x[r]);

@@ -60,4 +60,4 @@ python tests/parity_report.py 8192 > "$out/${tag}_parity_report_8192.json" 2> "$
 python tests/parity_report.py 4096 --fast-lane-ties --plain > "$out/${tag}_parity_report_4096_fast_lane_ties.json" 2> "$out/pr4.err"
 # the raw captures stay on the box: only summaries travel back (gpurun_out/ is capped at 64 MiB)
 rm -rf "$out"/kt3 "$out"/kt1 "$out"/pmc_*_FETCH_SIZE "$out"/pmc_*_WRITE_SIZE "$out"/pmc_all_[0-9]
-du -sh "$out"; ls -la "$out"; tail -3 "$out"/*.err
+du -sh "$out"; ls -la "$out"; for f in "$out"/*.err; do echo "== $f"; tail -n 3 "$f"; done
