@@ -542,6 +542,7 @@ int cilqr_set_option(cilqr_handle h, int32_t option, int64_t value) {
     case CILQR_OPT_TAIL_THRESHOLD:
       if (value < 0) return CILQR_ERR_ARG;
       h->tail_threshold = (int)(value > kTailMaxProblems ? kTailMaxProblems : value);
+      h->tail_threshold_submit = h->tail_threshold;   // an explicit choice holds for both kinds of call
       return CILQR_OK;
     case CILQR_OPT_EXACT_LANE_TIES:
       if (value != 0 && value != 1) return CILQR_ERR_ARG;
@@ -628,6 +629,7 @@ static int solve_sync(cilqr_solver* h, const cilqr_problem_batch* in, cilqr_solu
   cilqr_job& j = h->jobs[0];
   j.set = 0;
   j.spec_threshold = h->spec_threshold;
+  j.tail_threshold = h->tail_threshold;
   j.st1 = h->stream;
   j.st2 = h->stream;
   const int rc = solve_groups(h, j, in, out);
@@ -781,8 +783,8 @@ int job_begin(cilqr_solver* h, cilqr_job& j) {
   }
   // The tail of the batch (kernels_tail.hip) needs a private arena per problem; sized before the first kernel so
   // that no allocation falls into the solve.  (Grown only while no other solve is finishing: see cilqr_submit.)
-  if (h->tail_threshold > 0) {
-    const size_t need = (size_t)std::min(B, h->tail_threshold) * tail_workspace_bytes(j.d);
+  if (j.tail_threshold > 0) {
+    const size_t need = (size_t)std::min(B, j.tail_threshold) * tail_workspace_bytes(j.d);
     if (need > h->tail_ws_bytes) {
       std::unique_lock<std::mutex> lk(h->mu);
       h->cv.wait(lk, [h] { return !h->fin_busy || h->quit; });
@@ -825,7 +827,7 @@ int job_iterate(cilqr_solver* h, cilqr_job& j, int stage) {
   const int tail_threshold = 0;   // the test-only build re-evaluates whole trajectories in the reference's order
 #else
   // (a horizon whose per-step rows no longer fit beside the tail kernel's fixed LDS block stays in the lockstep loop)
-  const int tail_threshold = tail_supported(d) ? h->tail_threshold : 0;
+  const int tail_threshold = tail_supported(d) ? j.tail_threshold : 0;
 #endif
   int& it = j.it;
   int& n_hint = j.n_hint;
@@ -1109,6 +1111,7 @@ int cilqr_submit(cilqr_handle h, const cilqr_problem_batch* in, cilqr_solution_b
   j.out = *out;
   j.set = slot;
   j.spec_threshold = h->alone_on_device ? h->spec_threshold : h->spec_threshold_submit;
+  j.tail_threshold = h->alone_on_device ? h->tail_threshold : h->tail_threshold_submit;
   j.st1 = h->stream;
   j.st2 = h->stream2;
   j.rc = CILQR_OK;

@@ -86,6 +86,7 @@ struct cilqr_job {
   cilqr_solution_batch out;
   int set = 0;
   int spec_threshold = 0;   // the threshold of this solve (cilqr_solver::spec_threshold or spec_threshold_submit)
+  int tail_threshold = 0;   // likewise (cilqr_solver::tail_threshold or tail_threshold_submit)
   int phase = 0;            // 0 free, 1 queued, 2 first stage, 3 waiting for the finishing stage, 4 finishing, 5 done
   int rc = CILQR_OK;
   char err_text[256] = "";  // what the worker thread's g_last_hip_error held when rc was set (that variable is thread-local)
@@ -144,7 +145,12 @@ struct cilqr_solver {
   int round_group = 2;        // step sizes costed per sequential round (1, 2 or 4)
   int wave_threshold = 1024;  // active sets up to this size run the backward pass with a wavefront per problem
   int seq_rounds = 4;         // larger sets: this many round-by-round trials, then the rest at once
-  int tail_threshold = 256;   // active sets up to this size leave the lockstep loop: one workgroup per problem (kernels_tail.hip)
+  // active sets up to this size leave the lockstep loop: one workgroup per problem (kernels_tail.hip).  Like the speculation
+  // threshold it depends on company: a solve that has the GPU to itself (cilqr_solve_batch) is shortest when up to 1024 problems
+  // finish there (the kernel then runs four rounds of workgroups: 1.27 -> 1.31 M solves/s); beside other solves those workgroups
+  // hold a CU each for milliseconds and take it from the neighbours' bulk kernels (pool 1.97 -> 1.93 M), so submitted solves keep 256
+  int tail_threshold = 1024;
+  int tail_threshold_submit = 256;
   void* tail_ws = nullptr;    // private arenas of the tail's problems (lazily grown)
   size_t tail_ws_bytes = 0;
   void* tail_ws1 = nullptr;   // the same for a solve that reaches the tail without having been handed over (first stage)

@@ -198,7 +198,9 @@ int cilqr_set_stream(cilqr_handle h, void* hip_stream);
  * whole wavefront (operands in LDS, one output element per lane): the shortest chain of dependent work per step.
  * 0 = never.  Bit-identical results. */
 #define CILQR_OPT_WAVE_THRESHOLD 6
-/* CILQR_OPT_TAIL_THRESHOLD (default 256, at most 8192): once at most this many problems are still iterating they
+/* CILQR_OPT_TAIL_THRESHOLD (default 1024 for cilqr_solve_batch, 256 for solves submitted with cilqr_submit /
+ * cilqr_pool_submit -- beside other solves the tail's workgroups take CUs from the neighbours' bulk kernels; setting the
+ * option sets both; at most 8192): once at most this many problems are still iterating they
  * leave the lockstep loop; one workgroup per problem runs all its remaining iterations in a single launch
  * (kernels_tail.hip), so the stragglers of a batch no longer cost nine launches per iteration.  0 = lockstep to
  * the end.  Bit-identical results. */
