@@ -752,20 +752,27 @@ int job_begin(cilqr_solver* h, cilqr_job& j) {
   j.n_traj = (size_t)B * K * 10; j.n_hist = (size_t)B * (M + 1) * 5;
   j.n_itr = out->iter_trajs ? (size_t)B * out->max_iter_trajs * K * 10 : 0;
   j.n_at = out->alpha_trace ? (size_t)B * M : 0;
+  j.n_head = 0;
+  j.small_out = false;
   if (out->memory == CILQR_MEM_HOST) {
-    const size_t bytes = (j.n_traj + j.n_hist + j.n_itr) * 8 + (size_t)4 * B * 4 + j.n_at + 1024;
+    // staging block: traj | cost_hist | n_cost, status, n_iter, n_iter_trajs | alpha_trace | (8-byte pad) | iter_trajs --
+    // the iterates last, so that a small batch can fetch everything else (and the first few iterates) in one short copy
+    j.n_head = (j.n_traj + j.n_hist) * 8 + (((size_t)4 * B * 4 + j.n_at + 7) & ~(size_t)7);
+    const size_t bytes = j.n_head + j.n_itr * 8 + 1024;
     rc = grow(&js.out_stage, &js.out_stage_bytes, bytes);
     if (rc != CILQR_OK) return rc;
     double* p = static_cast<double*>(js.out_stage);
     j.o_traj = p; p += j.n_traj;
     j.o_hist = p; p += j.n_hist;
-    j.o_it = out->iter_trajs ? p : nullptr; p += j.n_itr;
     int* q = reinterpret_cast<int*>(p);
     j.o_nc = q; j.o_st = q + B; j.o_ni = q + 2 * B; j.o_nit = q + 3 * B;
     j.o_at = out->alpha_trace ? reinterpret_cast<signed char*>(q + 4 * B) : nullptr;
+    j.o_it = out->iter_trajs ? reinterpret_cast<double*>(static_cast<char*>(js.out_stage) + j.n_head) : nullptr;
+    j.small_out = j.n_head + j.n_itr * 8 <= kSmallTransfer;
     // the staging buffer is reused between solves: rows the kernels do not write (cost rows
-    // >= n_cost, iterates >= n_iter_trajs) must reach the caller as zeros, not as an earlier solve's data
-    HIP_TRY(hipMemsetAsync(j.o_hist, 0, (j.n_hist + j.n_itr) * 8, st));
+    // >= n_cost, iterates >= n_iter_trajs) must reach the caller as zeros, not as an earlier solve's data.  A small batch
+    // is handed out row by row on the host (job_finish), which takes the live rows only: nothing to clear
+    if (!j.small_out) HIP_TRY(hipMemsetAsync(j.o_hist, 0, j.n_head - j.n_traj * 8 + j.n_itr * 8, st));
   }
 
   if (h->cfg.init_guess == CILQR_INIT_TRACKER) launch_init_guess_tracker(j.d, h->tracker, B, st);   // cc:168 (InitGuess)
@@ -838,7 +845,10 @@ int job_iterate(cilqr_solver* h, cilqr_job& j, int stage) {
       if (n_hint == 0) break;                          // iterations it-kLead+1 .. it-1 were no-ops
     }
     bool hand_over = false;
-    if (stage == 1 && h->fin_threshold > 0 && n_hint <= h->fin_threshold) {
+    // (a synchronous call whose problems all go to the tail kernel next has nothing to gain from moving them first:
+    // no other solve is waiting for the main arena -- 17 us of a batch-of-one Plan)
+    const bool straight_to_tail = j.st1 == j.st2 && n_hint <= tail_threshold;
+    if (stage == 1 && h->fin_threshold > 0 && n_hint <= h->fin_threshold && !straight_to_tail) {
       // few enough problems left: they continue in the finishing arena, the main arena is free for the next solve.
       // Only if that arena is free -- while the solve before this one still finishes there, this one keeps iterating
       // where it is and asks again next iteration (small batches then run side by side, one in each arena).
@@ -959,13 +969,18 @@ int job_finish(cilqr_solver* h, cilqr_job& j) {
   launch_export_hist(j.gmain, B, j.o_hist, j.o_nc, j.o_st, j.o_ni, j.o_nit, j.o_at, st);
   if (j.tm.end()) return CILQR_ERR_DEVICE;
   HIP_TRY(hipGetLastError());
-  const size_t out_payload = (j.n_traj + j.n_hist + j.n_itr) * 8 + (size_t)4 * B * 4 + j.n_at;
-  const bool small_out = out->memory == CILQR_MEM_HOST && out_payload <= kSmallTransfer;
+  const bool small_out = out->memory == CILQR_MEM_HOST && j.small_out;
+  const size_t one_traj = ((size_t)h->cfg.n_steps + 1) * 10 * 8;                 // bytes of one iterate
+  const size_t per = out->iter_trajs ? (size_t)out->max_iter_trajs * one_traj : 0;   // iterate block of one problem
+  // a batch of one (the drop-in call) fetches its first iterates with the head: 8-9 exist on average, the capacity is
+  // max_iter + 1 (820 KB, 20 us of copy for 36 KB of data)
+  constexpr int kFirstIterates = 16;
+  const size_t first = (small_out && B == 1 && out->iter_trajs) ? (size_t)std::min(kFirstIterates, out->max_iter_trajs) * one_traj : 0;
   if (small_out) {
-    // a small batch: the whole staging block in one copy into pinned memory, handed out on the host below (seven
-    // pageable copies cost ~25 us each after the last kernel)
+    // a small batch: the head of the staging block in one copy into pinned memory, handed out on the host below (seven
+    // pageable copies cost ~25 us each after the last kernel); the iterates that exist follow once their counts are known
     if (js.out_pinned == nullptr) HIP_TRY(hipHostMalloc(&js.out_pinned, kSmallTransfer, hipHostMallocDefault));
-    HIP_TRY(hipMemcpyAsync(js.out_pinned, js.out_stage, out_payload, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(js.out_pinned, js.out_stage, j.n_head + first, hipMemcpyDeviceToHost, st));
   } else if (out->memory == CILQR_MEM_HOST) {
     HIP_TRY(hipMemcpyAsync(out->traj, j.o_traj, j.n_traj * 8, hipMemcpyDeviceToHost, st));
     // rows >= n_cost were zero-filled above
@@ -981,17 +996,37 @@ int job_finish(cilqr_solver* h, cilqr_job& j) {
   }
   HIP_TRY(hipStreamSynchronize(st));
   if (small_out) {   // same layout as the staging block (job_begin)
-    const char* q = static_cast<const char*>(js.out_pinned);
-    std::memcpy(out->traj, q, j.n_traj * 8); q += j.n_traj * 8;
-    std::memcpy(out->cost_hist, q, j.n_hist * 8); q += j.n_hist * 8;
-    const char* q_it = q;
-    q += j.n_itr * 8;
-    if (out->iter_trajs) {   // only the iterates that exist (the capacity is max_iter + 1 in the drop-in adapter: 820 KB per problem)
-      const int32_t* nit = reinterpret_cast<const int32_t*>(q + (size_t)3 * B * 4);
-      const size_t one = (size_t)h->cfg.n_steps + 1, per = (size_t)out->max_iter_trajs * one * 10 * 8;
+    char* pin = static_cast<char*>(js.out_pinned);
+    const char* q = pin + (j.n_traj + j.n_hist) * 8;
+    const int32_t* nc = reinterpret_cast<const int32_t*>(q);
+    const int32_t* nit = reinterpret_cast<const int32_t*>(q + (size_t)3 * B * 4);
+    if (out->iter_trajs) {
+      // the iterates that exist and did not come with the head (the capacity is max_iter + 1 in the drop-in adapter)
+      bool more = false;
       for (int b = 0; b < B; ++b) {
-        const size_t used = (size_t)std::min(std::max(nit[b], 0), out->max_iter_trajs) * one * 10 * 8;
-        std::memcpy(reinterpret_cast<char*>(out->iter_trajs) + (size_t)b * per, q_it + (size_t)b * per, used);
+        const size_t used = (size_t)std::min(std::max(nit[b], 0), out->max_iter_trajs) * one_traj;
+        const size_t have = (b == 0) ? std::min(first, used) : 0;
+        if (used > have) {
+          HIP_TRY(hipMemcpyAsync(pin + j.n_head + (size_t)b * per + have, reinterpret_cast<const char*>(j.o_it) + (size_t)b * per + have,
+                                 used - have, hipMemcpyDeviceToHost, st));
+          more = true;
+        }
+      }
+      if (more) HIP_TRY(hipStreamSynchronize(st));
+    }
+    std::memcpy(out->traj, pin, j.n_traj * 8);
+    {  // cost rows: the live ones; the rest of the caller's array is zero, as on every host path
+      const size_t row = 5 * 8, block = (size_t)(M + 1) * row;
+      std::memset(out->cost_hist, 0, j.n_hist * 8);
+      for (int b = 0; b < B; ++b) {
+        const size_t live = (size_t)std::min(std::max(nc[b], 0), M + 1) * row;
+        std::memcpy(reinterpret_cast<char*>(out->cost_hist) + (size_t)b * block, pin + j.n_traj * 8 + (size_t)b * block, live);
+      }
+    }
+    if (out->iter_trajs) {
+      for (int b = 0; b < B; ++b) {
+        const size_t used = (size_t)std::min(std::max(nit[b], 0), out->max_iter_trajs) * one_traj;
+        std::memcpy(reinterpret_cast<char*>(out->iter_trajs) + (size_t)b * per, pin + j.n_head + (size_t)b * per, used);
       }
     }
     std::memcpy(out->n_cost, q, (size_t)B * 4);

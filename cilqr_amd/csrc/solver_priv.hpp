@@ -106,6 +106,8 @@ struct cilqr_job {
   int *o_nc = nullptr, *o_st = nullptr, *o_ni = nullptr, *o_nit = nullptr;
   signed char* o_at = nullptr;
   size_t n_traj = 0, n_hist = 0, n_itr = 0, n_at = 0;
+  size_t n_head = 0;        // bytes of the staging block in front of the iterates (traj, cost_hist, counts, alpha_trace, pad)
+  bool small_out = false;   // host outputs small enough to travel through the pinned block
 };
 
 struct cilqr_solver {
