@@ -1194,6 +1194,47 @@ def test_iter_trajs_beyond_the_count_are_unspecified_on_every_path():
     opt.close()
 
 
+def test_small_host_batches_fetch_their_iterates_in_two_steps():
+    """A small host batch copies out the head of the staging block first (trajectory, cost rows, counts -- and, for a batch of
+    one, its first 16 iterates: solver.hip, job_finish) and the iterates that exist beyond that once their counts are known.
+    With tolerances of zero a solve keeps iterating, so a batch of one has more than 16 iterates and a batch of three fetches
+    every iterate in the second step: what arrives must be what the staged path of a large batch delivers for the same
+    problems -- trajectories, every live cost row (zeros behind them), every iterate below the count, the caller's bytes behind."""
+    sc = scenario.generate("mix11", 300, seed=33)
+    K, cap = sc["n_steps"] + 1, 64
+    opt = _opt(sc, rel_cost_tol=0.0, abs_cost_tol=0.0, max_iter=60)
+    M = opt.cfg.max_iter
+
+    def solve(n, first=0):
+        sub = {k: (v[first:first + n] if isinstance(v, np.ndarray) and v.shape[:1] == (300,) else v) for k, v in sc.items()}
+        prob, keep = opt._host_problem(sub)
+        traj, hist = np.zeros((n, K, 10)), np.full((n, M + 1, 5), 3.25)
+        nc, st, ni, nit = (np.zeros(n, np.int32) for _ in range(4))
+        it = np.full((n, cap, K, 10), -7.5)
+        sol = api.SolutionBatch(api.MEM_HOST, cap, traj.ctypes.data, hist.ctypes.data, nc.ctypes.data, st.ctypes.data,
+                                ni.ctypes.data, it.ctypes.data, nit.ctypes.data, None)
+        assert opt.solve_raw(prob, sol) == api.OK
+        del keep
+        return dict(traj=traj, hist=hist, nc=nc, st=st, ni=ni, it=it, nit=nit)
+
+    big = solve(300)
+    assert (big["nit"] > 16).sum() >= 100            # the case the second copy exists for is the common one here
+    b_long = int(np.argmax(big["nit"]))
+    for first, n in ((b_long, 1), (0, 1), (0, 3), (5, 2)):
+        small = solve(n, first)
+        sl = slice(first, first + n)
+        for k in ("traj", "nc", "st", "ni", "nit"):
+            assert np.array_equal(small[k], big[k][sl]), (k, first, n)
+        for b in range(n):
+            rows = int(small["nc"][b])
+            assert np.array_equal(small["hist"][b, :rows], big["hist"][first + b, :rows])
+            assert np.all(small["hist"][b, rows:] == 0.0) and np.all(big["hist"][first + b, rows:] == 0.0)
+            cnt = min(int(small["nit"][b]), cap)
+            assert np.array_equal(small["it"][b, :cnt], big["it"][first + b, :cnt]), (first, n, b, cnt)
+            assert np.all(small["it"][b, cnt:] == -7.5)
+    opt.close()
+
+
 def test_delta_v_evaluation_switch():
     """whether cc:383-384 see the updated Vx / Vxx (lazy `auto`, the default in product and oracle) or
     the ones the gains came from (eager) cannot be run against Eigen here, so BOTH readings stay built and checked: the
@@ -1269,6 +1310,16 @@ def test_tail_kernel_is_bit_identical_to_the_lockstep_loop(family, B, seed):
     plain = opt.plan(sc)
     for k in ("traj", "cost_hist", "n_cost", "status", "n_iter"):
         assert np.array_equal(ref[k], plain[k], equal_nan=True), k
+    # the tail kernel's quadratisation in its other form (one lane per knot instead of four lanes sharing a knot's planes;
+    # CILQR_TAIL_QUAD_SPLIT is read at every launch): the runs above took the split form wherever the horizon's candidate
+    # rows offer room for its sums (N = 50, 80), this one never does
+    os.environ["CILQR_TAIL_QUAD_SPLIT"] = "0"
+    try:
+        unsplit = _plan(opt, sc)
+    finally:
+        del os.environ["CILQR_TAIL_QUAD_SPLIT"]
+    for k in keys:
+        assert np.array_equal(ref[k], unsplit[k], equal_nan=True), (family, "unsplit", k)
     opt.close()
 
 
