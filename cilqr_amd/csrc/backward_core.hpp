@@ -539,8 +539,10 @@ CILQR_DEV void backward_team_problem(const DeviceState& s, int slot, double lamb
 //   54..57          B^T Vx with this step's B (gains) / with the previous step's B (its delta_V, see below)
 //   58..63  c       (B^T Vxx)(1, c) with the previous step's B
 // The 2x2 / 2-vector quantities (Quu, Qu, the inverse, k) are evaluated by every lane.  delta_V of a step needs
-// Qu / Quu on the UPDATED Vx / Vxx (cc:383-384), which are the next step's inputs: the spare lanes evaluate them
-// during the next step's first two stages, and the sums are taken one step late, in the same order.
+// Qu / Quu on the UPDATED Vx / Vxx (cc:383-384), which are the next step's inputs: the spare lanes evaluate their
+// B^T Vx / B^T Vxx B parts during the next step's first two stages and leave them in a row of the step they belong to;
+// the per-step terms of delta_V and of the gradient norm are evaluated after the recursion, a step per lane, and summed by
+// one lane in the recursion's order (end of backward_wave_problem).
 // Dense products with A's and B's exact zeros and ones stand for the sparse ones of backward_problem (x * 1 = x,
 // s + x * 0 = s), sums run k = 0..5 in order: bit-identical results (tested against both other kernels).
 // ---------------------------------------------------------------------------------------------

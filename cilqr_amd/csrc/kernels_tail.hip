@@ -17,7 +17,9 @@
 // with Bcap = 1, slot = 0.  Results are bit-identical to the lockstep path (tested with the tail switched off).
 //
 // Phases of one iteration (256 threads; `|` = __syncthreads):
-//   quadratize, one knot per thread | backward, wave 0 (one output element per lane) | exit test | rollouts of all 11 step sizes,
+//   quadratize (four lanes share a knot's planes | one lane per knot adds their sums up in plane order while another wave
+//   evaluates the state-only part; one knot per thread where the split form's scratch rows do not fit)
+//   | backward, wave 0 (one output element per lane) | exit test | rollouts of all 11 step sizes,
 //   11 lanes | knot costs of alpha_0..4 (5 K items over the block) | totals, 5 lanes | first passing index;
 //   only if none: alpha_5..9, then alpha_10 | the winner becomes the iterate | update_state | exports.
 // The first passing list index wins whatever the evaluation order (cc:246-265), so evaluating the candidates in
