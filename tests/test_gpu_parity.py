@@ -946,6 +946,27 @@ def test_long_horizon_more_knots_than_a_tail_workgroup_has_threads(both_paths):
     opt.close()
 
 
+def test_horizon_beyond_the_lds_budgets_of_the_wave_kernels():
+    """N = 1100: the per-step rows of the wave backward pass no longer fit the 64 KiB a launch gets without asking
+    (launch_backward_wave declines, the eight-lane kernel takes over) and the tail kernel's fixed LDS block no longer fits
+    either (tail_supported: the solve stays in the lockstep loop).  Both guards must leave a working solve behind: every
+    step replays in the oracle, and the options that would select the declined kernels change nothing."""
+    import dataclasses
+    spec = dataclasses.replace(scenario.SPECS["ped6"], n_steps=1100)
+    sc = scenario.generate(spec, 3, seed=71)
+    opt = _opt(sc, max_iter=25)
+    g = _plan(opt, sc)
+    assert set(np.unique(g["status"])) <= {api.ST_CONVERGED_ABS, api.ST_CONVERGED_REL, api.ST_GNORM, api.ST_MAX_ITER, api.ST_UNSOLVED}
+    steps = assert_steps(g, sc, oracle_cfg_from(opt.cfg), what="N=1100", max_excused_frac=0.1)
+    print(f"\nN=1100: steps {steps}")
+    opt.set_option(api.OPT_TAIL_THRESHOLD, 0)
+    opt.set_option(api.OPT_WAVE_THRESHOLD, 0)
+    h = _plan(opt, sc)
+    for k in ("traj", "cost_hist", "n_cost", "status", "n_iter", "iter_trajs", "n_iter_trajs", "alpha_trace"):
+        assert np.array_equal(g[k], h[k], equal_nan=True), k
+    opt.close()
+
+
 @pytest.mark.parametrize("family,distinct", [("mix11", 256), ("dyn20x", 128)])
 def test_full_size_batch_properties(family, distinct):
     """BASELINE configs[2] (B = 65536, N = 50, mix11) and configs[4] (B = 65536, N = 100, 20 dynamic obstacles, barriers
