@@ -937,34 +937,7 @@ int job_finish(cilqr_solver* h, cilqr_job& j) {
   const int M = h->cfg.max_iter, B = j.B;
   hipStream_t st = j.handed ? j.st2 : j.st1;
   j.tm.stream = st;
-  HIP_TRY(hipStreamSynchronize(st));
-  int it = j.it;
-  {  // lockstep iterations that had work, and the problem-steps each backward launch covered
-    int used = 0;
-    for (int i = 0; i < it; ++i) {
-      const int n_in = (i == 0) ? B : js.h_count[i - 1];
-      if (n_in > 0) used = i + 1;
-    }
-    for (int i : j.bwd_iter) {
-      const int n_in = (i == 0) ? B : js.h_count[i - 1];
-      if (n_in <= 0) continue;
-      j.prof.backward_launches += 1;
-      j.prof.backward_problem_steps += (int64_t)n_in * h->cfg.n_steps;
-    }
-    j.tm.full_flags.assign(j.bwd_iter.size(), 0);
-    j.tm.live_flags.assign(j.bwd_iter.size(), 0);
-    for (size_t k = 0; k < j.bwd_iter.size(); ++k) {
-      const int n_in = (j.bwd_iter[k] == 0) ? B : js.h_count[j.bwd_iter[k] - 1];
-      j.tm.full_flags[k] = (n_in == B);
-      j.tm.live_flags[k] = (n_in > 0);
-    }
-    it = used;
-    if (j.tail_used) {
-      it = std::max(it, js.h_count[M + 32]);
-      j.prof.tail_problems = j.tail_n;   // upper bound (the count the host knew when it enqueued the tail)
-    }
-  }
-  j.prof.iterations = it;
+  // (no wait here: the export and the copy out are enqueued behind the solve's last kernel, ONE host round trip for all of it)
   if (j.tm.begin(3)) return CILQR_ERR_DEVICE;
   launch_export_hist(j.gmain, B, j.o_hist, j.o_nc, j.o_st, j.o_ni, j.o_nit, j.o_at, st);
   if (j.tm.end()) return CILQR_ERR_DEVICE;
@@ -995,6 +968,33 @@ int job_finish(cilqr_solver* h, cilqr_job& j) {
     if (out->alpha_trace) HIP_TRY(hipMemcpyAsync(out->alpha_trace, j.o_at, j.n_at, hipMemcpyDeviceToHost, st));
   }
   HIP_TRY(hipStreamSynchronize(st));
+  int it = j.it;
+  {  // lockstep iterations that had work, and the problem-steps each backward launch covered
+    int used = 0;
+    for (int i = 0; i < it; ++i) {
+      const int n_in = (i == 0) ? B : js.h_count[i - 1];
+      if (n_in > 0) used = i + 1;
+    }
+    for (int i : j.bwd_iter) {
+      const int n_in = (i == 0) ? B : js.h_count[i - 1];
+      if (n_in <= 0) continue;
+      j.prof.backward_launches += 1;
+      j.prof.backward_problem_steps += (int64_t)n_in * h->cfg.n_steps;
+    }
+    j.tm.full_flags.assign(j.bwd_iter.size(), 0);
+    j.tm.live_flags.assign(j.bwd_iter.size(), 0);
+    for (size_t k = 0; k < j.bwd_iter.size(); ++k) {
+      const int n_in = (j.bwd_iter[k] == 0) ? B : js.h_count[j.bwd_iter[k] - 1];
+      j.tm.full_flags[k] = (n_in == B);
+      j.tm.live_flags[k] = (n_in > 0);
+    }
+    it = used;
+    if (j.tail_used) {
+      it = std::max(it, js.h_count[M + 32]);
+      j.prof.tail_problems = j.tail_n;   // upper bound (the count the host knew when it enqueued the tail)
+    }
+  }
+  j.prof.iterations = it;
   if (small_out) {   // same layout as the staging block (job_begin)
     char* pin = static_cast<char*>(js.out_pinned);
     const char* q = pin + (j.n_traj + j.n_hist) * 8;
