@@ -909,7 +909,7 @@ def run(args, rank, local_rank, world, comm, real_stdout):
         traffic = measure_backward_traffic(args, single["bwd_problem_steps"])
     latency = None
     if world == 1 and not args.no_latency:
-        latency = plan_latency(scenario, ("ped6", "mix11"), args.latency_scenes, 100 + args.seed, workers)
+        latency = plan_latency(scenario, ("ped6", "mix11", "dyn20"), args.latency_scenes, 100 + args.seed, workers)
 
     # sanity: every problem must have terminated with a valid status
     st = ctx[0].st.cpu().numpy()

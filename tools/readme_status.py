@@ -43,7 +43,10 @@ rows = [
     ("drop-in call: `planning::IlqrOptimizer::Plan` through the C++ adapter, batch of ONE, 256 scenes per family",
      "; ".join(f"{f}: mean {lat[f]['plan_b1']['mean_ms']:.2f} ms, median {lat[f]['plan_b1']['median_ms']:.2f}, p95 {lat[f]['plan_b1']['p95_ms']:.2f} "
                f"(CPU restatement on the same scenes: {lat[f]['cpu_restatement']['mean_ms']:.1f} / {lat[f]['cpu_restatement']['median_ms']:.1f} / {lat[f]['cpu_restatement']['p95_ms']:.1f})"
-               for f in ("mix11", "ped6")) + "; start of the round: 1.57 / 1.29 / 3.43 and 1.65 / 1.36 / 3.33 ms"),
+               for f in ("mix11", "ped6")) + "; start of the round: 1.57 / 1.29 / 3.43 and 1.65 / 1.36 / 3.33 ms"
+     + (f"; dyn20 (N = 100, 20 obstacles, Cmax = 24): {lat['dyn20']['plan_b1']['mean_ms']:.2f} / {lat['dyn20']['plan_b1']['median_ms']:.2f} / "
+        f"{lat['dyn20']['plan_b1']['p95_ms']:.2f} ms against {lat['dyn20']['cpu_restatement']['mean_ms']:.1f} / "
+        f"{lat['dyn20']['cpu_restatement']['median_ms']:.1f} / {lat['dyn20']['cpu_restatement']['p95_ms']:.1f}" if "dyn20" in lat else "")),
     ("same batch through host memory (PCIe-inclusive)", k(pc["solves_per_s_host_memory"])),
     ("CPU oracle, 1 thread, same scenes (all cores of the box's quota)", f"{b['cpu_baseline']['value']:.0f} solves/s ({b['cpu_baseline']['all_cores']['value'] / 1e3:.1f} k)"),
     ("`k_backward`, launch over the whole batch, alone on the GPU",
