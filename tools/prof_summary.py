@@ -84,7 +84,12 @@ def main():
         steps, warm, roof = rec["steps"], rec["warmup"], rec["roofline"]
         new_layout = "launches_contended" in roof      # round 4 on: top-level keys = ONE solve alone, *_contended = the timed region
         per_solve = roof["launches"] if new_layout else roof["launches"] // steps   # backward launches of one solve (lockstep iterations)
-        skip = (2 + warm) * per_solve                   # the two calibration solves and the warm-up steps come first
+        # the two calibration solves are synchronous calls, the warm-up and timed steps submitted ones: since the tail threshold
+        # depends on the kind of call (1024 / 256) they differ in the number of lockstep iterations, i.e. of backward launches
+        per_sync = per_solve
+        if new_layout:
+            per_solve = roof["launches_contended"] // steps
+        skip = 2 * per_sync + warm * per_solve          # the two calibration solves and the warm-up steps come first
         bw = [(s_, e_) for name, s_, e_, *_ in rows if short(name) in ("k_backward", "k_backward_team", "k_backward_wave")]
         win = bw[skip:skip + steps * per_solve]         # rows are sorted by start time; fences separate the regions
         if len(win) == steps * per_solve:
@@ -94,7 +99,7 @@ def main():
                   f"the rows above also hold the calibration, warm-up, one-handle and sequential legs of the same process):\n"
                   f"  launches {len(win)}  avg {avg * 1e3:.1f} us   -- bench.py roofline.avg_launch_ms_contended (HIP events, same run): {hip_ms * 1e3:.1f} us")
             if new_layout:
-                cal = bw[per_solve:2 * per_solve]        # the calibration solve: second solve of the process, alone on the GPU
+                cal = bw[per_sync:2 * per_sync]          # the calibration solve: second solve of the process, alone on the GPU
                 avg1 = sum(e_ - s_ for s_, e_ in cal) / len(cal) / 1e6
                 print(f"backward launches of the calibration solve (one solve alone on the GPU, {len(cal)} launches):\n"
                       f"  avg {avg1 * 1e3:.1f} us   -- bench.py roofline.avg_launch_ms (HIP events, same run): {roof['avg_launch_ms'] * 1e3:.1f} us")
