@@ -56,6 +56,7 @@ struct TailArgs {
   int* max_iter;   // host-visible: largest iteration count a problem of the tail reached
   int bwd_in_lds;  // lin, term, gains, U and the scalars are in LDS: the backward pass runs on ds_* instructions
   int fwd_in_lds;  // X, U, gains, goals, Xs, Us are: so do the rollouts
+  int fwd_src_in_lds;   // X, U, gains, goals only (the rollouts' loads)
   int quad_in_lds; // X, U, goals, cor, ccnt, lin, term
   int quad_scr;    // >= 0: the quadratisation runs in its split form, with its per-plane sums at this byte offset of the
                    // block's LDS (the candidates' rows -- parts, Xs, Us -- which are dead until the line search); -1: one lane per knot
@@ -152,13 +153,15 @@ __device__ __attribute__((noinline)) void tail_backward(int off_T, int off_view)
 #ifndef CILQR_TAIL_AHEAD
 #define CILQR_TAIL_AHEAD 4
 #endif
-template <bool InLds>
+// SrcLds: what a rollout READS (X, U, gains, goals) is in LDS; OutLds: so are the candidates' rows it writes (Xs, Us).  Long
+// horizons keep the first but not the second (eleven candidates of N = 100 no longer fit): the loads are what a step waits for.
+template <bool SrcLds, bool OutLds>
 __device__ __attribute__((noinline)) void tail_forward(int off_view) {
   extern __shared__ double lds[];
   const DeviceState& t = *reinterpret_cast<const DeviceState*>(reinterpret_cast<const char*>(lds) + off_view);
   const int tid = (int)threadIdx.x;
   // operands in LDS are a short round trip away: one step ahead is enough (and a quarter of the registers)
-  forward_core<OutSpecSolo<InLds>, InLds ? 1 : CILQR_TAIL_AHEAD, true, InLds>(t, 0, kAlpha[tid], OutSpecSolo<InLds>(t, tid));
+  forward_core<OutSpecSolo<OutLds>, SrcLds ? 1 : CILQR_TAIL_AHEAD, true, SrcLds>(t, 0, kAlpha[tid], OutSpecSolo<OutLds>(t, tid));
 }
 template <int D, bool EX, bool InLds>
 __device__ __attribute__((noinline)) void tail_quadratize(int off_view, int i) {
@@ -313,8 +316,9 @@ __global__ __launch_bounds__(kTailThreads) CILQR_TAIL_ATTR void k_tail(DeviceSta
     __syncthreads();
     if (!flag[0]) {
       if (tid < kNumAlpha) {                                               // cc:246-250, all step sizes
-        if (a.fwd_in_lds) tail_forward<true>(off_view);
-        else tail_forward<false>(off_view);
+        if (a.fwd_in_lds) tail_forward<true, true>(off_view);
+        else if (a.fwd_src_in_lds) tail_forward<true, false>(off_view);
+        else tail_forward<false, false>(off_view);
       }
       __syncthreads();
       TP(2);
@@ -484,8 +488,8 @@ void launch_tail(const DeviceState& g, void* workspace, int n_max, double* traj,
   auto in_lds = [&](size_t TailLayout::*f) { return a.S.*f != kNotInLds; };
   a.bwd_in_lds = in_lds(&TailLayout::lin) && in_lds(&TailLayout::term) && in_lds(&TailLayout::gains) && in_lds(&TailLayout::U) &&
                  in_lds(&TailLayout::dbl);
-  a.fwd_in_lds = in_lds(&TailLayout::X) && in_lds(&TailLayout::U) && in_lds(&TailLayout::gains) && in_lds(&TailLayout::goals) &&
-                 in_lds(&TailLayout::Xs) && in_lds(&TailLayout::Us);
+  a.fwd_src_in_lds = in_lds(&TailLayout::X) && in_lds(&TailLayout::U) && in_lds(&TailLayout::gains) && in_lds(&TailLayout::goals);
+  a.fwd_in_lds = a.fwd_src_in_lds && in_lds(&TailLayout::Xs) && in_lds(&TailLayout::Us);
   a.quad_in_lds = in_lds(&TailLayout::X) && in_lds(&TailLayout::U) && in_lds(&TailLayout::goals) && in_lds(&TailLayout::cor) &&
                   in_lds(&TailLayout::ccnt) && in_lds(&TailLayout::lin) && in_lds(&TailLayout::term);
   a.cost_in_lds = in_lds(&TailLayout::Xs) && in_lds(&TailLayout::Us) && in_lds(&TailLayout::parts) && in_lds(&TailLayout::goals) &&
