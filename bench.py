@@ -45,6 +45,41 @@ WORKLOADS = {("ped6", 4096): "configs[1]", ("mix11", 65536): "configs[2] (config
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def cpu_quota_cores():
+    """Cores' worth of CPU time this process tree may use: the cgroup's quota when there is one (the GPU boxes show 256
+    logical CPUs and grant 16), else None."""
+    try:
+        q_, p_ = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q_ == "max" else max(0.01, int(q_) / int(p_))
+    except Exception:   # noqa: BLE001
+        return None
+
+
+def scene_workers(world):
+    """Worker processes for the scene generator of ONE rank: every rank generates at the same time, so the cores are shared
+    out -- the quota's, not the logical CPUs' (256 workers under a 16-core quota only queue up)."""
+    quota = cpu_quota_cores()
+    cores = min(os.cpu_count() or 8, int(quota)) if quota else (os.cpu_count() or 8)
+    return max(1, min(32, cores // max(1, world)))
+
+
+def native_thread_count():
+    try:
+        for line in open("/proc/self/status"):
+            if line.startswith("Threads:"):
+                return int(line.split()[1])
+    except Exception:   # noqa: BLE001
+        pass
+    return None
+
+
+def cpu_seconds():
+    """user + system CPU seconds of this process, all threads (RUSAGE_SELF)."""
+    import resource
+    r = resource.getrusage(resource.RUSAGE_SELF)
+    return r.ru_utime + r.ru_stime
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -345,7 +380,9 @@ def dry_run(args, rank, world):
                 "ragged_history_rows_ok": (checks["ragged_rows"] if world > 1 else None),
                 "time_and_kappa_rebuilt_on_root": (checks["kappa_rebuilt"] if world > 1 else None), "gather_checks_ok": ok,
                 "mode": "multi" if getattr(args, "multi", False) else "ranks",
-                "spawned_by_bench": os.environ.get("CILQR_BENCH_SPAWNED") == "1"}
+                "spawned_by_bench": os.environ.get("CILQR_BENCH_SPAWNED") == "1",
+                # the host budget the real run would take: scene-generator workers per rank under the CPU quota
+                "scene_workers_per_rank": scene_workers(world), "cpu_quota_cores": cpu_quota_cores(), "logical_cpus": os.cpu_count()}
     return None
 
 
@@ -509,7 +546,8 @@ def dry_run_multi(args, comm):
     return {"metric": "CILQR solves/sec (dry run: launch plumbing only, nothing solved)", "value": None, "unit": "solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True, "ranks_reporting": world,
             "gather_in_rank_order": ok["rank_order"], "gathers": len(ok["steps"]), "gathers_in_step_order": ok["steps"] == list(range(steps)),
-            "ragged_history_rows_ok": ok["rows"], "gather_checks_ok": good, "mode": "multi", "spawned_by_bench": False}
+            "ragged_history_rows_ok": ok["rows"], "gather_checks_ok": good, "mode": "multi", "spawned_by_bench": False,
+            "scene_workers_per_rank": scene_workers(world), "cpu_quota_cores": cpu_quota_cores(), "logical_cpus": os.cpu_count()}
 
 
 def run(args, rank, local_rank, world, comm, real_stdout):
@@ -545,7 +583,7 @@ def run(args, rank, local_rank, world, comm, real_stdout):
     spec = scenario.SPECS[args.scene]
     B, N, K, cmax = args.batch, spec.n_steps, spec.n_steps + 1, spec.cmax
     t0 = time.time()
-    workers = max(1, min(32, (os.cpu_count() or 8) // max(1, world)))
+    workers = scene_workers(world)
     dp_info = None
     if args.coarse == "dp":
         # second scene source: DP coarse planner -> corridor producer -> the same solve
@@ -759,17 +797,41 @@ def run(args, rank, local_rank, world, comm, real_stdout):
     fence()
     if use_dist:
         gatherer.reset_stats()
+    cpu0 = cpu_seconds()
     t_start = time.perf_counter()
     run_steps(args.steps, True)
     fence()
     elapsed = time.perf_counter() - t_start
+    # host CPU of the timed region: what one rank's threads -- the loop, the handles' solver workers, the
+    # gather thread, RCCL's proxy -- burn per step, so that N ranks can be budgeted against the box's CPU quota
+    cpu_rank = cpu_seconds() - cpu0
+    n_threads = native_thread_count()
     gather_timed = dict(busy_s=gatherer.busy_s, count=gatherer.count) if use_dist else None
     if use_rccl:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        tc = torch.tensor([cpu_rank], dtype=torch.float64, device=dev)
+        ts = tc.clone()
+        dist.all_reduce(tc, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ts, op=dist.ReduceOp.SUM)
+        cpu_max, cpu_sum = float(tc.item()), float(ts.item())
     elif comm is not None:
         elapsed = comm.max_over_ranks(rank, elapsed)
+        cpu_sum = comm.max_over_ranks(rank, cpu_rank)    # threads of ONE process: every rank measured the whole process
+        cpu_max = cpu_sum / world
+    else:
+        cpu_max = cpu_sum = cpu_rank
+    quota = cpu_quota_cores()
+    host = {
+        "cpu_s_per_step_max_rank": round(cpu_max / args.steps, 5), "cpu_s_per_step_all_ranks": round(cpu_sum / args.steps, 5),
+        # cores kept busy by the timed region: CPU seconds / wall seconds, all ranks together, against the quota they share
+        "cores_busy_all_ranks": round(cpu_sum / elapsed, 3), "cpu_quota_cores": quota, "logical_cpus": os.cpu_count(),
+        "quota_fraction": (round(cpu_sum / elapsed / quota, 4) if quota else None),
+        "native_threads_this_rank": n_threads, "scene_workers_per_rank": workers,
+        "note": "resource.getrusage(RUSAGE_SELF) around the timed region, per rank (a process; with --multi the one process "
+                "is measured once and divided by the ranks for the per-rank figure); threads = /proc/self/status",
+    }
 
     # Extra (never `value`): the same gather through the C-ABI (cilqr_comm_* / cilqr_gather_results: librccl
     # called directly, no PyTorch), checked against the torch.distributed gather of the timed region.  Guarded
@@ -1152,6 +1214,7 @@ def run(args, rank, local_rank, world, comm, real_stdout):
             "status_histogram": np.bincount(st, minlength=7).tolist(),
             "scene_generation_s": round(t_gen, 1),
             "device_bytes": sum(c.opt.device_bytes() for c in ctx),
+            "host": host,
         }
     if hung:   # a stuck collective cannot be torn down: print the line and leave
         if rank == 0:

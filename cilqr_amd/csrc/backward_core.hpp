@@ -32,32 +32,30 @@ __host__ __device__ constexpr int h_kind(int r, int c) {
   return (r < 3 && c < 3) ? 2 : (r == c) ? 2 : 0;
 }
 
-struct Acc {
-  double v;
-  bool any;
-};
+// sequential accumulation over terms some of which are structural zeros (x_m below; Acc: dev_model.hpp)
 #define ACC_TERM(acc, t)            \
   do {                              \
     if ((acc).any) (acc).v += (t);  \
     else { (acc).v = (t); (acc).any = true; } \
   } while (0)
 
-// out[R][6] = M^T X with M = A (6x6) or B (6x2): out(r,c) = sum_k M(k,r) X(k,c)
+// out[R][6] = M^T X with M = A (6x6) or B (6x2): out(r,c) = sum_k M(k,r) X(k,c) -- an `X.transpose() * Y` product of the
+// reference: the six terms are added as sum6_xty says (dev_model.hpp), structural zeros dropping out of the tree
 template <int R, int xcols, bool IsA>
 CILQR_DEV void mt_x(const double* __restrict__ M, const double* __restrict__ X, double* out) {
 #pragma unroll
   for (int r = 0; r < R; ++r)
 #pragma unroll
     for (int c = 0; c < xcols; ++c) {
-      Acc a{0.0, false};
+      Acc t[6];
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
         const int kind = IsA ? a_kind(k, r) : b_kind(k, r);
-        if (kind == 0) continue;
+        if (kind == 0) { t[k] = Acc{0.0, false}; continue; }
         const double x = X[k * xcols + c];
-        const double t = (kind == 1) ? x : M[k * R + r] * x;
-        ACC_TERM(a, t);
+        t[k] = Acc{(kind == 1) ? x : M[k * R + r] * x, true};
       }
+      const Acc a = acc_sum6_xty(t);
       out[r * xcols + c] = a.any ? a.v : 0.0;
     }
 }
@@ -403,8 +401,8 @@ CILQR_DEV void backward_team_problem(const DeviceState& s, int slot, double lamb
     // entry c of A^T Vx, column c of A^T Vxx
     double AtVxc;
     {
-      double q = a0 * Vxa[0]; q += a1 * Vxa[1]; q += a2 * Vxa[2]; q += a3 * Vxa[3];
-      AtVxc = late ? q + (c4 ? Vxa[4] : Vxa[5]) : q;
+      // A^T Vx is an X^T Y product (sum6_xty): dense over this column's rows, with the exact zeros / ones of rows 4, 5
+      AtVxc = sum6_xty(a0 * Vxa[0], a1 * Vxa[1], a2 * Vxa[2], a3 * Vxa[3], c4 ? Vxa[4] : 0.0, (c == 5) ? Vxa[5] : 0.0);
     }
     double AtVc[6];
     mt_x<6, 1, true>(A, V, AtVc);
@@ -544,7 +542,8 @@ CILQR_DEV void backward_team_problem(const DeviceState& s, int slot, double lamb
 // the per-step terms of delta_V and of the gradient norm are evaluated after the recursion, a step per lane, and summed by
 // one lane in the recursion's order (end of backward_wave_problem).
 // Dense products with A's and B's exact zeros and ones stand for the sparse ones of backward_problem (x * 1 = x,
-// s + x * 0 = s), sums run k = 0..5 in order: bit-identical results (tested against both other kernels).
+// s + x * 0 = s); stage 1 (the X^T Y products) adds its terms as sum6_xty says, stage 2 in index order, like the other two
+// kernels: bit-identical results (tested against both).
 // ---------------------------------------------------------------------------------------------
 namespace wave {
 constexpr int oA = 0, oB = 36, oBo = 48, oV = 60, oVx = 96, oAtV = 102, oBtV = 138, oBtV2 = 150, oAtVx = 162,
@@ -694,9 +693,10 @@ CILQR_DEV void backward_wave_problem(const DeviceState& s, int slot, double lamb
     // ---- stage 1 ----
     double res1;
     {
-      double a = L[pm1] * L[px1];
-#pragma unroll
-      for (int k = 1; k < 6; ++k) a += L[pm1 + k * sm1] * L[px1 + k * sx1];
+      // every product of this stage is an X^T Y product of the reference: its six terms in sum6_xty's order
+      const double a = sum6_xty(L[pm1] * L[px1], L[pm1 + sm1] * L[px1 + sx1], L[pm1 + 2 * sm1] * L[px1 + 2 * sx1],
+                                L[pm1 + 3 * sm1] * L[px1 + 3 * sx1], L[pm1 + 4 * sm1] * L[px1 + 4 * sx1],
+                                L[pm1 + 5 * sm1] * L[px1 + 5 * sx1]);
       res1 = a;
       L[po1] = a;
     }

@@ -25,6 +25,44 @@ constexpr double kPi = 3.14159265358979323846;
 constexpr double kTwoPi = 2.0 * kPi;
 constexpr double kMathEps = 1e-10;  // algorithm/math/vec2d.h:33
 
+// ---- how the six products of a coefficient of `X.transpose() * Y` are added ----
+// Every such product of the path -- A^T Vx, B^T Vx, A^T Vxx, B^T Vxx (Backward, cc:348-353) and B^T P, A^T P (iqr,
+// cc:822-823) -- has a row-major left operand, so Eigen 3.4 evaluates each coefficient as
+// (lhs.row(i).transpose().cwiseProduct(rhs.col(j))).sum() (ProductEvaluators.h, product_evaluator<..LazyProduct..>::coeff),
+// and the reference's build (x86-64, -O2, no -march: CMakeLists.txt:9, i.e. SSE2, 2-double packets, no FMA) runs that sum
+// through the vectorised, completely unrolled redux (Redux.h: redux_vec_unroller<.., 0, 3> = p0 + (p1 + p2) on the packets
+// p_j = (t_2j, t_2j+1), then predux = low + high):
+//     (t0 + (t2 + t4)) + (t1 + (t3 + t5)).
+// Products whose left operand is a column-major matrix or temporary ((B^T Vxx) A, (A^T Vxx) A, K dx, ...) run
+// etor_product_packet_impl: pmul, then pmadd = padd(pmul) without FMA, k = 1..5 -- in index order; those stay sequential.
+// The CPU checker the tests use carries the same rule as its default (its CILQR_DOT_ORDER switch).
+// -DCILQR_DOT_ORDER_SEQUENTIAL: the other reading, index order everywhere (what rounds 1-4 shipped).  TEST-ONLY build
+// (`make dotseq` -> lib/libcilqr_hip_dotseq.so), held against the checker's sequential variant.
+CILQR_DEV double sum6_xty(double t0, double t1, double t2, double t3, double t4, double t5) {
+#ifdef CILQR_DOT_ORDER_SEQUENTIAL
+  return ((((t0 + t1) + t2) + t3) + t4) + t5;
+#else
+  return (t0 + (t2 + t4)) + (t1 + (t3 + t5));
+#endif
+}
+// The same sum over terms some of which are structural zeros (any == false): a missing term drops out of the tree
+// (s + 0 = s exactly), so sparse and dense evaluations of a product agree bit for bit (up to the sign of a zero).
+struct Acc {
+  double v;
+  bool any;
+};
+CILQR_DEV Acc acc_add(const Acc a, const Acc b) {
+  if (a.any && b.any) return Acc{a.v + b.v, true};
+  return a.any ? a : b;
+}
+CILQR_DEV Acc acc_sum6_xty(const Acc (&t)[6]) {
+#ifdef CILQR_DOT_ORDER_SEQUENTIAL
+  return acc_add(acc_add(acc_add(acc_add(acc_add(t[0], t[1]), t[2]), t[3]), t[4]), t[5]);
+#else
+  return acc_add(acc_add(t[0], acc_add(t[2], t[4])), acc_add(t[1], acc_add(t[3], t[5])));
+#endif
+}
+
 // fmod(a + pi, 2 pi) with the IEEE-exact fast paths (fmod is always exact, so the short
 // branches return bit-identical values to the library call).
 CILQR_DEV double normalize_angle(double angle) {

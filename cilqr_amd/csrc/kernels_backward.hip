@@ -6,7 +6,9 @@
 //   * delta_V_ is accumulated from Qu / Quu re-evaluated with the UPDATED Vx / Vxx, because the
 //     reference holds them as lazy Eigen `auto` expressions (cc:348-352 vs cc:383-384);
 //   * Vxx is symmetrised in place, column-major, without a temporary (cc:381);
-//   * products associate left to right and each dot product accumulates k = 0..5 in order.
+//   * products associate left to right; a coefficient of `X.transpose() * Y` (A^T Vx, A^T Vxx, B^T ...) adds its six terms as
+//     the reference's SSE2 build does, (t0 + (t2 + t4)) + (t1 + (t3 + t5)); every other dot product runs k = 0..5 in order
+//     (dev_model.hpp: sum6_xty).
 //
 // Memory: per step a lane reads 17 double2 (the non-constant entries of A, B, lx, lu, lxx, luu;
 // see state.hpp) + 1 double2 of U, and writes 7 double2 of gains: 18 KiB in + 7 KiB out per

@@ -319,17 +319,14 @@ __global__ __launch_bounds__(64) void k_init_guess(DeviceState s, int B) {
     A[15] = J.a23; A[16] = J.a24; A[17] = J.a25;
     A[22] = dt;
     Bm[5] = J.b21; Bm[6] = 0.5 * dt * dt; Bm[8] = dt; Bm[11] = dt;
-    // BtP = B^T P (2x6), sequential over the inner index
+    // BtP = B^T P (2x6): an X^T Y product, terms added as sum6_xty says (dev_model.hpp)
     double BtP[12];
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        double acc = Bm[0 * 2 + r] * P[0 * 6 + c];
-#pragma unroll
-        for (int k = 1; k < 6; ++k) acc += Bm[k * 2 + r] * P[k * 6 + c];
-        BtP[r * 6 + c] = acc;
-      }
+      for (int c = 0; c < 6; ++c)
+        BtP[r * 6 + c] = sum6_xty(Bm[0 * 2 + r] * P[0 * 6 + c], Bm[1 * 2 + r] * P[1 * 6 + c], Bm[2 * 2 + r] * P[2 * 6 + c],
+                                  Bm[3 * 2 + r] * P[3 * 6 + c], Bm[4 * 2 + r] * P[4 * 6 + c], Bm[5 * 2 + r] * P[5 * 6 + c]);
     double M[4], BtPA[12];
 #pragma unroll
     for (int r = 0; r < 2; ++r)
@@ -373,12 +370,9 @@ __global__ __launch_bounds__(64) void k_init_guess(DeviceState s, int B) {
 #pragma unroll
     for (int r = 0; r < 6; ++r)
 #pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        double acc = A[0 * 6 + r] * P[0 * 6 + c];
-#pragma unroll
-        for (int k = 1; k < 6; ++k) acc += A[k * 6 + r] * P[k * 6 + c];
-        AtP[r * 6 + c] = acc;
-      }
+      for (int c = 0; c < 6; ++c)   // A^T P: X^T Y again
+        AtP[r * 6 + c] = sum6_xty(A[0 * 6 + r] * P[0 * 6 + c], A[1 * 6 + r] * P[1 * 6 + c], A[2 * 6 + r] * P[2 * 6 + c],
+                                  A[3 * 6 + r] * P[3 * 6 + c], A[4 * 6 + r] * P[4 * 6 + c], A[5 * 6 + r] * P[5 * 6 + c]);
 #pragma unroll
     for (int r = 0; r < 6; ++r)
 #pragma unroll
@@ -429,7 +423,8 @@ __global__ __launch_bounds__(64) void k_init_guess(DeviceState s, int B) {
 // on one lane (2.2 us; 0.185 ms of a 1.7 ms Plan were this kernel).  Here the Jacobians at the goals -- which do not
 // depend on the sweep -- are evaluated for all steps side by side first, and every lane owns one output element of
 // every stage of the sweep: B^T P | A^T P, then M | (B^T P) A, then K, then A - B K, then the new P; each element is the
-// SAME dense 6-term dot product, k = 0..5 in order, that k_init_guess writes out (the exact zeros and ones of A and B
+// SAME dense 6-term dot product, in the same order (sum6_xty for A^T P and B^T P, index order for the rest), that k_init_guess
+// writes out (the exact zeros and ones of A and B
 // included), so the two kernels agree bit for bit (tests/test_gpu_parity.py).  The clamped closed-loop rollout stays
 // one dependent chain (lane 0), with the gains read back from LDS instead of global memory.
 // LDS: jac [N][12] | A 36 | B 12 | P 36 | BtP 12 | AtP 36 | M 4 | BtPA 12 | K 12 | AmBK 36 | Kall [N][12]
@@ -502,15 +497,11 @@ __global__ __launch_bounds__(64) void k_init_guess_wave(DeviceState s, int B) {
     sync();
     // ---- A^T P (36 lanes) | B^T P (12 lanes) ----
     if (lane < 36) {
-      double acc = A[0 * 6 + r6] * P[0 * 6 + c6];
-#pragma unroll
-      for (int k = 1; k < 6; ++k) acc += A[k * 6 + r6] * P[k * 6 + c6];
-      AtP[r6 * 6 + c6] = acc;
+      AtP[r6 * 6 + c6] = sum6_xty(A[0 * 6 + r6] * P[0 * 6 + c6], A[1 * 6 + r6] * P[1 * 6 + c6], A[2 * 6 + r6] * P[2 * 6 + c6],
+                                  A[3 * 6 + r6] * P[3 * 6 + c6], A[4 * 6 + r6] * P[4 * 6 + c6], A[5 * 6 + r6] * P[5 * 6 + c6]);
     } else if (s2_btp) {
-      double acc = Bm[0 * 2 + q2] * P[0 * 6 + c2];
-#pragma unroll
-      for (int k = 1; k < 6; ++k) acc += Bm[k * 2 + q2] * P[k * 6 + c2];
-      BtP[q2 * 6 + c2] = acc;
+      BtP[q2 * 6 + c2] = sum6_xty(Bm[0 * 2 + q2] * P[0 * 6 + c2], Bm[1 * 2 + q2] * P[1 * 6 + c2], Bm[2 * 2 + q2] * P[2 * 6 + c2],
+                                  Bm[3 * 2 + q2] * P[3 * 6 + c2], Bm[4 * 2 + q2] * P[4 * 6 + c2], Bm[5 * 2 + q2] * P[5 * 6 + c2]);
     }
     sync();
     // ---- M = R + (B^T P) B (4 lanes) | (B^T P) A (12 lanes) ----

@@ -188,7 +188,7 @@ class PeerGather:
     trajectory columns, the first max(n_cost) Cost rows, n_cost, status; the root rebuilds time and kappa as gather_results
     does.  Same order rule as the collective: every rank gathers its jobs in the order they finished."""
 
-    def __init__(self, world, B, K, M, root_device=None, derive=(0.1, 1.0), on_root=None):
+    def __init__(self, world, B, K, M, root_device=None, derive=(0.1, 1.0), on_root=None, timeout_s=600.0):
         """on_root(result): called on the root between the arrival of every rank's block and the release of the rows for the
         next job -- the only window in which the root tensors hold exactly one job (the returned dict aliases them)."""
         import threading
@@ -200,32 +200,48 @@ class PeerGather:
         self.nc = torch.zeros(world * B, dtype=torch.int32, **kw)
         self.st = torch.zeros(world * B, dtype=torch.int32, **kw)
         self.barrier = threading.Barrier(world)
+        self.timeout_s = timeout_s     # a rank that never arrives breaks the barrier instead of hanging the others
         self.on_root = on_root
 
     def gather_fn(self, rank):
         import torch
 
         def fn(traj, hist, nc, st):
+            try:
+                return body(traj, hist, nc, st)
+            except BaseException:
+                # a rank that fails must not leave the others waiting in the barrier for ever: breaking it raises
+                # BrokenBarrierError in every waiter, now and on every later job (GatherThread keeps the first error)
+                self.barrier.abort()
+                raise
+
+        def body(traj, hist, nc, st):
             lo, hi = rank * self.B, (rank + 1) * self.B
             cols = [1, 2, 3, 4, 5, 6, 8, 9]
-            self.traj[lo:hi, :, cols] = traj[:, :, cols].to(self.traj.device, non_blocking=True)
+            root = self.traj.device
+            self.traj[lo:hi, :, cols] = traj[:, :, cols].to(root, non_blocking=True)
             h = int(nc.max().item()) if self.B > 0 else 0
-            self.hist[lo:hi, :h] = hist[:, :h].to(self.hist.device, non_blocking=True)
-            self.nc[lo:hi] = nc.to(self.nc.device, non_blocking=True)
-            self.st[lo:hi] = st.to(self.st.device, non_blocking=True)
+            self.hist[lo:hi, :h] = hist[:, :h].to(root, non_blocking=True)
+            self.hist[lo:hi, h:] = 0.0     # rows past this job's longest history: zero, as every other host path pads them
+            self.nc[lo:hi] = nc.to(root, non_blocking=True)
+            self.st[lo:hi] = st.to(root, non_blocking=True)
             if traj.is_cuda:
+                # the peer copies are ordered on this rank's stream, the writes into the root tensors on the ROOT device's
+                # current stream of this thread: both must have drained before the barrier says "every block has landed"
                 torch.cuda.current_stream().synchronize()
-            self.barrier.wait()          # every rank's block of this job has landed
+            if root.type == "cuda":
+                torch.cuda.current_stream(root).synchronize()
+            self.barrier.wait(self.timeout_s)          # every rank's block of this job has landed
             res = None
             if rank == 0:
                 dt_, wb_ = self.derive
-                self.traj[:, :, 0] = torch.arange(self.K, dtype=torch.float64, device=self.traj.device)[None, :] * dt_
+                self.traj[:, :, 0] = torch.arange(self.K, dtype=torch.float64, device=root)[None, :] * dt_
                 self.traj[:, :, 7] = torch.tan(self.traj[:, :, 6]) / wb_
                 if self.traj.is_cuda:
-                    torch.cuda.current_stream().synchronize()
+                    torch.cuda.current_stream(root).synchronize()
                 res = {"traj": self.traj, "cost_hist": self.hist, "n_cost": self.nc, "status": self.st}
                 if self.on_root is not None:
                     self.on_root(res)
-            self.barrier.wait()          # the root has read / rebuilt before the next job overwrites the rows
+            self.barrier.wait(self.timeout_s)          # the root has read / rebuilt before the next job overwrites the rows
             return res
         return fn

@@ -71,7 +71,8 @@ struct Lane { double a, b, c; Segment seg; };
 // that tests/semantics_report.py can run the variants side by side and count the solves each one moves.
 //
 // CILQR_DOT_ORDER -- how the six products of a 6-term dot product are added (2-term sums have one order):
-//   0 "sequential"   ((((t0+t1)+t2)+t3)+t4)+t5 everywhere.  This oracle's default since round 1.
+//   0 "sequential"   ((((t0+t1)+t2)+t3)+t4)+t5 everywhere.  This oracle's default in rounds 1-4; now the variant the
+//                    test-only product twin libcilqr_hip_dotseq.so is held against.
 //   1 "eigen_redux"  (t0+(t1+t2)) + (t3+(t4+t5)) everywhere: a coefficient of a small fixed-size product is
 //                    (lhs.row(i).transpose().cwiseProduct(rhs.col(j))).sum() (Eigen/src/Core/ProductEvaluators.h,
 //                    product_evaluator<..LazyProduct..>::coeff), and sum() of a fixed-size expression unrolls through
@@ -89,7 +90,8 @@ struct Lane { double a, b, c; Segment seg; };
 //                        etor_product_packet_impl: res = pmul(l0, r0); res = pmadd(l_k, r_k, res), k = 1..5, and pmadd
 //                        without FMA is padd(pmul(a, b), c): sequential.
 //                    Best reading of the default x86-64 -O2 build of CMakeLists.txt:9; not executable here.
-// The product kernels (cilqr_amd/csrc/backward_core.hpp) implement order 0.
+//                    THE DEFAULT since round 5, and what the product kernels implement (cilqr_amd/csrc/dev_model.hpp:
+//                    sum6_xty; backward_core.hpp, kernels_load.hip).
 //
 // CILQR_DV_EVAL -- cc:348-352 declare Qu, Quu with `auto`: lazy expressions that hold references to Vx, Vxx.
 //   lazy  (default) cc:383-384 re-evaluate them AFTER cc:379-381 overwrote Vx, Vxx: delta_V_ uses the new value function
@@ -97,7 +99,7 @@ struct Lane { double a, b, c; Segment seg; };
 //   eager delta_V_ uses the Qu, Quu that K and k were computed from (what the author most likely meant; what a
 //         compiler would do if `auto` were a Matrix).  -DCILQR_DV_EVAL_EAGER, also in backward_core.hpp.
 #ifndef CILQR_DOT_ORDER
-#define CILQR_DOT_ORDER 0
+#define CILQR_DOT_ORDER 2
 #endif
 #ifdef CILQR_DV_EVAL_EAGER
 constexpr int kDvEagerDefault = 1;

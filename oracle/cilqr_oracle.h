@@ -48,7 +48,7 @@ enum {
 void oracle_default_config(oracle_config* c, int n_steps);
 
 /* The two unverifiable readings of Eigen's semantics as switches (cilqr_oracle.cc, top): dv_eval 0 = lazy (default),
- * 1 = eager; dot_order 0 = sequential (default), 1 = eigen_redux, 2 = eigen_sse2; negative = unchanged.  Process-wide,
+ * 1 = eager; dot_order 0 = sequential, 1 = eigen_redux, 2 = eigen_sse2 (default); negative = unchanged.  Process-wide,
  * between solves only.  Returns dv_eval | dot_order << 8 as now set. */
 int oracle_set_semantics(int dv_eval, int dot_order);
 /* test hook: a 6-term dot product through this file's MatTMul (transposed_lhs = 1) / MatMul (0) with the order now set */

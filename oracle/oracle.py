@@ -137,12 +137,24 @@ def lib():
     return _LIB
 
 
+DOT_ORDER_SEQUENTIAL, DOT_ORDER_EIGEN_REDUX, DOT_ORDER_EIGEN_SSE2 = 0, 1, 2
+DOT_ORDER_DEFAULT = DOT_ORDER_EIGEN_SSE2      # -DCILQR_DOT_ORDER of cilqr_oracle.cc; what the product kernels implement
+SEMANTICS_DEFAULT = 0 | DOT_ORDER_DEFAULT << 8   # what set_semantics returns with both switches at their defaults
+
+
 def set_semantics(dv_eval: int = -1, dot_order: int = -1) -> int:
     """The oracle's two switches for what cannot be checked against Eigen here (cilqr_oracle.cc, top): dv_eval 0 lazy /
     1 eager, dot_order 0 sequential / 1 eigen_redux / 2 eigen_sse2; negative leaves a switch alone.  Process-wide."""
     L = lib()
     L.oracle_set_semantics.restype = C.c_int
     return L.oracle_set_semantics(C.c_int(dv_eval), C.c_int(dot_order))
+
+
+def reset_semantics() -> int:
+    """Both switches back to the defaults (lazy delta_V_, eigen_sse2 dot order)."""
+    r = set_semantics(0, DOT_ORDER_DEFAULT)
+    assert r == SEMANTICS_DEFAULT, r
+    return r
 
 
 def default_config(n_steps: int = 50, **over) -> OracleConfig:

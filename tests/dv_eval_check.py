@@ -49,9 +49,9 @@ def main():
         o = orc.Oracle(ocfg)
         assert o.set_problem(sc["start"][b], sc["coarse"][b], sc["corridor"][b], sc["ccount"][b], sc["left"], sc["right"]) == 0
         qb = {k: q[k][b] for k in q}
-        orc.set_semantics(0, 0)
+        orc.set_semantics(0, -1)
         oK, ok_, dV_lazy = o.backward(float(lam[b]), qb)
-        orc.set_semantics(1, 0)
+        orc.set_semantics(1, -1)
         oK1, ok1, dV_eager = o.backward(float(lam[b]), qb)
         assert np.array_equal(oK, oK1) and np.array_equal(ok_, ok1)        # the switch touches delta_V_ only
         assert rel_err(Kfb[b], oK, 1e-6) < 1e-9 and rel_err(kff[b], ok_, 1e-6) < 1e-9
@@ -65,9 +65,9 @@ def main():
     sc = scenario.generate("mix11", n, seed=77)
     opt = api.BatchIlqrOptimizer(cfg, batch_capacity=n, cmax=sc["cmax"])
     g = opt.plan(sc, max_iter_trajs=48, alpha_trace=True)
-    orc.set_semantics(1, 0)
+    orc.set_semantics(1, -1)
     rep = assert_steps(g, sc, ocfg, what="eager delta_V build against the eager oracle")
-    orc.set_semantics(0, 0)
+    orc.set_semantics(0, -1)
     opt.close()
     print(json.dumps({"ok": True, "worst_dV_error_vs_eager_oracle": worst_eager, "stage_problems_differing_from_lazy": n_differs_from_lazy,
                       "steps": {k: v for k, v in rep.items() if k != "failed"}}))

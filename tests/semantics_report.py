@@ -4,8 +4,8 @@ What the two UNPINNED readings of Eigen's semantics are worth (VERDICT r03, item
 
 The oracle (oracle/cilqr_oracle.cc) carries two switches for what nothing in this image can check against Eigen 3.4:
   CILQR_DV_EVAL    lazy (default: cc:383-384 re-evaluate the `auto` expressions Qu, Quu on the UPDATED Vx, Vxx) / eager
-  CILQR_DOT_ORDER  sequential (default) / eigen_redux (halving tree, an Eigen build without SIMD) /
-                   eigen_sse2 (X^T * Y products: even/odd packet redux; plain-lhs products: sequential pmadd)
+  CILQR_DOT_ORDER  eigen_sse2 (default since round 5: X^T * Y products: even/odd packet redux; plain-lhs products:
+                   sequential pmadd) / sequential (rounds 1-4) / eigen_redux (halving tree, an Eigen build without SIMD)
 This script solves the same scenes under every variant and reports, per scene family, how many problems move away from
 the default variant by more than the parity tolerance (1e-4: status, iteration count, every accepted step size, every
 Cost row, final trajectory) -- over all problems and over the ORACLE-STABLE ones (those the default oracle reproduces
@@ -13,7 +13,7 @@ itself under a 4e-16 input perturbation, the set the GPU parity gate is held on)
 unstable under that perturbation anyway.  A variant that moves no stable problem is indistinguishable from the default
 at the gate's resolution: whichever reading is right, the verdict of the parity tests is the same.
 
-    python tests/semantics_report.py [problems-per-family]  >  profiles/r04_semantics_sensitivity.json
+    python tests/semantics_report.py [problems-per-family]  >  profiles/r05_semantics_sensitivity.json
 """
 import json
 import os
@@ -27,8 +27,8 @@ import numpy as np  # noqa: E402
 
 FAMILIES = (("ped6", 201), ("mix11", 202), ("demo80", 203), ("dyn20", 204))
 DOT = {"sequential": 0, "eigen_redux": 1, "eigen_sse2": 2}
-VARIANTS = (("dv_lazy+dot_eigen_redux", 0, 1), ("dv_lazy+dot_eigen_sse2", 0, 2), ("dv_eager+dot_sequential", 1, 0),
-            ("dv_eager+dot_eigen_sse2", 1, 2))
+VARIANTS = (("dv_lazy+dot_sequential", 0, 0), ("dv_lazy+dot_eigen_redux", 0, 1), ("dv_eager+dot_eigen_sse2", 1, 2),
+            ("dv_eager+dot_sequential", 1, 0))     # against the default: dv_lazy + dot_eigen_sse2
 
 
 def family_report(family, seed, nb, variants=VARIANTS):
@@ -37,7 +37,7 @@ def family_report(family, seed, nb, variants=VARIANTS):
     from parity_util import PERTURB_EPS, N_PERTURB, REL_TOL, oracle_reference, solution_errors
     sc = scenario.generate(family, nb, seed=seed, workers=8)
     cfg = orc.default_config(sc["n_steps"])
-    assert orc.set_semantics(0, 0) == 0
+    orc.reset_semantics()
     t0 = time.time()
     ref = oracle_reference(sc, cfg)               # default variant + stability mask (8 perturbed re-runs)
     stable = ref["stable"]
@@ -48,7 +48,7 @@ def family_report(family, seed, nb, variants=VARIANTS):
         try:
             r = orc.solve_batch(sc, cfg, want_trace=True)
         finally:
-            orc.set_semantics(0, 0)
+            orc.reset_semantics()
         moved, moved_stable, flow, flow_stable = 0, 0, 0, 0
         worst_stable = 0.0
         errs = []
@@ -78,7 +78,7 @@ def family_report(family, seed, nb, variants=VARIANTS):
 
 
 def build_report(n=1024, families=FAMILIES):
-    rep = {"what": "oracle variants against the default oracle (dv lazy, dot sequential); see tests/semantics_report.py",
+    rep = {"what": "oracle variants against the default oracle (dv lazy, dot eigen_sse2); see tests/semantics_report.py",
            "problems_per_family": n, "families": {}}
     for fam, seed in families:
         rep["families"][fam] = family_report(fam, seed, n)

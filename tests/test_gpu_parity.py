@@ -1274,6 +1274,68 @@ def test_delta_v_evaluation_switch():
     print(f"\neager delta_V build: {rep}")
 
 
+def test_dot_order_switch():
+    """the product sums every `X.transpose() * Y` coefficient of Backward / iqr as the reference's default
+    x86-64 -O2 (SSE2) build of Eigen does, (t0 + (t2 + t4)) + (t1 + (t3 + t5)) (cilqr_amd/csrc/dev_model.hpp: sum6_xty) -- the
+    oracle's default too, so every other parity test of this file holds that reading.  The other reading (index order, what
+    rounds 1-4 shipped) stays built and checked like the eager delta_V: libcilqr_hip_dotseq.so against the oracle's
+    sequential variant, in a child process: tests/dot_order_check.py."""
+    import json
+    import subprocess
+    import sys
+    lib = os.path.join(ROOT, "cilqr_amd", "lib", "libcilqr_hip_dotseq.so")
+    assert os.path.exists(lib), f"{lib} is missing (make -C cilqr_amd/csrc dotseq; __graft_entry__.build() does it)"
+    r = subprocess.run([sys.executable, os.path.join(HERE, "dot_order_check.py")], env=dict(os.environ, CILQR_LIB=lib),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rep["ok"] and rep["steps"]["steps"] > 1000
+    print(f"\nsequential dot-order build: {rep}")
+
+
+def test_backward_gains_follow_the_references_dot_order():
+    """The same statement for the PRODUCT library: fed with identical stage inputs, its gains equal the default (eigen_sse2)
+    oracle's more closely than the sequential oracle's on most problems, in all three mappings (bit-identical to each other)."""
+    from oracle import oracle as orc
+    B = 96
+    sc = scenario.generate("mix11", B, seed=53)
+    opt = _opt(sc)
+    ocfg = oracle_cfg_from(opt.cfg)
+    opt.stage_load(sc)
+    opt.stage_init_guess()
+    opt.stage_quadratize()
+    q = {k: opt.read(t) for k, t in dict(A=api.T_A, B=api.T_B, lx=api.T_LX, lu=api.T_LU, lxx=api.T_LXX, luu=api.T_LUU).items()}
+    lam = np.linspace(0.5, 3.0, B)
+    forms = {}
+    for name, team, wave in (("wave", 4096, 1024), ("team", 4096, 0), ("lane", 0, 0)):
+        opt.set_option(api.OPT_TEAM_THRESHOLD, team)
+        opt.set_option(api.OPT_WAVE_THRESHOLD, wave)
+        opt.stage_backward(lam)
+        forms[name] = (opt.read(api.T_KFB), opt.read(api.T_KFF), opt.read(api.T_DV))
+    for name in ("team", "lane"):
+        for a, b in zip(forms[name], forms["wave"]):
+            assert np.array_equal(a, b), f"{name} and wave mappings differ"
+    Kfb = forms["wave"][0]
+    closer, exact, exact_seq = 0, 0, 0
+    try:
+        for b in range(B):
+            o = orc.Oracle(ocfg)
+            assert o.set_problem(sc["start"][b], sc["coarse"][b], sc["corridor"][b], sc["ccount"][b], sc["left"], sc["right"]) == 0
+            qb = {k: q[k][b] for k in q}
+            orc.set_semantics(-1, orc.DOT_ORDER_SEQUENTIAL)
+            oK0, _, _ = o.backward(float(lam[b]), qb)
+            orc.set_semantics(-1, orc.DOT_ORDER_EIGEN_SSE2)
+            oK2, _, _ = o.backward(float(lam[b]), qb)
+            closer += int(np.abs(Kfb[b] - oK2).max() < np.abs(Kfb[b] - oK0).max())
+            exact += int(np.array_equal(Kfb[b], oK2))
+            exact_seq += int(np.array_equal(Kfb[b], oK0))
+    finally:
+        orc.reset_semantics()
+    print(f"\ngains of {B} problems: closer to the eigen_sse2 oracle {closer}, bit-equal to it {exact}, bit-equal to the sequential oracle {exact_seq}")
+    assert closer >= B // 2 and exact >= exact_seq, (closer, exact, exact_seq)
+    opt.close()
+
+
 def test_speculative_line_search_is_bit_identical_to_round_by_round(lockstep_only):
     """Small active sets evaluate all 11 step sizes at once; the first passing index must win exactly
     as in the sequential loop (ilqr_optimizer.cc:246-265), so both modes give the same bits."""

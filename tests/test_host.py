@@ -293,6 +293,10 @@ def test_bench_rehearses_configs3_at_eight_ranks_without_a_gpu():
         assert rec["gathers"] == 5 and rec["gather_in_rank_order"] is True and rec["gathers_in_step_order"] is True, (name, rec)
         assert rec["ragged_history_rows_ok"] is True and rec["gather_checks_ok"] is True, (name, rec)
         assert rec["mode"] == ("multi" if name == "multi" else "ranks") and rec["spawned_by_bench"] is (name == "spawned")
+        # the host budget of the real run: eight ranks generate their scenes at the same time, so the
+        # generator's worker processes are capped by the cores the box grants -- its CPU quota where there is one -- per rank
+        cores = min(rec["logical_cpus"], int(rec["cpu_quota_cores"])) if rec["cpu_quota_cores"] else rec["logical_cpus"]
+        assert 1 <= rec["scene_workers_per_rank"] <= max(1, cores // 8), (name, rec)
     # mismatches are errors, never a smaller run: the launcher started 2 ranks for --gpus 8; --multi under a launcher
     r = subprocess.run([sys.executable, bench, "--gpus", "8", "--dry-run"], env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"),
                        capture_output=True, text=True, timeout=120)

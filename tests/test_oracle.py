@@ -306,13 +306,13 @@ def test_dot_order_switch_adds_six_terms_in_the_documented_orders():
                 assert L.oracle_dot6(a.ctypes.data, b.ctypes.data, 0) == plain, order
                 assert L.oracle_dot6(a.ctypes.data, b.ctypes.data, 1) == transposed, order
     finally:
-        assert orc.set_semantics(0, 0) == 0
+        orc.reset_semantics()
     assert n_diff > 1000          # the orders do round differently on such data
 
 
 def test_semantics_switches_move_only_what_they_should():
     """dv_eval touches delta_V_ and nothing else of a backward pass; a dot order moves gains by rounding only; the defaults
-    (lazy, sequential) are what the golden fixtures were made with (test_oracle_reproduces_golden runs on them)."""
+    (lazy, eigen_sse2) are what the golden fixtures were made with (test_oracle_reproduces_golden runs on them)."""
     g = np.load(os.path.join(HERE, "golden", "mix11_n50.npz"))
     o = orc.Oracle(n_steps=int(g["n_steps"]))
     o.set_problem(g["start"][0], g["coarse"][0], g["corridor"][0], g["ccount"][0], g["left"], g["right"])
@@ -320,12 +320,12 @@ def test_semantics_switches_move_only_what_they_should():
     q = o.quadratize(X, U)
     K0, k0, dV0 = o.backward(1.0, q)
     try:
-        assert orc.set_semantics(1, -1) == 1
+        assert orc.set_semantics(1, -1) == (1 | orc.DOT_ORDER_DEFAULT << 8)
         K1, k1, dV1 = o.backward(1.0, q)
         assert np.array_equal(K0, K1) and np.array_equal(k0, k1)
         assert np.all(np.abs(dV1 - dV0) > 1e-9 * np.abs(dV0))            # a different quantity, not a rounding
         orc.set_semantics(0, -1)
-        for order in (1, 2):
+        for order in (orc.DOT_ORDER_SEQUENTIAL, orc.DOT_ORDER_EIGEN_REDUX):
             orc.set_semantics(-1, order)
             K2, k2, dV2 = o.backward(1.0, q)
             assert not np.array_equal(K0, K2)
@@ -333,6 +333,6 @@ def test_semantics_switches_move_only_what_they_should():
             X2, _ = o.init_guess()
             assert np.abs(X2 - X).max() < 1e-9
     finally:
-        assert orc.set_semantics(0, 0) == 0
+        orc.reset_semantics()
     K3, k3, dV3 = o.backward(1.0, q)
     assert np.array_equal(K3, K0) and np.array_equal(dV3, dV0)
