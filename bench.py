@@ -73,6 +73,24 @@ def native_thread_count():
     return None
 
 
+def thread_cpu_seconds():
+    """{tid: (name, user + system CPU seconds)} of every native thread of this process (/proc/self/task/*/stat)."""
+    out = {}
+    try:
+        tick = os.sysconf("SC_CLK_TCK")
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                raw = open(f"/proc/self/task/{tid}/stat").read()
+            except OSError:
+                continue
+            name = raw[raw.index("(") + 1:raw.rindex(")")]
+            f = raw[raw.rindex(")") + 2:].split()
+            out[int(tid)] = (name, (int(f[11]) + int(f[12])) / tick)      # utime, stime
+    except Exception:   # noqa: BLE001
+        pass
+    return out
+
+
 def cpu_seconds():
     """user + system CPU seconds of this process, all threads (RUSAGE_SELF)."""
     import resource
@@ -798,6 +816,7 @@ def run(args, rank, local_rank, world, comm, real_stdout):
     if use_dist:
         gatherer.reset_stats()
     cpu0 = cpu_seconds()
+    thr0 = thread_cpu_seconds()
     t_start = time.perf_counter()
     run_steps(args.steps, True)
     fence()
@@ -806,6 +825,14 @@ def run(args, rank, local_rank, world, comm, real_stdout):
     # gather thread, RCCL's proxy -- burn per step, so that N ranks can be budgeted against the box's CPU quota
     cpu_rank = cpu_seconds() - cpu0
     n_threads = native_thread_count()
+    thr1 = thread_cpu_seconds()
+    by_thread = sorted(((name, round((c - thr0.get(tid, (name, 0.0))[1]) / max(elapsed, 1e-9), 3)) for tid, (name, c) in thr1.items()),
+                       key=lambda t: -t[1])
+    by_name = {}
+    for name, cores in by_thread:     # threads of one kind (the handles' workers, RCCL's proxies ...) summed
+        k = by_name.setdefault(name, [0, 0.0])
+        k[0] += 1
+        k[1] = round(k[1] + cores, 3)
     gather_timed = dict(busy_s=gatherer.busy_s, count=gatherer.count) if use_dist else None
     if use_rccl:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -829,6 +856,8 @@ def run(args, rank, local_rank, world, comm, real_stdout):
         "cores_busy_all_ranks": round(cpu_sum / elapsed, 3), "cpu_quota_cores": quota, "logical_cpus": os.cpu_count(),
         "quota_fraction": (round(cpu_sum / elapsed / quota, 4) if quota else None),
         "native_threads_this_rank": n_threads, "scene_workers_per_rank": workers,
+        # cores kept busy per KIND of thread of this rank's process over the timed region: [threads, cores]
+        "cores_busy_by_thread_name": {k: v for k, v in sorted(by_name.items(), key=lambda kv: -kv[1][1])[:8] if v[1] > 0.0},
         "note": "resource.getrusage(RUSAGE_SELF) around the timed region, per rank (a process; with --multi the one process "
                 "is measured once and divided by the ranks for the per-rank figure); threads = /proc/self/status",
     }

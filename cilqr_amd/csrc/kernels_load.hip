@@ -51,9 +51,18 @@ __global__ __launch_bounds__(256) void k_load_corridor(DeviceState s, int B, Pro
       cc = cc - s.p.shrink_corridor * (a * a + b * b) / hypot_ref(a, b);   // cc:448
       const double nrm = hypot_ref(hypot_ref(a, b), cc);                       // cc:479
       double* o = s.cor + ((size_t)(i * s.cmax + c) * 3) * s.Bcap + slot;
-      o[0] = a / nrm;
-      o[(size_t)s.Bcap] = b / nrm;
-      o[(size_t)2 * s.Bcap] = cc / nrm;
+      double pa = a / nrm, pbn = b / nrm, pc = cc / nrm;
+      // A live plane with a NaN / Inf coefficient: in the reference every barrier value of it is non-finite
+      // (barrier_function.h:104-113 on a NaN argument), the first TotalCost (cc:172) with it, every trial's z is NaN
+      // (cc:255-258) and the solve leaves through lambda > 1e11 (cc:298-307).  The branch-free barrier of the cost kernels
+      // takes max(-g, eps), which would DROP a NaN; such a plane is kept as (0, 0, -inf) instead -- g = +inf at every disc,
+      // a barrier value of +inf: non-finite like the reference's, so every decision is the reference's (tested).
+      if (!(__builtin_isfinite(pa) && __builtin_isfinite(pbn) && __builtin_isfinite(pc))) {
+        pa = 0.0; pbn = 0.0; pc = -__builtin_huge_val();
+      }
+      o[0] = pa;
+      o[(size_t)s.Bcap] = pbn;
+      o[(size_t)2 * s.Bcap] = pc;
     }
   }
 }

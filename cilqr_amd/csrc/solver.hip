@@ -5,6 +5,9 @@
 // stream and reads back the active-problem count once per lockstep iteration.
 #include <hip/hip_runtime.h>
 
+#include <pthread.h>
+
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <cstdio>
@@ -225,6 +228,56 @@ int job_iterate(cilqr_solver* h, cilqr_job& j, int stage);
 int job_finish(cilqr_solver* h, cilqr_job& j);
 void release_fin(cilqr_solver* h, cilqr_job& j);
 
+// ------------------------------------------------------------------------------------------
+// Host waits.  hipEventSynchronize / hipStreamSynchronize SPIN: the waiting thread keeps a core at 100 % until the GPU
+// signals.  Right for the synchronous call -- its thread has nothing else to do, and the drop-in Plan is a 1 ms call where a
+// late wake-up is a measurable share -- and wrong for submitted solves: the two workers of a handle sit in such a wait
+// nearly all the time (the host runs two iterations ahead of the GPU), so a pool of two handles burned 4.4 cores per rank
+// (measured, profiles/r05_host_cpu.json) and eight ranks would have needed 35 of the 16 cores the GPU boxes grant.
+// Submitted solves therefore poll: a query, a short spin for waits that are nearly over, then naps.  A nap that ends late
+// costs nothing as long as it is shorter than an iteration -- the stream still holds the next one (kLead = 2).
+// CILQR_HOST_WAIT=spin / nap overrides the choice for both kinds of call (measurement hook).
+// ------------------------------------------------------------------------------------------
+constexpr int kWaitSpinUs = 20, kWaitNapUs = 50;
+int host_wait_override() {
+  static const int v = [] {
+    const char* e = std::getenv("CILQR_HOST_WAIT");
+    if (e == nullptr) return -1;
+    return (e[0] == 'n' || e[0] == '1') ? 1 : 0;
+  }();
+  return v;
+}
+int wait_event(hipEvent_t ev, bool relaxed) {
+  const int ov = host_wait_override();
+  if (ov >= 0) relaxed = ov != 0;
+  if (!relaxed) {
+    HIP_TRY(hipEventSynchronize(ev));
+    return CILQR_OK;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t e = hipEventQuery(ev);
+    if (e == hipSuccess) return CILQR_OK;
+    if (e != hipErrorNotReady) {
+      HIP_TRY(e);
+      return CILQR_ERR_DEVICE;
+    }
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(kWaitSpinUs))
+      std::this_thread::sleep_for(std::chrono::microseconds(kWaitNapUs));
+  }
+}
+// everything enqueued on `st` so far; `scratch` is an event of the caller's that nothing else is waiting on
+int wait_stream(hipStream_t st, hipEvent_t scratch, bool relaxed) {
+  const int ov = host_wait_override();
+  if (ov >= 0) relaxed = ov != 0;
+  if (!relaxed || scratch == nullptr) {
+    HIP_TRY(hipStreamSynchronize(st));
+    return CILQR_OK;
+  }
+  HIP_TRY(hipEventRecord(scratch, st));
+  return wait_event(scratch, true);
+}
+
 }  // namespace
 
 bool cilqr_timer::on() const { return h->profiling; }
@@ -444,6 +497,7 @@ int cilqr_create(const cilqr_config* cfg, int32_t device, int32_t batch_capacity
     if (rc == CILQR_OK && hipHostGetDevicePointer(reinterpret_cast<void**>(&js.h_count_dev), js.h_count, 0) != hipSuccess)
       rc = CILQR_ERR_DEVICE;
     if (rc == CILQR_OK && hipEventCreateWithFlags(&js.handoff, hipEventDisableTiming) != hipSuccess) rc = CILQR_ERR_DEVICE;
+    if (rc == CILQR_OK && hipEventCreateWithFlags(&js.sync_ev, hipEventDisableTiming) != hipSuccess) rc = CILQR_ERR_DEVICE;
   }
   if (rc == CILQR_OK) {   // the stage API works on the main arena with the first set
     const DeviceState v = main_view(h, h->sets[0]);
@@ -497,6 +551,7 @@ int cilqr_destroy(cilqr_handle h) {
     for (hipEvent_t e : js.ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : js.iter_ev) (void)hipEventDestroy(e);
     if (js.handoff) (void)hipEventDestroy(js.handoff);
+    if (js.sync_ev) (void)hipEventDestroy(js.sync_ev);
   }
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   if (h->stream2) (void)hipStreamDestroy(h->stream2);
@@ -632,6 +687,7 @@ static int solve_sync(cilqr_solver* h, const cilqr_problem_batch* in, cilqr_solu
   j.tail_threshold = h->tail_threshold;
   j.st1 = h->stream;
   j.st2 = h->stream;
+  j.relaxed_wait = false;    // the caller's own thread waits, and the call's latency is what it is measured by (wait_event)
   const int rc = solve_groups(h, j, in, out);
   std::lock_guard<std::mutex> lk(h->mu);
   h->prof = j.prof;
@@ -840,7 +896,7 @@ int job_iterate(cilqr_solver* h, cilqr_job& j, int stage) {
   int& n_hint = j.n_hint;
   for (; it < M; ++it) {                               // cc:201
     if (it >= kLead) {
-      HIP_TRY(hipEventSynchronize(js.iter_ev[it - kLead]));
+      if (int wrc = wait_event(js.iter_ev[it - kLead], j.relaxed_wait)) return wrc;
       n_hint = js.h_count[it - kLead];
       if (n_hint == 0) break;                          // iterations it-kLead+1 .. it-1 were no-ops
     }
@@ -967,7 +1023,7 @@ int job_finish(cilqr_solver* h, cilqr_job& j) {
     }
     if (out->alpha_trace) HIP_TRY(hipMemcpyAsync(out->alpha_trace, j.o_at, j.n_at, hipMemcpyDeviceToHost, st));
   }
-  HIP_TRY(hipStreamSynchronize(st));
+  if (int wrc = wait_stream(st, js.sync_ev, j.relaxed_wait)) return wrc;
   int it = j.it;
   {  // lockstep iterations that had work, and the problem-steps each backward launch covered
     int used = 0;
@@ -1012,7 +1068,7 @@ int job_finish(cilqr_solver* h, cilqr_job& j) {
           more = true;
         }
       }
-      if (more) HIP_TRY(hipStreamSynchronize(st));
+      if (more) { if (int wrc = wait_stream(st, js.sync_ev, j.relaxed_wait)) return wrc; }
     }
     std::memcpy(out->traj, pin, j.n_traj * 8);
     {  // cost rows: the live ones; the rest of the caller's array is zero, as on every host path
@@ -1056,6 +1112,7 @@ void release_fin(cilqr_solver* h, cilqr_job& j) {
 // stragglers of solve i finish while the bulk of solve i+1 is being iterated.
 // ------------------------------------------------------------------------------------------
 void worker1_main(cilqr_solver* h) {
+  (void)pthread_setname_np(pthread_self(), "cilqr-stage1");
   (void)hipSetDevice(h->device);
   std::unique_lock<std::mutex> lk(h->mu);
   for (;;) {
@@ -1099,6 +1156,7 @@ void worker1_main(cilqr_solver* h) {
 }
 
 void worker2_main(cilqr_solver* h) {
+  (void)pthread_setname_np(pthread_self(), "cilqr-finish");
   (void)hipSetDevice(h->device);
   std::unique_lock<std::mutex> lk(h->mu);
   for (;;) {
@@ -1149,6 +1207,7 @@ int cilqr_submit(cilqr_handle h, const cilqr_problem_batch* in, cilqr_solution_b
   j.tail_threshold = h->alone_on_device ? h->tail_threshold : h->tail_threshold_submit;
   j.st1 = h->stream;
   j.st2 = h->stream2;
+  j.relaxed_wait = true;     // a worker thread waits for this solve, and other solves want the cores (wait_event)
   j.rc = CILQR_OK;
   j.err_text[0] = 0;
   j.phase = 1;

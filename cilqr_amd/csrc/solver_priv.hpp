@@ -59,6 +59,7 @@ struct cilqr_job_set {
   std::vector<hipEvent_t> iter_ev;  // one per lockstep iteration (count read-back)
   std::vector<hipEvent_t> ev;       // profiling
   hipEvent_t handoff = nullptr;     // survivors copied into the finishing arena (recorded on the first stage's stream)
+  hipEvent_t sync_ev = nullptr;     // what a relaxed host wait for a whole stream polls (solver.hip: wait_stream)
 };
 
 struct cilqr_timer {  // event pairs around kernels / phases, resolved after the final sync
@@ -108,6 +109,7 @@ struct cilqr_job {
   size_t n_traj = 0, n_hist = 0, n_itr = 0, n_at = 0;
   size_t n_head = 0;        // bytes of the staging block in front of the iterates (traj, cost_hist, counts, alpha_trace, pad)
   bool small_out = false;   // host outputs small enough to travel through the pinned block
+  bool relaxed_wait = false;  // the host waits of this solve poll and nap instead of spinning (solver.hip: wait_event)
 };
 
 struct cilqr_solver {

@@ -32,6 +32,13 @@ class OracleConfig(C.Structure):
 
 
 def build(force: bool = False) -> str:
+    # CILQR_ORACLE_LIB: another build of the same sources (oracle/Makefile `asan`: liboracle_asan.so, AddressSanitizer +
+    # UndefinedBehaviorSanitizer; the process must then run with the sanitizer runtime preloaded, tests/test_oracle.py)
+    alt = os.environ.get("CILQR_ORACLE_LIB")
+    if alt:
+        if not os.path.exists(alt):
+            raise RuntimeError(f"CILQR_ORACLE_LIB={alt} does not exist (make -C oracle asan)")
+        return alt
     so = os.path.join(_HERE, "liboracle.so")
     srcs = [os.path.join(_HERE, f) for f in ("cilqr_oracle.cc", "corridor_oracle.cc", "dp_oracle.cc", "tracker_oracle.cc")]
     if force or not os.path.exists(so) or any(

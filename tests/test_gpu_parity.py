@@ -374,6 +374,129 @@ def test_exit_paths(over, expect, both_paths):
     opt.close()
 
 
+# ---------------------------------------------------------------------------------------------
+# hostile inputs (VERDICT r04 missing #4): what the reference's arithmetic does with NaN / Inf, inside a batch
+# ---------------------------------------------------------------------------------------------
+def _poison_cases(cmax):
+    """(problem index, what, how).  Every one of them makes the reference's first TotalCost non-finite (cc:172), so every trial
+    of every iteration is rejected -- z = dcost / expected is NaN, cc:255-258 -- and the solve leaves through lambda > 1e11
+    after ten iterations (cc:298-307) with one Cost row and the init guess as its trajectory; a NaN behind a knot's live
+    plane count is never read."""
+    return [
+        (11, "start x NaN", lambda s, b: s["start"].__setitem__((b, 0), np.nan)),
+        (37, "start x +Inf", lambda s, b: s["start"].__setitem__((b, 0), np.inf)),
+        (58, "start v NaN", lambda s, b: s["start"].__setitem__((b, 3), np.nan)),
+        (64, "coarse[20].x NaN", lambda s, b: s["coarse"].__setitem__((b, 20, 0), np.nan)),
+        (65, "coarse[20].x +Inf", lambda s, b: s["coarse"].__setitem__((b, 20, 0), np.inf)),
+        (99, "coarse[N].y NaN", lambda s, b: s["coarse"].__setitem__((b, -1, 1), np.nan)),
+        (127, "coarse[20].theta -Inf", lambda s, b: s["coarse"].__setitem__((b, 20, 2), -np.inf)),
+        (128, "plane a NaN", lambda s, b: s["corridor"].__setitem__((b, 10, 0, 0), np.nan)),
+        (191, "plane c +Inf", lambda s, b: s["corridor"].__setitem__((b, 10, 0, 2), np.inf)),
+        (192, "plane c -Inf", lambda s, b: s["corridor"].__setitem__((b, 30, 1, 2), -np.inf)),
+        (255, "plane b NaN, last knot", lambda s, b: s["corridor"].__setitem__((b, -1, 2, 1), np.nan)),
+        (299, "NaN behind the live planes", lambda s, b: s["corridor"].__setitem__((b, 10, cmax - 1, 0), np.nan)),
+    ]
+
+
+def _same_or_both_nonfinite(a, b, tol, what):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    fa, fb = np.isfinite(a), np.isfinite(b)
+    assert np.array_equal(fa, fb), f"{what}: finite / non-finite pattern differs"
+    if fa.any():
+        scale = max(1.0, float(np.abs(b[fb]).max()))
+        assert float(np.abs(a[fa] - b[fb]).max()) <= tol * scale, what
+
+
+def test_hostile_inputs_inside_a_batch(both_paths):
+    """One NaN / Inf problem of every kind inside a batch of 300 (start, coarse knot, plane coefficient): status, iteration
+    count and Cost-row count as the oracle's on the same poisoned inputs (UNSOLVED after ten iterations), the trajectory =
+    the init guess with the oracle's finite / non-finite pattern, a non-finite Cost total and every category the oracle has finite; every other
+    problem of the batch bit-identical to the same batch without the poisoned problems; no hang."""
+    B = 300
+    clean = scenario.generate("mix11", B, seed=97)
+    assert (clean["ccount"][:, [10, 30, -1]] >= 3).all() and (clean["ccount"][299, 10] < clean["cmax"])
+    opt = _opt(clean)
+    g0 = _plan(opt, clean)
+    sc = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in clean.items()}
+    cases = _poison_cases(clean["cmax"])
+    for b, _, f in cases:
+        f(sc, b)
+    g1 = _plan(opt, sc)
+    bad = np.zeros(B, bool)
+    bad[[b for b, _, _ in cases[:-1]]] = True          # the last case poisons nothing that is read
+    for k in ("traj", "cost_hist", "status", "n_cost", "n_iter"):
+        assert np.array_equal(g1[k][~bad], g0[k][~bad]), f"{k}: a finite neighbour changed"
+    ocfg = oracle_cfg_from(opt.cfg)
+    sub = {k: (np.ascontiguousarray(v[bad]) if isinstance(v, np.ndarray) and v.shape[:1] == (B,) else v) for k, v in sc.items()}
+    ref = orc.solve_batch(sub, ocfg)
+    idx = np.nonzero(bad)[0]
+    assert (ref["status"] == api.ST_UNSOLVED).all() and (ref["n_cost"] == 1).all() and (ref["n_iter"] == 10).all()
+    for j, b in enumerate(idx):
+        what = [w for i, w, _ in cases if i == b][0]
+        assert g1["status"][b] == ref["status"][j] and g1["n_cost"][b] == ref["n_cost"][j] and g1["n_iter"][b] == ref["n_iter"][j], \
+            (what, g1["status"][b], g1["n_cost"][b], g1["n_iter"][b])
+        _same_or_both_nonfinite(g1["traj"][b], ref["traj"][j], 1e-9, f"{what}: trajectory")
+        # the only Cost row: its total is non-finite on both sides (that is what rejects every trial).  Category by category
+        # the library may be finite where the reference is NaN: the branch-free barrier takes max(-g, eps) (dev_model.hpp),
+        # which drops the NaN of a constraint evaluated at a NaN *state* -- that state's J term carries the NaN into the total
+        # instead.  Never the other way round, and finite on both sides means equal.
+        row, rrow = g1["cost_hist"][b, 0], ref["cost_hist"][j, 0]
+        assert not np.isfinite(row[0]) and not np.isfinite(rrow[0]), (what, row, rrow)
+        for c in range(1, 5):
+            if np.isfinite(rrow[c]):
+                assert np.isfinite(row[c]) and abs(row[c] - rrow[c]) <= 1e-9 * max(1.0, abs(rrow[c])), (what, c, row, rrow)
+    opt.close()
+
+
+def test_hostile_lane_tables(both_paths):
+    """A NaN in a lane point: the two segments that touch it have NaN distances, the strict `<` of cc:610-613 never picks
+    them, and the solve goes on with the others -- oracle and library alike."""
+    sc = scenario.generate("mix11", 64, seed=98)
+    sc["left"] = sc["left"].copy()
+    sc["left"][7, 0] = np.nan
+    opt = _opt(sc)
+    g = _plan(opt, sc)
+    ocfg = oracle_cfg_from(opt.cfg)
+    ref = oracle_reference(sc, ocfg)
+    assert_parity(g, ref, max_unstable_frac=0.125, what="one NaN lane point")
+    assert_steps(g, sc, ocfg, what="one NaN lane point")
+    assert np.isfinite(g["traj"]).all()
+    # no finite lane end point at all: the reference's loop indexes [-1] (undefined behaviour; the oracle takes segment 0 and
+    # ends UNSOLVED).  The boundary refuses the call instead -- there is no box to build the lane grid over
+    sc["left"] = np.full_like(sc["left"], np.nan)
+    sc["right"] = np.full_like(sc["right"], np.nan)
+    with pytest.raises(api.CilqrError) as e:
+        _plan(opt, sc)
+    assert e.value.code == api.ERR_ARG
+    ref = orc.solve_batch(sc, ocfg)
+    assert (ref["status"] == api.ST_UNSOLVED).all() and (ref["n_iter"] == 10).all()
+    opt.close()
+
+
+def test_degenerate_limits(both_paths):
+    """max_iter = 1 (the smallest the boundary accepts; 0 is CILQR_ERR_ARG like every other non-positive size) and a batch whose
+    every knot has a plane count of 0 (no corridor term at all, cc:560-581 loop bodies never run)."""
+    sc = scenario.generate("ped6", 40, seed=99)
+    with pytest.raises(api.CilqrError):
+        _opt(sc, max_iter=0)
+    opt = _opt(sc, max_iter=1)
+    g = _plan(opt, sc)
+    ocfg = oracle_cfg_from(opt.cfg)
+    ref = oracle_reference(sc, ocfg)
+    assert_parity(g, ref, max_unstable_frac=0.125, what="max_iter = 1")
+    assert set(np.unique(g["status"])) <= {api.ST_MAX_ITER, api.ST_CONVERGED_ABS, api.ST_CONVERGED_REL}
+    opt.close()
+    sc["ccount"] = np.zeros_like(sc["ccount"])
+    opt = _opt(sc)
+    g = _plan(opt, sc)
+    ocfg = oracle_cfg_from(opt.cfg)
+    ref = oracle_reference(sc, ocfg)
+    assert_parity(g, ref, max_unstable_frac=0.125, what="no corridor planes")
+    assert_steps(g, sc, ocfg, what="no corridor planes")
+    assert (g["cost_hist"][:, 0, 3] == 0.0).all()          # the corridor category of every Cost row is an empty sum
+    opt.close()
+
+
 def test_ragged_counts_single_problem_and_odd_batches(both_paths):
     sc = scenario.generate("mix11", 130, seed=61)
     # ragged corridor: drop to the 4 box planes on some knots, keep everything on others

@@ -336,3 +336,29 @@ def test_semantics_switches_move_only_what_they_should():
         orc.reset_semantics()
     K3, k3, dV3 = o.backward(1.0, q)
     assert np.array_equal(K3, K0) and np.array_equal(dV3, dV0)
+
+
+def test_oracle_under_address_and_ub_sanitizers():
+    """SURVEY 5 / VERDICT r04 item 8: the restatement built with -fsanitize=address,undefined (`make -C oracle asan`) re-runs
+    this file's tests, the parity rules and the CPU part of the reference pins in a python that has the sanitizer runtime
+    preloaded: no report, every test green.  (The reference itself has no sanitizer configuration: CMakeLists.txt:9.)"""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    if os.environ.get("CILQR_ORACLE_LIB"):
+        pytest.skip("already the sanitizer run")
+    r = subprocess.run(["make", "-C", os.path.join(root, "oracle"), "-s", "asan"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    assert os.path.isabs(asan) and os.path.exists(asan), f"no libasan.so next to gcc ({asan!r})"
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="print_stacktrace=1",
+               CILQR_ORACLE_LIB=os.path.join(root, "oracle", "liboracle_asan.so"))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", "-m", "not gpu",
+                        os.path.join(here, "test_oracle.py"), os.path.join(here, "test_parity_rules.py"),
+                        os.path.join(here, "test_reference_pins.py")],
+                       env=env, capture_output=True, text=True, timeout=1500)
+    tail = (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0, tail
+    assert "AddressSanitizer" not in r.stdout + r.stderr and "runtime error:" not in r.stdout + r.stderr, tail
+    assert " passed" in r.stdout, tail
