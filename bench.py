@@ -858,6 +858,7 @@ def run(args, rank, local_rank, world, comm, real_stdout):
         "native_threads_this_rank": n_threads, "scene_workers_per_rank": workers,
         # cores kept busy per KIND of thread of this rank's process over the timed region: [threads, cores]
         "cores_busy_by_thread_name": {k: v for k, v in sorted(by_name.items(), key=lambda kv: -kv[1][1])[:8] if v[1] > 0.0},
+        "busiest_threads": [[name, cores] for name, cores in by_thread[:6] if cores > 0.0],
         "note": "resource.getrusage(RUSAGE_SELF) around the timed region, per rank (a process; with --multi the one process "
                 "is measured once and divided by the ranks for the per-rank figure); threads = /proc/self/status",
     }

@@ -633,6 +633,13 @@ CILQR_DEV int scratch_index(const DeviceState& s, int slot) { return s.posn ? s.
 CILQR_DEV int active_count(const DeviceState& s, int n_host) {
   return s.n_dev ? min(*s.n_dev, n_host) : n_host;
 }
+// entries a pass over a device-side list takes: the list's count (n_ptr) less the `off` entries earlier passes took,
+// at most n_max; no list count = the active list
+CILQR_DEV int list_count(const DeviceState& s, const int* __restrict__ n_ptr, int off, int n_max) {
+  if (n_ptr == nullptr) return active_count(s, n_max);
+  const int left = *n_ptr - off;
+  return left < 0 ? 0 : (left < n_max ? left : n_max);
+}
 
 // small helpers for the batch-fastest pair layout
 CILQR_DEV double2 ld2(const double2* __restrict__ base, int row, int Bcap, int slot) {

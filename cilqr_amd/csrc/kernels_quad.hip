@@ -89,9 +89,9 @@ extern "C" void cilqr_debug_cost_profile(unsigned long long* out, int reset) {  
 // speculative line search: knot i of candidate alpha_{r0 + blockIdx.z} of list entry j
 template <int D, bool EX>
 __global__ __launch_bounds__(256) CILQR_COST_ATTR void k_spec_cost(DeviceState s, const int* __restrict__ list,
-                                                   const int* __restrict__ n_ptr, int n_max, int r0) {
+                                                   const int* __restrict__ n_ptr, int off, int n_max, int r0) {
   extern __shared__ double lds[];
-  const int n = n_ptr ? min(*n_ptr, n_max) : active_count(s, n_max);
+  const int n = list_count(s, n_ptr, off, n_max);   // `list` points at entry `off` already
   if ((int)(blockIdx.x * blockDim.x) >= n) return;
   const double* lanes = stage_lanes(s, lds);
   const int i = blockIdx.y, r = r0 + blockIdx.z;
@@ -118,10 +118,10 @@ __global__ __launch_bounds__(256) CILQR_COST_ATTR void k_spec_cost(DeviceState s
 // packed, the same knot costs are 4.6x faster (measured: 897 -> 155 us in the first iteration of the bench batch).
 template <int D, int P, bool EX>
 __global__ __launch_bounds__(256) CILQR_COST_ATTR void k_spec_cost_packed(DeviceState s, const int* __restrict__ list,
-                                                                          const int* __restrict__ n_ptr, int n_max,
+                                                                          const int* __restrict__ n_ptr, int off, int n_max,
                                                                           int r0, int r_end) {
   extern __shared__ double lds[];
-  const int n = n_ptr ? min(*n_ptr, n_max) : active_count(s, n_max);
+  const int n = list_count(s, n_ptr, off, n_max);
   constexpr int per_block = 256 / P;
   if ((int)(blockIdx.x * per_block) >= n) return;
   const double* lanes = stage_lanes(s, lds);
@@ -147,13 +147,13 @@ __global__ __launch_bounds__(256) CILQR_COST_ATTR void k_spec_cost_packed(Device
 // (eight, then four for what is left), so what depends on the problem and the knot only -- corridor planes, goal --
 // travels once per group instead of once per candidate; for the sparse pending list of the hybrid schedule this is
 // also what keeps a load instruction from touching 64 different cache lines.
-void launch_spec_cost(const DeviceState& s, const int* list, const int* n_ptr, int n_max, int n_grid, int r0,
+void launch_spec_cost(const DeviceState& s, const int* list, const int* n_ptr, int off, int n_max, int n_grid, int r0,
                       int sparse, hipStream_t st) {
   const size_t lds = lane_lds_bytes(s);
   const bool five = s.p.num_of_disc == 5;
   if (!sparse) {   // a dense list: one lane per problem is already coalesced, one grid layer per candidate (measured: 2 % faster)
     dim3 g((n_grid + 255) / 256, s.p.K, kNumAlpha - r0);
-    CILQR_LAUNCH_BY_DISCS(k_spec_cost, g, dim3(256), lds, st, s, list, n_ptr, n_max, r0);
+    CILQR_LAUNCH_BY_DISCS(k_spec_cost, g, dim3(256), lds, st, s, list, n_ptr, off, n_max, r0);
     return;
   }
   for (int a = r0; a < kNumAlpha;) {
@@ -162,7 +162,7 @@ void launch_spec_cost(const DeviceState& s, const int* list, const int* n_ptr, i
     const int e = a + (P < left ? P : left);
     const int per_block = 256 / P;
     dim3 g((n_grid + per_block - 1) / per_block, s.p.K);
-#define CILQR_SC1(DD, PP, EE) hipLaunchKernelGGL((k_spec_cost_packed<DD, PP, EE>), g, dim3(256), lds, st, s, list, n_ptr, n_max, a, e)
+#define CILQR_SC1(DD, PP, EE) hipLaunchKernelGGL((k_spec_cost_packed<DD, PP, EE>), g, dim3(256), lds, st, s, list, n_ptr, off, n_max, a, e)
 #define CILQR_SC(DD, PP) do { if (s.exact_ties) CILQR_SC1(DD, PP, true); else CILQR_SC1(DD, PP, false); } while (0)
     if (P == 8) { if (five) CILQR_SC(5, 8); else CILQR_SC(0, 8); }
     else if (P == 4) { if (five) CILQR_SC(5, 4); else CILQR_SC(0, 4); }

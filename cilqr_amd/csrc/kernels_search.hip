@@ -89,8 +89,8 @@ __global__ __launch_bounds__(64) CILQR_ROLL_ATTR void k_search_round(DeviceState
 // trajectory and the gains of a step (11 pairs, the same for every step size) are read once per eight lanes
 // (see k_spec_cost_packed in kernels_quad.hip)
 __global__ __launch_bounds__(64) CILQR_ROLL_ATTR void k_spec_forward_packed(DeviceState s, const int* __restrict__ list,
-                                                            const int* __restrict__ n_ptr, int n_max, int r0) {
-  const int n = n_ptr ? min(*n_ptr, n_max) : active_count(s, n_max);
+                                                            const int* __restrict__ n_ptr, int off, int n_max, int r0) {
+  const int n = list_count(s, n_ptr, off, n_max);   // `list` points at entry `off` of the device-side list already
   constexpr int per_block = 64 / 8;
   const int r = r0 + (threadIdx.x & 7);
   if (r >= kNumAlpha) return;
@@ -101,8 +101,8 @@ __global__ __launch_bounds__(64) CILQR_ROLL_ATTR void k_spec_forward_packed(Devi
 }
 
 __global__ __launch_bounds__(64) CILQR_ROLL_ATTR void k_spec_forward(DeviceState s, const int* __restrict__ list,
-                                                     const int* __restrict__ n_ptr, int n_max, int r0, int open) {
-  const int n = n_ptr ? min(*n_ptr, n_max) : active_count(s, n_max);
+                                                     const int* __restrict__ n_ptr, int off, int n_max, int r0, int open) {
+  const int n = list_count(s, n_ptr, off, n_max);
   const int r = r0 + blockIdx.y;
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
     const int slot = list[j];
@@ -121,8 +121,8 @@ __global__ __launch_bounds__(64) CILQR_ROLL_ATTR void k_spec_forward(DeviceState
 
 // total cost of candidate alpha_r of list entry j: knot partials summed in index order
 __global__ __launch_bounds__(64) void k_spec_reduce(DeviceState s, const int* __restrict__ list,
-                                                    const int* __restrict__ n_ptr, int n_max, int r0, int open) {
-  const int n = n_ptr ? min(*n_ptr, n_max) : active_count(s, n_max);
+                                                    const int* __restrict__ n_ptr, int off, int n_max, int r0, int open) {
+  const int n = list_count(s, n_ptr, off, n_max);
   const int r = r0 + blockIdx.y;
   const size_t cap = (size_t)s.spec_cap;
   const int K = s.p.K, N = s.p.N;
@@ -166,8 +166,8 @@ __global__ __launch_bounds__(64) void k_spec_reduce(DeviceState s, const int* __
 
 // first passing alpha wins (cc:246-261)
 __global__ __launch_bounds__(64) void k_spec_pick(DeviceState s, const int* __restrict__ list,
-                                                  const int* __restrict__ n_ptr, int n_max, int r0) {
-  const int n = n_ptr ? min(*n_ptr, n_max) : active_count(s, n_max);
+                                                  const int* __restrict__ n_ptr, int off, int n_max, int r0) {
+  const int n = list_count(s, n_ptr, off, n_max);
   const size_t cap = (size_t)s.spec_cap;
   const int Bc = s.Bcap;
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
@@ -204,8 +204,8 @@ __global__ __launch_bounds__(64) void k_spec_pick(DeviceState s, const int* __re
 
 // the accepted candidate becomes the iterate: one thread per (list entry, knot)
 __global__ __launch_bounds__(256) void k_spec_copy(DeviceState s, const int* __restrict__ list,
-                                                   const int* __restrict__ n_ptr, int n_max, int r0) {
-  const int n = n_ptr ? min(*n_ptr, n_max) : active_count(s, n_max);
+                                                   const int* __restrict__ n_ptr, int off, int n_max, int r0) {
+  const int n = list_count(s, n_ptr, off, n_max);
   const int i = blockIdx.y;
   const size_t cap = (size_t)s.spec_cap;
   const int K = s.p.K, N = s.p.N, Bc = s.Bcap;
@@ -348,31 +348,82 @@ __global__ __launch_bounds__(256) void k_multi_copy(DeviceState s, int n_max, in
   }
 }
 
-static void launch_spec(const DeviceState& s, const int* list, const int* n_ptr, int n_max, int n_grid, int r0,
+// ---- views of the candidate arena (DeviceState::spec_rows) ----
+// The allocation holds spec_rows x Bcap cells (a cell = one candidate: K x 3 + N pairs of Xs / Us, K x 3 pairs of parts).
+// Eleven rows: every view is the plain [step size][...][Bcap] layout.  Four rows (arenas of >= 32768 slots, where the
+// eleven-row arena was 4.1 GB of a handle's 11.7): the pre-rolled rounds use rows 0..3 at stride Bcap; once the last
+// k_round_pick has run and k_multi_copy has moved the accepted candidates out, ALL of those cells are dead, and the step
+// sizes that are left (7 after four rounds) of the problems that rejected every round are laid over them with a shorter
+// stride E = rows x Bcap / 7: entry j of the pending list, step size r -> row r - R of a [7][...][E] layout.  E entries fit
+// at once; a pending list longer than E (possible only while more than E problems are active: early iterations, adversarial
+// scenes) takes further passes over the same cells.  The base pointers are moved back by R rows of the NEW stride so that the
+// kernels' `row r` arithmetic lands on row r - R (address arithmetic only; nothing below the allocation is touched).
+static int spec_entries(const DeviceState& s, int n_steps_sizes) {
+  static const int forced = [] {   // test hook: a tiny E drives the multi-pass path with a handful of problems
+    const char* e = std::getenv("CILQR_SPEC_PASS_ENTRIES");
+    return e ? std::atoi(e) : 0;
+  }();
+  if (s.spec_rows >= kNumAlpha) return s.Bcap;
+  const long long cells = (long long)s.spec_rows * s.Bcap;
+  int E = (int)(cells / n_steps_sizes);
+  if (E >= 64) E = E / 64 * 64;
+  if (E > s.Bcap) E = s.Bcap;
+  if (forced > 0 && forced < E) E = forced;
+  return E;
+}
+static DeviceState spec_view(const DeviceState& s, int row0, int stride) {
+  DeviceState v = s;
+  if (s.spec_rows >= kNumAlpha) return v;          // the plain layout: rows are step sizes, stride is the capacity
+  const size_t K = (size_t)s.p.K, N = (size_t)s.p.N;
+  v.spec_cap = stride;
+  v.Xs = reinterpret_cast<double2*>(reinterpret_cast<uintptr_t>(s.Xs) - (uintptr_t)row0 * K * 3 * (size_t)stride * sizeof(double2));
+  v.Us = reinterpret_cast<double2*>(reinterpret_cast<uintptr_t>(s.Us) - (uintptr_t)row0 * N * (size_t)stride * sizeof(double2));
+  v.parts = reinterpret_cast<double2*>(reinterpret_cast<uintptr_t>(s.parts) - (uintptr_t)row0 * K * kPartPairs * (size_t)stride * sizeof(double2));
+  return v;
+}
+// most problems an all-eleven pass over the ACTIVE list can take (launch_linesearch falls back to rounds above it)
+int spec_open_capacity(const DeviceState& s) { return spec_entries(s, kNumAlpha); }
+
+// one pass: step sizes r0..10 of entries [off, off + n_max) of the list (n_ptr: its device-side length; nullptr = the active list)
+static void launch_spec(const DeviceState& s, const int* list, const int* n_ptr, int off, int n_max, int n_grid, int r0,
                         int open, hipStream_t st) {
   const int na = kNumAlpha - r0;
+  const int* lp = list + off;
   // the pending list of the hybrid schedule is sparse and unordered: packed kernels (eight lanes per problem)
   const int sparse = (!open && na <= 8) ? 1 : 0;
   if (sparse)
-    hipLaunchKernelGGL(k_spec_forward_packed, dim3((n_grid + 7) / 8), dim3(64), 0, st, s, list, n_ptr, n_max, r0);
+    hipLaunchKernelGGL(k_spec_forward_packed, dim3((n_grid + 7) / 8), dim3(64), 0, st, s, lp, n_ptr, off, n_max, r0);
   else
-    hipLaunchKernelGGL(k_spec_forward, dim3((n_grid + 63) / 64, na), dim3(64), 0, st, s, list, n_ptr, n_max, r0, open);
-  launch_spec_cost(s, list, n_ptr, n_max, n_grid, r0, sparse, st);
-  hipLaunchKernelGGL(k_spec_reduce, dim3((n_grid + 63) / 64, na), dim3(64), 0, st, s, list, n_ptr, n_max, r0, open);
-  hipLaunchKernelGGL(k_spec_pick, dim3((n_grid + 63) / 64), dim3(64), 0, st, s, list, n_ptr, n_max, r0);
-  hipLaunchKernelGGL(k_spec_copy, dim3((n_grid + 255) / 256, s.p.K), dim3(256), 0, st, s, list, n_ptr, n_max, r0);
+    hipLaunchKernelGGL(k_spec_forward, dim3((n_grid + 63) / 64, na), dim3(64), 0, st, s, lp, n_ptr, off, n_max, r0, open);
+  launch_spec_cost(s, lp, n_ptr, off, n_max, n_grid, r0, sparse, st);
+  hipLaunchKernelGGL(k_spec_reduce, dim3((n_grid + 63) / 64, na), dim3(64), 0, st, s, lp, n_ptr, off, n_max, r0, open);
+  hipLaunchKernelGGL(k_spec_pick, dim3((n_grid + 63) / 64), dim3(64), 0, st, s, lp, n_ptr, off, n_max, r0);
+  hipLaunchKernelGGL(k_spec_copy, dim3((n_grid + 255) / 256, s.p.K), dim3(256), 0, st, s, lp, n_ptr, off, n_max, r0);
+}
+// the step sizes R..10 of the problems on pending list R (all n_act of them at worst), in as many passes as the arena asks for
+static void launch_spec_remainder(const DeviceState& s, int R, int n_act, hipStream_t st) {
+  const int E = spec_entries(s, kNumAlpha - R);
+  const DeviceState v = spec_view(s, R, E);
+  for (int off = 0; off < n_act; off += E) {
+    const int n_max = (n_act - off < E) ? n_act - off : E;
+    // the first pass is sized for the usual few per cent of the active problems (threads stride over the rest); a further
+    // pass finds its share of the list empty unless the scenes are adversarial, and is sized for that
+    const int want = (off == 0) ? (n_act + 3) / 4 : (n_max + 15) / 16;
+    const int n_grid = want < n_max ? (want > 0 ? want : 1) : n_max;
+    launch_spec(v, s.pend + (size_t)R * s.Bcap, s.counters + R, off, n_max, n_grid, R, 0, st);
+  }
 }
 
 // seq_rounds: how many step sizes are tried round by round before the rest is evaluated at once
 void launch_linesearch(const DeviceState& s, int n_act, int spec_threshold, int seq_rounds, int round_group,
                        hipStream_t st) {
   if (n_act == 0) return;
-  if (n_act <= spec_threshold) {
-    launch_spec(s, s.act, nullptr, n_act, n_act, 0, 1, st);
+  if (n_act <= spec_threshold && n_act <= spec_open_capacity(s)) {
+    launch_spec(spec_view(s, 0, spec_open_capacity(s)), s.act, nullptr, 0, n_act, n_act, 0, 1, st);
     return;
   }
   const int R = seq_rounds < 1 ? 1 : (seq_rounds > kNumAlpha ? kNumAlpha : seq_rounds);
-  if (R <= kMaxPreRolled) {
+  if (R <= kMaxPreRolled && R <= s.spec_rows) {
     // pre-rolled rounds: one pass rolls out alpha_0 .. alpha_{R-1} of every active problem
     const dim3 gf((n_act + 63) / 64), bf(64);
     if (R <= 4) {   // one rollout per lane (measured: 3.9 -> 2.9 ms per solve against four rollouts per lane)
@@ -393,10 +444,7 @@ void launch_linesearch(const DeviceState& s, int n_act, int spec_threshold, int 
       r0 += G;
     }
     hipLaunchKernelGGL(k_multi_copy, dim3((n_act + 255) / 256, s.p.K), dim3(256), 0, st, s, n_act, R);
-    if (R < kNumAlpha) {
-      const int n_grid = (n_act + 3) / 4;
-      launch_spec(s, s.pend + (size_t)R * s.Bcap, s.counters + R, n_act, n_grid, R, 0, st);
-    }
+    if (R < kNumAlpha) launch_spec_remainder(s, R, n_act, st);
     return;
   }
   hipLaunchKernelGGL(k_search_open, dim3((n_act + 63) / 64), dim3(64), 0, st, s, n_act);
@@ -410,11 +458,9 @@ void launch_linesearch(const DeviceState& s, int n_act, int spec_threshold, int 
     hipLaunchKernelGGL(k_search_round, dim3((n_act + 63) / 64), dim3(64), 0, st, s, r, n_act,
                        (r + 1 < R || R == kNumAlpha) ? 1 : 0);
   }
-  if (R < kNumAlpha) {
-    // the problems that rejected alpha_0..alpha_{R-1}: all remaining step sizes in one pass
-    const int n_grid = (n_act + 3) / 4;
-    launch_spec(s, s.pend + (size_t)R * s.Bcap, s.counters + R, n_act, n_grid, R, 0, st);
-  }
+  // the problems that rejected alpha_0..alpha_{R-1}: all remaining step sizes at once (the round-by-round rollouts went
+  // into the iterates' own other buffers, so the whole candidate arena is free for them)
+  if (R < kNumAlpha) launch_spec_remainder(s, R, n_act, st);
 }
 
 // per-problem bookkeeping after the line search (cc:272-308, 312-319) + next active list

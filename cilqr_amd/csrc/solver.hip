@@ -43,13 +43,18 @@ int dev_alloc(cilqr_solver* h, T** p, size_t count) {
 constexpr int64_t kTailMaxProblems = 8192;
 constexpr size_t kSmallTransfer = (size_t)4 << 20;   // host batches up to this many bytes travel as one pinned block each way   // CILQR_OPT_TAIL_THRESHOLD is clamped to this
 
-int grow(void** p, size_t* have, size_t need) {
+// the lazily grown blocks of a handle (staging, tail workspaces).  Their sizes are owned by the thread that grows them;
+// what another thread may ask for at any time -- cilqr_device_bytes -- is the atomic sum kept beside them (found by the
+// ThreadSanitizer run of tools/tsan_run.sh: the sizes themselves used to be read there)
+int grow(cilqr_solver* h, void** p, size_t* have, size_t need) {
   if (need <= *have) return CILQR_OK;
   if (*p) HIP_TRY(hipFree(*p));
   *p = nullptr;
+  h->grown_bytes.fetch_sub((int64_t)*have, std::memory_order_relaxed);
   *have = 0;
   HIP_TRY(hipMalloc(p, need));
   *have = need;
+  h->grown_bytes.fetch_add((int64_t)need, std::memory_order_relaxed);
   return CILQR_OK;
 }
 
@@ -123,7 +128,7 @@ int do_load(cilqr_solver* h, const cilqr_problem_batch* in, cilqr_job_set& js, D
   pv.station = nullptr;
   if (in->memory == CILQR_MEM_HOST) {
     const size_t bytes = (n_start + n_coarse + n_cor + n_sta) * sizeof(double) + n_cnt * sizeof(int) + 1024;
-    const int g = grow(&h->in_stage, &h->in_stage_bytes, bytes);
+    const int g = grow(h, &h->in_stage, &h->in_stage_bytes, bytes);
     if (g != CILQR_OK) return g;
     double* d = static_cast<double*>(h->in_stage);
     const size_t payload = (n_start + n_coarse + n_cor + n_sta) * sizeof(double) + n_cnt * sizeof(int);
@@ -451,10 +456,15 @@ int cilqr_create(const cilqr_config* cfg, int32_t device, int32_t batch_capacity
     ALLOCS(gnorm, cap);
     ALLOCS(part, K * kPartPairs * cap);
     ALLOCS(trial, 5 * cap);
-    t.spec_cap = (int)cap;   // every active problem can have all 11 candidates in flight (4 GB at B = 65536)
-    ALLOCS(Xs, (size_t)kNumAlpha * K * 3 * cap);
-    ALLOCS(Us, (size_t)kNumAlpha * N * cap);
-    ALLOCS(parts, (size_t)kNumAlpha * K * kPartPairs * cap);
+    // Candidate arena: all eleven step sizes of every slot for small arenas; FOUR per slot from 32768 slots on -- what the
+    // pre-rolled rounds need, re-strided afterwards for the rest (kernels_search.hip, spec_view): 1.5 GB instead of 4.1 GB
+    // at B = 65536, N = 50.  CILQR_SPEC_ROWS (4..11) forces the count (tests drive the four-row layout with small batches).
+    t.spec_cap = (int)cap;
+    t.spec_rows = (cap >= 32768) ? 4 : kNumAlpha;
+    if (const char* e = std::getenv("CILQR_SPEC_ROWS")) t.spec_rows = std::min(kNumAlpha, std::max(4, std::atoi(e)));
+    ALLOCS(Xs, (size_t)t.spec_rows * K * 3 * cap);
+    ALLOCS(Us, (size_t)t.spec_rows * N * cap);
+    ALLOCS(parts, (size_t)t.spec_rows * K * kPartPairs * cap);
     ALLOCS(spec_tot, (size_t)kNumAlpha * 5 * cap);
     ALLOCS(pend, (size_t)(kNumAlpha + 1) * cap);
     ALLOCS(counters, 64);
@@ -575,7 +585,7 @@ int cilqr_set_option(cilqr_handle h, int32_t option, int64_t value) {
       return CILQR_OK;
     case CILQR_OPT_SPEC_THRESHOLD:
       if (value < 0) return CILQR_ERR_ARG;
-      h->spec_threshold = (int)(value > h->ds.spec_cap ? h->ds.spec_cap : value);
+      h->spec_threshold = (int)std::min<int64_t>(value, spec_open_capacity(h->ds));
       h->spec_threshold_submit = h->spec_threshold;   // an explicit choice holds for both kinds of call
       return CILQR_OK;
     case CILQR_OPT_SEQ_ROUNDS:
@@ -647,8 +657,7 @@ int cilqr_get_profile(cilqr_handle h, cilqr_profile* out) {
 
 int64_t cilqr_device_bytes(cilqr_handle h) {
   if (h == nullptr) return 0;
-  return h->bytes + (int64_t)h->in_stage_bytes + (int64_t)h->sets[0].out_stage_bytes + (int64_t)h->sets[1].out_stage_bytes +
-         (int64_t)h->tail_ws_bytes + (int64_t)h->tail_ws1_bytes;
+  return h->bytes + h->grown_bytes.load(std::memory_order_relaxed);   // arenas (fixed at create) + staging and tail workspaces
 }
 
 static int solve_sync(cilqr_solver* h, const cilqr_problem_batch* in, cilqr_solution_batch* out);
@@ -815,7 +824,7 @@ int job_begin(cilqr_solver* h, cilqr_job& j) {
     // the iterates last, so that a small batch can fetch everything else (and the first few iterates) in one short copy
     j.n_head = (j.n_traj + j.n_hist) * 8 + (((size_t)4 * B * 4 + j.n_at + 7) & ~(size_t)7);
     const size_t bytes = j.n_head + j.n_itr * 8 + 1024;
-    rc = grow(&js.out_stage, &js.out_stage_bytes, bytes);
+    rc = grow(h, &js.out_stage, &js.out_stage_bytes, bytes);
     if (rc != CILQR_OK) return rc;
     double* p = static_cast<double*>(js.out_stage);
     j.o_traj = p; p += j.n_traj;
@@ -852,10 +861,10 @@ int job_begin(cilqr_solver* h, cilqr_job& j) {
       std::unique_lock<std::mutex> lk(h->mu);
       h->cv.wait(lk, [h] { return !h->fin_busy || h->quit; });
       if (h->quit) return CILQR_ERR_STATE;   // the handle is being destroyed
-      rc = grow(&h->tail_ws, &h->tail_ws_bytes, need);
+      rc = grow(h, &h->tail_ws, &h->tail_ws_bytes, need);
       if (rc != CILQR_OK) return rc;
     }
-    rc = grow(&h->tail_ws1, &h->tail_ws1_bytes, need);   // only ever used by the first stage (this thread)
+    rc = grow(h, &h->tail_ws1, &h->tail_ws1_bytes, need);   // only ever used by the first stage (this thread)
     if (rc != CILQR_OK) return rc;
   }
   launch_init_counters(j.d, B, st);

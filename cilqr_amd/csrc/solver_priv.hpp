@@ -1,6 +1,7 @@
 // Private to cilqr_amd/csrc: the solver handle behind `cilqr_handle` (include/cilqr.h) and the
 // error-reporting macro shared by the translation units that implement the C-ABI.
 #pragma once
+#include <atomic>
 
 #include <hip/hip_runtime.h>
 
@@ -130,6 +131,7 @@ struct cilqr_solver {
   hipStream_t stream2 = nullptr;   // finishing stage of asynchronous solves (high priority: short, latency-bound kernels)
   std::vector<void*> allocs;
   int64_t bytes = 0;
+  std::atomic<int64_t> grown_bytes{0};   // staging blocks + tail workspaces, grown by the solving threads (solver.hip: grow)
   // staging (lazily grown): problem-major copy of host inputs on the device
   void* in_stage = nullptr;
   size_t in_stage_bytes = 0;
@@ -147,7 +149,8 @@ struct cilqr_solver {
   bool alone_on_device = false;   // a shard of cilqr_multi_*: its device is the caller's alone, submitted solves take spec_threshold
   int team_threshold = 4096;  // active sets up to this size run the backward pass with 8 lanes per problem
   int round_group = 2;        // step sizes costed per sequential round (1, 2 or 4)
-  int wave_threshold = 1024;  // active sets up to this size run the backward pass with a wavefront per problem
+  int wave_threshold = 3072;  // active sets up to this size run the backward pass with a wavefront per problem (1024 until
+                              // round 5: re-swept after the wave form had become a third faster, tools/bwd_forms_sweep.py)
   int seq_rounds = 4;         // larger sets: this many round-by-round trials, then the rest at once
   // active sets up to this size leave the lockstep loop: one workgroup per problem (kernels_tail.hip).  Like the speculation
   // threshold it depends on company: a solve that has the GPU to itself (cilqr_solve_batch) is shortest when up to 1024 problems

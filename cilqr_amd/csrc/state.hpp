@@ -146,12 +146,17 @@ struct DeviceState {
   // [max_iter][Bcap] by PROBLEM: accepted alpha index of every iteration (-1 all rejected, -2 gradient-norm exit)
   signed char* atrace;
 
-  // speculative line search (all 11 step sizes at once) for small active sets: candidates and
-  // cost partials indexed by [alpha][...][list position], capacity spec_cap list entries
+  // Candidate arena of the line search: rollouts and their per-knot cost partials, indexed [step size][...][list position]
+  // with row stride spec_cap.  The arena holds spec_rows x capacity candidates ("cells"): all eleven step sizes of every slot
+  // for small arenas, FOUR per slot for the big ones (kernels_search.hip, launch_linesearch: the pre-rolled rounds use rows
+  // 0..3 at stride capacity; what they leave dead is then re-strided for the remaining step sizes of the problems that
+  // rejected them all, or -- small active sets -- for all eleven of every active problem).  A launch sees ONE such view:
+  // spec_cap and the three pointers are set per launch by the host (spec_view below), the kernels index as they always did.
   int spec_cap;
-  double2* Xs;       // [11][K][3][spec_cap]
-  double2* Us;       // [11][N][spec_cap]
-  double2* parts;    // [11][K][3][spec_cap]
+  int spec_rows;     // candidates per slot the allocation holds (4 or 11); the allocation's capacity is Bcap
+  double2* Xs;       // [rows][K][3][spec_cap]
+  double2* Us;       // [rows][N][spec_cap]
+  double2* parts;    // [rows][K][3][spec_cap]
   double* spec_tot;  // [11][5][spec_cap] total cost of every candidate
 
   // work lists
@@ -194,8 +199,9 @@ void launch_set_trajectory(const DeviceState& s, int B, const double* X, const d
 void launch_cost_only(const DeviceState& s, const int* list, int n, int cand, hipStream_t st);
 void launch_cost_knots(const DeviceState& s, const int* list, const int* n_ptr, int n_max, int n_grid,
                        int cand, int skip_done, hipStream_t st);
-void launch_spec_cost(const DeviceState& s, const int* list, const int* n_ptr, int n_max, int n_grid, int r0,
+void launch_spec_cost(const DeviceState& s, const int* list, const int* n_ptr, int off, int n_max, int n_grid, int r0,
                       int sparse, hipStream_t st);
+int spec_open_capacity(const DeviceState& s);   // most active problems an all-eleven-step-sizes pass can take (kernels_search.hip)
 void launch_round_cost(const DeviceState& s, int r0, int group, int n_max, int n_grid, hipStream_t st);
 void launch_init_cost_commit(const DeviceState& s, int n, hipStream_t st);
 void launch_quadratize(const DeviceState& s, const int* list, int n, int only_upd, hipStream_t st);

@@ -194,7 +194,7 @@ int cilqr_set_stream(cilqr_handle h, void* hip_stream);
  * of a problem sit in neighbouring lanes and share its corridor / goal reads; a round may cost a candidate the
  * sequential loop would not have reached, the first passing index still wins.  Bit-identical results. */
 #define CILQR_OPT_ROUND_GROUP 7
-/* CILQR_OPT_WAVE_THRESHOLD (default 1024): backward passes over at most this many problems give every problem a
+/* CILQR_OPT_WAVE_THRESHOLD (default 3072): backward passes over at most this many problems give every problem a
  * whole wavefront (operands in LDS, one output element per lane): the shortest chain of dependent work per step.
  * 0 = never.  Bit-identical results. */
 #define CILQR_OPT_WAVE_THRESHOLD 6

@@ -1459,6 +1459,34 @@ def test_backward_gains_follow_the_references_dot_order():
     opt.close()
 
 
+def test_four_row_candidate_arena_is_bit_identical(lockstep_only, tmp_path):
+    """Arenas of >= 32768 slots hold FOUR candidates per slot instead of eleven (solver.hip: spec_rows): the
+    pre-rolled rounds use them, and what is left dead afterwards is re-strided for the remaining step sizes of the problems
+    that rejected every round -- in several passes when there are more of those than fit.  A child process forces that
+    layout onto a small batch (CILQR_SPEC_ROWS=4) with passes of 8 entries and holds three schedules against this process's
+    solve with the plain eleven-row arena, bit for bit (tests/spec_rows_check.py); dyn20x scenes with zero tolerances: many
+    iterations, many rejected rounds."""
+    import json
+    import subprocess
+    import sys
+    sc = scenario.generate("dyn20x", 200, seed=96)
+    over = dict(max_iter=30, abs_cost_tol=0.0, rel_cost_tol=0.0)
+    opt = _opt(sc, **over)
+    g = opt.plan(sc, max_iter_trajs=3, alpha_trace=True)
+    opt.close()
+    beyond = int((g["alpha_trace"] >= 4).sum())
+    assert beyond >= 64, beyond          # enough problem-iterations accept a step size of the remainder passes to fill several
+    path = str(tmp_path / "ref.npz")
+    np.savez(path, **{k: sc[k] for k in ("start", "coarse", "corridor", "ccount", "left", "right")}, n_steps=sc["n_steps"],
+             cmax=sc["cmax"], cfg_over=json.dumps(over), **{"ref_" + k: g[k] for k in ("traj", "cost_hist", "status", "n_cost", "n_iter", "alpha_trace")})
+    r = subprocess.run([sys.executable, os.path.join(HERE, "spec_rows_check.py"), path],
+                       env=dict(os.environ, CILQR_SPEC_ROWS="4", CILQR_SPEC_PASS_ENTRIES="8"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rep["ok"] and rep["accepted_beyond_four_rounds"]["rounds"] == beyond
+    print(f"\nfour-row arena: {rep}")
+
+
 def test_speculative_line_search_is_bit_identical_to_round_by_round(lockstep_only):
     """Small active sets evaluate all 11 step sizes at once; the first passing index must win exactly
     as in the sequential loop (ilqr_optimizer.cc:246-265), so both modes give the same bits."""
