@@ -249,7 +249,9 @@ def measure_backward_traffic(args, problem_steps_per_solve):
             # the launch over the whole batch: the first backward dispatch of a solve (largest grid, fewest bytes among those)
             gcol = "grid_size_x" if "grid_size_x" in cols else ("grid_size" if "grid_size" in cols else None)
             if gcol:
-                per = con.execute(f"select sum(value), max({gcol}) from counters_collection where {kcol} like '%k_backward%' and "
+                # (the lane-per-problem kernel only: a wavefront-per-problem launch of 3072 problems has three times the
+                # work-items of the launch over 65536 problems)
+                per = con.execute(f"select sum(value), max({gcol}) from counters_collection where {kcol} like '%k_backward(%' and "
                                   f"counter_name = ? group by dispatch_id", (c,)).fetchall()
                 gmax = max(p[1] for p in per)
                 full[c] = min(p[0] for p in per if p[1] == gmax)

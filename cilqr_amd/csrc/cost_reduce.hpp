@@ -18,17 +18,17 @@ CILQR_DEV void reduce_cost(const DeviceState& s, int slot, int cand, double* c5)
 #pragma unroll 8
   for (int i = 0; i < K; ++i) {
     const double2* o = s.part + (size_t)i * kPartPairs * Bc + slot;
-    const double2 a = o[0], b = o[(size_t)Bc], c = o[(size_t)2 * Bc];
+    const double2 a = o[0], c = o[(size_t)2 * Bc];     // (J, bounds) of the state; (corridor, lane)
     j += a.x;
-    dx += b.x;
+    dx += a.y;
     cc += c.x;
     lc += c.y;
   }
 #pragma unroll 8
   for (int i = 0; i < N; ++i) {   // control terms follow the state terms (cc:510-513)
-    const double2* o = s.part + (size_t)i * kPartPairs * Bc + slot;
-    j += o[0].y;
-    du += o[(size_t)Bc].y;
+    const double2 b = s.part[((size_t)i * kPartPairs + 1) * Bc + slot];   // (J, bounds) of the control
+    j += b.x;
+    du += b.y;
   }
   const double dyn = dx + du;                      // cc:550
   c5[0] = j + dyn + cc + lc;                       // cc:429

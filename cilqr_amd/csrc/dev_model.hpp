@@ -529,7 +529,7 @@ CILQR_DEV int nearest_segment_scan(const double* __restrict__ tab, int n, double
   for (int s = 0; s < n; ++s) {
     int code = -2;
     const double d2 = exact ? segment_dist2_code(tab + s * kLaneFields, s, px, py, &code) : segment_dist2(tab + s * kLaneFields, px, py);
-    if (exact) suspect |= near_tie(d2, best) && code != bcode;
+    if (exact) suspect |= near_tie(d2, best) & (code != bcode);
     if (d2 < best) {
       best = d2;
       bi = s;
@@ -573,21 +573,30 @@ CILQR_DEV int nearest_from_cell(const DeviceState& s, const double* __restrict__
   // of the wave, tested with a ballot, so the loop is a scalar branch around straight-line
   // predicated code instead of a divergent loop with its exec-mask bookkeeping; a lane past the
   // end of its list tests row 0 and discards the result.
+  // The list travels as a 128-bit shift register: byte 1 of the lowest word is the next candidate (byte 0 of the cell was the
+  // count), one funnel shift per word and iteration instead of a four-way select on the trip counter.
+  unsigned q0 = w[0], q1 = w[1], q2 = w[2], q3 = w[3];
 #pragma unroll 1
   for (int k = 1; __builtin_amdgcn_ballot_w64(k <= cnt) != 0; ++k) {
-    const unsigned word = (k < 4) ? w[0] : (k < 8) ? w[1] : (k < 12) ? w[2] : w[3];
-    const int seg = (k <= cnt) ? (int)((word >> ((k & 3) * 8)) & 0xffu) : 0;
+    const bool in = k <= cnt;
+    const int seg = in ? (int)((q0 >> 8) & 0xffu) : 0;
+    q0 = __builtin_amdgcn_alignbit(q1, q0, 8);
+    q1 = __builtin_amdgcn_alignbit(q2, q1, 8);
+    q2 = __builtin_amdgcn_alignbit(q3, q2, 8);
+    q3 >>= 8;
     double d2;
     bool take;
     if constexpr (exact) {
       int code;
       d2 = segment_dist2_code(tab + seg * kLaneFields, seg, px, py, &code);
-      suspect |= (k <= cnt) && near_tie(d2, best) && code != bcode;
-      take = (k <= cnt) && (d2 < best);
+      // bitwise, not short-circuit: three compares and two s_and are cheaper than the two nested divergent branches (exec
+      // saved and restored around each) the compiler makes of `&&` here
+      suspect |= in & near_tie(d2, best) & (code != bcode);
+      take = in & (d2 < best);
       bcode = take ? code : bcode;
     } else {
       d2 = segment_dist2(tab + seg * kLaneFields, px, py);
-      take = (k <= cnt) && (d2 < best);
+      take = in & (d2 < best);
     }
     best = take ? d2 : best;
     bi = take ? seg : bi;
@@ -624,6 +633,19 @@ CILQR_DEV void assume_lds(T* ptr) {
 #else
   (void)ptr;
 #endif
+}
+
+// Which list position a workgroup of the wavefront-per-problem kernels takes (k_backward_wave, k_init_guess_wave).  A wavefront fetches ONE pair (16 B) of each of its problem's rows per step (lin,
+// term, gains at the problem's position, U at its slot); the other seven pairs of the same 128-byte line belong to the next
+// seven positions.  Workgroups are dealt to the eight XCDs round-robin (block b on XCD b % 8: observed, not promised -- a
+// wrong guess only costs speed), and every XCD has an L2 of its own: with position = blockIdx those eight wavefronts sat
+// on eight XCDs and every line was fetched into eight L2s -- 2280 B per problem-step through FETCH_SIZE against 288 B read
+// (rocprofv3 --pmc, a launch of 2703 problems; found when CILQR_OPT_WAVE_THRESHOLD went from 1024 to 3072 and the backward
+// pass's counted bytes rose from 418 to 466 B per problem-step).  Block b = 8 k + x takes position
+// (k / 8) * 64 + x * 8 + k % 8: eight consecutive positions -- one line of every row -- per XCD.  A bijection on [0, 64 m).
+CILQR_DEV int xcd_local_position(int b) {
+  const int x = b & 7, k = b >> 3;
+  return ((k >> 3) << 6) + (x << 3) + (k & 7);
 }
 
 // where the per-iteration scratch of a slot (lin, term, gains) lives: see DeviceState::posn

@@ -145,17 +145,17 @@ __global__ __launch_bounds__(64) void k_spec_reduce(DeviceState s, const int* __
 #pragma unroll 8
     for (int i = 0; i < K; ++i) {
       const double2* o = pb + (size_t)i * kPartPairs * cap;
-      const double2 a = o[0], b = o[cap], c = o[2 * cap];
+      const double2 a = o[0], c = o[2 * cap];     // (J, bounds) of the state; (corridor, lane): quad_core.hpp, knot_cost
       jj += a.x;
-      dx += b.x;
+      dx += a.y;
       cc += c.x;
       lc += c.y;
     }
 #pragma unroll 8
     for (int i = 0; i < N; ++i) {
-      const double2* o = pb + (size_t)i * kPartPairs * cap;
-      jj += o[0].y;
-      du += o[cap].y;
+      const double2 b = pb[((size_t)i * kPartPairs + 1) * cap];   // (J, bounds) of the control
+      jj += b.x;
+      du += b.y;
     }
     const double dyn = dx + du;
     t[0] = jj + dyn + cc + lc;
@@ -293,17 +293,17 @@ __global__ __launch_bounds__(64) void k_round_pick(DeviceState s, int r0, int G,
 #pragma unroll 8
       for (int i = 0; i < K; ++i) {
         const double2* o = pb + (size_t)i * kPartPairs * cap;
-        const double2 a = o[0], b = o[cap], c = o[2 * cap];
+        const double2 a = o[0], c = o[2 * cap];     // (J, bounds) of the state; (corridor, lane): quad_core.hpp, knot_cost
         jj += a.x;
-        dx += b.x;
+        dx += a.y;
         cc += c.x;
         lc += c.y;
       }
 #pragma unroll 8
       for (int i = 0; i < N; ++i) {
-        const double2* o = pb + (size_t)i * kPartPairs * cap;
-        jj += o[0].y;
-        du += o[cap].y;
+        const double2 b = pb[((size_t)i * kPartPairs + 1) * cap];   // (J, bounds) of the control
+        jj += b.x;
+        du += b.y;
       }
       const double dyn = dx + du;
       const double c5[5] = {jj + dyn + cc + lc, jj, dyn, cc, lc};
@@ -328,10 +328,13 @@ __global__ __launch_bounds__(64) void k_round_pick(DeviceState s, int r0, int G,
   }
 }
 
-// the candidate accepted in a pre-rolled round becomes the iterate: one thread per (position, knot)
+// the candidate accepted in a pre-rolled round becomes the iterate: one thread per (position, kCopyKnots knots) -- the three
+// dependent look-ups (position -> slot -> accepted index, buffer) are paid once per kCopyKnots x 4 pairs instead of once per
+// four (until round 5: one thread per knot), and a thread has that many independent copies in flight
+constexpr int kCopyKnots = 4;
 __global__ __launch_bounds__(256) void k_multi_copy(DeviceState s, int n_max, int G) {
   const int n = active_count(s, n_max);
-  const int i = blockIdx.y;
+  const int i0 = blockIdx.y * kCopyKnots;
   const size_t cap = (size_t)s.spec_cap;
   const int K = s.p.K, N = s.p.N, Bc = s.Bcap;
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
@@ -339,12 +342,17 @@ __global__ __launch_bounds__(256) void k_multi_copy(DeviceState s, int n_max, in
     const int acc = s.acc_idx[slot];
     if (acc < 0 || acc >= G) continue;
     const int nb = s.cur[slot];
-    const double2* xb = s.Xs + ((size_t)acc * K + i) * 3 * cap + j;
-    double2* o = s.X + ((size_t)nb * K + i) * 3 * Bc + slot;
-    o[0] = xb[0];
-    o[(size_t)Bc] = xb[cap];
-    o[(size_t)2 * Bc] = xb[2 * cap];
-    if (i < N) s.U[((size_t)nb * N + i) * Bc + slot] = s.Us[((size_t)acc * N + i) * cap + j];
+#pragma unroll
+    for (int d = 0; d < kCopyKnots; ++d) {
+      const int i = i0 + d;
+      if (i >= K) break;
+      const double2* xb = s.Xs + ((size_t)acc * K + i) * 3 * cap + j;
+      double2* o = s.X + ((size_t)nb * K + i) * 3 * Bc + slot;
+      o[0] = xb[0];
+      o[(size_t)Bc] = xb[cap];
+      o[(size_t)2 * Bc] = xb[2 * cap];
+      if (i < N) s.U[((size_t)nb * N + i) * Bc + slot] = s.Us[((size_t)acc * N + i) * cap + j];
+    }
   }
 }
 
@@ -443,7 +451,7 @@ void launch_linesearch(const DeviceState& s, int n_act, int spec_threshold, int 
       hipLaunchKernelGGL(k_round_pick, dim3((n_act + 63) / 64), dim3(64), 0, st, s, r0, G, n_act, (r0 + G == R) ? 1 : 0);
       r0 += G;
     }
-    hipLaunchKernelGGL(k_multi_copy, dim3((n_act + 255) / 256, s.p.K), dim3(256), 0, st, s, n_act, R);
+    hipLaunchKernelGGL(k_multi_copy, dim3((n_act + 255) / 256, (s.p.K + kCopyKnots - 1) / kCopyKnots), dim3(256), 0, st, s, n_act, R);
     if (R < kNumAlpha) launch_spec_remainder(s, R, n_act, st);
     return;
   }

@@ -339,17 +339,17 @@ __global__ __launch_bounds__(kTailThreads) CILQR_TAIL_ATTR void k_tail(DeviceSta
 #pragma unroll 8
           for (int i = 0; i < K; ++i) {
             const double2* o = pp + (size_t)i * kPartPairs;
-            const double2 aa = o[0], bb = o[1], c2 = o[2];
+            const double2 aa = o[0], c2 = o[2];     // (J, bounds) of the state; (corridor, lane)
             jj += aa.x;
-            dx += bb.x;
+            dx += aa.y;
             cc += c2.x;
             lc += c2.y;
           }
 #pragma unroll 8
           for (int i = 0; i < N; ++i) {
-            const double2* o = pp + (size_t)i * kPartPairs;
-            jj += o[0].y;
-            du += o[1].y;
+            const double2 bb = pp[(size_t)i * kPartPairs + 1];   // (J, bounds) of the control
+            jj += bb.x;
+            du += bb.y;
           }
           const double dyn = dx + du;
           double* tr = tot + r * 5;

@@ -77,7 +77,10 @@ CILQR_DEV void mask_first_chunk(int cnt, PlaneChunk<C>& pc) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// cost partials of one knot.  x, u: the knot's state / control; out[0], out[stride], out[2*stride]
+// cost partials of one knot.  x, u: the knot's state / control.  Three pairs: out[0] = (J, bound barriers) of the STATE,
+// out[stride] = the same of the CONTROL, out[2*stride] = (corridor, lane).  The totals add all state terms before the first
+// control term (cc:510-513, 550): a reader sums pairs 0 and 2 over the knots, then pair 1 over the steps -- every pair is
+// read once (until round 5 the pairs were (J state, J control), (bounds state, bounds control): two of them read twice)
 // ---------------------------------------------------------------------------------------------
 // bound barriers of one knot (DynamicsCost cc:518-551); returns {state part, control part}
 CILQR_DEV double2 knot_bound_cost(const Params& p, int i, const double* x, const double* u) {
@@ -150,8 +153,8 @@ CILQR_DEV void knot_cost_core(const DeviceState& s, const double* __restrict__ l
     py[j] = x1 + p.disc_off[j] * sn;
   }
   // the partial sums that are complete leave now (eight registers less through the two loops below)
-  out[0] = make_double2(jx, ju);
-  out[stride] = dyn;
+  out[0] = make_double2(jx, dyn.x);
+  out[stride] = make_double2(ju, dyn.y);
   // CorridorCost cc:553-581: planes outer (each read once), discs inner; one log for the knot
   for (int c0 = 0; c0 < cnt; c0 += C) {
     PlaneChunk<C> nx;
@@ -254,8 +257,8 @@ CILQR_DEV void knot_cost_generic(const DeviceState& s, const double* __restrict_
     bar_accumulate(p, g, lall);
     bar_renormalize(lall);
   }
-  out[0] = make_double2(jx, ju);
-  out[stride] = dyn;
+  out[0] = make_double2(jx, dyn.x);
+  out[stride] = make_double2(ju, dyn.y);
   out[2 * stride] = make_double2(bar_group_value(p, call), bar_group_value(p, lall));
 }
 

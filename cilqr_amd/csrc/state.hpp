@@ -17,7 +17,7 @@
 //                                     reference too: vehicle_model.cc:61-85, ilqr_optimizer.cc:642-650)
 //   term   [9][Bcap]       double2   lx_N 6 | lxx_N (3x3 block + 3 diagonal)
 //   gains  [N][7][Bcap]    double2   K (2x6 row-major) | k (2)
-//   part   [K][3][Bcap]    double2   per-knot cost partials (Jx, Ju) (dyn_x, dyn_u) (corridor, lane)
+//   part   [K][3][Bcap]    double2   per-knot cost partials (J, bounds) of the state | of the control | (corridor, lane)
 //   hist   [max_iter+1][5][Bcap] double
 //
 // Lane tables are shared by the batch and read through wave-uniform (scalar) loads.

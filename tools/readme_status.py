@@ -1,10 +1,10 @@
 #!/usr/bin/env python
-"""Prints the status table of README.md from the committed profiles of a round:  python tools/readme_status.py r04"""
+"""Prints the status table of README.md from the committed profiles of a round:  python tools/readme_status.py r05"""
 import json
 import os
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 P = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
 
 
@@ -36,14 +36,15 @@ failed = sum(v["steps"]["n_failed"] for v in pr["families"].values())
 rows = [
     ("CILQR solves/s, 1 GPU (target ≥ 100 k): a pool of two handles on the GPU (`cilqr_pool_*`), two solves in flight on each, "
      f"{b['device_bytes'] / 1e9:.1f} GB, the reference's exact lane-tie rule",
-     f"**{M(b['value'])}** ({b['ms_per_step']:.1f} ms per 65536-problem solve; three handles: {M(h3['value'])}; round 3: 1.94 M with the fast tie rule, 1.89 M with the exact one)"),
-    ("the same through ONE handle with two solves in flight (`cilqr_submit` / `cilqr_wait`), 11.7 GB",
+     f"**{M(b['value'])}** ({b['ms_per_step']:.1f} ms per 65536-problem solve; three handles: {M(h3['value'])}; round 4: 2.02 M at 23.5 GB with the index-order dot products)"),
+    ("the same through ONE handle with two solves in flight (`cilqr_submit` / `cilqr_wait`), "
+     f"{b['one_handle']['device_bytes'] / 1e9:.1f} GB (11.7 until round 5)",
      f"{M(b['one_handle']['value'])} ({b['one_handle']['ms_per_step']:.1f} ms)"),
-    ("one batch at a time (`cilqr_solve_batch`)", f"{M(b['single_batch']['value'])} ({b['single_batch']['ms_per_step']:.1f} ms; round 3: 1.21–1.23 M)"),
+    ("one batch at a time (`cilqr_solve_batch`)", f"{M(b['single_batch']['value'])} ({b['single_batch']['ms_per_step']:.1f} ms; round 4: 1.27–1.32 M)"),
     ("drop-in call: `planning::IlqrOptimizer::Plan` through the C++ adapter, batch of ONE, 256 scenes per family",
      "; ".join(f"{f}: mean {lat[f]['plan_b1']['mean_ms']:.2f} ms, median {lat[f]['plan_b1']['median_ms']:.2f}, p95 {lat[f]['plan_b1']['p95_ms']:.2f} "
                f"(CPU restatement on the same scenes: {lat[f]['cpu_restatement']['mean_ms']:.1f} / {lat[f]['cpu_restatement']['median_ms']:.1f} / {lat[f]['cpu_restatement']['p95_ms']:.1f})"
-               for f in ("mix11", "ped6")) + "; start of the round: 1.57 / 1.29 / 3.43 and 1.65 / 1.36 / 3.33 ms"
+               for f in ("mix11", "ped6"))
      + (f"; dyn20 (N = 100, 20 obstacles, Cmax = 24): {lat['dyn20']['plan_b1']['mean_ms']:.2f} / {lat['dyn20']['plan_b1']['median_ms']:.2f} / "
         f"{lat['dyn20']['plan_b1']['p95_ms']:.2f} ms against {lat['dyn20']['cpu_restatement']['mean_ms']:.1f} / "
         f"{lat['dyn20']['cpu_restatement']['median_ms']:.1f} / {lat['dyn20']['cpu_restatement']['p95_ms']:.1f}" if "dyn20" in lat else "")),
@@ -53,11 +54,14 @@ rows = [
      f"{r['full_batch_avg_launch_ms']:.3f} ms: {r['frac_full_batch']:.2f} of the 8 TB/s peak on its HBM traffic as counted in the run "
      f"({r['bytes_per_problem_step_full_batch_launch']:.0f} B per problem-step, `rocprofv3 --pmc`); {r['frac_full_batch_algorithmic']:.2f} × peak on the dense SURVEY §8(d) bytes (34 of 96 scalars are stored)"),
     ("backward pass, all launches of a solve (65536 → 256 problems), alone on the GPU (`roofline.frac`)",
-     f"{r['frac']:.2f} of peak on counted bytes ({r['bytes_per_problem_step']:.0f} B per problem-step; 536 at the start of the round), {r['frac_algorithmic']:.2f} on dense bytes"),
+     f"{r['frac']:.2f} of peak on counted bytes ({r['bytes_per_problem_step']:.0f} B per problem-step), {r['frac_algorithmic']:.2f} on dense bytes; round 4: 0.34 / 0.73 with the wavefront-per-problem mapping up to 1024 problems instead of 3072"),
     ("configs[1] (B = 4096) / configs[4] (B = 65536, N = 100; barriers active at the init guess)",
      f"{k(c1['value'])} / {M(c4['value'])} ({k(c4x['value'])}) solves/s"),
     ("DP coarse planner → corridor producer → solver (`bench.py --coarse dp`)", f"{M(dp['value'])} solves/s"),
     ("the opt-in fast lane-tie rule (`CILQR_OPT_EXACT_LANE_TIES` = 0)", f"{M(ft['value'])} solves/s"),
+    ("host CPU of one rank in the timed region (16-core quota on the GPU box; eight ranks share it)",
+     f"{b['host']['cores_busy_all_ranks']:.2f} cores ({b['host']['cpu_s_per_step_max_rank'] * 1e3:.0f} CPU-ms per step); with the spinning waits of round 4: "
+     f"{J('bench_host_wait_spin')['host']['cores_busy_all_ranks']:.2f} cores"),
     (f"parity vs oracle (32768 scenes, `profiles/{tag}_parity_report_8192.json`, exact lane ties, no `lane_tie` excuse)",
      f"{differ} of {stable} oracle-stable problems differ at 1e-4; {within} of {steps} iteration steps replay in the oracle at 1e-8, {exc} are shown "
      f"discontinuous there, {failed} fail; 4–9 % of scenes are chaotic in the oracle itself (DESIGN.md §5)"),

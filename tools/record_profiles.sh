@@ -8,7 +8,7 @@
 #   usage (through gpurun): bash tools/record_profiles.sh r02
 # then copy gpurun_out/<tag>/*.{json,txt} into profiles/ (see DESIGN.md "Measurement").
 set -u
-tag=${1:-r04}
+tag=${1:-r05}
 root=$(cd "$(dirname "$0")/.." && pwd)
 out=$root/gpurun_out/$tag
 mkdir -p "$out"
@@ -43,7 +43,12 @@ done
 python tools/kernel_rooflines.py "$out" "$tag" > "$out/${tag}_kernel_rooflines.json" 2> "$out/kr.err"
 CILQR_BENCH_FORCE_DIST=1 python bench.py --cpu-sample 0 --no-latency > "$out/${tag}_bench_force_dist.json" 2> "$out/fd.err"
 CILQR_BENCH_MULTI_DEVICES=0,0 python bench.py --gpus 2 --multi --cpu-sample 0 --no-latency > "$out/${tag}_bench_multi_two_shards_one_gpu.json" 2> "$out/mu.err"
-python tools/mall_probe.py > "$out/${tag}_mall_probe.json" 2> "$out/mall.err"
+# host CPU of the timed region (round 5): the default (submitted solves nap in their host waits) against spinning waits
+CILQR_HOST_WAIT=spin python bench.py --cpu-sample 0 --no-latency > "$out/${tag}_bench_host_wait_spin.json" 2> "$out/spin.err"
+python tools/bwd_forms_sweep.py > "$out/${tag}_backward_forms_sweep.json" 2> "$out/forms.err"
+bash tools/tsan_run.sh "$out/${tag}_tsan.log" 40 > "$out/tsan.out" 2>&1
+python tools/tsan_summary.py "$out/${tag}_tsan.log" > "$out/${tag}_tsan_summary.txt" 2>&1
+rm -f "$out/${tag}_tsan.log"   # 600 KB of reports about the HIP runtime's own threads: the summary travels
 python bench.py --pipeline 1 --cpu-sample 0 --no-latency > "$out/${tag}_bench_one_handle.json" 2> "$out/h1.err"
 python bench.py --pipeline 3 --cpu-sample 0 --no-latency > "$out/${tag}_bench_three_handles.json" 2> "$out/h3.err"
 python bench.py --steps 20 --warmup 5 --cpu-sample 0 --no-latency > "$out/${tag}_bench_steps20_warmup5.json" 2> "$out/s20.err"
