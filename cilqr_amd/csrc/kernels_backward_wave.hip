@@ -16,7 +16,7 @@ namespace cilqr {
 __global__ __launch_bounds__(64) void k_backward_wave(DeviceState s, const int* __restrict__ list, int n,
                                                       const double* __restrict__ lambda_override) {
   extern __shared__ double lds[];   // wave::lds_doubles(N)
-  const int j = xcd_local_position((int)blockIdx.x);   // the grid is a multiple of 64 blocks
+  const int j = (gridDim.x & 63u) == 0 ? xcd_local_position((int)blockIdx.x) : (int)blockIdx.x;   // small launches: as they are
   if (j >= active_count(s, n)) return;
   const int slot = list ? list[j] : j;
   const double lambda = lambda_override ? lambda_override[slot] : s.lambda[slot];
@@ -29,7 +29,7 @@ bool launch_backward_wave(const DeviceState& s, const int* list, int n, const do
                           hipEvent_t ev_start, hipEvent_t ev_stop) {
   const size_t lds = wave::lds_doubles(s.p.N) * sizeof(double);
   if (lds > 64 * 1024) return false;
-  hipExtLaunchKernelGGL(k_backward_wave, dim3((n + 63) / 64 * 64), dim3(64), lds, st, ev_start, ev_stop, 0, s, list, n, lambda_override);
+  hipExtLaunchKernelGGL(k_backward_wave, dim3(n >= 64 ? (n + 63) / 64 * 64 : n), dim3(64), lds, st, ev_start, ev_stop, 0, s, list, n, lambda_override);
   return true;
 }
 

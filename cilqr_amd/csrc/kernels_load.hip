@@ -441,7 +441,8 @@ __global__ __launch_bounds__(64) void k_init_guess(DeviceState s, int B) {
 constexpr int kIgFixed = 36 + 12 + 36 + 12 + 36 + 4 + 12 + 12 + 36;
 __global__ __launch_bounds__(64) void k_init_guess_wave(DeviceState s, int B) {
   extern __shared__ double ig_lds[];
-  const int slot = xcd_local_position((int)blockIdx.x);   // eight consecutive slots -- one 128-byte line of every row -- per XCD
+  // eight consecutive slots -- one 128-byte line of every row -- per XCD (a handful of problems: launched as they are)
+  const int slot = (gridDim.x & 63u) == 0 ? xcd_local_position((int)blockIdx.x) : (int)blockIdx.x;
   if (slot >= B) return;
   const int lane = threadIdx.x;
   const Params& p = s.p;
@@ -589,7 +590,7 @@ void launch_init_guess(const DeviceState& s, int B, hipStream_t st) {
   const size_t lds = ((size_t)s.p.N * 24 + kIgFixed) * sizeof(double);
   const bool wave = forced >= 0 ? forced != 0 : B <= kInitGuessWaveMax;
   if (wave && lds <= 64 * 1024)
-    hipLaunchKernelGGL(k_init_guess_wave, dim3((B + 63) / 64 * 64), dim3(64), lds, st, s, B);
+    hipLaunchKernelGGL(k_init_guess_wave, dim3(B >= 64 ? (B + 63) / 64 * 64 : B), dim3(64), lds, st, s, B);
   else
     hipLaunchKernelGGL(k_init_guess, dim3((B + 63) / 64), dim3(64), 0, st, s, B);
 }

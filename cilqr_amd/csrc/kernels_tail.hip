@@ -226,7 +226,11 @@ template <int D, bool EX>
 __global__ __launch_bounds__(kTailThreads) CILQR_TAIL_ATTR void k_tail(DeviceState g, TailArgs a, int n_max) {
   extern __shared__ double lds[];
   const int n = active_count(g, n_max);
-  const int blk = blockIdx.x;
+  // list position (and private arena) of this workgroup: eight consecutive positions per XCD, because the copy-in below
+  // gathers 8 or 16 bytes per row of the batch arena and the rest of each 128-byte line belongs to the neighbours
+  // (dev_model.hpp: xcd_local_position; needs a grid of a multiple of 64 workgroups -- a handful of problems, the drop-in call
+  // among them, is launched as it is)
+  const int blk = (gridDim.x & 63u) == 0 ? xcd_local_position((int)blockIdx.x) : (int)blockIdx.x;
   if (blk >= n) return;
   const int tid = threadIdx.x;
   (void)stage_lanes(g, lds);   // lane tables -> the start of the dynamic shared array (read by the phase functions)
@@ -508,11 +512,11 @@ void launch_tail(const DeviceState& g, void* workspace, int n_max, double* traj,
   }
   const size_t lds = fixed + used;
   if (g.p.num_of_disc == 5) {
-    if (g.exact_ties) hipLaunchKernelGGL((k_tail<5, true>), dim3(n_max), dim3(kTailThreads), lds, st, g, a, n_max);
-    else hipLaunchKernelGGL((k_tail<5, false>), dim3(n_max), dim3(kTailThreads), lds, st, g, a, n_max);
+    if (g.exact_ties) hipLaunchKernelGGL((k_tail<5, true>), dim3(n_max >= 64 ? (n_max + 63) / 64 * 64 : n_max), dim3(kTailThreads), lds, st, g, a, n_max);
+    else hipLaunchKernelGGL((k_tail<5, false>), dim3(n_max >= 64 ? (n_max + 63) / 64 * 64 : n_max), dim3(kTailThreads), lds, st, g, a, n_max);
   } else {
-    if (g.exact_ties) hipLaunchKernelGGL((k_tail<0, true>), dim3(n_max), dim3(kTailThreads), lds, st, g, a, n_max);
-    else hipLaunchKernelGGL((k_tail<0, false>), dim3(n_max), dim3(kTailThreads), lds, st, g, a, n_max);
+    if (g.exact_ties) hipLaunchKernelGGL((k_tail<0, true>), dim3(n_max >= 64 ? (n_max + 63) / 64 * 64 : n_max), dim3(kTailThreads), lds, st, g, a, n_max);
+    else hipLaunchKernelGGL((k_tail<0, false>), dim3(n_max >= 64 ? (n_max + 63) / 64 * 64 : n_max), dim3(kTailThreads), lds, st, g, a, n_max);
   }
 }
 

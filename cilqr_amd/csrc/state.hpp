@@ -111,7 +111,11 @@ struct DeviceState {
   // lin / term / gains are per-ITERATION scratch (written by the quadratisation, read by the backward pass, whose gains
   // the rollouts read): a slot's rows live at its POSITION in the iteration's active list (posn), not at the slot, so
   // that the three big streams of an iteration stay dense while the slots thin out between two re-packings
-  // (dev_model.hpp: scratch_index).  posn == nullptr (stage API views, the tail kernel's private view): position = slot.
+  // (dev_model.hpp: scratch_index).  posn == nullptr (the tail kernel's private view): position = slot.  The stage API works
+  // on the main arena WITH its posn: cilqr_stage_load's k_load_goals writes the identity, and every solve clears the stage
+  // flags (solver.hip: h->stage = 0), so a stage call can only follow a load -- it never sees a solve's positions.
+  // Inside a solve: k_update writes the NEXT iteration's positions, so nothing launched after it in an iteration
+  // (exports, re-packing) may call scratch_index for the current one -- none does.
   double2* lin;    // [N][17][Bcap]
   double2* term;   // [9][Bcap]
   double2* gains;  // [N][7][Bcap]

@@ -115,14 +115,22 @@ class GatherThread:
     GPU) a stream of their own, while the caller submits the next jobs.  Every rank must `put` its finished jobs in the same
     order: the ranks' collectives pair up by position in that order.  `on_done(tag)` is called after the gather of `tag`
     (hand the result buffers back to whoever reuses them).  `drain()` blocks until everything put so far is gathered and
-    re-raises the first error of the thread; call it before any collective of the caller's own."""
+    re-raises the first error of the thread; call it before any collective of the caller's own.
 
-    def __init__(self, device=None, dst=0, derive=None, on_done=None, gather_fn=None):
+    After an error the thread gathers nothing more (its tags keep coming back through `on_done`, so the caller's loop does
+    not stall on its own slots) -- but the OTHER ranks are then waiting for this one: inside `dist.gather` on the collective
+    path, where only the end of this process (what `drain()` raising leads to in bench.py, and what every launcher turns into
+    the end of the job) releases them; in the barrier of `PeerGather` on the one-process path, which the failing rank breaks
+    (`threading.BrokenBarrierError` in every waiter).  `on_error(exc)`, if given, is called once, on the gather thread, at the
+    first error: the place to tear a process group down early."""
+
+    def __init__(self, device=None, dst=0, derive=None, on_done=None, gather_fn=None, on_error=None):
         """gather_fn(traj, hist, nc, st) -> result replaces the torch.distributed gather (bench.py --multi: the ranks are
         threads of one process and results travel by peer copies, see PeerGather)."""
         import queue
         import threading
         self.device, self.dst, self.derive, self.on_done = device, dst, derive, on_done
+        self.on_error = on_error
         self.gather_fn = gather_fn or (lambda t, h, n, s: gather_results(t, h, n, s, dst=self.dst, densify=False, derive=self.derive))
         self.q = queue.Queue()
         self.error = None
@@ -157,8 +165,14 @@ class GatherThread:
                     else:
                         res = self.gather_fn(traj, hist, nc, st)
                     self.last, self.last_tag = res, tag
-            except Exception as e:   # noqa: BLE001  (kept for drain(); the tags keep coming back so nothing deadlocks)
+            except Exception as e:   # noqa: BLE001  (kept for drain(); the tags keep coming back so the local loop goes on)
+                first = self.error is None
                 self.error = e
+                if first and self.on_error is not None:
+                    try:
+                        self.on_error(e)
+                    except Exception:   # noqa: BLE001
+                        pass
             self.busy_s += time.perf_counter() - t0
             self.count += 1
             if self.on_done is not None:

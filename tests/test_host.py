@@ -430,3 +430,63 @@ def test_cpp_adapter_compiles_as_cxx14_against_the_c_abi(built, tmp_path, types)
     hdr = open(os.path.join(ROOT, "include", "cilqr.h")).read()
     includes = re.findall(r"#include\s+[<\"]([^>\"]+)", hdr)
     assert includes == ["stdint.h"]             # plain C: no HIP, C++ or torch headers at the boundary
+
+
+def test_peer_gather_pads_history_rows_and_never_hangs_on_a_failing_rank():
+    """cilqr_amd/distributed.py: PeerGather (results of several GPUs driven by ONE process, bench.py --multi), on CPU tensors.
+    (a) the Cost rows beyond a job's longest history are zero on the root, whatever an earlier job left there (every other host
+    path pads them with zeros); (b) a rank whose gather raises breaks the barrier: the other rank gets BrokenBarrierError at
+    once instead of waiting for ever."""
+    import threading
+    import torch
+    from cilqr_amd.distributed import GatherThread, PeerGather
+    world, B, K, M = 2, 4, 3, 6
+    peer = PeerGather(world, B, K, M, root_device=None, derive=(0.1, 1.0), timeout_s=20.0)
+    fns = [peer.gather_fn(r) for r in range(world)]
+
+    def job(rank, n_rows, fill, out):
+        traj = torch.full((B, K, 10), float(fill), dtype=torch.float64)
+        hist = torch.full((B, M + 1, 5), float(fill), dtype=torch.float64)
+        nc = torch.full((B,), n_rows, dtype=torch.int32)
+        st = torch.full((B,), 2, dtype=torch.int32)
+        out[rank] = fns[rank](traj, hist, nc, st)
+
+    for n_rows, fill in ((6, 7.0), (2, 9.0)):          # a long job, then a short one into the same root tensors
+        res = [None, None]
+        ts = [threading.Thread(target=job, args=(r, n_rows, fill, res)) for r in range(world)]
+        [t.start() for t in ts]
+        [t.join(30.0) for t in ts]
+        assert not any(t.is_alive() for t in ts)
+        g = res[0]
+        assert torch.all(g["cost_hist"][:, :n_rows] == fill) and torch.all(g["cost_hist"][:, n_rows:] == 0.0), n_rows
+        assert torch.all(g["n_cost"] == n_rows) and res[1] is None
+    # (b) rank 1 fails before it reaches the barrier: rank 0 must come back with an error, quickly
+    errors = {}
+
+    def good():
+        try:
+            job(0, 3, 1.0, [None, None])
+        except BaseException as e:   # noqa: BLE001
+            errors[0] = e
+
+    def bad():
+        try:
+            fns[1](torch.zeros((B, K, 10), dtype=torch.float64), torch.zeros((B, M + 1, 5), dtype=torch.float64),
+                   None, torch.zeros(B, dtype=torch.int32))          # n_cost missing: raises inside the gather
+        except BaseException as e:   # noqa: BLE001
+            errors[1] = e
+
+    ts = [threading.Thread(target=good), threading.Thread(target=bad)]
+    [t.start() for t in ts]
+    [t.join(15.0) for t in ts]
+    assert not any(t.is_alive() for t in ts), "a rank is still waiting in the barrier"
+    assert isinstance(errors.get(0), threading.BrokenBarrierError) and 1 in errors, errors
+    # the same through GatherThread: drain() re-raises, on_error is called once
+    seen = []
+    gt = GatherThread(device=None, gather_fn=lambda *a: (_ for _ in ()).throw(RuntimeError("boom")), on_error=seen.append)
+    gt.put("tag", None, None, None, None)
+    gt.put("tag2", None, None, None, None)
+    with pytest.raises(RuntimeError):
+        gt.drain()
+    gt.close()
+    assert len(seen) == 1 and gt.count == 2
