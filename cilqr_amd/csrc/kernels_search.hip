@@ -11,8 +11,6 @@
 //   [reduce + accept test, or roll out alpha_{r+1} and join pending list r+1] -> cost -> ...
 // The first passing list index wins, as in the sequential loop.  Pending lists are compacted
 // with wave-aggregated atomics; their order only affects coalescing, never results.
-#include <cstdlib>
-
 #include "search_core.hpp"
 
 namespace cilqr {
@@ -443,13 +441,10 @@ void launch_linesearch(const DeviceState& s, int n_act, int spec_threshold, int 
     else if (R == 5) hipLaunchKernelGGL(k_multi_forward<5>, gf, bf, 0, st, s, n_act);
     else hipLaunchKernelGGL(k_multi_forward<6>, gf, bf, 0, st, s, n_act);
     // G step sizes per round (round_group; the last round takes what is left of R)
-    // CILQR_ROUND_SCHEDULE=211 (measurement hook): two step sizes in the first round, one per round afterwards
-    static const bool taper = [] { const char* e = std::getenv("CILQR_ROUND_SCHEDULE"); return e && std::atoi(e) == 211; }();
     for (int r0 = 0; r0 < R;) {
-      int G = (round_group >= 4 && R - r0 >= 4) ? 4 : ((round_group >= 2 && R - r0 >= 2) ? 2 : 1);
-      if (taper && r0 > 0) G = 1;
+      const int G = (round_group >= 4 && R - r0 >= 4) ? 4 : ((round_group >= 2 && R - r0 >= 2) ? 2 : 1);
       // later rounds carry a fraction of the batch: shrink the grids, stride inside
-      const int shrink = (r0 == 0) ? 1 : ((r0 == 1 || G > 1 || (taper && r0 == 2)) ? 2 : 8);
+      const int shrink = (r0 == 0) ? 1 : ((r0 == 1 || G > 1) ? 2 : 8);
       const int n_grid = (n_act + shrink - 1) / shrink;
       launch_round_cost(s, r0, G, n_act, n_grid, st);
       // one lane per pending problem (never strided: a lane sums whole cost columns)

@@ -206,7 +206,11 @@ def test_parity_report():
         with open(os.path.join(out_dir, "parity_report.json"), "w") as f:
             json.dump(rep, f, indent=1)
     for fam, r in rep["families"].items():
-        assert not r["stable_but_different"], (fam, r["stable_but_different"][:10])
+        # a problem the 8-run stability mask called stable and the library solves differently is looked at again with 64 fresh
+        # oracle re-runs: if the oracle itself never moves, it is a mismatch (none allowed); if it does, the mask missed an
+        # unstable problem (a flip rate of 20 % passes eight runs one time in six) -- at most one in a thousand may
+        assert not r["stable_but_different_confirmed"], (fam, r["stable_but_different_second_look"])
+        assert len(r["stable_but_different"]) <= max(1, r["problems"] // 1000), (fam, r["stable_but_different_second_look"])
         assert r["oracle_unstable"] <= 0.10 * r["problems"], (fam, r["oracle_unstable"])
         assert r["steps"]["n_failed"] == 0, (fam, r["steps"]["failed"][:5])
         assert r["steps"]["excused_discontinuous_in_oracle"] <= 0.01 * r["steps"]["replayed"], (fam, r["steps"])

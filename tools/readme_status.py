@@ -29,6 +29,8 @@ pc = J("pcie_inclusive")
 pr = J("parity_report_8192")
 stable = sum(v["oracle_stable"] for v in pr["families"].values())
 differ = sum(len(v["stable_but_different"]) for v in pr["families"].values())
+confirmed = sum(len(v.get("stable_but_different_confirmed", v["stable_but_different"])) for v in pr["families"].values())
+looks = [l for v in pr["families"].values() for l in v.get("stable_but_different_second_look", [])]
 steps = sum(v["steps"]["replayed"] for v in pr["families"].values())
 within = sum(v["steps"]["within_1e-8"] for v in pr["families"].values())
 exc = sum(v["steps"]["excused_discontinuous_in_oracle"] for v in pr["families"].values())
@@ -63,7 +65,9 @@ rows = [
      f"{b['host']['cores_busy_all_ranks']:.2f} cores ({b['host']['cpu_s_per_step_max_rank'] * 1e3:.0f} CPU-ms per step); with the spinning waits of round 4: "
      f"{J('bench_host_wait_spin')['host']['cores_busy_all_ranks']:.2f} cores"),
     (f"parity vs oracle (32768 scenes, `profiles/{tag}_parity_report_8192.json`, exact lane ties, no `lane_tie` excuse)",
-     f"{differ} of {stable} oracle-stable problems differ at 1e-4; {within} of {steps} iteration steps replay in the oracle at 1e-8, {exc} are shown "
+     f"{confirmed} of {stable} oracle-stable problems differ at 1e-4"
+     + (f" ({differ} differ among those the 8-run mask called stable: " + ", ".join(f"the oracle itself ends elsewhere in {l['ended_elsewhere']} of {l['oracle_reruns']} further re-runs" for l in looks) + ")" if differ else "")
+     + f"; {within} of {steps} iteration steps replay in the oracle at 1e-8, {exc} are shown "
      f"discontinuous there, {failed} fail; 4–9 % of scenes are chaotic in the oracle itself (DESIGN.md §5)"),
 ]
 print("| quantity | value |\n|---|---|")
