@@ -5,6 +5,7 @@
 // stream and reads back the active-problem count once per lockstep iteration.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
 #include <pthread.h>
 
 #include <chrono>
@@ -296,7 +297,41 @@ int cilqr_timer::reserve() {
   }
   return 0;
 }
+// roctx ranges around the phases of a solve (tracing), for `rocprofv3 --marker-trace --kernel-trace`: the host-side
+// span in which a phase's kernels are enqueued, named cilqr:quadratize / backward / linesearch / other / tail.  Off unless
+// CILQR_ROCTX=1 is in the environment when the first solve starts (the library is dlopened then; absent = no ranges).
+namespace {
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+};
+const Roctx& roctx() {
+  static const Roctx r = [] {
+    Roctx x;
+    const char* e = std::getenv("CILQR_ROCTX");
+    if (e == nullptr || e[0] != '1') return x;
+    void* lib = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+    if (lib == nullptr) lib = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+    if (lib == nullptr) return x;
+    x.push = reinterpret_cast<int (*)(const char*)>(dlsym(lib, "roctxRangePushA"));
+    x.pop = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
+    if (x.push == nullptr || x.pop == nullptr) x.push = nullptr, x.pop = nullptr;
+    return x;
+  }();
+  return r;
+}
+constexpr const char* kPhaseName[5] = {"cilqr:quadratize", "cilqr:backward", "cilqr:linesearch", "cilqr:other", "cilqr:tail"};
+}  // namespace
+static void cilqr_phase_mark_begin(int k) {
+  if (roctx().push) (void)roctx().push(kPhaseName[k >= 0 && k < 5 ? k : 3]);
+}
+static void cilqr_phase_mark_end() {
+  if (roctx().pop) (void)roctx().pop();
+}
+
 int cilqr_timer::begin(int k) {
+  marked = roctx().push != nullptr;
+  if (marked) cilqr_phase_mark_begin(k);
   open = wants(k);
   if (!open) return 0;
   if (reserve()) return -1;
@@ -314,6 +349,7 @@ int cilqr_timer::pair(int k, hipEvent_t* a, hipEvent_t* b) {
   return 0;
 }
 int cilqr_timer::end() {
+  if (marked) { cilqr_phase_mark_end(); marked = false; }
   if (!open) return 0;
   open = false;
   return hipEventRecord(js->ev[next++], stream) == hipSuccess ? 0 : -1;
@@ -971,7 +1007,9 @@ int job_iterate(cilqr_solver* h, cilqr_job& j, int stage) {
     launch_quadratize(d, d.act, n_hint, 0, st);        // cc:203-214
     hipEvent_t eb0, eb1;
     if (j.tm.end() || j.tm.pair(1, &eb0, &eb1)) return CILQR_ERR_DEVICE;
+    cilqr_phase_mark_begin(1);
     launch_backward(d, d.act, n_hint, nullptr, h->team_threshold, h->wave_threshold, st, eb0, eb1);    // cc:218
+    cilqr_phase_mark_end();
     if (j.tm.begin(2)) return CILQR_ERR_DEVICE;
     j.bwd_iter.push_back(it);
     launch_linesearch(d, n_hint, j.spec_threshold, h->seq_rounds, h->round_group, st);  // cc:235-270

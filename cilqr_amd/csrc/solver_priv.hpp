@@ -71,6 +71,7 @@ struct cilqr_timer {  // event pairs around kernels / phases, resolved after the
   std::vector<int> kind;  // 0 quad, 1 backward, 2 linesearch, 3 other, 4 tail
   std::vector<char> full_flags, live_flags;  // per backward launch: covered the whole batch / had work
   bool open = false;   // the last begin() recorded an event, so the matching end() must too
+  bool marked = false; // the last begin() opened a roctx range (CILQR_ROCTX=1), so the matching end() closes it
   bool on() const;
   bool wants(int k) const;
   int reserve();

@@ -330,6 +330,29 @@ def test_bench_distributed_paths_on_one_gpu():
     assert abs(rec["value"] - 2 * 2048 * 1e3 / rec["ms_per_step"]) <= 1e-3 * rec["value"]
 
 
+@pytest.mark.gpu
+def test_host_cpu_budget_of_a_rank_and_phase_ranges():
+    """eight ranks share the 16 cores a GPU box grants, so a rank may not keep more than two of them busy.
+    Submitted solves nap in their host waits (solver.hip: wait_event): the bench line's `host` record -- getrusage around the
+    timed region -- must stay under 2 cores for one rank (4.4 with the spinning waits of round 4, which CILQR_HOST_WAIT=spin
+    brings back: checked to be the larger figure, so the measurement can see the difference).  Also: CILQR_ROCTX=1 opens the
+    roctx ranges of the solve's phases without changing anything else (same status histogram)."""
+    bench = os.path.join(ROOT, "bench.py")
+    common = ["--steps", "12", "--warmup", "3", "--no-traffic", "--no-latency", "--cpu-sample", "0", "--cpu-configs", "0", "--no-profile"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    recs = {}
+    for name, extra in (("nap", {"CILQR_ROCTX": "1"}), ("spin", {"CILQR_HOST_WAIT": "spin"})):
+        r = subprocess.run([sys.executable, bench] + common, env=dict(env, **extra), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        recs[name] = _one_json_line(r.stdout)
+    nap, spin = recs["nap"]["host"], recs["spin"]["host"]
+    assert nap["native_threads_this_rank"] > 4 and nap["scene_workers_per_rank"] >= 1
+    assert nap["cores_busy_all_ranks"] < 2.0, nap
+    assert spin["cores_busy_all_ranks"] > nap["cores_busy_all_ranks"] + 1.0, (nap, spin)
+    assert recs["nap"]["status_histogram"] == recs["spin"]["status_histogram"]
+    assert recs["nap"]["value"] > 0.9 * recs["spin"]["value"]
+
+
 TYPES = ("stand-ins", "reference headers")
 
 
