@@ -310,8 +310,10 @@ const Roctx& roctx() {
     Roctx x;
     const char* e = std::getenv("CILQR_ROCTX");
     if (e == nullptr || e[0] != '1') return x;
-    void* lib = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
-    if (lib == nullptr) lib = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+    // rocprofv3 listens to the SDK's roctx (librocprofiler-sdk-roctx); the roctracer-era libroctx64 is the fallback
+    void* lib = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+    if (lib == nullptr) lib = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (lib == nullptr) lib = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
     if (lib == nullptr) return x;
     x.push = reinterpret_cast<int (*)(const char*)>(dlsym(lib, "roctxRangePushA"));
     x.pop = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
