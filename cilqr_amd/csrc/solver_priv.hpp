@@ -145,8 +145,9 @@ struct cilqr_solver {
   int spec_threshold = 8192;  // active sets up to this size evaluate all 11 step sizes at once (cilqr_solve_batch)
   // ... and for solves submitted with cilqr_submit: other solves share the GPU then, and eleven candidates per problem
   // where two or three would do is throughput taken from them (measured: pool of two 1.90 -> 1.98 M solves/s, one handle
-  // with two solves in flight 1.67 -> 1.72 M; the sequential call loses 1 % at 2048, hence the two defaults)
-  int spec_threshold_submit = 2048;
+  // with two solves in flight 1.67 -> 1.72 M; the sequential call loses 1 % at 2048, hence the two defaults).  Round 5, re-swept
+  // beside the tail threshold below after the backward mappings had moved: 1024 with 128 there, pool of two 2.03-2.06 -> 2.07 M on two boxes
+  int spec_threshold_submit = 1024;
   bool alone_on_device = false;   // a shard of cilqr_multi_*: its device is the caller's alone, submitted solves take spec_threshold
   int team_threshold = 4096;  // active sets up to this size run the backward pass with 8 lanes per problem
   int round_group = 2;        // step sizes costed per sequential round (1, 2 or 4)
@@ -156,9 +157,10 @@ struct cilqr_solver {
   // active sets up to this size leave the lockstep loop: one workgroup per problem (kernels_tail.hip).  Like the speculation
   // threshold it depends on company: a solve that has the GPU to itself (cilqr_solve_batch) is shortest when up to 1024 problems
   // finish there (the kernel then runs four rounds of workgroups: 1.27 -> 1.31 M solves/s); beside other solves those workgroups
-  // hold a CU each for milliseconds and take it from the neighbours' bulk kernels (pool 1.97 -> 1.93 M), so submitted solves keep 256
+  // hold a CU each for milliseconds and take it from the neighbours' bulk kernels (pool 1.97 -> 1.93 M), so submitted solves keep
+  // fewer: 256 until round 5, 128 since (profiles/r05_cost_kernel_experiments.txt 6)
   int tail_threshold = 1024;
-  int tail_threshold_submit = 256;
+  int tail_threshold_submit = 128;
   void* tail_ws = nullptr;    // private arenas of the tail's problems (lazily grown)
   size_t tail_ws_bytes = 0;
   void* tail_ws1 = nullptr;   // the same for a solve that reaches the tail without having been handed over (first stage)

@@ -175,7 +175,7 @@ int cilqr_set_stream(cilqr_handle h, void* hip_stream);
 /* Tuning knobs that never change results.  CILQR_OPT_SPEC_THRESHOLD: lockstep iterations with at
  * most this many active problems evaluate all 11 line-search step sizes concurrently instead of
  * round by round (0 disables).  Default: 8192 for cilqr_solve_batch (the shortest solve when the GPU is the caller's
- * alone), 2048 for solves submitted with cilqr_submit / cilqr_pool_submit (eleven candidates where two or three
+ * alone), 1024 for solves submitted with cilqr_submit / cilqr_pool_submit (eleven candidates where two or three
  * would do is throughput taken from the other solves in flight: +4 % on a pool of two); setting the option sets both. */
 #define CILQR_OPT_SPEC_THRESHOLD 1
 /* CILQR_OPT_SEQ_ROUNDS (default 4, 1..11): with more active problems than the threshold above, this
@@ -198,7 +198,7 @@ int cilqr_set_stream(cilqr_handle h, void* hip_stream);
  * whole wavefront (operands in LDS, one output element per lane): the shortest chain of dependent work per step.
  * 0 = never.  Bit-identical results. */
 #define CILQR_OPT_WAVE_THRESHOLD 6
-/* CILQR_OPT_TAIL_THRESHOLD (default 1024 for cilqr_solve_batch, 256 for solves submitted with cilqr_submit /
+/* CILQR_OPT_TAIL_THRESHOLD (default 1024 for cilqr_solve_batch, 128 for solves submitted with cilqr_submit /
  * cilqr_pool_submit -- beside other solves the tail's workgroups take CUs from the neighbours' bulk kernels; setting the
  * option sets both; at most 8192): once at most this many problems are still iterating they
  * leave the lockstep loop; one workgroup per problem runs all its remaining iterations in a single launch
