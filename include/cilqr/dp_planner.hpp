@@ -31,6 +31,7 @@
 #include <algorithm>
 #include <array>
 #include <cmath>
+#include <initializer_list>
 #include <limits>
 #include <utility>
 #include <vector>
@@ -353,73 +354,60 @@ class DpEnvironment {
 };
 
 // ---- ComputePathProfile, discrete_points_math.cc:27-176 ---------------------------------------------------------
+// Heading, arc length, speed, acceleration and curvature of a polyline sampled every `dt` seconds.  Every finite difference
+// of the reference is one operator -- "value at the upper neighbour minus value at the lower neighbour", the neighbours clamped
+// to the ends of the line -- applied to the points (heading, first derivative over s) and to its own output (second
+// derivative); written as that operator here, the operands and the order of every operation as in the reference, so the
+// results are the same bits (tests/test_reference_pins.py holds the checker against the reference's own function,
+// tests/test_dp_planner.py this one against the checker).
+namespace dp_detail {
+struct Span {            // the neighbours a knot's differences are taken over
+  std::size_t lo, hi;
+  bool two_sided() const { return hi - lo == 2; }
+};
+inline Span SpanAt(std::size_t i, std::size_t n) { return Span{i > 0 ? i - 1 : 0, i + 1 < n ? i + 1 : n - 1}; }
+}  // namespace dp_detail
+
 inline bool ComputePathProfile(double dt, const std::vector<std::pair<double, double>>& xy, std::vector<double>* headings,
                                std::vector<double>* accumulated_s, std::vector<double>* speeds,
                                std::vector<double>* accelerations, std::vector<double>* kappas) {
-  headings->clear();
-  accumulated_s->clear();
-  speeds->clear();
-  accelerations->clear();
-  kappas->clear();
-  if (xy.size() < 2) return false;
-  const std::size_t n = xy.size();
-  std::vector<double> dxs(n), dys(n), xds(n), yds(n), xdds(n), ydds(n);
+  const std::size_t n = xy.size() >= 2 ? xy.size() : 0;
+  for (std::vector<double>* out : {headings, accumulated_s, speeds, accelerations, kappas}) out->assign(n, 0.0);
+  if (n == 0) return false;
+  std::vector<double>& s = *accumulated_s;
+  std::vector<double>& v = *speeds;
+  std::vector<double>& a = *accelerations;
+
+  // chord direction over the span (halved where the span is two-sided, before atan2 sees it) and the running chord length
   for (std::size_t i = 0; i < n; ++i) {
-    if (i == 0) {
-      dxs[i] = xy[i + 1].first - xy[i].first;
-      dys[i] = xy[i + 1].second - xy[i].second;
-    } else if (i == n - 1) {
-      dxs[i] = xy[i].first - xy[i - 1].first;
-      dys[i] = xy[i].second - xy[i - 1].second;
-    } else {
-      dxs[i] = 0.5 * (xy[i + 1].first - xy[i - 1].first);
-      dys[i] = 0.5 * (xy[i + 1].second - xy[i - 1].second);
+    const dp_detail::Span sp = dp_detail::SpanAt(i, n);
+    const double scale = sp.two_sided() ? 0.5 : 1.0;
+    const double cx = xy[sp.hi].first - xy[sp.lo].first, cy = xy[sp.hi].second - xy[sp.lo].second;
+    (*headings)[i] = std::atan2(scale * cy, scale * cx);   // a factor of one changes no bit
+    if (i > 0) {
+      const double ex = xy[i - 1].first - xy[i].first, ey = xy[i - 1].second - xy[i].second;
+      s[i] = std::sqrt(ex * ex + ey * ey) + s[i - 1];
     }
   }
-  for (std::size_t i = 0; i < n; ++i) headings->push_back(std::atan2(dys[i], dxs[i]));
-  double distance = 0.0;
-  accumulated_s->push_back(distance);
-  double fx = xy[0].first, fy = xy[0].second;
-  for (std::size_t i = 1; i < n; ++i) {
-    const double nx = xy[i].first, ny = xy[i].second;
-    const double seg = std::sqrt((fx - nx) * (fx - nx) + (fy - ny) * (fy - ny));
-    accumulated_s->push_back(seg + distance);
-    distance += seg;
-    fx = nx;
-    fy = ny;
-  }
-  const std::vector<double>& acc = *accumulated_s;
-  for (std::size_t i = 1; i < n; ++i) speeds->push_back((acc[i] - acc[i - 1]) / dt);
-  speeds->push_back(speeds->back());
-  for (std::size_t i = 1; i < speeds->size(); ++i) accelerations->push_back(((*speeds)[i] - (*speeds)[i - 1]) / dt);
-  accelerations->push_back(accelerations->back());
+  // forward differences in time; the last knot repeats its predecessor
+  for (std::size_t i = 0; i + 1 < n; ++i) v[i] = (s[i + 1] - s[i]) / dt;
+  v[n - 1] = v[n - 2];
+  for (std::size_t i = 0; i + 1 < n; ++i) a[i] = (v[i + 1] - v[i]) / dt;
+  a[n - 1] = a[n - 2];
+
+  // derivatives with respect to arc length: d/ds of a sampled pair (p, q) = span difference over the span's arc length
+  struct Pair { double p, q; };
+  std::vector<Pair> d1(n), d2(n);
+  auto over_s = [&](auto&& sample, std::size_t i) {
+    const dp_detail::Span sp = dp_detail::SpanAt(i, n);
+    const Pair hi = sample(sp.hi), lo = sample(sp.lo);
+    return Pair{(hi.p - lo.p) / (s[sp.hi] - s[sp.lo]), (hi.q - lo.q) / (s[sp.hi] - s[sp.lo])};
+  };
+  for (std::size_t i = 0; i < n; ++i) d1[i] = over_s([&](std::size_t k) { return Pair{xy[k].first, xy[k].second}; }, i);
+  for (std::size_t i = 0; i < n; ++i) d2[i] = over_s([&](std::size_t k) { return d1[k]; }, i);
   for (std::size_t i = 0; i < n; ++i) {
-    if (i == 0) {
-      xds[i] = (xy[i + 1].first - xy[i].first) / (acc[i + 1] - acc[i]);
-      yds[i] = (xy[i + 1].second - xy[i].second) / (acc[i + 1] - acc[i]);
-    } else if (i == n - 1) {
-      xds[i] = (xy[i].first - xy[i - 1].first) / (acc[i] - acc[i - 1]);
-      yds[i] = (xy[i].second - xy[i - 1].second) / (acc[i] - acc[i - 1]);
-    } else {
-      xds[i] = (xy[i + 1].first - xy[i - 1].first) / (acc[i + 1] - acc[i - 1]);
-      yds[i] = (xy[i + 1].second - xy[i - 1].second) / (acc[i + 1] - acc[i - 1]);
-    }
-  }
-  for (std::size_t i = 0; i < n; ++i) {
-    if (i == 0) {
-      xdds[i] = (xds[i + 1] - xds[i]) / (acc[i + 1] - acc[i]);
-      ydds[i] = (yds[i + 1] - yds[i]) / (acc[i + 1] - acc[i]);
-    } else if (i == n - 1) {
-      xdds[i] = (xds[i] - xds[i - 1]) / (acc[i] - acc[i - 1]);
-      ydds[i] = (yds[i] - yds[i - 1]) / (acc[i] - acc[i - 1]);
-    } else {
-      xdds[i] = (xds[i + 1] - xds[i - 1]) / (acc[i + 1] - acc[i - 1]);
-      ydds[i] = (yds[i + 1] - yds[i - 1]) / (acc[i + 1] - acc[i - 1]);
-    }
-  }
-  for (std::size_t i = 0; i < n; ++i) {
-    const double a = xds[i], b = yds[i];
-    kappas->push_back((a * ydds[i] - b * xdds[i]) / (std::sqrt(a * a + b * b) * (a * a + b * b) + 1e-6));
+    const double g2 = d1[i].p * d1[i].p + d1[i].q * d1[i].q;
+    (*kappas)[i] = (d1[i].p * d2[i].q - d1[i].q * d2[i].p) / (std::sqrt(g2) * g2 + 1e-6);
   }
   return true;
 }
