@@ -28,7 +28,7 @@ OPT_ROUND_GROUP = 7
 OPT_FINISH_THRESHOLD = 8
 OPT_EXACT_LANE_TIES = 9
 ST_RUNNING, ST_CONVERGED_ABS, ST_CONVERGED_REL, ST_GNORM, ST_UNSOLVED, ST_MAX_ITER, ST_NO_CORRIDOR = range(7)
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 T_GOALS, T_CORRIDOR, T_LANES, T_X, T_U, T_XCAND, T_UCAND, T_A, T_B, T_LX, T_LU, T_LXX, T_LUU, \
     T_KFB, T_KFF, T_DV, T_GNORM = range(17)
@@ -121,7 +121,7 @@ class Profile(C.Structure):
 
 EXPORTS = [
     "cilqr_abi_version", "cilqr_build_id", "cilqr_default_config", "cilqr_create", "cilqr_destroy", "cilqr_set_stream",
-    "cilqr_set_option", "cilqr_set_profiling", "cilqr_get_profile", "cilqr_device_bytes", "cilqr_solve_batch",
+    "cilqr_set_option", "cilqr_get_option", "cilqr_set_profiling", "cilqr_get_profile", "cilqr_device_bytes", "cilqr_solve_batch",
     "cilqr_submit", "cilqr_wait", "cilqr_device_math", "cilqr_stage_load", "cilqr_stage_init_guess", "cilqr_stage_set_trajectory",
     "cilqr_stage_total_cost", "cilqr_stage_quadratize", "cilqr_stage_backward", "cilqr_stage_forward",
     "cilqr_stage_read", "cilqr_stage_nearest_lane", "cilqr_open_loop_rollout", "cilqr_error_string",
@@ -163,6 +163,8 @@ def lib():
         L.cilqr_set_stream.argtypes = [C.c_void_p, C.c_void_p]
         L.cilqr_set_profiling.argtypes = [C.c_void_p, C.c_int32]
         L.cilqr_set_option.argtypes = [C.c_void_p, C.c_int32, C.c_int64]
+        L.cilqr_get_option.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.cilqr_get_option.restype = C.c_int
         L.cilqr_get_profile.argtypes = [C.c_void_p, C.POINTER(Profile)]
         L.cilqr_solve_batch.argtypes = [C.c_void_p, C.POINTER(ProblemBatch), C.POINTER(SolutionBatch)]
         L.cilqr_submit.argtypes = [C.c_void_p, C.POINTER(ProblemBatch), C.POINTER(SolutionBatch)]
@@ -301,6 +303,14 @@ class BatchIlqrOptimizer:
         rc = self.L.cilqr_set_option(self.h, option, value)
         if rc != OK:
             raise CilqrError(rc, "in cilqr_set_option")
+
+    def get_option(self, option: int):
+        """(value for cilqr_solve_batch, value for submitted solves) of a cilqr_set_option code"""
+        a, b = C.c_int64(0), C.c_int64(0)
+        rc = self.L.cilqr_get_option(self.h, option, C.byref(a), C.byref(b))
+        if rc != OK:
+            raise CilqrError(rc, "in cilqr_get_option")
+        return int(a.value), int(b.value)
 
     def set_tracker_config(self, **over):
         """Override fields of the tracker init guess's configuration (reference defaults otherwise)."""

@@ -18,6 +18,7 @@
 // The kernel is a once-per-solve prologue (3.3 M corridors for 65536 x 51 knots).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "state.hpp"
 
@@ -31,24 +32,91 @@ struct P2f {
   float x, y;
 };
 
+// Order-preserving image of a float32: as unsigned integers the images compare exactly as the floats do (-0 folded onto
+// +0 first; NaNs have no place in that order -- waves that hold one sort on the generic path below).
+__device__ inline uint32_t ordered_bits(float v) {
+  const uint32_t u = __float_as_uint(v + 0.0f);
+  return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+
+// rank(i) = number of points that sort before point i by (x, y, index) -- the stable sort of the monotone chain, through
+// ranks.  The points of a lane live in scratch memory; read in the inner loop of an n^2 count they were 90 % of the kernel's
+// memory traffic (2 n^2 loads per hull: 66 GB per 65536 x 51 corridors).  Here every lane loads its points ONCE into
+// registers, as 64-bit keys (x image high, y image low: one integer compare per pair), and the double loop is unrolled
+// completely, so every key is a register the compiler names: no load in it at all.  Lanes hold different counts: keys past a
+// lane's count are all-ones (they sort behind everything and are never stored); `nmax`, the largest count of the wave, ends
+// the unrolled loops early with scalar branches.
+template <int CAP, typename Idx>
+__device__ void rank_sort_in_registers(const P2f* p, int n, int nmax, Idx* order) {
+  uint64_t key[CAP];
+#pragma unroll
+  for (int c = 0; c < CAP; ++c) {
+    key[c] = ~0ull;
+    if (c < nmax && c < n) {
+      const P2f q = p[c];
+      key[c] = ((uint64_t)ordered_bits(q.x) << 32) | ordered_bits(q.y);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < CAP; ++i) {
+    if (i < nmax) {      // (wave-uniform: a scalar branch around the rest of the unrolled body -- no early exit, which
+      int rank = 0;      // would keep the compiler from unrolling and the keys from becoming registers)
+#pragma unroll
+      for (int jb = 0; jb < CAP; jb += 8) {
+        if (jb < nmax) {
+#pragma unroll
+          for (int j = jb; j < jb + 8; ++j) {
+            if (j < CAP && j != i)   // equal points: the earlier index first
+              rank += (j < i) ? (key[j] <= key[i] ? 1 : 0) : (key[j] < key[i] ? 1 : 0);
+          }
+        }
+      }
+      if (i < n) order[rank] = (Idx)i;
+    }
+  }
+}
+
 // strictly convex hull of p[0..n): indices into p, counter-clockwise (y up) from the
 // lexicographically smallest point; `order` and `h` are caller-provided work arrays of n and 2n
 // entries (exact predicates keep at most n + 1 on the stack; with float32 rounding a nearly
 // collinear point can survive in both chains, and 2n - 1 pushes is the hard bound).  Returns the
-// number of hull vertices.
-template <typename Idx>
+// number of hull vertices.  CAP > 0: the register sort above for waves whose counts all fit CAP.
+template <int CAP, typename Idx>
 __device__ int hull_indices(const P2f* p, int n, Idx* order, Idx* h) {
-  // stable sort by (x, y) through ranks: rank(i) = number of points that sort before point i.
-  // n^2 comparisons, but the loads of the inner loop do not depend on each other (an insertion
-  // sort is a chain of dependent memory round trips, which is what a lane of this kernel waits on).
-  for (int i = 0; i < n; ++i) {
-    const P2f q = p[i];
-    int rank = 0;
-    for (int j = 0; j < n; ++j) {
-      const P2f r = p[j];
-      rank += (r.x < q.x || (r.x == q.x && (r.y < q.y || (r.y == q.y && j < i)))) ? 1 : 0;
+  bool in_registers = false;
+  if (CAP > 0) {
+    bool plain = n <= CAP;
+    for (int i = 0; i < n && plain; ++i) plain = (p[i].x == p[i].x) && (p[i].y == p[i].y);   // (n loads; a NaN ends the scan)
+    in_registers = __all(plain ? 1 : 0) != 0;
+    if (in_registers) {
+      // largest count among the lanes that are HERE (the call sits inside divergent branches: a butterfly of shuffles would
+      // read lanes that are not), bit by bit through votes -- the result is the same scalar in every lane
+      int nmax = 0;
+#pragma unroll
+      for (int b = 6; b >= 0; --b) {
+        const int cand = nmax | (1 << b);
+        if (__any(n >= cand ? 1 : 0)) nmax = cand;
+      }
+      nmax = __builtin_amdgcn_readfirstlane(nmax);
+      rank_sort_in_registers<(CAP > 0 ? CAP : 1), Idx>(p, n, nmax, order);
     }
-    order[rank] = (Idx)i;
+  }
+  if (!in_registers) {
+    // the same ranks by float comparisons, points read from scratch: n^2 comparisons, but the loads of the inner loop do
+    // not depend on each other (an insertion sort is a chain of dependent memory round trips).  A NaN coordinate compares
+    // false with everything, so two points can land on one rank and leave another rank without a point: every entry is set
+    // first, so that what the scans read for such a rank is a point of this lane (what the reference's cv::convexHull makes of
+    // a NaN is undefined; here it is at least the same corridor on every run and in every instantiation)
+    for (int i = 0; i < n; ++i) order[i] = (Idx)0;
+    for (int i = 0; i < n; ++i) {
+      const P2f q = p[i];
+      int rank = 0;
+      for (int j = 0; j < n; ++j) {
+        const P2f r = p[j];
+        rank += (r.x < q.x || (r.x == q.x && (r.y < q.y || (r.y == q.y && j < i)))) ? 1 : 0;
+      }
+      order[rank] = (Idx)i;
+    }
   }
   auto cross = [&](int o, int a, int b) {
     const float ax = p[a].x - p[o].x, ay = p[a].y - p[o].y;
@@ -84,7 +152,7 @@ __device__ void make_clockwise(Idx* h, int k) {
 // the count zeroed), ccount [n]
 // (m >= 3 half-planes, or -1 no points, -2 fewer than 4 flipped points, -3 more than cmax
 // half-planes, -4 degenerate hull); *n_failed counts the knots with a negative code.
-template <int MAXP, typename Idx>
+template <int MAXP, typename Idx, int BIG, int SMALL>
 __global__ __launch_bounds__(64) void k_build_corridors(int n, CorridorParams cp, const double* __restrict__ knots,
                                                         const double* __restrict__ points,
                                                         const int* __restrict__ count, int pmax,
@@ -150,7 +218,7 @@ __global__ __launch_bounds__(64) void k_build_corridors(int n, CorridorParams cp
     code = -2;
   } else {
     flip[nf] = P2f{0.0f, 0.0f};
-    const int n1 = hull_indices(flip, nf + 1, order, hull);  // cc:184
+    const int n1 = hull_indices<BIG, Idx>(flip, nf + 1, order, hull);  // cc:184
     if (n1 < 3 || n1 > nf + 1) {   // more vertices than points: float32 predicates disagreed (degenerate)
       code = -4;
     } else {
@@ -181,7 +249,7 @@ __global__ __launch_bounds__(64) void k_build_corridors(int n, CorridorParams cp
         ix = 0.99 * safe_radius * dx / d + ox;
         iy = 0.99 * safe_radius * dy / d + oy;
       }
-      const int n2 = hull_indices(vd, n1, order, hull);  // cc:218
+      const int n2 = hull_indices<SMALL, Idx>(vd, n1, order, hull);  // cc:218
       if (n2 < 3 || n2 > n1) {
         code = -4;
       } else {
@@ -209,7 +277,7 @@ __global__ __launch_bounds__(64) void k_build_corridors(int n, CorridorParams cp
             idx = (idx + 1 == n1) ? 0 : idx + 1;
           }
         }
-        const int n3 = hull_indices(dual, nt, order, hull);  // cc:241-242
+        const int n3 = hull_indices<SMALL, Idx>(dual, nt, order, hull);  // cc:241-242
         if (n3 < 3 || n3 > nt) {
           code = -4;
         } else if (n3 > cmax) {
@@ -269,17 +337,19 @@ void launch_build_corridors(int n, const CorridorParams& cp, const double* knots
   // Unused dynamic LDS caps the kernel at 16 waves per CU.  A lane's working set lives in scratch
   // memory; with every wave slot filled (32 per CU) the scratch of the waves in flight (1.2 GB)
   // streams through HBM on every access, at half that the kernel is 20 % faster (measured).
-  constexpr int lds_pad = 10000;
+  int lds_pad = 10000;
+  if (const char* e = getenv("CILQR_COR_LDS_PAD")) lds_pad = atoi(e);   // TEMPORARY sweep hook
   // two capacities: a lane's scratch working set scales with it
   const int need = pmax + 4 * cp.per_edge;
   if (need <= 56)
-    hipLaunchKernelGGL((k_build_corridors<56, unsigned char>), dim3((n + 63) / 64), dim3(64), lds_pad, st, n, cp, knots,
+    hipLaunchKernelGGL((k_build_corridors<56, unsigned char, 57, 16>), dim3((n + 63) / 64), dim3(64), lds_pad, st, n, cp, knots,
                        points, count, pmax, corridor, ccount, cmax, n_failed, polygons);
   else if (need <= 96)
-    hipLaunchKernelGGL((k_build_corridors<96, unsigned char>), dim3((n + 63) / 64), dim3(64), lds_pad, st, n, cp, knots,
+    hipLaunchKernelGGL((k_build_corridors<96, unsigned char, 0, 16>), dim3((n + 63) / 64), dim3(64), lds_pad, st, n, cp, knots,
                        points, count, pmax, corridor, ccount, cmax, n_failed, polygons);
-  else   // is_multiple_sample scenes: six samples per obstacle edge and per box edge
-    hipLaunchKernelGGL((k_build_corridors<kCorMaxPts, unsigned short>), dim3((n + 63) / 64), dim3(64), lds_pad, st, n, cp,
+  else   // is_multiple_sample scenes: six samples per obstacle edge and per box edge (every sort on the generic path: the
+         // kernel the two above are held against bit for bit, tests/test_corridor.py)
+    hipLaunchKernelGGL((k_build_corridors<kCorMaxPts, unsigned short, 0, 0>), dim3((n + 63) / 64), dim3(64), lds_pad, st, n, cp,
                        knots, points, count, pmax, corridor, ccount, cmax, n_failed, polygons);
 }
 

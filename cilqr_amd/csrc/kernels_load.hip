@@ -790,6 +790,50 @@ void launch_export_hist(const DeviceState& s, int B, double* cost_hist, int* n_c
 }
 
 // ---------------------------------------------------------------------------------------------
+// Ragged export of the Cost history (large batches in host memory): offsets, then the live rows.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_hist_row_offsets(DeviceState s, int B, long long* __restrict__ off) {
+  __shared__ long long part[1024];
+  const int t = threadIdx.x, nt = blockDim.x;
+  const int per = (B + nt - 1) / nt;
+  const int lo = min(B, t * per), hi = min(B, lo + per);
+  long long sum = 0;
+  for (int b = lo; b < hi; ++b) sum += s.n_cost[b];
+  part[t] = sum;
+  __syncthreads();
+  if (t == 0) {
+    long long run = 0;
+    for (int i = 0; i < nt; ++i) {
+      const long long v = part[i];
+      part[i] = run;
+      run += v;
+    }
+    off[B] = run;
+  }
+  __syncthreads();
+  long long run = part[t];
+  for (int b = lo; b < hi; ++b) {
+    off[b] = run;
+    run += s.n_cost[b];
+  }
+}
+// a thread per (problem, row slot): the threads of a wave read one row of 64 neighbouring problems (contiguous in the
+// batch-fastest history) and write it where the problem's rows start
+__global__ void k_export_hist_rows(DeviceState s, int B, const long long* __restrict__ off, double* __restrict__ rows) {
+  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= B) return;
+  const int nc = s.n_cost[slot];
+  double* o = rows + off[slot] * 5;
+  for (int r = 0; r < nc; ++r)
+#pragma unroll
+    for (int c = 0; c < 5; ++c) o[r * 5 + c] = s.hist[((size_t)r * 5 + c) * s.Pcap + slot];
+}
+void launch_export_hist_rows(const DeviceState& s, int B, long long* off, double* rows, hipStream_t st) {
+  hipLaunchKernelGGL(k_hist_row_offsets, dim3(1), dim3(1024), 0, st, s, B, off);
+  hipLaunchKernelGGL(k_export_hist_rows, dim3((B + 255) / 256), dim3(256), 0, st, s, B, off, rows);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Open-loop rollout: x_{k+1} = f(x_k, u_k) for B independent (x0, U) pairs, problem-major I/O.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_rollout(Params p, int B, const double* __restrict__ x0,

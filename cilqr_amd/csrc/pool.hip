@@ -60,7 +60,7 @@ cilqr_handle cilqr_pool_handle_at(cilqr_pool_handle p, int32_t k) {
   return p->handle[(size_t)k];
 }
 
-int32_t cilqr_pool_depth(cilqr_pool_handle p) { return p ? 2 * (int32_t)p->handle.size() : 0; }
+int32_t cilqr_pool_depth(cilqr_pool_handle p) { return p ? kJobRing * (int32_t)p->handle.size() : 0; }
 
 int cilqr_pool_set_option(cilqr_pool_handle p, int32_t option, int64_t value) {
   if (p == nullptr) return CILQR_ERR_NULL;
@@ -82,7 +82,7 @@ int64_t cilqr_pool_device_bytes(cilqr_pool_handle p) {
 int cilqr_pool_submit(cilqr_pool_handle p, const cilqr_problem_batch* in, cilqr_solution_batch* out) {
   if (p == nullptr || in == nullptr || out == nullptr) return CILQR_ERR_NULL;
   const long long n = (long long)p->handle.size();
-  if (p->submitted - p->collected >= 2 * n) return CILQR_ERR_STATE;   // the oldest solve has to be waited for first
+  if (p->submitted - p->collected >= kJobRing * n) return CILQR_ERR_STATE;   // the oldest solve has to be waited for first
   const int rc = cilqr_submit(p->handle[(size_t)(p->submitted % n)], in, out);
   if (rc == CILQR_OK) ++p->submitted;
   return rc;

@@ -114,11 +114,68 @@ DeviceState main_view(const cilqr_solver* h, const cilqr_job_set& js) {
   return v;
 }
 
-// upload (if needed) + prepare kernels, on stream `st`, into the arena `*v` (whose lane geometry is filled in here)
-int do_load(cilqr_solver* h, const cilqr_problem_batch* in, cilqr_job_set& js, DeviceState* v, hipStream_t st) {
-  const int rc = check_problem(h, in);
-  if (rc != CILQR_OK) return rc;
-  HIP_TRY(hipSetDevice(h->device));
+// pinned host blocks of a job set, grown like the device blocks (never while a copy into them is in flight: the solve that
+// owns the set is the only user)
+int grow_pinned(void** p, size_t* have, size_t need) {
+  if (need <= *have) return CILQR_OK;
+  if (*p) HIP_TRY(hipHostFree(*p));
+  *p = nullptr;
+  *have = 0;
+  HIP_TRY(hipHostMalloc(p, need, hipHostMallocDefault));
+  *have = need;
+  return CILQR_OK;
+}
+
+// Host arrays travel on two streams of the handle's own, created when the first large host batch shows up: HIP maps streams
+// onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 unless the environment says otherwise) in the order they are created, and a
+// handle that only ever sees device arrays should not spend queues on streams it never uses (a pool of two handles with four
+// streams each put both first stages on one queue: 2.00 -> 1.84 M solves/s, measured).
+int io_streams(cilqr_solver* h) {
+  std::lock_guard<std::mutex> lk(h->io_mu);
+  if (h->stream_in == nullptr) HIP_TRY(hipStreamCreateWithFlags(&h->stream_in, hipStreamNonBlocking));
+  if (h->stream_out == nullptr) HIP_TRY(hipStreamCreateWithFlags(&h->stream_out, hipStreamNonBlocking));
+  return CILQR_OK;
+}
+
+// An input buffer for a solve's host arrays: a free one, or one whose last user's load kernels are known to have run.
+// `block`: wait until one is given back (the transfer thread); otherwise -1 when both belong to solves.
+int acquire_in_buffer(cilqr_solver* h, bool block) {
+  std::unique_lock<std::mutex> lk(h->mu);
+  for (;;) {
+    for (int k = 0; k < 2; ++k) {
+      cilqr_in_buffer& b = h->in_bufs[k];
+      if (b.state == 1) continue;
+      const bool wait_loaded = b.state == 2;
+      b.state = 1;
+      lk.unlock();
+      if (wait_loaded && hipEventSynchronize(b.loaded) != hipSuccess) return -2;
+      return k;
+    }
+    if (!block || h->quit) return -1;
+    h->cv.wait(lk);
+  }
+}
+void release_in_buffer(cilqr_solver* h, int k, hipStream_t st) {   // behind the kernels on `st` that read it
+  if (k < 0) return;
+  const bool recorded = hipEventRecord(h->in_bufs[k].loaded, st) == hipSuccess;
+  {
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->in_bufs[k].state = recorded ? 2 : 0;
+  }
+  h->cv.notify_all();
+}
+
+size_t input_payload_bytes(const cilqr_solver* h, const cilqr_problem_batch* in) {
+  const size_t B = (size_t)in->batch, K = (size_t)in->n_knots;
+  const bool want_station = h->cfg.init_guess == CILQR_INIT_TRACKER && in->coarse_station != nullptr;
+  return (B * 4 + B * K * 6 + B * K * in->cmax * 3 + (want_station ? B * K : 0)) * sizeof(double) + B * K * sizeof(int);
+}
+
+// Where the kernels find the problem-major inputs: the caller's own arrays (device memory), or a copy of them in the job
+// set's staging block, enqueued on `st` (host memory).  A small batch travels through one pinned block in one copy; a large
+// one array by array -- from pageable memory the runtime's own staged path sustains 51 GB/s on these boxes (57 from pinned
+// memory; tools/host_path_probe.cc), so nothing is gained by copying through a ring of our own first.
+int stage_inputs(cilqr_solver* h, const cilqr_problem_batch* in, cilqr_in_buffer* ib, hipStream_t st, ProblemView* out_pv) {
   const int B = in->batch, K = in->n_knots;
   ProblemView pv;
   pv.cmax_in = in->cmax;
@@ -129,10 +186,13 @@ int do_load(cilqr_solver* h, const cilqr_problem_batch* in, cilqr_job_set& js, D
   pv.station = nullptr;
   if (in->memory == CILQR_MEM_HOST) {
     const size_t bytes = (n_start + n_coarse + n_cor + n_sta) * sizeof(double) + n_cnt * sizeof(int) + 1024;
-    const int g = grow(h, &h->in_stage, &h->in_stage_bytes, bytes);
-    if (g != CILQR_OK) return g;
-    double* d = static_cast<double*>(h->in_stage);
     const size_t payload = (n_start + n_coarse + n_cor + n_sta) * sizeof(double) + n_cnt * sizeof(int);
+    // (a small batch lands in a block of its own: it is staged by the solving thread on the solve's stream, so the next
+    // small batch's copy is ordered behind this one's load kernels by the stream itself)
+    if (payload > kSmallTransfer && ib == nullptr) return CILQR_ERR_STATE;
+    const int g = payload <= kSmallTransfer ? grow(h, &h->in_small, &h->in_small_bytes, kSmallTransfer + 1024) : grow(h, &ib->p, &ib->bytes, bytes);
+    if (g != CILQR_OK) return g;
+    double* d = static_cast<double*>(payload <= kSmallTransfer ? h->in_small : ib->p);
     if (payload <= kSmallTransfer) {
       // a small batch (the drop-in call is a batch of one): the five arrays go through ONE pinned block and ONE copy --
       // five pageable copies cost ~10 us each before the first kernel can start
@@ -174,6 +234,40 @@ int do_load(cilqr_solver* h, const cilqr_problem_batch* in, cilqr_job_set& js, D
     pv.ccount = in->corridor_count;
     if (want_station) pv.station = in->coarse_station;
   }
+  *out_pv = pv;
+  return CILQR_OK;
+}
+
+// inputs staged (unless `staged` says the transfer thread has done it: the caller has made `st` wait for its event) +
+// prepare kernels, on stream `st`, into the arena `*v` (whose lane geometry is filled in here)
+int load_kernels(cilqr_solver* h, const cilqr_problem_batch* in, cilqr_job_set& js, DeviceState* v, hipStream_t st, const ProblemView& pv);
+
+int do_load(cilqr_solver* h, const cilqr_problem_batch* in, cilqr_job_set& js, DeviceState* v, hipStream_t st,
+            const ProblemView* staged = nullptr, int staged_buf = -1) {
+  int rc = check_problem(h, in);
+  if (rc != CILQR_OK) { release_in_buffer(h, staged_buf, st); return rc; }
+  HIP_TRY(hipSetDevice(h->device));
+  ProblemView pv;
+  int buf = staged_buf;
+  if (staged) {
+    pv = *staged;
+  } else {
+    if (in->memory == CILQR_MEM_HOST && input_payload_bytes(h, in) > kSmallTransfer) {
+      // (never refused: the transfer thread uploads for a solve only once every solve before it is past its load, so at
+      // most one buffer is ever ahead of the solve that stages here)
+      buf = acquire_in_buffer(h, false);
+      if (buf < 0) return buf == -1 ? CILQR_ERR_STATE : CILQR_ERR_DEVICE;
+    }
+    rc = stage_inputs(h, in, buf >= 0 ? &h->in_bufs[buf] : nullptr, st, &pv);
+  }
+  if (rc == CILQR_OK) rc = load_kernels(h, in, js, v, st, pv);
+  release_in_buffer(h, buf, st);
+  return rc;
+}
+
+int load_kernels(cilqr_solver* h, const cilqr_problem_batch* in, cilqr_job_set& js, DeviceState* v, hipStream_t st, const ProblemView& pv) {
+  const int B = in->batch;
+  const bool want_station = h->cfg.init_guess == CILQR_INIT_TRACKER && in->coarse_station != nullptr;
   h->tracker.have_station = want_station ? 1 : 0;
   // The lane tables of consecutive solves are usually the same road: their device image and the lane grid built
   // from them (0.35 ms per solve) are kept while the caller's tables do not change by a bit.
@@ -546,6 +640,12 @@ int cilqr_create(const cilqr_config* cfg, int32_t device, int32_t batch_capacity
       rc = CILQR_ERR_DEVICE;
     if (rc == CILQR_OK && hipEventCreateWithFlags(&js.handoff, hipEventDisableTiming) != hipSuccess) rc = CILQR_ERR_DEVICE;
     if (rc == CILQR_OK && hipEventCreateWithFlags(&js.sync_ev, hipEventDisableTiming) != hipSuccess) rc = CILQR_ERR_DEVICE;
+    if (rc == CILQR_OK && hipEventCreateWithFlags(&js.exported, hipEventDisableTiming) != hipSuccess) rc = CILQR_ERR_DEVICE;
+  }
+  for (cilqr_in_buffer& b : h->in_bufs) {
+    if (rc == CILQR_OK && (hipEventCreateWithFlags(&b.ready, hipEventDisableTiming) != hipSuccess ||
+                           hipEventCreateWithFlags(&b.loaded, hipEventDisableTiming) != hipSuccess))
+      rc = CILQR_ERR_DEVICE;
   }
   if (rc == CILQR_OK) {   // the stage API works on the main arena with the first set
     const DeviceState v = main_view(h, h->sets[0]);
@@ -581,20 +681,35 @@ int cilqr_destroy(cilqr_handle h) {
     h->cv.notify_all();
     h->worker1.join();
     h->worker2.join();
+    h->worker_io.join();
   }
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->stream2) (void)hipStreamSynchronize(h->stream2);
+  if (h->stream_in) (void)hipStreamSynchronize(h->stream_in);
+  if (h->stream_out) (void)hipStreamSynchronize(h->stream_out);
   cilqr_comm_release(h);
   for (void* p : h->allocs) (void)hipFree(p);
-  if (h->in_stage) (void)hipFree(h->in_stage);
+  for (cilqr_in_buffer& b : h->in_bufs) {
+    if (b.p) (void)hipFree(b.p);
+    if (b.ready) (void)hipEventDestroy(b.ready);
+    if (b.loaded) (void)hipEventDestroy(b.loaded);
+  }
+  if (h->in_small) (void)hipFree(h->in_small);
   if (h->in_pinned) (void)hipHostFree(h->in_pinned);
   if (h->in_pinned_ev) (void)hipEventDestroy(h->in_pinned_ev);
+  if (h->cor_fail) (void)hipFree(h->cor_fail);
+  if (h->cor_fail_host) (void)hipHostFree(h->cor_fail_host);
+  if (h->cor_done) (void)hipEventDestroy(h->cor_done);
   if (h->tail_ws) (void)hipFree(h->tail_ws);
   if (h->tail_ws1) (void)hipFree(h->tail_ws1);
   for (cilqr_job_set& js : h->sets) {
     if (js.out_stage) (void)hipFree(js.out_stage);
+    if (js.row_off) (void)hipFree(js.row_off);
     if (js.out_pinned) (void)hipHostFree(js.out_pinned);
+    if (js.host_counts) (void)hipHostFree(js.host_counts);
+    if (js.host_rows) (void)hipHostFree(js.host_rows);
+    if (js.exported) (void)hipEventDestroy(js.exported);
     if (js.h_count) (void)hipHostFree(js.h_count);
     for (hipEvent_t e : js.ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : js.iter_ev) (void)hipEventDestroy(e);
@@ -603,6 +718,8 @@ int cilqr_destroy(cilqr_handle h) {
   }
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   if (h->stream2) (void)hipStreamDestroy(h->stream2);
+  if (h->stream_in) (void)hipStreamDestroy(h->stream_in);
+  if (h->stream_out) (void)hipStreamDestroy(h->stream_out);
   delete h;
   return CILQR_OK;
 }
@@ -660,6 +777,26 @@ int cilqr_set_option(cilqr_handle h, int32_t option, int64_t value) {
   }
 }
 
+int cilqr_get_option(cilqr_handle h, int32_t option, int64_t* value, int64_t* value_submitted) {
+  if (h == nullptr || value == nullptr) return CILQR_ERR_NULL;
+  int64_t v = 0, vs = 0;
+  switch (option) {
+    case CILQR_OPT_COMPACTION: v = vs = h->compaction ? h->compact_percent : 0; break;
+    case CILQR_OPT_SPEC_THRESHOLD: v = h->spec_threshold; vs = h->spec_threshold_submit; break;
+    case CILQR_OPT_SEQ_ROUNDS: v = vs = h->seq_rounds; break;
+    case CILQR_OPT_TEAM_THRESHOLD: v = vs = h->team_threshold; break;
+    case CILQR_OPT_ROUND_GROUP: v = vs = h->round_group; break;
+    case CILQR_OPT_WAVE_THRESHOLD: v = vs = h->wave_threshold; break;
+    case CILQR_OPT_TAIL_THRESHOLD: v = h->tail_threshold; vs = h->tail_threshold_submit; break;
+    case CILQR_OPT_EXACT_LANE_TIES: v = vs = h->ds.exact_ties; break;
+    case CILQR_OPT_FINISH_THRESHOLD: v = vs = h->fin_threshold; break;
+    default: return CILQR_ERR_ARG;
+  }
+  *value = v;
+  if (value_submitted) *value_submitted = vs;
+  return CILQR_OK;
+}
+
 void cilqr_default_tracker_config(cilqr_tracker_config* c) {
   if (c == nullptr) return;
   c->weight_l = 1e-1; c->weight_theta = 1e-12; c->weight_delta = 1e-12; c->weight_delta_rate = 0.1; c->preview_time = 0.2;   // :18-25
@@ -715,6 +852,8 @@ static int solve_groups(cilqr_solver* h, cilqr_job& j, const cilqr_problem_batch
 static int solve_one(cilqr_solver* h, cilqr_job& j, const cilqr_problem_batch* in, cilqr_solution_batch* out) {
   if (in) j.in = *in; else std::memset(&j.in, 0, sizeof(j.in));
   j.out = *out;
+  j.upload = 0;          // staged inline, on the solve's own stream
+  j.zero_inline = true;
   int rc = (in == nullptr) ? CILQR_ERR_NULL : job_begin(h, j);
   if (rc == CILQR_OK) rc = job_iterate(h, j, 1);
   if (rc == CILQR_OK && j.handed) rc = job_iterate(h, j, 2);
@@ -821,6 +960,20 @@ DeviceState twin_of(const DeviceState& own, const DeviceState& tw) {
   return t;
 }
 
+// bytes of the output staging block in front of the iterates, and whether host outputs of this size travel through the
+// small pinned block (one copy, handed out on the host) or ragged (job_finish)
+size_t out_head_bytes(const cilqr_solver* h, int B, const cilqr_solution_batch* out) {
+  const size_t K = (size_t)h->cfg.n_steps + 1, M = (size_t)h->cfg.max_iter;
+  const size_t n_traj = (size_t)B * K * 10, n_hist = (size_t)B * (M + 1) * 5, n_at = out->alpha_trace ? (size_t)B * M : 0;
+  return (n_traj + n_hist) * 8 + (((size_t)4 * B * 4 + n_at + 7) & ~(size_t)7);
+}
+bool host_out_is_big(const cilqr_solver* h, int B, const cilqr_solution_batch* out) {
+  if (out->memory != CILQR_MEM_HOST) return false;
+  const size_t K = (size_t)h->cfg.n_steps + 1;
+  const size_t n_itr = out->iter_trajs ? (size_t)B * (size_t)std::max(out->max_iter_trajs, 0) * K * 10 : 0;
+  return out_head_bytes(h, B, out) + n_itr * 8 > kSmallTransfer;
+}
+
 // Arguments, staging, load, init guess and its cost (cc:64-78, 141-173), on the first stage's stream.
 int job_begin(cilqr_solver* h, cilqr_job& j) {
   const cilqr_problem_batch* in = &j.in;
@@ -839,7 +992,34 @@ int job_begin(cilqr_solver* h, cilqr_job& j) {
   j.bwd_iter.clear();
   if (j.tm.begin(3)) return CILQR_ERR_DEVICE;
   j.gmain = main_view(h, js);
-  int rc = do_load(h, in, js, &j.gmain, st);
+  int rc;
+  if (j.upload != 0) {
+    // the transfer thread has been copying this solve's arrays since it was submitted (worker_io_main): wait until every
+    // copy is enqueued and the event behind the last one recorded, then let the stream wait for that event
+    {
+      std::unique_lock<std::mutex> lk(h->mu);
+      h->cv.wait(lk, [&] { return j.upload == 3 || j.upload < 0; });
+    }
+    if (j.upload < 0) {
+      std::snprintf(g_last_hip_error, sizeof(g_last_hip_error), "%s", j.err_text);
+      {
+        std::lock_guard<std::mutex> lk(h->mu);
+        j.past_load = true;
+      }
+      h->cv.notify_all();
+      return j.upload_rc;
+    }
+    HIP_TRY(hipStreamWaitEvent(st, h->in_bufs[j.in_buf].ready, 0));
+    rc = do_load(h, in, js, &j.gmain, st, &j.pv, j.in_buf);
+    j.in_buf = -1;   // (given back behind the load kernels, whatever happened)
+  } else {
+    rc = do_load(h, in, js, &j.gmain, st);
+  }
+  {   // (the transfer thread uploads for the next solve only now: worker_io_main)
+    std::lock_guard<std::mutex> lk(h->mu);
+    j.past_load = true;
+  }
+  h->cv.notify_all();
   if (rc != CILQR_OK) return rc;
   h->stage = 0;   // the main arena no longer holds what cilqr_stage_load put there
   const int B = in->batch, K = in->n_knots, M = h->cfg.max_iter;
@@ -857,10 +1037,11 @@ int job_begin(cilqr_solver* h, cilqr_job& j) {
   j.n_at = out->alpha_trace ? (size_t)B * M : 0;
   j.n_head = 0;
   j.small_out = false;
+  j.big_out = false;
   if (out->memory == CILQR_MEM_HOST) {
     // staging block: traj | cost_hist | n_cost, status, n_iter, n_iter_trajs | alpha_trace | (8-byte pad) | iter_trajs --
     // the iterates last, so that a small batch can fetch everything else (and the first few iterates) in one short copy
-    j.n_head = (j.n_traj + j.n_hist) * 8 + (((size_t)4 * B * 4 + j.n_at + 7) & ~(size_t)7);
+    j.n_head = out_head_bytes(h, B, out);
     const size_t bytes = j.n_head + j.n_itr * 8 + 1024;
     rc = grow(h, &js.out_stage, &js.out_stage_bytes, bytes);
     if (rc != CILQR_OK) return rc;
@@ -871,11 +1052,17 @@ int job_begin(cilqr_solver* h, cilqr_job& j) {
     j.o_nc = q; j.o_st = q + B; j.o_ni = q + 2 * B; j.o_nit = q + 3 * B;
     j.o_at = out->alpha_trace ? reinterpret_cast<signed char*>(q + 4 * B) : nullptr;
     j.o_it = out->iter_trajs ? reinterpret_cast<double*>(static_cast<char*>(js.out_stage) + j.n_head) : nullptr;
-    j.small_out = j.n_head + j.n_itr * 8 <= kSmallTransfer;
-    // the staging buffer is reused between solves: rows the kernels do not write (cost rows
-    // >= n_cost, iterates >= n_iter_trajs) must reach the caller as zeros, not as an earlier solve's data.  A small batch
-    // is handed out row by row on the host (job_finish), which takes the live rows only: nothing to clear
-    if (!j.small_out) HIP_TRY(hipMemsetAsync(j.o_hist, 0, j.n_head - j.n_traj * 8 + j.n_itr * 8, st));
+    j.big_out = host_out_is_big(h, B, out);
+    j.small_out = !j.big_out;
+    // The staging buffer is reused between solves.  Its Cost rows reach the caller through the live rows only, on either
+    // path (a small batch is handed out row by row in job_finish, a large one downloads them packed); the iterates of a large
+    // batch travel as the dense block they are, so the entries the kernels do not write (>= n_iter_trajs) are cleared here
+    if (j.big_out && j.n_itr) HIP_TRY(hipMemsetAsync(j.o_it, 0, j.n_itr * 8, st));
+    if (j.big_out) {
+      rc = grow(h, reinterpret_cast<void**>(&js.row_off), &js.row_off_bytes, ((size_t)B + 1) * sizeof(long long));
+      if (rc == CILQR_OK) rc = grow_pinned(&js.host_counts, &js.host_counts_bytes, (size_t)4 * B * sizeof(int));
+      if (rc != CILQR_OK) return rc;
+    }
   }
 
   if (h->cfg.init_guess == CILQR_INIT_TRACKER) launch_init_guess_tracker(j.d, h->tracker, B, st);   // cc:168 (InitGuess)
@@ -906,6 +1093,10 @@ int job_begin(cilqr_solver* h, cilqr_job& j) {
     if (rc != CILQR_OK) return rc;
   }
   launch_init_counters(j.d, B, st);
+  // rows >= n_cost of the caller's cost_hist are zero on every host path (include/cilqr.h).  A large batch receives its live
+  // rows only, so the array is cleared on the host -- by the transfer thread for a submitted solve, here (behind the first
+  // kernels, which keep the GPU busy meanwhile) for the synchronous call
+  if (j.big_out && j.zero_inline) std::memset(out->cost_hist, 0, j.n_hist * 8);
   j.n_hint = B;   // upper bound of the active count of the iteration being enqueued
   j.span = B;     // slots occupied in the current arena (upper bound)
   return CILQR_OK;
@@ -1044,7 +1235,9 @@ int job_finish(cilqr_solver* h, cilqr_job& j) {
   j.tm.stream = st;
   // (no wait here: the export and the copy out are enqueued behind the solve's last kernel, ONE host round trip for all of it)
   if (j.tm.begin(3)) return CILQR_ERR_DEVICE;
-  launch_export_hist(j.gmain, B, j.o_hist, j.o_nc, j.o_st, j.o_ni, j.o_nit, j.o_at, st);
+  const bool big_out = out->memory == CILQR_MEM_HOST && j.big_out;
+  launch_export_hist(j.gmain, B, big_out ? nullptr : j.o_hist, j.o_nc, j.o_st, j.o_ni, j.o_nit, j.o_at, st);
+  if (big_out) launch_export_hist_rows(j.gmain, B, js.row_off, j.o_hist, st);   // the live rows, packed, where the dense block used to go
   if (j.tm.end()) return CILQR_ERR_DEVICE;
   HIP_TRY(hipGetLastError());
   const bool small_out = out->memory == CILQR_MEM_HOST && j.small_out;
@@ -1059,18 +1252,28 @@ int job_finish(cilqr_solver* h, cilqr_job& j) {
     // pageable copies cost ~25 us each after the last kernel); the iterates that exist follow once their counts are known
     if (js.out_pinned == nullptr) HIP_TRY(hipHostMalloc(&js.out_pinned, kSmallTransfer, hipHostMallocDefault));
     HIP_TRY(hipMemcpyAsync(js.out_pinned, js.out_stage, j.n_head + first, hipMemcpyDeviceToHost, st));
-  } else if (out->memory == CILQR_MEM_HOST) {
-    HIP_TRY(hipMemcpyAsync(out->traj, j.o_traj, j.n_traj * 8, hipMemcpyDeviceToHost, st));
-    // rows >= n_cost were zero-filled above
-    HIP_TRY(hipMemcpyAsync(out->cost_hist, j.o_hist, j.n_hist * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(out->n_cost, j.o_nc, (size_t)B * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(out->status, j.o_st, (size_t)B * 4, hipMemcpyDeviceToHost, st));
-    if (out->n_iter) HIP_TRY(hipMemcpyAsync(out->n_iter, j.o_ni, (size_t)B * 4, hipMemcpyDeviceToHost, st));
-    if (out->iter_trajs) {
-      HIP_TRY(hipMemcpyAsync(out->iter_trajs, j.o_it, j.n_itr * 8, hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipMemcpyAsync(out->n_iter_trajs, j.o_nit, (size_t)B * 4, hipMemcpyDeviceToHost, st));
-    }
-    if (out->alpha_trace) HIP_TRY(hipMemcpyAsync(out->alpha_trace, j.o_at, j.n_at, hipMemcpyDeviceToHost, st));
+  } else if (big_out) {
+    // A large batch: everything is downloaded on the handle's download stream, so that the kernels of the NEXT solve's
+    // finishing stage do not queue behind 0.3 GB of copies.  First the counts (they size the packed rows), then the
+    // trajectories straight into the caller's array; the finishing arena goes back as soon as the last kernel is known to
+    // be done, i.e. before the copies are
+    if (int src = io_streams(h)) return src;
+    hipStream_t so = h->stream_out;
+    HIP_TRY(hipEventRecord(js.exported, st));
+    HIP_TRY(hipStreamWaitEvent(so, js.exported, 0));
+    HIP_TRY(hipMemcpyAsync(js.host_counts, j.o_nc, (size_t)4 * B * 4, hipMemcpyDeviceToHost, so));   // n_cost | status | n_iter | n_iter_trajs
+    HIP_TRY(hipEventRecord(js.sync_ev, so));
+    if (int wrc = wait_event(js.sync_ev, j.relaxed_wait)) return wrc;
+    release_fin(h, j);
+    const int32_t* nc = static_cast<const int32_t*>(js.host_counts);
+    size_t rows = 0;
+    for (int b = 0; b < B; ++b) rows += (size_t)std::min(std::max(nc[b], 0), M + 1);
+    if (int grc = grow_pinned(&js.host_rows, &js.host_rows_bytes, std::max(rows + rows / 2, (size_t)B * 16) * 5 * 8)) return grc;
+    HIP_TRY(hipMemcpyAsync(js.host_rows, j.o_hist, rows * 5 * 8, hipMemcpyDeviceToHost, so));
+    HIP_TRY(hipMemcpyAsync(out->traj, j.o_traj, j.n_traj * 8, hipMemcpyDeviceToHost, so));
+    if (out->iter_trajs) HIP_TRY(hipMemcpyAsync(out->iter_trajs, j.o_it, j.n_itr * 8, hipMemcpyDeviceToHost, so));
+    if (out->alpha_trace) HIP_TRY(hipMemcpyAsync(out->alpha_trace, j.o_at, j.n_at, hipMemcpyDeviceToHost, so));
+    st = so;
   }
   if (int wrc = wait_stream(st, js.sync_ev, j.relaxed_wait)) return wrc;
   int it = j.it;
@@ -1100,6 +1303,25 @@ int job_finish(cilqr_solver* h, cilqr_job& j) {
     }
   }
   j.prof.iterations = it;
+  if (big_out) {
+    if (j.io_busy) {   // the transfer thread clears the caller's cost_hist behind the upload: done long ago, but make sure
+      std::unique_lock<std::mutex> lk(h->mu);
+      h->cv.wait(lk, [&] { return !j.io_busy; });
+    }
+    const char* q = static_cast<const char*>(js.host_counts);
+    const int32_t* nc = reinterpret_cast<const int32_t*>(q);
+    const size_t row = 5 * 8, block = (size_t)(M + 1) * row;
+    const char* src = static_cast<const char*>(js.host_rows);
+    for (int b = 0; b < B; ++b) {   // live rows into the caller's dense array; the rest of it is zero already
+      const size_t live = (size_t)std::min(std::max(nc[b], 0), M + 1) * row;
+      std::memcpy(reinterpret_cast<char*>(out->cost_hist) + (size_t)b * block, src, live);
+      src += live;
+    }
+    std::memcpy(out->n_cost, q, (size_t)B * 4);
+    std::memcpy(out->status, q + (size_t)B * 4, (size_t)B * 4);
+    if (out->n_iter) std::memcpy(out->n_iter, q + (size_t)2 * B * 4, (size_t)B * 4);
+    if (out->iter_trajs) std::memcpy(out->n_iter_trajs, q + (size_t)3 * B * 4, (size_t)B * 4);
+  }
   if (small_out) {   // same layout as the staging block (job_begin)
     char* pin = static_cast<char*>(js.out_pinned);
     const char* q = pin + (j.n_traj + j.n_hist) * 8;
@@ -1160,6 +1382,24 @@ void release_fin(cilqr_solver* h, cilqr_job& j) {
 // handle's stream, worker 2 the finishing stage on a second (high-priority) stream, so the few hundred
 // stragglers of solve i finish while the bulk of solve i+1 is being iterated.
 // ------------------------------------------------------------------------------------------
+// A solve is over (done, or failed anywhere on the way): the transfer thread has let go of it, its input buffer -- if its
+// load never got to give it back -- is free again, and the solve behind it may upload.
+void job_io_settle(cilqr_solver* h, cilqr_job& j) {
+  {
+    std::unique_lock<std::mutex> lk(h->mu);
+    h->cv.wait(lk, [&] { return !j.io_busy; });
+  }
+  if (j.in_buf >= 0) {
+    release_in_buffer(h, j.in_buf, j.st1);
+    j.in_buf = -1;
+  }
+  {
+    std::lock_guard<std::mutex> lk(h->mu);
+    j.past_load = true;
+  }
+  h->cv.notify_all();
+}
+
 void worker1_main(cilqr_solver* h) {
   (void)pthread_setname_np(pthread_self(), "cilqr-stage1");
   (void)hipSetDevice(h->device);
@@ -1169,13 +1409,19 @@ void worker1_main(cilqr_solver* h) {
     h->cv.wait(lk, [&] {
       if (h->quit) return true;
       for (int k = 0; k < h->job_count; ++k) {   // oldest first
-        cilqr_job& c = h->jobs[(h->job_head + k) % 2];
-        if (c.phase == 1) { job = &c; return true; }
+        cilqr_job& c = h->jobs[(h->job_head + k) % kJobRing];
+        if (c.phase == 1) {       // the oldest queued solve starts as soon as one of the two job sets is free
+          if (h->set_busy[0] && h->set_busy[1]) return false;
+          job = &c;
+          return true;
+        }
       }
       return false;
     });
     if (h->quit) return;
     job->phase = 2;
+    job->set = h->set_busy[0] ? 1 : 0;
+    h->set_busy[job->set] = true;
     lk.unlock();
     cilqr_job& j = *job;
     int rc;
@@ -1196,10 +1442,12 @@ void worker1_main(cilqr_solver* h) {
         release_fin(h, j);
       }
     }
+    if (!to_stage2) job_io_settle(h, j);   // (a failed solve: nothing of it may still touch the caller's arrays)
     lk.lock();
     j.rc = rc;
     if (rc != CILQR_OK) std::snprintf(j.err_text, sizeof(j.err_text), "%s", g_last_hip_error);
     j.phase = to_stage2 ? 3 : 5;
+    if (!to_stage2) h->set_busy[j.set] = false;
     h->cv.notify_all();
   }
 }
@@ -1213,7 +1461,7 @@ void worker2_main(cilqr_solver* h) {
     h->cv.wait(lk, [&] {
       if (h->quit) return true;
       for (int k = 0; k < h->job_count; ++k) {
-        cilqr_job& c = h->jobs[(h->job_head + k) % 2];
+        cilqr_job& c = h->jobs[(h->job_head + k) % kJobRing];
         if (c.phase == 3) { job = &c; return true; }
       }
       return false;
@@ -1226,10 +1474,72 @@ void worker2_main(cilqr_solver* h) {
     if (rc == CILQR_OK) rc = job_finish(h, j);
     else (void)hipStreamSynchronize(j.st2);
     release_fin(h, j);
+    job_io_settle(h, j);
     lk.lock();
     j.rc = rc;
     if (rc != CILQR_OK) std::snprintf(j.err_text, sizeof(j.err_text), "%s", g_last_hip_error);
     j.phase = 5;
+    h->set_busy[j.set] = false;
+    h->cv.notify_all();
+  }
+}
+
+// Host arrays of submitted solves.  A handle accepts one solve more than it keeps in flight (kJobRing), and that solve's
+// inputs travel while the solve in front of it iterates: on a stream of their own, into whichever of the two input buffers
+// is free, as soon as every older solve is past its load -- so the 1.46 GB of a bench batch (26 ms of PCIe at 57 GB/s) never
+// leave the main arena idle.  From pageable memory hipMemcpyAsync returns when the copy is done, which is why a thread of its
+// own issues it.  Behind the upload the same thread clears the caller's dense cost_hist (rows >= n_cost are zero on every host
+// path; the live rows arrive packed and are scattered in job_finish).
+void worker_io_main(cilqr_solver* h) {
+  (void)pthread_setname_np(pthread_self(), "cilqr-transfer");
+  (void)hipSetDevice(h->device);
+  std::unique_lock<std::mutex> lk(h->mu);
+  for (;;) {
+    cilqr_job* job = nullptr;
+    h->cv.wait(lk, [&] {
+      if (h->quit) return true;
+      bool older_past_load = true;
+      for (int k = 0; k < h->job_count; ++k) {   // oldest first
+        cilqr_job& c = h->jobs[(h->job_head + k) % kJobRing];
+        if (c.io_busy && !c.io_taken && (c.upload != 1 || older_past_load)) { job = &c; return true; }
+        older_past_load = older_past_load && c.past_load;
+      }
+      return false;
+    });
+    if (h->quit) return;
+    cilqr_job& j = *job;
+    j.io_taken = true;
+    const bool upload = j.upload == 1;
+    if (upload) j.upload = 2;
+    lk.unlock();
+    int rc = CILQR_OK;
+    if (upload) {
+      rc = check_problem(h, &j.in);
+      if (rc == CILQR_OK) rc = io_streams(h);
+      int buf = -1;
+      if (rc == CILQR_OK) {
+        buf = acquire_in_buffer(h, true);
+        if (buf < 0) rc = CILQR_ERR_DEVICE;
+      }
+      if (rc == CILQR_OK) rc = stage_inputs(h, &j.in, &h->in_bufs[buf], h->stream_in, &j.pv);
+      if (rc == CILQR_OK && hipEventRecord(h->in_bufs[buf].ready, h->stream_in) != hipSuccess) rc = CILQR_ERR_DEVICE;
+      if (rc != CILQR_OK && buf >= 0) {   // nothing will read it
+        (void)hipStreamSynchronize(h->stream_in);
+        release_in_buffer(h, buf, h->stream_in);
+        buf = -1;
+      }
+      lk.lock();
+      j.in_buf = buf;
+      j.upload_rc = rc;
+      if (rc != CILQR_OK) std::snprintf(j.err_text, sizeof(j.err_text), "%s", g_last_hip_error);
+      j.upload = (rc == CILQR_OK) ? 3 : -1;
+      h->cv.notify_all();
+      lk.unlock();
+    }
+    if (j.zero_by_io && j.out.cost_hist != nullptr)
+      std::memset(j.out.cost_hist, 0, (size_t)j.in.batch * ((size_t)h->cfg.max_iter + 1) * 5 * 8);
+    lk.lock();
+    j.io_busy = false;
     h->cv.notify_all();
   }
 }
@@ -1241,22 +1551,34 @@ extern "C" {
 int cilqr_submit(cilqr_handle h, const cilqr_problem_batch* in, cilqr_solution_batch* out) {
   if (h == nullptr || in == nullptr || out == nullptr) return CILQR_ERR_NULL;
   std::lock_guard<std::mutex> lk(h->mu);
-  if (h->job_count >= 2) return CILQR_ERR_STATE;   // two solves in flight: collect the oldest first (cilqr_wait)
+  if (h->job_count >= kJobRing) return CILQR_ERR_STATE;   // two in flight and one queued: collect the oldest first (cilqr_wait)
   if (!h->workers_started) {
     h->worker1 = std::thread(worker1_main, h);
     h->worker2 = std::thread(worker2_main, h);
+    h->worker_io = std::thread(worker_io_main, h);
     h->workers_started = true;
   }
-  const int slot = (h->job_head + h->job_count) % 2;
+  const int slot = (h->job_head + h->job_count) % kJobRing;
   cilqr_job& j = h->jobs[slot];
   j.in = *in;
   j.out = *out;
-  j.set = slot;
+  j.set = 0;            // taken when the first stage starts (worker1_main)
+  j.in_buf = -1;
+  j.past_load = false;
   j.spec_threshold = h->alone_on_device ? h->spec_threshold : h->spec_threshold_submit;
   j.tail_threshold = h->alone_on_device ? h->tail_threshold : h->tail_threshold_submit;
   j.st1 = h->stream;
   j.st2 = h->stream2;
   j.relaxed_wait = true;     // a worker thread waits for this solve, and other solves want the cores (wait_event)
+  // host arrays of a large batch: the transfer thread starts on them now (worker_io_main)
+  const bool plain = in->n_lane_groups <= 1 && in->batch > 0 && in->batch <= h->capacity;
+  j.upload = (plain && in->memory == CILQR_MEM_HOST && check_problem(h, in) == CILQR_OK &&
+              input_payload_bytes(h, in) > kSmallTransfer) ? 1 : 0;
+  j.zero_by_io = plain && out->cost_hist != nullptr && host_out_is_big(h, in->batch, out);
+  j.zero_inline = !j.zero_by_io;
+  j.io_busy = j.upload == 1 || j.zero_by_io;
+  j.io_taken = false;
+  j.upload_rc = CILQR_OK;
   j.rc = CILQR_OK;
   j.err_text[0] = 0;
   j.phase = 1;
@@ -1275,7 +1597,7 @@ int cilqr_wait(cilqr_handle h) {
   h->prof = j.prof;
   if (rc != CILQR_OK) std::snprintf(g_last_hip_error, sizeof(g_last_hip_error), "%s", j.err_text);   // the caller's cilqr_error_string
   j.phase = 0;
-  h->job_head = (h->job_head + 1) % 2;
+  h->job_head = (h->job_head + 1) % kJobRing;
   h->job_count -= 1;
   return rc;
 }
@@ -1523,14 +1845,22 @@ int cilqr_build_corridors(cilqr_handle h, const cilqr_corridor_config* cfg, int3
   const size_t b_cor = n * (size_t)cmax * 3 * 8, b_poly = polygons ? n * (size_t)cmax * 2 * 8 : 0;
   CorridorParams cp{cfg->max_diff_x, cfg->max_diff_y, cfg->radius, cfg->max_axis_x, cfg->max_axis_y,
                     cfg->is_multiple_sample ? 6 : 2};
-  void *t_in = nullptr, *t_out = nullptr, *t_fail = nullptr;
+  void *t_in = nullptr, *t_out = nullptr;
   int rc = CILQR_OK;
+  // the failure counter and its landing place on the host belong to the handle: a hipMalloc / hipFree per call is a
+  // device-wide synchronisation, i.e. a producer that runs beside solves in flight (other handles, a pool) would wait for
+  // all of them
+  if (h->cor_fail == nullptr) {
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->cor_fail), 256));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->cor_fail_host), 64, hipHostMallocDefault));
+    HIP_TRY(hipEventCreateWithFlags(&h->cor_done, hipEventDisableTiming));
+  }
+  int* t_fail = h->cor_fail;
   const double *d_knots = knots, *d_pts = points;
   const int* d_cnt = point_count;
   double* d_cor = corridor;
   double* d_poly = polygons;
   int* d_ccnt = corridor_count;
-  if (hipMalloc(&t_fail, 256) != hipSuccess) return CILQR_ERR_DEVICE;
   if (hipMemsetAsync(t_fail, 0, 4, h->stream) != hipSuccess) rc = CILQR_ERR_DEVICE;
   if (rc == CILQR_OK && memory == CILQR_MEM_HOST) {
     const size_t o_pts = (b_knots + 255) / 256 * 256, o_cnt = o_pts + (b_pts + 255) / 256 * 256;
@@ -1553,8 +1883,7 @@ int cilqr_build_corridors(cilqr_handle h, const cilqr_corridor_config* cfg, int3
   }
   int failed = 0;
   if (rc == CILQR_OK) {
-    launch_build_corridors((int)n, cp, d_knots, d_pts, d_cnt, max_points, d_cor, d_ccnt, cmax,
-                           static_cast<int*>(t_fail), d_poly, h->stream);
+    launch_build_corridors((int)n, cp, d_knots, d_pts, d_cnt, max_points, d_cor, d_ccnt, cmax, t_fail, d_poly, h->stream);
     if (hipGetLastError() != hipSuccess) rc = CILQR_ERR_DEVICE;
     if (rc == CILQR_OK && memory == CILQR_MEM_HOST) {
       if (hipMemcpyAsync(corridor, d_cor, b_cor, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
@@ -1563,13 +1892,19 @@ int cilqr_build_corridors(cilqr_handle h, const cilqr_corridor_config* cfg, int3
         rc = CILQR_ERR_DEVICE;
     }
     if (rc == CILQR_OK &&
-        hipMemcpyAsync(&failed, t_fail, 4, hipMemcpyDeviceToHost, h->stream) != hipSuccess)
+        hipMemcpyAsync(h->cor_fail_host, t_fail, 4, hipMemcpyDeviceToHost, h->stream) != hipSuccess)
       rc = CILQR_ERR_DEVICE;
-    if (hipStreamSynchronize(h->stream) != hipSuccess) rc = CILQR_ERR_DEVICE;
+    // a large batch is milliseconds of kernel time: the caller's thread naps through it instead of spinning (it usually has
+    // solves in flight whose worker threads want the cores); a small one is waited for the short way
+    if (rc == CILQR_OK && n >= (size_t)1 << 18) {
+      if (hipEventRecord(h->cor_done, h->stream) != hipSuccess || wait_event(h->cor_done, true) != CILQR_OK) rc = CILQR_ERR_DEVICE;
+    } else if (hipStreamSynchronize(h->stream) != hipSuccess) {
+      rc = CILQR_ERR_DEVICE;
+    }
+    if (rc == CILQR_OK) failed = *h->cor_fail_host;
   }
   if (t_in) (void)hipFree(t_in);
   if (t_out) (void)hipFree(t_out);
-  (void)hipFree(t_fail);
   if (n_failed) *n_failed = failed;
   return rc;
 }

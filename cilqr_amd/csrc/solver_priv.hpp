@@ -54,9 +54,17 @@ struct cilqr_job_set {
   int* h_count = nullptr;           // pinned, written by k_update through h_count_dev
   int* h_count_dev = nullptr;
   int* tail_iter_dev = nullptr;     // largest iteration count reached inside the tail kernel
+  // host arrays (CILQR_MEM_HOST) on the way out: the staging of ONE solve in flight (the way in: cilqr_in_buffer)
   void* out_stage = nullptr;        // problem-major results on the device when the caller's buffers are host memory
   size_t out_stage_bytes = 0;
   void* out_pinned = nullptr;       // small host batches: the staging block lands here in one copy
+  long long* row_off = nullptr;     // device [B + 1]: first packed Cost row of every problem, total (large host batches)
+  size_t row_off_bytes = 0;
+  void* host_counts = nullptr;      // pinned: n_cost | status | n_iter | n_iter_trajs of a large host batch
+  size_t host_counts_bytes = 0;
+  void* host_rows = nullptr;        // pinned: its LIVE Cost rows, packed (scattered into the caller's dense array on the host)
+  size_t host_rows_bytes = 0;
+  hipEvent_t exported = nullptr;    // recorded on the solve's stream behind its last kernel (what the download stream waits for)
   std::vector<hipEvent_t> iter_ev;  // one per lockstep iteration (count read-back)
   std::vector<hipEvent_t> ev;       // profiling
   hipEvent_t handoff = nullptr;     // survivors copied into the finishing arena (recorded on the first stage's stream)
@@ -81,13 +89,29 @@ struct cilqr_timer {  // event pairs around kernels / phases, resolved after the
   void resolve(cilqr_profile* p);
 };
 
+// Host arrays on the way in: a problem-major copy of the caller's inputs on the device.  A buffer belongs to a solve from the
+// start of its upload until its load kernels are enqueued; two of them, so that the arrays of the NEXT solve travel while this
+// one iterates (solver.hip: worker_io_main).
+struct cilqr_in_buffer {
+  void* p = nullptr;
+  size_t bytes = 0;
+  hipEvent_t ready = nullptr;    // recorded on the upload stream behind the last input copy
+  hipEvent_t loaded = nullptr;   // recorded on the solve's stream behind the load kernels that read the buffer
+  int state = 0;                 // 0 free; 1 owned by a solve; 2 given back: free once `loaded` has happened
+};
+
+// Solves a handle accepts before the oldest is collected: two in flight (first stage / finishing stage) and one more, queued,
+// whose host arrays are uploaded meanwhile -- without it the main arena would sit idle for the length of an upload between
+// two solves (26 ms of a 33 ms step on the bench workload, measured: 1.40 M solves/s from host arrays against 1.98 M).
+constexpr int kJobRing = 3;
+
 // One solve on its way through the handle: first stage (load, init guess, the lockstep iterations over the bulk of
 // the batch, in the main arena), hand-over of the survivors, finishing stage (remaining lockstep iterations + the
 // per-problem tail kernel in the small finishing arena, final export).
 struct cilqr_job {
   cilqr_problem_batch in;
   cilqr_solution_batch out;
-  int set = 0;
+  int set = 0;              // the cilqr_job_set it runs on: taken when its first stage starts, given back when it is done
   int spec_threshold = 0;   // the threshold of this solve (cilqr_solver::spec_threshold or spec_threshold_submit)
   int tail_threshold = 0;   // likewise (cilqr_solver::tail_threshold or tail_threshold_submit)
   int phase = 0;            // 0 free, 1 queued, 2 first stage, 3 waiting for the finishing stage, 4 finishing, 5 done
@@ -112,6 +136,22 @@ struct cilqr_job {
   size_t n_head = 0;        // bytes of the staging block in front of the iterates (traj, cost_hist, counts, alpha_trace, pad)
   bool small_out = false;   // host outputs small enough to travel through the pinned block
   bool relaxed_wait = false;  // the host waits of this solve poll and nap instead of spinning (solver.hip: wait_event)
+  // Host inputs of a submitted solve travel ahead of it: the handle's transfer thread (solver.hip: worker_io_main) copies
+  // them into the job set's staging on a stream of its own as soon as the solve is SUBMITTED, i.e. while the solve before it
+  // still iterates; the first stage then only waits for the event behind the last copy.  upload: 0 = not delegated (device
+  // inputs, a small batch, the synchronous call: staged inline by the solving thread), 1 = queued, 2 = being copied,
+  // 3 = every copy enqueued and the event recorded, -1 = failed (upload_rc).
+  int upload = 0;
+  int upload_rc = CILQR_OK;
+  cilqr::ProblemView pv;      // where the staged inputs lie (filled by whoever staged them)
+  bool past_load = false;     // its inputs are staged and its load kernels enqueued (or it failed before): the transfer thread may
+                              // upload for the solve behind it
+  int in_buf = -1;            // the cilqr_in_buffer they lie in (-1: the caller's own device arrays)
+  bool io_busy = false;       // the transfer thread still works for this solve (upload, zero fill of the caller's cost_hist)
+  bool io_taken = false;      // ... and has picked it up
+  bool zero_by_io = false;    // large host outputs of a submitted solve: the transfer thread clears the caller's cost_hist
+  bool zero_inline = false;   // large host outputs of a solve without the transfer thread: the solving thread clears cost_hist
+  bool big_out = false;       // host outputs that travel ragged: trajectory straight into the caller's array, live Cost rows packed
 };
 
 struct cilqr_solver {
@@ -130,15 +170,18 @@ struct cilqr_solver {
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // finishing stage of asynchronous solves (high priority: short, latency-bound kernels)
+  hipStream_t stream_in = nullptr;   // host arrays: uploads of submitted solves (the transfer thread), beside the solves' kernels
+  hipStream_t stream_out = nullptr;  // host arrays: downloads of finished solves, so that the next solve's kernels need not queue behind them
   std::vector<void*> allocs;
   int64_t bytes = 0;
   std::atomic<int64_t> grown_bytes{0};   // staging blocks + tail workspaces, grown by the solving threads (solver.hip: grow)
-  // staging (lazily grown): problem-major copy of host inputs on the device
-  void* in_stage = nullptr;
-  size_t in_stage_bytes = 0;
+  void* in_small = nullptr;         // small host batches: their device block (the large ones: in_bufs)
+  size_t in_small_bytes = 0;
   void* in_pinned = nullptr;        // small host batches: the input arrays leave from here in one copy
   hipEvent_t in_pinned_ev = nullptr;
   cilqr_job_set sets[2];
+  bool set_busy[2] = {false, false};   // (under mu) a submitted solve runs on the set
+  cilqr_in_buffer in_bufs[2];
   double* lambda_stage = nullptr;
   int B = 0;               // problems loaded
   int stage = 0;           // bit0 loaded, bit1 iterate, bit2 quadratized, bit3 gains
@@ -166,12 +209,13 @@ struct cilqr_solver {
   void* tail_ws1 = nullptr;   // the same for a solve that reaches the tail without having been handed over (first stage)
   size_t tail_ws1_bytes = 0;
   // asynchronous submit / wait: two jobs in flight, one worker thread per stage
-  std::thread worker1, worker2;
+  std::thread worker1, worker2, worker_io;
+  std::mutex io_mu;           // creation of stream_in / stream_out (solver.hip: io_streams)
   std::mutex mu;
   std::condition_variable cv;
   bool workers_started = false, quit = false;
   bool fin_busy = false;      // the finishing arena holds a solve
-  cilqr_job jobs[2];          // ring: jobs[k] uses sets[k]
+  cilqr_job jobs[kJobRing];   // ring of submitted solves, oldest at job_head
   int job_head = 0;           // oldest job not yet collected by cilqr_wait
   int job_count = 0;          // submitted and not yet collected
   // profiling
@@ -179,5 +223,8 @@ struct cilqr_solver {
   int profiling_level = 1;
   cilqr_profile prof;         // of the last solve that completed
   cilqr_comm* comm = nullptr;   // multi-GPU results gather (cilqr_comm_create)
+  int* cor_fail = nullptr;        // cilqr_build_corridors: failure counter on the device, where it lands on the host, its event
+  int* cor_fail_host = nullptr;
+  hipEvent_t cor_done = nullptr;
   cilqr::TrackerParams tracker;   // CILQR_INIT_TRACKER
 };

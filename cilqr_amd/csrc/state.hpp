@@ -232,6 +232,10 @@ void launch_export_iter_traj(const DeviceState& s, const int* list, int n, doubl
                              int max_iter_trajs, hipStream_t st);
 void launch_export_hist(const DeviceState& s, int B, double* cost_hist, int* n_cost, int* status,
                         int* n_iter, int* n_iter_trajs, signed char* alpha_trace, hipStream_t st);
+// the LIVE Cost rows only, packed problem after problem: off [B + 1] = first row of every problem and the total (an
+// exclusive prefix sum of n_cost, built here), rows [off[B]][5].  What a large batch in host memory downloads instead of
+// the dense [B][max_iter + 1][5] array (24 MB instead of 527 MB on the bench workload).
+void launch_export_hist_rows(const DeviceState& s, int B, long long* off, double* rows, hipStream_t st);
 // corridor producer (kernels_corridor.hip)
 constexpr int kCorMaxPts = 320;  // obstacle points of one knot + the 8 (24) box points
 struct CorridorParams {

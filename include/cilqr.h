@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define CILQR_ABI_VERSION 5
+#define CILQR_ABI_VERSION 6
 
 #define CILQR_NX 6  /* state  (x, y, theta, v, a, delta)   vehicle_model.h:11 */
 #define CILQR_NU 2  /* control (jerk, delta_rate)           vehicle_model.h:12 */
@@ -223,6 +223,9 @@ int cilqr_set_stream(cilqr_handle h, void* hip_stream);
  * excuse (tests/parity_util.py). */
 #define CILQR_OPT_EXACT_LANE_TIES 9
 int cilqr_set_option(cilqr_handle h, int32_t option, int64_t value);
+/* the value in force (for the options with two defaults -- CILQR_OPT_SPEC_THRESHOLD, CILQR_OPT_TAIL_THRESHOLD -- the one of
+ * cilqr_solve_batch in *value and, if value_submitted is not NULL, the one of submitted solves there) */
+int cilqr_get_option(cilqr_handle h, int32_t option, int64_t* value, int64_t* value_submitted);
 /* enable = 1: HIP events around every phase of every lockstep iteration (cilqr_profile complete; about 4 %
  * slower: ~800 event records per solve); enable = 2: around the backward launches only (backward_* fields;
  * under 1 %); 0: none. */
@@ -247,12 +250,18 @@ int cilqr_set_tracker_config(cilqr_handle h, const cilqr_tracker_config* cfg);
 
 /* Asynchronous form of cilqr_solve_batch: submit returns at once (the structs are copied, the
  * arrays they point to -- inputs and outputs -- must stay valid and distinct per solve until its wait),
- * wait blocks for the result code of the OLDEST submitted solve.  Up to TWO solves may be in flight on a
- * handle (a third submit returns CILQR_ERR_STATE): the handle iterates the bulk of solve i+1 in its main
- * arena while the last few thousand problems of solve i -- the latency-bound part of a solve: lockstep
- * iterations over few problems, then the per-problem tail kernel -- finish in a small second arena on a
- * second stream (CILQR_OPT_FINISH_THRESHOLD).  Keep the handle fed:
- *     submit(A); submit(B); wait(); submit(C); wait(); submit(D); ...
+ * wait blocks for the result code of the OLDEST submitted solve.  A handle accepts up to THREE solves before the
+ * oldest is collected (a fourth submit returns CILQR_ERR_STATE): TWO are in flight -- the handle iterates the bulk of
+ * solve i+1 in its main arena while the last few thousand problems of solve i (the latency-bound part of a solve: lockstep
+ * iterations over few problems, then the per-problem tail kernel) finish in a small second arena on a second stream
+ * (CILQR_OPT_FINISH_THRESHOLD) -- and the third is queued behind them.  Keep the handle fed:
+ *     submit(A); submit(B); submit(C); wait(); submit(D); wait(); submit(E); ...
+ * Host arrays (CILQR_MEM_HOST) of more than 4 MB take a path of their own on a submitted solve: the inputs of the queued
+ * solve are uploaded on a separate stream while the solve in front of it iterates (which is what the third place is for:
+ * an upload is as long as most of a solve); the results come back on another one -- trajectories straight into the caller's
+ * array, the LIVE Cost rows packed (24 MB instead of the dense 527 MB on the bench workload) and scattered into the
+ * caller's dense cost_hist on the host, whose other rows the library clears.  Pinned or pageable memory alike (57 / 51 GB/s
+ * measured); from the moment of the submit until the wait returns the library reads the inputs and writes the outputs.
  * Results are bit-identical to cilqr_solve_batch.  cilqr_get_profile reports the solve the last wait
  * collected.  A handle is not re-entrant: between a submit and the wait that collects it, call only
  * cilqr_submit / cilqr_wait on it (cilqr_solve_batch and cilqr_stage_load return CILQR_ERR_STATE). */
@@ -421,8 +430,8 @@ int64_t cilqr_multi_device_bytes(cilqr_multi_handle m);
  * cilqr_submit overlaps the latency-bound end of a solve with the bulk of the next one.  What stays idle then is inside
  * the bulk itself (a backward pass or a rollout is one lane per problem: N dependent steps on a fraction of the chip once
  * the active set has shrunk); other solves' cost kernels fit there.  A pool owns n_handles handles on one device
- * (n_handles x the memory of one; 1..16) and runs submitted solve s on handle s % n_handles: up to 2 x n_handles solves in
- * flight, cilqr_pool_wait collects the OLDEST.  Keep it fed:
+ * (n_handles x the memory of one; 1..16) and runs submitted solve s on handle s % n_handles: up to 3 x n_handles solves
+ * submitted (two in flight and one queued per handle, see cilqr_submit), cilqr_pool_wait collects the OLDEST.  Keep it fed:
  *     for (i = 0; i < depth; ++i) submit(batch[i]);   then   wait(); submit(next); wait(); submit(next); ...
  * The rules of cilqr_submit hold per solve (structs copied, arrays valid and distinct until the wait that collects them; a
  * submit beyond the depth returns CILQR_ERR_STATE).  Results are bit-identical to cilqr_solve_batch.  Measured on the
@@ -437,7 +446,7 @@ int cilqr_pool_create(const cilqr_config* cfg, int32_t device, int32_t n_handles
 int cilqr_pool_destroy(cilqr_pool_handle p);
 int cilqr_pool_submit(cilqr_pool_handle p, const cilqr_problem_batch* in, cilqr_solution_batch* out);
 int cilqr_pool_wait(cilqr_pool_handle p);
-int32_t cilqr_pool_depth(cilqr_pool_handle p);   /* 2 x n_handles */
+int32_t cilqr_pool_depth(cilqr_pool_handle p);   /* 3 x n_handles */
 /* handle k (0 <= k < n_handles) for what the pool has no call of its own for -- cilqr_set_profiling, cilqr_set_stream, a
  * synchronous cilqr_solve_batch, the stage entry points; NULL while solves are in flight on the pool.  Owned by the pool. */
 cilqr_handle cilqr_pool_handle_at(cilqr_pool_handle p, int32_t k);

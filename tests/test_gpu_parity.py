@@ -778,7 +778,7 @@ def test_submit_wait_keeps_batches_in_flight_on_separate_handles():
 
 @pytest.mark.parametrize("finish_threshold", [-1, 3000, 0])
 def test_two_solves_in_flight_on_one_handle(finish_threshold):
-    """cilqr_submit keeps TWO solves in flight on one handle: the survivors of solve i move into the handle's finishing
+    """cilqr_submit keeps TWO solves in flight on one handle (and a third queued behind them): the survivors of solve i move into the handle's finishing
     arena (CILQR_OPT_FINISH_THRESHOLD) and finish on a second stream while solve i+1 is iterated in the main arena.
     Five different batches -- larger than the finishing arena, smaller than it (handed over before the first iteration),
     smaller than the tail threshold (never handed over) -- through one handle, results bit-identical to
@@ -822,13 +822,14 @@ def test_two_solves_in_flight_on_one_handle(finish_threshold):
                 if hasattr(a, "zero_"):
                     a.zero_()
                 else:
-                    a[...] = 0
+                    a[...] = -3      # host arrays arrive dirty
         torch.cuda.synchronize()
         assert opt.submit_raw(jobs[0][2], jobs[0][3]) == api.OK
         assert opt.submit_raw(jobs[1][2], jobs[1][3]) == api.OK
-        assert opt.submit_raw(jobs[2][2], jobs[2][3]) == api.ERR_STATE     # two in flight: collect first
-        assert opt.solve_raw(jobs[2][2], jobs[2][3]) == api.ERR_STATE
-        nxt = 2
+        assert opt.submit_raw(jobs[2][2], jobs[2][3]) == api.OK            # the third is queued (its host arrays travel meanwhile)
+        assert opt.submit_raw(jobs[3][2], jobs[3][3]) == api.ERR_STATE     # two in flight and one queued: collect first
+        assert opt.solve_raw(jobs[3][2], jobs[3][3]) == api.ERR_STATE
+        nxt = 3
         for i in range(len(jobs)):
             assert opt.wait() == api.OK                       # the oldest one
             if nxt < len(jobs):
@@ -843,6 +844,8 @@ def test_two_solves_in_flight_on_one_handle(finish_threshold):
             hist = host(got[1])
             for b in range(0, sizes[i], 37):
                 assert np.array_equal(hist[b, :nc[b]], ref["cost_hist"][b, :nc[b]])
+            if not hasattr(got[1], "cpu"):       # host memory: the whole array, zero rows included
+                assert np.array_equal(hist, ref["cost_hist"]), (rep, i)
         assert opt.wait() == api.ERR_STATE
     again = opt.plan(scenes[0], alpha_trace=True)            # the synchronous call works again
     for k in ("traj", "cost_hist", "n_cost", "status", "n_iter", "alpha_trace"):
@@ -1182,8 +1185,8 @@ def test_nearest_lane_grid_equals_linear_scan():
 
 
 def test_handle_pool_deals_batches_round_robin_bit_identically():
-    """cilqr_pool_*: three handles on one GPU, seven different batches submitted as a stream (up to depth = 6 in
-    flight, the oldest collected first).  Every batch comes back bit-identical to the synchronous call; a submit beyond
+    """cilqr_pool_*: two handles on one GPU, seven different batches submitted as a stream (up to depth = 6 submitted:
+    two in flight and one queued per handle, the oldest collected first).  Every batch comes back bit-identical to the synchronous call; a submit beyond
     the depth and a wait on an empty pool are refused; destroy collects what is still in flight."""
     torch = pytest.importorskip("torch")
     sizes = [9000, 700, 8500, 100, 9000, 3000, 5000]
@@ -1191,8 +1194,8 @@ def test_handle_pool_deals_batches_round_robin_bit_identically():
     cfg = api.default_config(scenes[0]["n_steps"])
     one = api.BatchIlqrOptimizer(cfg, batch_capacity=max(sizes), cmax=scenes[0]["cmax"], max_lane_segments=64)
     sync = [one.plan(sc) for sc in scenes]
-    pool = api.HandlePool(cfg, device=0, handles=3, batch_capacity=max(sizes), cmax=scenes[0]["cmax"], max_lane_segments=64)
-    assert pool.depth() == 6 and pool.device_bytes() > 2 * api.BatchIlqrOptimizer.device_bytes(pool.handle_at(0))
+    pool = api.HandlePool(cfg, device=0, handles=2, batch_capacity=max(sizes), cmax=scenes[0]["cmax"], max_lane_segments=64)
+    assert pool.depth() == 6 and pool.device_bytes() > 1.5 * api.BatchIlqrOptimizer.device_bytes(pool.handle_at(0))
     K, M = cfg.n_steps + 1, cfg.max_iter
     jobs = []
     for sc in scenes:
@@ -1201,7 +1204,9 @@ def test_handle_pool_deals_batches_round_robin_bit_identically():
         prob = one.make_problem(B, keep["start"].ctypes.data, keep["coarse"].ctypes.data, keep["corridor"].ctypes.data,
                                 keep["ccount"].ctypes.data, sc["cmax"], keep["left"].ctypes.data, keep["right"].ctypes.data,
                                 keep["left"].shape[0], keep["right"].shape[0], api.MEM_HOST)
-        bufs = (np.zeros((B, K, 10)), np.zeros((B, M + 1, 5)), np.zeros(B, np.int32), np.zeros(B, np.int32), np.zeros(B, np.int32))
+        # (the caller's arrays arrive dirty: rows >= n_cost of cost_hist come back as zeros on every host path, include/cilqr.h)
+        bufs = (np.full((B, K, 10), np.nan), np.full((B, M + 1, 5), np.nan), np.full(B, -9, np.int32), np.full(B, -9, np.int32),
+                np.full(B, -9, np.int32))
         sol = api.SolutionBatch(api.MEM_HOST, 0, bufs[0].ctypes.data, bufs[1].ctypes.data, bufs[2].ctypes.data,
                                 bufs[3].ctypes.data, bufs[4].ctypes.data, None, None)
         jobs.append((keep, bufs, prob, sol))
