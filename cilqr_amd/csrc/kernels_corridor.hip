@@ -18,7 +18,8 @@
 // The kernel is a once-per-solve prologue (3.3 M corridors for 65536 x 51 knots).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
+
+#include <type_traits>
 
 #include "state.hpp"
 
@@ -33,47 +34,58 @@ struct P2f {
 };
 
 // Order-preserving image of a float32: as unsigned integers the images compare exactly as the floats do (-0 folded onto
-// +0 first; NaNs have no place in that order -- waves that hold one sort on the generic path below).
+// +0 first; NaNs have no place in that order -- waves that hold one sort by float comparisons).
 __device__ inline uint32_t ordered_bits(float v) {
   const uint32_t u = __float_as_uint(v + 0.0f);
   return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+
+// A loop the COMPILER'S FRONT END unrolls (template recursion; f is called with std::integral_constant<int, B> ... <E - 1>).
+// `#pragma unroll` unrolls in a pass that runs after the last scalar-replacement pass, so an array indexed by the loop
+// variable stayed in scratch memory even though every index had become a constant (measured: 464 B of scratch, the 57 sort
+// keys of the rank sorts); indexed by template constants from the start it becomes registers.
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
 }
 
 // rank(i) = number of points that sort before point i by (x, y, index) -- the stable sort of the monotone chain, through
 // ranks.  The points of a lane live in scratch memory; read in the inner loop of an n^2 count they were 90 % of the kernel's
 // memory traffic (2 n^2 loads per hull: 66 GB per 65536 x 51 corridors).  Here every lane loads its points ONCE into
 // registers, as 64-bit keys (x image high, y image low: one integer compare per pair), and the double loop is unrolled
-// completely, so every key is a register the compiler names: no load in it at all.  Lanes hold different counts: keys past a
+// by the front end (static_for), so every key is a register the compiler names: no load in it at all.  Lanes hold different counts: keys past a
 // lane's count are all-ones (they sort behind everything and are never stored); `nmax`, the largest count of the wave, ends
 // the unrolled loops early with scalar branches.
 template <int CAP, typename Idx>
-__device__ void rank_sort_in_registers(const P2f* p, int n, int nmax, Idx* order) {
+__device__ __forceinline__ void rank_sort_in_registers(const P2f* p, int n, int nmax, Idx* order) {
   uint64_t key[CAP];
-#pragma unroll
-  for (int c = 0; c < CAP; ++c) {
+  static_for<0, CAP>([&](auto C) {
+    constexpr int c = decltype(C)::value;
     key[c] = ~0ull;
     if (c < nmax && c < n) {
       const P2f q = p[c];
       key[c] = ((uint64_t)ordered_bits(q.x) << 32) | ordered_bits(q.y);
     }
-  }
-#pragma unroll
-  for (int i = 0; i < CAP; ++i) {
-    if (i < nmax) {      // (wave-uniform: a scalar branch around the rest of the unrolled body -- no early exit, which
-      int rank = 0;      // would keep the compiler from unrolling and the keys from becoming registers)
-#pragma unroll
-      for (int jb = 0; jb < CAP; jb += 8) {
+  });
+  static_for<0, CAP>([&](auto I) {
+    constexpr int i = decltype(I)::value;
+    if (i < nmax) {      // (wave-uniform: a scalar branch around the rest of the body)
+      int rank = 0;
+      static_for<0, (CAP + 7) / 8>([&](auto JB) {
+        constexpr int jb = decltype(JB)::value * 8;
         if (jb < nmax) {
-#pragma unroll
-          for (int j = jb; j < jb + 8; ++j) {
-            if (j < CAP && j != i)   // equal points: the earlier index first
-              rank += (j < i) ? (key[j] <= key[i] ? 1 : 0) : (key[j] < key[i] ? 1 : 0);
-          }
+          static_for<jb, (jb + 8 < CAP ? jb + 8 : CAP)>([&](auto J) {
+            constexpr int j = decltype(J)::value;   // equal points: the earlier index first
+            if constexpr (j != i) rank += (j < i) ? (key[j] <= key[i] ? 1 : 0) : (key[j] < key[i] ? 1 : 0);
+          });
         }
-      }
+      });
       if (i < n) order[rank] = (Idx)i;
     }
-  }
+  });
 }
 
 // strictly convex hull of p[0..n): indices into p, counter-clockwise (y up) from the
@@ -337,19 +349,19 @@ void launch_build_corridors(int n, const CorridorParams& cp, const double* knots
   // Unused dynamic LDS caps the kernel at 16 waves per CU.  A lane's working set lives in scratch
   // memory; with every wave slot filled (32 per CU) the scratch of the waves in flight (1.2 GB)
   // streams through HBM on every access, at half that the kernel is 20 % faster (measured).
-  int lds_pad = 10000;
-  if (const char* e = getenv("CILQR_COR_LDS_PAD")) lds_pad = atoi(e);   // TEMPORARY sweep hook
-  // two capacities: a lane's scratch working set scales with it
+  constexpr int lds_pad = 10000;
+  // three capacities: a lane's scratch working set scales with it
   const int need = pmax + 4 * cp.per_edge;
+  const dim3 grid((n + 63) / 64), block(64);
   if (need <= 56)
-    hipLaunchKernelGGL((k_build_corridors<56, unsigned char, 57, 16>), dim3((n + 63) / 64), dim3(64), lds_pad, st, n, cp, knots,
+    hipLaunchKernelGGL((k_build_corridors<56, unsigned char, 57, 16>), grid, block, lds_pad, st, n, cp, knots,
                        points, count, pmax, corridor, ccount, cmax, n_failed, polygons);
   else if (need <= 96)
-    hipLaunchKernelGGL((k_build_corridors<96, unsigned char, 0, 16>), dim3((n + 63) / 64), dim3(64), lds_pad, st, n, cp, knots,
+    hipLaunchKernelGGL((k_build_corridors<96, unsigned char, 0, 16>), grid, block, lds_pad, st, n, cp, knots,
                        points, count, pmax, corridor, ccount, cmax, n_failed, polygons);
   else   // is_multiple_sample scenes: six samples per obstacle edge and per box edge (every sort on the generic path: the
          // kernel the two above are held against bit for bit, tests/test_corridor.py)
-    hipLaunchKernelGGL((k_build_corridors<kCorMaxPts, unsigned short, 0, 0>), dim3((n + 63) / 64), dim3(64), lds_pad, st, n, cp,
+    hipLaunchKernelGGL((k_build_corridors<kCorMaxPts, unsigned short, 0, 0>), grid, block, lds_pad, st, n, cp,
                        knots, points, count, pmax, corridor, ccount, cmax, n_failed, polygons);
 }
 
