@@ -161,23 +161,42 @@ def oracle_reference(scene: dict, cfg=None, n_perturb: int = N_PERTURB, eps: flo
     return r0
 
 
-def second_look(scene: dict, cfg, b: int, n_perturb: int = 64, eps: float = PERTURB_EPS, stable_tol: float = STABLE_TOL, seed: int = 999):
-    """How often the oracle itself ends elsewhere on problem `b` under `n_perturb` FRESH perturbations of the same size.
-    The stability mask rests on N_PERTURB = 8 re-runs: a problem that flips in one run of five is called stable with
-    probability 0.17, and among tens of thousands of problems a few such slip through.  A problem that differs from the
-    library although the mask called it stable is looked at again with this; zero flips = a real mismatch."""
+MIN_FLIPS = 4          # of 64 fresh oracle re-runs: fewer endings elsewhere than this and the problem counts as stable after all
+
+
+def second_look(scene: dict, cfg, b: int, gpu: dict | None = None, n_perturb: int = 64, eps: float = PERTURB_EPS,
+                stable_tol: float = STABLE_TOL, seed: int = 999, max_perturb: int = 256, tol: float = REL_TOL):
+    """How often the oracle itself ends elsewhere on problem `b` under `n_perturb` FRESH perturbations of the same size -- and
+    whether the library's ending is ONE OF the oracle's.  The stability mask rests on N_PERTURB = 8 re-runs: a problem that
+    flips in one run of five is called stable with probability 0.17, and among tens of thousands of problems a few such slip
+    through.  A problem that differs from the library although the mask called it stable is looked at again with this.  It is
+    excused (`excused`) only if the oracle moves in at least MIN_FLIPS of the re-runs AND -- when the library's result is given --
+    that result agrees within `tol` (control flow, cost rows, trajectory) with the ending of at least one perturbed oracle run
+    (the search goes on up to `max_perturb` runs while the oracle keeps flipping and no run has matched yet).  Anything else
+    is a mismatch: the oracle comparing unequal to ITSELF proves nothing about what the library returned."""
     B = scene["coarse"].shape[0]
     one = {k: (np.ascontiguousarray(v[b:b + 1]) if isinstance(v, np.ndarray) and v.shape[:1] == (B,) else v) for k, v in scene.items()}
+    g1 = None
+    if gpu is not None:
+        g1 = {k: (v[b:b + 1] if isinstance(v, np.ndarray) and v.shape[:1] == (B,) else v) for k, v in gpu.items()}
     r0 = orc.solve_batch(one, cfg, want_trace=True)
     rng = np.random.default_rng(seed + b)
-    flips = 0
-    for _ in range(n_perturb):
+    flips = matches = runs = 0
+    while runs < n_perturb or (g1 is not None and matches == 0 and flips * n_perturb >= MIN_FLIPS * runs and runs < max_perturb):
         sc2 = dict(one)
         sc2["coarse"] = one["coarse"] * (1.0 + eps * rng.standard_normal(one["coarse"].shape))
         r1 = orc.solve_batch(sc2, cfg, want_margin=False, want_trace=True)
+        runs += 1
         flow, e_cost, e_traj = solution_errors(r1, r0, 0)
         flips += int((not flow) or max(e_cost, e_traj) > stable_tol)
-    return {"problem": int(b), "oracle_reruns": int(n_perturb), "ended_elsewhere": int(flips)}
+        if g1 is not None:
+            gflow, g_cost, g_traj = solution_errors(g1, r1, 0)
+            matches += int(gflow and max(g_cost, g_traj) <= tol)
+    flips_in_first = flips if runs == n_perturb else None
+    enough = flips * n_perturb >= MIN_FLIPS * runs
+    return {"problem": int(b), "oracle_reruns": int(runs), "ended_elsewhere": int(flips), "ended_elsewhere_in_the_first_64": flips_in_first,
+            "library_result_equals_a_perturbed_oracle_ending": (int(matches) if g1 is not None else None),
+            "excused": bool(enough and (g1 is None or matches > 0))}
 
 
 def assert_parity(gpu: dict, ref: dict, tol=REL_TOL, max_unstable_frac=MAX_UNSTABLE_FRAC, what=""):

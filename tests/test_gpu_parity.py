@@ -99,8 +99,14 @@ def test_stage_parity(family, B, seed):
         assert rel_err(cost[b], o.total_cost(X[b], U[b])) < STAGE_TOL
         oq = o.quadratize(X[b], U[b])
         for k in q:
-            scale = max(1.0, float(np.abs(oq[k]).max()))
-            assert np.max(np.abs(q[k][b] - oq[k])) / scale < STAGE_TOL, k
+            # per ENTRY: relative to the entry itself, with a floor of 1e-3 of the largest entry of the same knot (a sum of
+            # barrier terms of 1e5 leaves 1e-11 of absolute rounding in every entry of its knot -- but a wrong small entry at a
+            # knot without such terms, or three decades under its knot's largest, no longer hides behind the tensor's maximum)
+            o_k, g_k = oq[k], q[k][b]
+            knot_max = np.abs(o_k).reshape(o_k.shape[0], -1).max(axis=1).reshape((-1,) + (1,) * (o_k.ndim - 1))
+            scale = np.maximum(np.abs(o_k), 1e-3 * np.maximum(knot_max, 1e-3))
+            worst = np.max(np.abs(g_k - o_k) / scale)
+            assert worst < STAGE_TOL, (k, float(worst), np.unravel_index(np.argmax(np.abs(g_k - o_k) / scale), o_k.shape))
         oK, ok_, odV = o.backward(float(lam[b]), {k: q[k][b] for k in q})
         assert rel_err(Kfb[b], oK, 1e-6) < STAGE_TOL and rel_err(kff[b], ok_, 1e-6) < STAGE_TOL
         assert rel_err(dV[b], odV, 1e-6) < STAGE_TOL
@@ -206,9 +212,10 @@ def test_parity_report():
         with open(os.path.join(out_dir, "parity_report.json"), "w") as f:
             json.dump(rep, f, indent=1)
     for fam, r in rep["families"].items():
-        # a problem the 8-run stability mask called stable and the library solves differently is looked at again with 64 fresh
-        # oracle re-runs: if the oracle itself never moves, it is a mismatch (none allowed); if it does, the mask missed an
-        # unstable problem (a flip rate of 20 % passes eight runs one time in six) -- at most one in a thousand may
+        # a problem the 8-run stability mask called stable and the library solves differently is looked at again with 64+ fresh
+        # oracle re-runs (parity_util.second_look): it is a mismatch (none allowed) unless the oracle itself ends elsewhere in at
+        # least 4 of 64 AND the library's result is one of those endings within 1e-4 -- then the mask missed an unstable problem
+        # (a flip rate of 20 % passes eight runs one time in six); at most one in a thousand may
         assert not r["stable_but_different_confirmed"], (fam, r["stable_but_different_second_look"])
         assert len(r["stable_but_different"]) <= max(1, r["problems"] // 1000), (fam, r["stable_but_different_second_look"])
         assert r["oracle_unstable"] <= 0.10 * r["problems"], (fam, r["oracle_unstable"])
