@@ -95,6 +95,18 @@ def cost_err(a, ref):
     return float(np.max(np.abs(a - ref) / scale))
 
 
+def entry_err(got, ref):
+    """Worst error of a stage tensor [knot, ...] per ENTRY: relative to the entry itself, with a floor of 1e-3 of the largest
+    entry of the same knot (a sum of barrier terms of 1e5 leaves 1e-11 of absolute rounding in every entry of its knot -- but a
+    wrong small entry at a knot without such terms, or within three decades of its knot's largest, does not hide behind the
+    tensor's maximum).  Returns (worst, index of the worst entry)."""
+    got, ref = np.asarray(got), np.asarray(ref)
+    knot_max = np.abs(ref).reshape(ref.shape[0], -1).max(axis=1).reshape((-1,) + (1,) * (ref.ndim - 1))
+    scale = np.maximum(np.abs(ref), 1e-3 * np.maximum(knot_max, 1e-3))
+    e = np.abs(got - ref) / scale
+    return float(e.max()), tuple(int(i) for i in np.unravel_index(int(np.argmax(e)), ref.shape))
+
+
 def solution_errors(gpu: dict, ref: dict, b: int):
     """(control flow equal?, cost error, trajectory error) of problem b."""
     nc = int(ref["n_cost"][b])
