@@ -136,6 +136,10 @@ def parse_args(argv=None):
                     help="where the coarse trajectories come from: the generator's smooth best-clearance pick, or the DP coarse "
                          "planner (cilqr_dp_plan: the reference's own producer, kinked paths) with corridors built from the "
                          "obstacle points by cilqr_build_corridors; 512 distinct scenes tiled to the batch")
+    ap.add_argument("--gather", default="torch", choices=["torch", "c_abi"],
+                    help="what carries the per-step results gather of a multi-rank run inside the timed region: torch.distributed's "
+                         "gather (RCCL) or cilqr_gather_results (the library's own grouped ncclSend / ncclRecv, no PyTorch in the "
+                         "exchange); the other one is run once after the timed region and compared with it")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the two extra legs (never `value`): pcie_inclusive = the same stream of batches with every array in HOST "
                          "memory, end_to_end = obstacle points -> cilqr_build_corridors -> solve, both through the pool")
@@ -423,11 +427,15 @@ class ThreadComm:
         self.bar.wait(timeout=600.0)
 
     def max_over_ranks(self, rank, v):
+        return max(self.all_ranks(rank, v))
+
+    def all_ranks(self, rank, v):
+        """every rank's value, in rank order (the process group's all_gather)"""
         self.vals[rank] = v
         self.barrier()
-        m = max(self.vals)
+        out = list(self.vals)
         self.barrier()
-        return m
+        return out
 
 
 def main():
@@ -713,7 +721,32 @@ def run(args, rank, local_rank, world, comm, real_stdout):
 
     # 8 of the 10 trajectory columns travel (time and kappa are functions of the others)
     gatherer = None
-    if use_rccl:
+    cabi_handle, cabi_out = None, None
+    if use_rccl and args.gather == "c_abi":
+        # cilqr_gather_results carries the timed region.  The communicator sits on a small handle of its own: a handle is
+        # driven by one thread at a time, and its stream must not queue the exchange behind a solve's kernels.
+        cabi_handle = api.BatchIlqrOptimizer(cfg, device=local_rank, batch_capacity=64, cmax=cmax, max_lane_segments=smax)
+        ids = [api.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        cabi_handle.comm_create(ids[0], rank, world)
+        if rank == 0:
+            cabi_out = dict(traj=torch.zeros((world * B, K, 10), dtype=torch.float64, device=dev),
+                            hist=torch.zeros((world * B, M + 1, 5), dtype=torch.float64, device=dev),
+                            nc=torch.zeros(world * B, dtype=torch.int32, device=dev), st=torch.zeros(world * B, dtype=torch.int32, device=dev))
+            cabi_sol = api.SolutionBatch(api.MEM_DEVICE, 0, cabi_out["traj"].data_ptr(), cabi_out["hist"].data_ptr(),
+                                         cabi_out["nc"].data_ptr(), cabi_out["st"].data_ptr(), None, None, None)
+
+        def cabi_gather(traj_, hist_, nc_, st_):
+            local = api.SolutionBatch(api.MEM_DEVICE, 0, traj_.data_ptr(), hist_.data_ptr(), nc_.data_ptr(), st_.data_ptr(), None, None, None)
+            rc_ = cabi_handle.gather_results_raw(B, local, 0, cabi_sol if rank == 0 else None)
+            if rc_ != api.OK:
+                raise api.CilqrError(rc_, "in cilqr_gather_results (timed region)")
+            return ({"traj": cabi_out["traj"], "n_cost": cabi_out["nc"], "status": cabi_out["st"], "cost_hist": cabi_out["hist"]}
+                    if rank == 0 else None)
+
+        torch.cuda.synchronize()
+        gatherer = GatherThread(device=dev, on_done=slot_gathered, gather_fn=cabi_gather)
+    elif use_rccl:
         gatherer = GatherThread(device=dev, dst=0, derive=(cfg.dt, cfg.wheel_base), on_done=slot_gathered)
     elif comm is not None:      # --multi: peer copies into tensors on rank 0's device
         if rank == 0:
@@ -839,24 +872,46 @@ def run(args, rank, local_rank, world, comm, real_stdout):
         k[0] += 1
         k[1] = round(k[1] + cores, 3)
     gather_timed = dict(busy_s=gatherer.busy_s, count=gatherer.count) if use_dist else None
+    # First-contact insurance for runs this container cannot rehearse: the figures of EVERY rank on the
+    # line, not only their maximum, and a check that block r of what rank 0 gathered IS rank r's result.
+    def checksum(traj_, nc_, st_):
+        """64-bit, position-dependent (wrapping int64 arithmetic), of the 8 travelling trajectory columns, n_cost and status."""
+        t8 = traj_[:, :, [1, 2, 3, 4, 5, 6, 8, 9]].contiguous().view(torch.int64).reshape(-1)
+        w = torch.arange(t8.numel(), dtype=torch.int64, device=t8.device) * 2 + 1
+        ints = torch.cat([nc_.to(torch.int64), st_.to(torch.int64)])
+        wi = torch.arange(ints.numel(), dtype=torch.int64, device=ints.device) * 2 + 0x9E3779B1
+        return int(((t8 * w).sum() + (ints * wi).sum() * 31).item())
+
+    my_sum = None
+    if use_dist and last_gather[-1] is not None:
+        sl_ = last_gather[-1]
+        my_sum = checksum(sl_.traj, sl_.nc, sl_.st)
     if use_rccl:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        tc = torch.tensor([cpu_rank], dtype=torch.float64, device=dev)
-        ts = tc.clone()
-        dist.all_reduce(tc, op=dist.ReduceOp.MAX)
-        dist.all_reduce(ts, op=dist.ReduceOp.SUM)
-        cpu_max, cpu_sum = float(tc.item()), float(ts.item())
+        mine = torch.tensor([elapsed, cpu_rank, float(gatherer.busy_s)], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [[float(x) for x in e.tolist()] for e in every]
+        sums = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(sums, torch.tensor([my_sum if my_sum is not None else 0], dtype=torch.int64, device=dev))
+        rank_sums = [int(x.item()) for x in sums]
     elif comm is not None:
-        elapsed = comm.max_over_ranks(rank, elapsed)
-        cpu_sum = comm.max_over_ranks(rank, cpu_rank)    # threads of ONE process: every rank measured the whole process
-        cpu_max = cpu_sum / world
+        per_rank = comm.all_ranks(rank, [elapsed, cpu_rank / world, float(gatherer.busy_s)])   # (one process: its CPU time shared out)
+        rank_sums = comm.all_ranks(rank, my_sum if my_sum is not None else 0)
     else:
-        cpu_max = cpu_sum = cpu_rank
+        per_rank, rank_sums = [[elapsed, cpu_rank, 0.0]], []
+    elapsed = max(p_[0] for p_ in per_rank)
+    cpu_max, cpu_sum = max(p_[1] for p_ in per_rank), sum(p_[1] for p_ in per_rank)
+    gather_verified = None
+    if use_dist and rank == 0 and last_gather[0] is not None:
+        res_ = last_gather[0]
+        gather_verified = 0
+        for r_ in range(world):
+            blk = slice(r_ * B, (r_ + 1) * B)
+            gather_verified += int(checksum(res_["traj"][blk], res_["n_cost"][blk], res_["status"][blk]) == rank_sums[r_])
     quota = cpu_quota_cores()
     host = {
         "cpu_s_per_step_max_rank": round(cpu_max / args.steps, 5), "cpu_s_per_step_all_ranks": round(cpu_sum / args.steps, 5),
+        "cores_busy_per_rank": [round(p_[1] / max(p_[0], 1e-9), 3) for p_ in per_rank],
         # cores kept busy by the timed region: CPU seconds / wall seconds, all ranks together, against the quota they share
         "cores_busy_all_ranks": round(cpu_sum / elapsed, 3), "cpu_quota_cores": quota, "logical_cpus": os.cpu_count(),
         "quota_fraction": (round(cpu_sum / elapsed / quota, 4) if quota else None),
@@ -872,7 +927,24 @@ def run(args, rank, local_rank, world, comm, real_stdout):
     # called directly, no PyTorch), checked against the torch.distributed gather of the timed region.  Guarded
     # by a watchdog: a multi-rank send / recv cannot be rehearsed on a 1-GPU box.
     cabi = None
-    if use_rccl:
+    hung = False
+    if use_rccl and args.gather == "c_abi":
+        # the timed region went through cilqr_gather_results: the torch.distributed gather of the same (last) step beside it
+        from cilqr_amd.distributed import gather_results as torch_gather
+        sl_ = last_gather[-1]
+        tg = torch_gather(sl_.traj, sl_.hist, sl_.nc, sl_.st, dst=0, densify=False, derive=(cfg.dt, cfg.wheel_base))
+        cabi = {"ok": True, "carried_the_timed_region": True}
+        if rank == 0:
+            g_ = last_gather[0]
+            cols = [1, 2, 3, 4, 5, 6, 8, 9]
+            cabi["ranks"] = world
+            cabi["identical_to_torch_gather"] = bool(
+                torch.equal(g_["traj"][:, :, cols], tg["traj"][:, :, cols]) and torch.equal(g_["n_cost"], tg["n_cost"])
+                and torch.equal(g_["status"], tg["status"])
+                and torch.equal(g_["cost_hist"][torch.arange(M + 1, device=dev)[None, :] < g_["n_cost"][:, None].long()], tg["hist_rows"])
+                and bool(torch.allclose(g_["traj"][:, :, 7], tg["traj"][:, :, 7], rtol=1e-15, atol=0.0)))
+            cabi["rank0_block_identical_to_local"] = bool(torch.equal(g_["traj"][:B], sl_.traj))
+    elif use_rccl:
         import threading
         res = {}
 
@@ -923,8 +995,6 @@ def run(args, rank, local_rank, world, comm, real_stdout):
         th.join(120.0)
         cabi = dict(res) if not th.is_alive() else {"ok": False, "error": "no return within 120 s"}
         hung = th.is_alive()
-    else:
-        hung = False
 
     # the same steps through ONE of the handles (two solves in flight on it): what a caller with one handle's memory gets
     one_handle = None
@@ -1335,6 +1405,12 @@ def run(args, rank, local_rank, world, comm, real_stdout):
             "one_handle": one_handle,
             "results_identical_across_solves_in_flight": same,
             "c_abi_gather": cabi,
+            # every rank's own figures (the line's ms_per_step is their maximum) and the check that block r of the last gathered
+            # step on rank 0 is rank r's result (a 64-bit position-dependent checksum computed where the result was produced)
+            "per_rank": ({"ms_per_step": [round(1e3 * p_[0] / args.steps, 3) for p_ in per_rank],
+                          "gather_thread_busy_ms_per_step": [round(1e3 * p_[2] / args.steps, 3) for p_ in per_rank]} if use_dist else None),
+            "gather_verified_ranks": gather_verified,
+            "results_gather_carrier": (args.gather if use_rccl else None),
             "results_gather_thread": ({"gathers": gather_timed["count"],
                                        "busy_ms_per_gather": round(1e3 * gather_timed["busy_s"] / max(1, gather_timed["count"]), 3),
                                        "note": "rank 0's gather thread (own stream): pack, agree on the ragged length, RCCL gather, unpack "
@@ -1367,6 +1443,9 @@ def run(args, rank, local_rank, world, comm, real_stdout):
     pool.close()
     if gatherer is not None:
         gatherer.close()
+    if cabi_handle is not None:      # (after the last leg that gathers: the one-handle leg of a one-rank rehearsal still does)
+        cabi_handle.comm_destroy()
+        cabi_handle.close()
     if use_rccl:
         dist.barrier()
         dist.destroy_process_group()

@@ -731,6 +731,41 @@ def test_gather_results_through_the_c_abi_single_rank():
     opt.close()
 
 
+def test_gather_results_more_live_rows_than_the_message_region_holds():
+    """A rank's message has room for 32 live Cost rows per problem; zero tolerances make a batch keep 43 on average: the rows
+    beyond the region travel in the second exchange (comm.hip, step 4).  One rank: packed in two windows, unpacked from two
+    buffers -- the gathered history equals the local one row for row."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    sc = scenario.generate("mix11", 60, seed=161)
+    B, K = 60, sc["n_steps"] + 1
+    cfg = api.default_config(sc["n_steps"], rel_cost_tol=0.0, abs_cost_tol=0.0, max_iter=90)
+    opt = api.BatchIlqrOptimizer(cfg, batch_capacity=B, cmax=sc["cmax"])
+    M = cfg.max_iter
+    g = opt.plan(sc)
+    assert int(g["n_cost"].sum()) > 32 * B + 200
+    loc = dict(traj=torch.from_numpy(g["traj"]).to(dev), hist=torch.from_numpy(g["cost_hist"]).to(dev),
+               nc=torch.from_numpy(g["n_cost"]).to(dev), st=torch.from_numpy(g["status"]).to(dev), ni=torch.from_numpy(g["n_iter"]).to(dev))
+    gat = {k: torch.full_like(v, -7) for k, v in loc.items()}
+
+    def sol(d):
+        return api.SolutionBatch(api.MEM_DEVICE, 0, d["traj"].data_ptr(), d["hist"].data_ptr(), d["nc"].data_ptr(),
+                                 d["st"].data_ptr(), d["ni"].data_ptr(), None, None)
+
+    torch.cuda.synchronize()
+    opt.comm_create(api.comm_unique_id(), 0, 1)
+    for _ in range(2):      # (the second call: the same staging blocks again)
+        assert opt.gather_results_raw(B, sol(loc), 0, sol(gat)) == api.OK
+        torch.cuda.synchronize()
+        for k in ("traj", "nc", "st", "ni"):
+            assert torch.equal(gat[k], loc[k]), k
+        live = torch.arange(M + 1, device=dev)[None, :] < loc["nc"][:, None].long()
+        assert torch.equal(gat["hist"][live], loc["hist"][live]) and bool((gat["hist"][~live] == -7).all())
+        gat["hist"].fill_(-7)
+    opt.comm_destroy()
+    opt.close()
+
+
 def test_submit_wait_keeps_batches_in_flight_on_separate_handles():
     """cilqr_submit / cilqr_wait: three handles on three streams solve three different batches
     concurrently; every result equals the synchronous solve of the same batch, bit for bit.

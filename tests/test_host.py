@@ -414,12 +414,19 @@ def test_bench_line_has_the_contract_fields_on_the_gpu():
                 "avg_launch_ms", "avg_launch_ms_contended", "launches", "launches_contended", "full_batch_avg_launch_ms"):
         assert isinstance(roof[key], (int, float)) and roof[key] > 0, key
     assert roof["frac_contended"] <= roof["frac"] * 1.25 and roof["bytes_per_problem_step_minimum"] == 400
-    assert abs(roof["achieved"] - roof["algorithmic_bytes_per_launch"] / (roof["avg_launch_ms"] * 1e-3) / 1e9) <= 0.01 * roof["achieved"]
+    # achieved and frac are quoted on the SAME bytes (the HBM bytes really moved); the dense SURVEY 8(d) figure stands beside them
+    assert abs(roof["achieved"] / roof["peak"] - roof["frac"]) <= 2e-4 and "achieved_basis" in roof
+    assert abs(roof["achieved_algorithmic"] / roof["peak"] - roof["frac_algorithmic"]) <= 2e-4
+    assert abs(roof["achieved_algorithmic"] - roof["algorithmic_bytes_per_launch"] / (roof["avg_launch_ms"] * 1e-3) / 1e9) <= 0.01 * roof["achieved_algorithmic"]
     assert roof["launches_contended"] >= 7 * roof["launches"] * 0.5
     cpu = rec["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] == 1 and cpu["value"] > 0 and cpu["unit"] == "solves/s" and "sample" in cpu
     assert rec["results_identical_across_solves_in_flight"] is True
     assert rec["one_handle"]["value"] > 0 and rec["single_batch"]["value"] > 0
+    # the two figures of a caller whose arrays are not in HBM yet: host arrays through the pool, obstacle points -> corridors -> solve
+    assert rec["pcie_inclusive"]["value"] > 0 and rec["pcie_inclusive"]["identical_to_device_resident"] is True
+    assert rec["end_to_end"]["value"] > 0 and rec["end_to_end"]["identical_across_steps_and_to_the_sequential_call"] is True
+    assert rec["end_to_end"]["corridors_failed"] == 0
 
 
 def test_header_is_plain_c99_and_the_pool_calls_link(built, tmp_path):
