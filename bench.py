@@ -1393,6 +1393,7 @@ def run(args, rank, local_rank, world, comm, real_stdout):
                                    f"seed {args.seed}",
                        "batch_per_gpu": B, "n_steps": N, "cmax": cmax, "batches_in_flight": P * D, "handles": P, "in_flight_per_handle": D,
                        "exact_lane_ties": not args.fast_lane_ties,
+                       "backward_thresholds": {"team": thr_team, "wave": thr_wave},     # cilqr_get_option: what the library holds
                        "coarse_trajectories": ("DP coarse planner (cilqr_dp_plan) + cilqr_build_corridors" if dp_info else "scene generator"),
                        "dp_scene_source": dp_info,
                        "results_gather": ("rccl" if use_rccl else "peer copies (one process, --multi)" if comm is not None else "none"),

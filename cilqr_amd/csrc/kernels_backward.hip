@@ -12,7 +12,8 @@
 //
 // Memory: per step a lane reads 17 double2 (the non-constant entries of A, B, lx, lu, lxx, luu;
 // see state.hpp) + 1 double2 of U, and writes 7 double2 of gains: 18 KiB in + 7 KiB out per
-// wave-step, every access 16 B/lane and 1 KiB contiguous per wave.  Structural zeros/ones of A and
+// wave-step, every access 16 B/lane and 1 KiB contiguous per wave; the reads of the next step go straight into LDS
+// (global_load_lds_dwordx4) while this step computes.  Structural zeros/ones of A and
 // B are skipped at compile time; adding an exact zero never changes an IEEE sum, so the results
 // are those of the dense recursion.
 #include <hip/hip_ext.h>
@@ -38,11 +39,12 @@ __global__ __launch_bounds__(64) void k_backward_team(DeviceState s, const int* 
 
 __global__ __launch_bounds__(64, 1) void k_backward(DeviceState s, const int* __restrict__ list, int n,
                                                      const double* __restrict__ lambda_override) {
+  __shared__ double2 stage[2 * (kLinPairs + 1) * 64];   // the next step's operands, double-buffered (backward_core.hpp)
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= active_count(s, n)) return;
   const int slot = list ? list[j] : j;
   const double lambda = lambda_override ? lambda_override[slot] : s.lambda[slot];
-  backward_problem<true>(s, slot, lambda);
+  backward_problem<true>(s, slot, lambda, stage);
 }
 
 // one wavefront per problem: kernels_backward_wave.hip (a file of its own: it is scheduled for ILP, this one is not)

@@ -78,17 +78,25 @@ int main(int argc, char** argv) {
     CHECK(cilqr_solve_batch(h, &in, &ref.sol));
     CHECK(cilqr_destroy(h));
   }
-  // 2. two solves in flight on ONE handle (first stage / finishing stage on the handle's two worker threads)
+  // 2. ONE handle kept full: two solves in flight (first stage / finishing stage on two worker threads) and a third queued
+  //    whose host arrays the transfer thread uploads meanwhile (ABI 6); host arrays in and out, so the upload-ahead and the
+  //    ragged download run on every solve
   {
     cilqr_handle h = nullptr;
     CHECK(cilqr_create(&cfg, 0, B, cmax, smax, &h));
-    Out a(B, K, M), b(B, K, M);
+    Out a(B, K, M), b(B, K, M), c(B, K, M);
     for (int round = 0; round < 3; ++round) {
       CHECK(cilqr_submit(h, &in, &a.sol));
       CHECK(cilqr_submit(h, &in, &b.sol));
+      CHECK(cilqr_submit(h, &in, &c.sol));
+      if (cilqr_submit(h, &in, &c.sol) != CILQR_ERR_STATE) { std::fprintf(stderr, "a fourth submit was accepted\n"); return 21; }
+      CHECK(cilqr_wait(h));                                   // a is complete ...
+      if (!a.same(ref)) { std::fprintf(stderr, "first of three: results differ\n"); return 22; }
+      CHECK(cilqr_submit(h, &in, &a.sol));                    // ... and its arrays go in again behind b and c
       CHECK(cilqr_wait(h));
       CHECK(cilqr_wait(h));
-      if (!a.same(ref) || !b.same(ref)) { std::fprintf(stderr, "two solves in flight: results differ\n"); return 20; }
+      CHECK(cilqr_wait(h));
+      if (!a.same(ref) || !b.same(ref) || !c.same(ref)) { std::fprintf(stderr, "three solves on one handle: results differ\n"); return 20; }
     }
     CHECK(cilqr_destroy(h));
   }

@@ -53,9 +53,18 @@ def main():
             dur[name] = (int(m.group(1)), float(m.group(2)))
     solves_trace = dur["k_load_goals"][0]
     solves_pmc = int(sq["k_load_goals"]["disp"])
+    # Round 6: the counter passes carry --kernel-trace, so the durations of the very dispatches the counters were summed over are
+    # in the same capture (column dur_ms of file 1).  Counters and durations from different runs held different mixes of
+    # synchronous and submitted solves (other thresholds, other kernels): a fraction of 1.14 in round 5's record came from that.
+    same_run = all("dur_ms" in v for v in sq.values()) and len(sq) > 0
+    if same_run:
+        dur = {k: (int(v["disp"]), v["dur_ms"]) for k, v in sq.items()}
+        solves_trace = solves_pmc
     out = {"source": [f"{tag}_pmc_all_kernels_{i}.txt" for i in (1, 2, 3, 4)] + [f"{tag}_kernel_stats.txt"],
            "command": "python bench.py --steps 1 --warmup 0 --in-flight 1 --cpu-sample 0 (counters: one rocprofv3 --pmc pass per file)",
-           "per": "solve of 65536 problems", "clock_hz_assumed": CLOCK_HZ, "kernels": {}}
+           "per": "solve of 65536 problems", "clock_hz_assumed": CLOCK_HZ,
+           "durations_from": ("the counter capture itself (rocprofv3 --pmc ... --kernel-trace: the same dispatches)" if same_run
+                              else f"{tag}_kernel_stats.txt (another run of the same command)"), "kernels": {}}
     for k, (calls, total_ms) in sorted(dur.items(), key=lambda kv: -kv[1][1]):
         if k not in sq:
             continue

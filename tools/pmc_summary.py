@@ -22,6 +22,15 @@ def main():
     agg = {}
     for k, cn, v, n in rows:
         agg.setdefault(k.split("(")[0].replace("void ", "").replace("cilqr::", ""), {})[cn] = (v, n)
+    # durations of the SAME dispatches (a capture made with --pmc ... --kernel-trace holds them): column dur_ms
+    if "kernels" in tabs:
+        try:
+            for k, tot_ns, n in c.execute("select name, sum(end - start), count(*) from kernels group by name"):
+                key = k.split("(")[0].replace("void ", "").replace("cilqr::", "")
+                if key in agg:
+                    agg[key]["dur_ms"] = (tot_ns / 1e6, n)
+        except sqlite3.Error:
+            pass
     names = sorted({cn for d in agg.values() for cn in d})
     print(f"{'kernel':28s} {'disp':>6s} " + " ".join(f"{n[:18]:>18s}" for n in names))
     for k, d in sorted(agg.items(), key=lambda kv: -max(v[0] for v in kv[1].values())):

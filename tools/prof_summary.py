@@ -57,7 +57,16 @@ def main():
     for k, v in sorted(stats.items(), key=lambda kv: -kv[1][1])[:30]:
         print(f"{k[:44]:44s} {v[0]:7d} {v[1] / 1e6:10.3f} {v[1] / v[0] / 1e3:9.1f} {v[2] / 1e3:9.1f} {v[3] / 1e3:9.1f} {100 * v[1] / tot:6.2f}")
     print(f"{'TOTAL':44s} {sum(v[0] for v in stats.values()):7d} {tot / 1e6:10.3f}")
-    # the roofline kernel by launch size (grid x = problems rounded up to 64)
+    # the roofline kernel by launch size (grid x = problems rounded up to 64); the thresholds between the three mappings as the
+    # LIBRARY holds them (bench.py writes cilqr_get_option's answers into config.backward_thresholds)
+    thr_team = thr_wave = "?"
+    if a.bench_json:
+        import json as _json
+        try:
+            thr = _json.loads(open(a.bench_json).read().strip().splitlines()[-1])["config"]["backward_thresholds"]
+            thr_team, thr_wave = thr["team"], thr["wave"]
+        except Exception:   # noqa: BLE001
+            pass
     sizes = {}
     for name, s_, e_, gx, *_ in rows:
         if short(name) not in ("k_backward", "k_backward_team", "k_backward_wave"):
@@ -66,14 +75,15 @@ def main():
             gx = gx // 8          # eight lanes per problem
         if short(name) == "k_backward_wave":
             gx = gx // 64         # a wavefront per problem
-        b = ">=65536" if gx >= 65536 else (">=8192" if gx >= 8192 else (">=1024" if gx >= 1024 else "<1024"))
+        b = ">=65536" if gx >= 65536 else (">=8192" if gx >= 8192 else (f">{thr_team} (one lane)" if short(name) == "k_backward" else
+                                                                        ("eight lanes" if short(name) == "k_backward_team" else "a wavefront")))
         st = sizes.setdefault(b, [0, 0, 0])
         st[0] += 1; st[1] += e_ - s_; st[2] += gx
     if sizes:
         print("\nbackward kernels by launch size (problems per launch; k_backward: one lane per problem; k_backward_team,\n"
-              "eight lanes, launches of at most CILQR_OPT_TEAM_THRESHOLD = 4096 problems; k_backward_wave, a wavefront,\n"
-              "at most CILQR_OPT_WAVE_THRESHOLD = 1024; with N = 50 as in the default bench):")
-        for b in (">=65536", ">=8192", ">=1024", "<1024"):
+              f"eight lanes, launches of at most CILQR_OPT_TEAM_THRESHOLD = {thr_team} problems; k_backward_wave, a wavefront,\n"
+              f"at most CILQR_OPT_WAVE_THRESHOLD = {thr_wave}; with N = 50 as in the default bench):")
+        for b in (">=65536", ">=8192", f">{thr_team} (one lane)", "eight lanes", "a wavefront"):
             if b in sizes:
                 n, t, g = sizes[b]
                 print(f"  {b:8s} launches {n:5d}  avg {t / n / 1e3:8.1f} us  avg problems {g / n:9.0f}  "
@@ -85,7 +95,7 @@ def main():
         new_layout = "launches_contended" in roof      # round 4 on: top-level keys = ONE solve alone, *_contended = the timed region
         per_solve = roof["launches"] if new_layout else roof["launches"] // steps   # backward launches of one solve (lockstep iterations)
         # the two calibration solves are synchronous calls, the warm-up and timed steps submitted ones: since the tail threshold
-        # depends on the kind of call (1024 / 256) they differ in the number of lockstep iterations, i.e. of backward launches
+        # depends on the kind of call (CILQR_OPT_TAIL_THRESHOLD: one value for cilqr_solve_batch, one for submitted solves) they differ in the number of lockstep iterations, i.e. of backward launches
         per_sync = per_solve
         if new_layout:
             per_solve = roof["launches_contended"] // steps
