@@ -1086,6 +1086,14 @@ def run(args, rank, local_rank, world, comm, real_stdout):
         same_h = all(bool(np.array_equal(x.traj, ref_t) and np.array_equal(x.nc, ref_nc) and np.array_equal(x.st, ctx[0].st.cpu().numpy())
                           and np.array_equal(x.ni, ctx[0].ni.cpu().numpy()) and np.array_equal(x.hist[live], ref_h[live])
                           and not x.hist[~live].any()) for x in hs[:2])
+        # the synchronous call on the same arrays (what the drop-in adapter would do with a batch this size): nothing overlaps,
+        # upload + solve + download one after the other
+        t_sync = []
+        for _ in range(3):
+            t1 = time.perf_counter()
+            if opt.solve_raw(prob_h, hs[0].sol) != api.OK:
+                raise api.CilqrError(-1, "in pcie_inclusive synchronous call")
+            t_sync.append(time.perf_counter() - t1)
         in_b = sum(v.nbytes for v in h_in.values())
         pcie = {"value": round(B * n_extra / dt_h, 1), "unit": "solves/s", "ms_per_step": round(1e3 * dt_h / n_extra, 3), "steps": n_extra,
                 "memory": "pageable host arrays in and out (numpy), CILQR_MEM_HOST through cilqr_pool_submit",
@@ -1093,6 +1101,8 @@ def run(args, rank, local_rank, world, comm, real_stdout):
                 "output_bytes_per_step_travelling": int(hs[0].traj.nbytes + int(ref_nc.sum()) * 40 + 4 * B * 4),
                 "pcie_floor_ms_per_step_at_57_GBps": round(in_b / 57e9 * 1e3, 2),
                 "host_cores_busy": round(cores_h, 2), "submitted_at_once": depth,
+                "synchronous_call": {"value": round(B / min(t_sync[1:]), 1), "unit": "solves/s", "ms_per_step": round(1e3 * min(t_sync[1:]), 3),
+                                     "note": "cilqr_solve_batch with the same host arrays, one batch at a time (round 5: 454 k)"},
                 "identical_to_device_resident": same_h, "device_bytes": pool.device_bytes()}
         del hs, h_in
 

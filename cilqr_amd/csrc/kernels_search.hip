@@ -11,6 +11,9 @@
 //   [reduce + accept test, or roll out alpha_{r+1} and join pending list r+1] -> cost -> ...
 // The first passing list index wins, as in the sequential loop.  Pending lists are compacted
 // with wave-aggregated atomics; their order only affects coalescing, never results.
+#include <cstdio>
+#include <cstdlib>
+
 #include "search_core.hpp"
 
 namespace cilqr {
@@ -383,6 +386,13 @@ static DeviceState spec_view(const DeviceState& s, int row0, int stride) {
   DeviceState v = s;
   if (s.spec_rows >= kNumAlpha) return v;          // the plain layout: rows are step sizes, stride is the capacity
   const size_t K = (size_t)s.p.K, N = (size_t)s.p.N;
+  // The base pointers move back by row0 rows of the new stride: rows below row0 are never addressed (every kernel of a pass
+  // starts at r0 = row0), and rows row0..10 at that stride must lie inside the cells the arena owns.  Checked here, on the
+  // host, for every launch (nothing else holds these three facts together).
+  if (row0 < 0 || stride <= 0 || (size_t)(kNumAlpha - row0) * (size_t)stride > (size_t)s.spec_rows * (size_t)s.Bcap) {
+    std::fprintf(stderr, "cilqr: candidate view [%d..10] x %d does not fit %d x %d cells\n", row0, stride, s.spec_rows, s.Bcap);
+    std::abort();
+  }
   v.spec_cap = stride;
   v.Xs = reinterpret_cast<double2*>(reinterpret_cast<uintptr_t>(s.Xs) - (uintptr_t)row0 * K * 3 * (size_t)stride * sizeof(double2));
   v.Us = reinterpret_cast<double2*>(reinterpret_cast<uintptr_t>(s.Us) - (uintptr_t)row0 * N * (size_t)stride * sizeof(double2));

@@ -333,12 +333,13 @@ void release_fin(cilqr_solver* h, cilqr_job& j);
 // signals.  Right for the synchronous call -- its thread has nothing else to do, and the drop-in Plan is a 1 ms call where a
 // late wake-up is a measurable share -- and wrong for submitted solves: the two workers of a handle sit in such a wait
 // nearly all the time (the host runs two iterations ahead of the GPU), so a pool of two handles burned 4.4 cores per rank
-// (measured, profiles/r05_host_cpu.json) and eight ranks would have needed 35 of the 16 cores the GPU boxes grant.
+// (measured, profiles/r05_bench_host_wait_spin.json) and eight ranks would have needed 35 of the 16 cores the GPU boxes grant.
 // Submitted solves therefore poll: a query, a short spin for waits that are nearly over, then naps.  A nap that ends late
 // costs nothing as long as it is shorter than an iteration -- the stream still holds the next one (kLead = 2).
 // CILQR_HOST_WAIT=spin / nap overrides the choice for both kinds of call (measurement hook).
 // ------------------------------------------------------------------------------------------
 constexpr int kWaitSpinUs = 20, kWaitNapUs = 50;
+constexpr int kWaitSpinShortUs = 250, kShortIterationProblems = 2048;   // the nap policy by work size
 int host_wait_override() {
   static const int v = [] {
     const char* e = std::getenv("CILQR_HOST_WAIT");
@@ -347,7 +348,7 @@ int host_wait_override() {
   }();
   return v;
 }
-int wait_event(hipEvent_t ev, bool relaxed) {
+int wait_event(hipEvent_t ev, bool relaxed, int spin_us = kWaitSpinUs) {
   const int ov = host_wait_override();
   if (ov >= 0) relaxed = ov != 0;
   if (!relaxed) {
@@ -362,7 +363,7 @@ int wait_event(hipEvent_t ev, bool relaxed) {
       HIP_TRY(e);
       return CILQR_ERR_DEVICE;
     }
-    if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(kWaitSpinUs))
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us))
       std::this_thread::sleep_for(std::chrono::microseconds(kWaitNapUs));
   }
 }
@@ -1134,7 +1135,8 @@ int job_iterate(cilqr_solver* h, cilqr_job& j, int stage) {
   int& n_hint = j.n_hint;
   for (; it < M; ++it) {                               // cc:201
     if (it >= kLead) {
-      if (int wrc = wait_event(js.iter_ev[it - kLead], j.relaxed_wait)) return wrc;
+      // (few problems left: an iteration is ~100 us, and a nap that ends late costs a whole one -- spin longer before napping)
+      if (int wrc = wait_event(js.iter_ev[it - kLead], j.relaxed_wait, n_hint < kShortIterationProblems ? kWaitSpinShortUs : kWaitSpinUs)) return wrc;
       n_hint = js.h_count[it - kLead];
       if (n_hint == 0) break;                          // iterations it-kLead+1 .. it-1 were no-ops
     }
