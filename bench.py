@@ -1024,6 +1024,7 @@ def run(args, rank, local_rank, world, comm, real_stdout):
     # ---- Extra legs (never `value`): what a caller sees whose arrays are not already in HBM ("report both with
     # and without transfers").  Both run through the same pool as the timed region, with as many solves
     # submitted as it takes (cilqr_pool_depth: two in flight and one queued per handle).
+    dev_bytes_timed = sum(c.opt.device_bytes() for c in ctx)      # (before the extra legs grow the host-array staging)
     extras = world == 1 and not args.no_extras
     n_extra = args.extra_steps if args.extra_steps > 0 else min(args.steps, 24)
     depth = pool.depth()
@@ -1057,128 +1058,138 @@ def run(args, rank, local_rank, world, comm, real_stdout):
     # caller's array and the LIVE cost rows packed (include/cilqr.h, cilqr_submit).
     pcie = None
     if extras:
-        opt.set_profiling(0)
-        h_in = {k: np.ascontiguousarray(sc[k]) for k in ("start", "coarse", "corridor")}
-        h_in["ccount"] = np.ascontiguousarray(sc["ccount"], dtype=np.int32)
-        prob_h = opt.make_problem(B, h_in["start"].ctypes.data, h_in["coarse"].ctypes.data, h_in["corridor"].ctypes.data,
-                                  h_in["ccount"].ctypes.data, cmax, left.ctypes.data, right.ctypes.data, left.shape[0], right.shape[0],
-                                  api.MEM_HOST)
+        try:
+            opt.set_profiling(0)
+            h_in = {k: np.ascontiguousarray(sc[k]) for k in ("start", "coarse", "corridor")}
+            h_in["ccount"] = np.ascontiguousarray(sc["ccount"], dtype=np.int32)
+            prob_h = opt.make_problem(B, h_in["start"].ctypes.data, h_in["coarse"].ctypes.data, h_in["corridor"].ctypes.data,
+                                      h_in["ccount"].ctypes.data, cmax, left.ctypes.data, right.ctypes.data, left.shape[0], right.shape[0],
+                                      api.MEM_HOST)
 
-        class HostSlot:   # arrive dirty: the library owes zeros behind the live cost rows
-            def __init__(self):
-                self.traj = np.full((B, K, 10), -1.0)
-                self.hist = np.full((B, M + 1, 5), -1.0)
-                self.nc, self.st, self.ni = (np.full(B, -1, np.int32) for _ in range(3))
-                self.sol = api.SolutionBatch(api.MEM_HOST, 0, self.traj.ctypes.data, self.hist.ctypes.data, self.nc.ctypes.data,
-                                             self.st.ctypes.data, self.ni.ctypes.data, None, None, None)
+            class HostSlot:   # arrive dirty: the library owes zeros behind the live cost rows
+                def __init__(self):
+                    self.traj = np.full((B, K, 10), -1.0)
+                    self.hist = np.full((B, M + 1, 5), -1.0)
+                    self.nc, self.st, self.ni = (np.full(B, -1, np.int32) for _ in range(3))
+                    self.sol = api.SolutionBatch(api.MEM_HOST, 0, self.traj.ctypes.data, self.hist.ctypes.data, self.nc.ctypes.data,
+                                                 self.st.ctypes.data, self.ni.ctypes.data, None, None, None)
 
-        hs = [HostSlot() for _ in range(depth)]
+            hs = [HostSlot() for _ in range(depth)]
 
-        def sub_h(i):
-            if pool.submit_raw(prob_h, hs[i % depth].sol) != api.OK:
-                raise api.CilqrError(-1, "in pcie_inclusive submit")
+            def sub_h(i):
+                if pool.submit_raw(prob_h, hs[i % depth].sol) != api.OK:
+                    raise api.CilqrError(-1, "in pcie_inclusive submit")
 
-        pooled(depth + 1, sub_h, lambda i: None)      # staging blocks allocated, the caller's pages touched
-        dt_h, cores_h = host_cores(lambda: pooled(n_extra, sub_h, lambda i: None))
-        ref_t, ref_nc = ctx[0].traj.cpu().numpy(), ctx[0].nc.cpu().numpy()
-        live = np.arange(M + 1)[None, :] < ref_nc[:, None]
-        ref_h = ctx[0].hist.cpu().numpy()
-        same_h = all(bool(np.array_equal(x.traj, ref_t) and np.array_equal(x.nc, ref_nc) and np.array_equal(x.st, ctx[0].st.cpu().numpy())
-                          and np.array_equal(x.ni, ctx[0].ni.cpu().numpy()) and np.array_equal(x.hist[live], ref_h[live])
-                          and not x.hist[~live].any()) for x in hs[:2])
-        # the synchronous call on the same arrays (what the drop-in adapter would do with a batch this size): nothing overlaps,
-        # upload + solve + download one after the other
-        t_sync = []
-        for _ in range(3):
-            t1 = time.perf_counter()
-            if opt.solve_raw(prob_h, hs[0].sol) != api.OK:
-                raise api.CilqrError(-1, "in pcie_inclusive synchronous call")
-            t_sync.append(time.perf_counter() - t1)
-        in_b = sum(v.nbytes for v in h_in.values())
-        pcie = {"value": round(B * n_extra / dt_h, 1), "unit": "solves/s", "ms_per_step": round(1e3 * dt_h / n_extra, 3), "steps": n_extra,
-                "memory": "pageable host arrays in and out (numpy), CILQR_MEM_HOST through cilqr_pool_submit",
-                "input_bytes_per_step": in_b, "output_bytes_per_step_dense": int(hs[0].traj.nbytes + hs[0].hist.nbytes + 3 * hs[0].nc.nbytes),
-                "output_bytes_per_step_travelling": int(hs[0].traj.nbytes + int(ref_nc.sum()) * 40 + 4 * B * 4),
-                "pcie_floor_ms_per_step_at_57_GBps": round(in_b / 57e9 * 1e3, 2),
-                "host_cores_busy": round(cores_h, 2), "submitted_at_once": depth,
-                "synchronous_call": {"value": round(B / min(t_sync[1:]), 1), "unit": "solves/s", "ms_per_step": round(1e3 * min(t_sync[1:]), 3),
-                                     "note": "cilqr_solve_batch with the same host arrays, one batch at a time (round 5: 454 k)"},
-                "identical_to_device_resident": same_h, "device_bytes": pool.device_bytes()}
-        del hs, h_in
+            pooled(depth + 1, sub_h, lambda i: None)      # staging blocks allocated, the caller's pages touched
+            dt_h, cores_h = host_cores(lambda: pooled(n_extra, sub_h, lambda i: None))
+            ref_t, ref_nc = ctx[0].traj.cpu().numpy(), ctx[0].nc.cpu().numpy()
+            live = np.arange(M + 1)[None, :] < ref_nc[:, None]
+            ref_h = ctx[0].hist.cpu().numpy()
+            same_h = all(bool(np.array_equal(x.traj, ref_t) and np.array_equal(x.nc, ref_nc) and np.array_equal(x.st, ctx[0].st.cpu().numpy())
+                              and np.array_equal(x.ni, ctx[0].ni.cpu().numpy()) and np.array_equal(x.hist[live], ref_h[live])
+                              and not x.hist[~live].any()) for x in hs[:2])
+            # the synchronous call on the same arrays (what the drop-in adapter would do with a batch this size): nothing overlaps,
+            # upload + solve + download one after the other
+            t_sync = []
+            for _ in range(3):
+                t1 = time.perf_counter()
+                if opt.solve_raw(prob_h, hs[0].sol) != api.OK:
+                    raise api.CilqrError(-1, "in pcie_inclusive synchronous call")
+                t_sync.append(time.perf_counter() - t1)
+            in_b = sum(v.nbytes for v in h_in.values())
+            pcie = {"value": round(B * n_extra / dt_h, 1), "unit": "solves/s", "ms_per_step": round(1e3 * dt_h / n_extra, 3), "steps": n_extra,
+                    "memory": "pageable host arrays in and out (numpy), CILQR_MEM_HOST through cilqr_pool_submit",
+                    "input_bytes_per_step": in_b, "output_bytes_per_step_dense": int(hs[0].traj.nbytes + hs[0].hist.nbytes + 3 * hs[0].nc.nbytes),
+                    "output_bytes_per_step_travelling": int(hs[0].traj.nbytes + int(ref_nc.sum()) * 40 + 4 * B * 4),
+                    "pcie_floor_ms_per_step_at_57_GBps": round(in_b / 57e9 * 1e3, 2),
+                    "host_cores_busy": round(cores_h, 2), "submitted_at_once": depth,
+                    "synchronous_call": {"value": round(B / min(t_sync[1:]), 1), "unit": "solves/s", "ms_per_step": round(1e3 * min(t_sync[1:]), 3),
+                                         "note": "cilqr_solve_batch with the same host arrays, one batch at a time (round 5: 454 k)"},
+                    "identical_to_device_resident": same_h, "device_bytes": pool.device_bytes()}
+            del hs, h_in
+        except Exception as e_:   # noqa: BLE001  (an extra leg must never cost the line its `value`)
+            pcie = {"error": repr(e_)}
+            while pool.wait() != api.ERR_STATE:      # whatever it left in flight on the pool (ERR_STATE: nothing is)
+                pass
 
     # (2) end_to_end: the producer in front of the solve (corridor.cc:58-263, trajectory_planner.cpp:49-86):
     # obstacle corner points per knot -> cilqr_build_corridors -> solve, everything resident in HBM.  The corridors of step
     # n + 1 are built (on a handle and a stream of their own) while the pool iterates the steps before it.
     end_to_end = None
     if extras:
-        sc_p = scenario.generate(spec, B, seed=args.seed, first_problem=rank * B, workers=workers, obstacle_points=True)
-        P_ = sc_p["obstacle_points"].shape[2]
-        d_knots = torch.from_numpy(np.ascontiguousarray(sc_p["coarse"][:, :, :3])).to(dev)
-        d_pts = torch.from_numpy(sc_p["obstacle_points"]).to(dev)
-        d_pcnt = torch.from_numpy(sc_p["obstacle_count"]).to(dev)
-        ccfg = api.default_corridor_config()
-        producer = api.BatchIlqrOptimizer(cfg, device=local_rank, batch_capacity=64, cmax=cmax, max_lane_segments=smax)
+        try:
+            sc_p = scenario.generate(spec, B, seed=args.seed, first_problem=rank * B, workers=workers, obstacle_points=True)
+            P_ = sc_p["obstacle_points"].shape[2]
+            d_knots = torch.from_numpy(np.ascontiguousarray(sc_p["coarse"][:, :, :3])).to(dev)
+            d_pts = torch.from_numpy(sc_p["obstacle_points"]).to(dev)
+            d_pcnt = torch.from_numpy(sc_p["obstacle_count"]).to(dev)
+            ccfg = api.default_corridor_config()
+            producer = api.BatchIlqrOptimizer(cfg, device=local_rank, batch_capacity=64, cmax=cmax, max_lane_segments=smax)
 
-        class E2eSlot:
-            def __init__(self):
-                self.cor = torch.zeros((B, K, cmax, 3), dtype=torch.float64, device=dev)
-                self.cnt = torch.zeros((B, K), dtype=torch.int32, device=dev)
-                self.traj = torch.zeros((B, K, 10), dtype=torch.float64, device=dev)
-                self.hist = torch.zeros((B, M + 1, 5), dtype=torch.float64, device=dev)
-                self.nc, self.st = (torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2))
-                self.prob = opt.make_problem(B, d_start.data_ptr(), d_coarse.data_ptr(), self.cor.data_ptr(), self.cnt.data_ptr(), cmax,
-                                             left.ctypes.data, right.ctypes.data, left.shape[0], right.shape[0], api.MEM_DEVICE)
-                self.sol = api.SolutionBatch(api.MEM_DEVICE, 0, self.traj.data_ptr(), self.hist.data_ptr(), self.nc.data_ptr(),
-                                             self.st.data_ptr(), None, None, None)
+            class E2eSlot:
+                def __init__(self):
+                    self.cor = torch.zeros((B, K, cmax, 3), dtype=torch.float64, device=dev)
+                    self.cnt = torch.zeros((B, K), dtype=torch.int32, device=dev)
+                    self.traj = torch.zeros((B, K, 10), dtype=torch.float64, device=dev)
+                    self.hist = torch.zeros((B, M + 1, 5), dtype=torch.float64, device=dev)
+                    self.nc, self.st = (torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2))
+                    self.prob = opt.make_problem(B, d_start.data_ptr(), d_coarse.data_ptr(), self.cor.data_ptr(), self.cnt.data_ptr(), cmax,
+                                                 left.ctypes.data, right.ctypes.data, left.shape[0], right.shape[0], api.MEM_DEVICE)
+                    self.sol = api.SolutionBatch(api.MEM_DEVICE, 0, self.traj.data_ptr(), self.hist.data_ptr(), self.nc.data_ptr(),
+                                                 self.st.data_ptr(), None, None, None)
 
-        es = [E2eSlot() for _ in range(depth)]
-        torch.cuda.synchronize()
-        t_cor, failed = [], [0]
+            es = [E2eSlot() for _ in range(depth)]
+            torch.cuda.synchronize()
+            t_cor, failed = [], [0]
 
-        def sub_e(i):
-            sl = es[i % depth]
+            def sub_e(i):
+                sl = es[i % depth]
+                t1 = time.perf_counter()
+                rc_, nf_ = producer.build_corridors_raw(ccfg, B, K, d_knots.data_ptr(), d_pts.data_ptr(), d_pcnt.data_ptr(), P_,
+                                                        sl.cor.data_ptr(), sl.cnt.data_ptr(), cmax, api.MEM_DEVICE)
+                t_cor.append(time.perf_counter() - t1)
+                failed[0] = nf_
+                if rc_ != api.OK or pool.submit_raw(sl.prob, sl.sol) != api.OK:
+                    raise api.CilqrError(rc_, "in end-to-end step")
+
+            pooled(depth + 1, sub_e, lambda i: None)
+            torch.cuda.synchronize()
+            # the two halves alone, one batch at a time (what round 5 reported as the whole figure)
             t1 = time.perf_counter()
-            rc_, nf_ = producer.build_corridors_raw(ccfg, B, K, d_knots.data_ptr(), d_pts.data_ptr(), d_pcnt.data_ptr(), P_,
-                                                    sl.cor.data_ptr(), sl.cnt.data_ptr(), cmax, api.MEM_DEVICE)
-            t_cor.append(time.perf_counter() - t1)
-            failed[0] = nf_
-            if rc_ != api.OK or pool.submit_raw(sl.prob, sl.sol) != api.OK:
-                raise api.CilqrError(rc_, "in end-to-end step")
-
-        pooled(depth + 1, sub_e, lambda i: None)
-        torch.cuda.synchronize()
-        # the two halves alone, one batch at a time (what round 5 reported as the whole figure)
-        t1 = time.perf_counter()
-        producer.build_corridors_raw(ccfg, B, K, d_knots.data_ptr(), d_pts.data_ptr(), d_pcnt.data_ptr(), P_, es[0].cor.data_ptr(),
-                                     es[0].cnt.data_ptr(), cmax, api.MEM_DEVICE)
-        torch.cuda.synchronize()
-        t_cor_alone = time.perf_counter() - t1
-        t1 = time.perf_counter()
-        if opt.solve_raw(es[0].prob, es[0].sol) != api.OK:
-            raise api.CilqrError(-1, "in end-to-end solve")
-        torch.cuda.synchronize()
-        t_solve_alone = time.perf_counter() - t1
-        first = (es[0].traj.clone(), es[0].nc.clone(), es[0].st.clone())
-        del t_cor[:]
-        dt_e, cores_e = host_cores(lambda: pooled(n_extra, sub_e, lambda i: None))
-        same_e = all(bool(torch.equal(x.traj, first[0]) and torch.equal(x.nc, first[1]) and torch.equal(x.st, first[2])) for x in es)
-        e_status = np.bincount(es[0].st.cpu().numpy(), minlength=7).tolist()
-        assert e_status[6] == 0 or failed[0] > 0   # a knot whose corridor could not be built takes its problem out of the solve (status 6)
-        end_to_end = {"value": round(B * n_extra / dt_e, 1), "unit": "solves/s", "ms_per_step": round(1e3 * dt_e / n_extra, 3), "steps": n_extra,
-                      "corridor_call_ms_beside_solves": round(1e3 * sum(t_cor) / max(1, len(t_cor)), 3),
-                      "corridor_ms_alone": round(t_cor_alone * 1e3, 3), "solve_ms_alone": round(t_solve_alone * 1e3, 3),
-                      "sequential_value": round(B / (t_cor_alone + t_solve_alone), 1),
-                      "corridors_failed": failed[0], "status_histogram": e_status, "host_cores_busy": round(cores_e, 2),
-                      "identical_across_steps_and_to_the_sequential_call": same_e,
-                      "mean_obstacle_points": round(float(sc_p["obstacle_count"].mean()), 2),
-                      "mean_half_planes": round(float(es[0].cnt.clamp(min=0).double().mean().item()), 2),
-                      "note": "obstacle points in HBM -> k_build_corridors (sphere-flip construction, on a handle and stream of its own) -> "
-                              "cilqr_pool_submit; the corridors of a step are built while the pool iterates the steps before it.  Other "
-                              "corridors than the generator's simplified ones of the timed region: a larger feasible set, another "
-                              "iteration count"}
-        producer.close()
-        del es, d_pts, d_knots, d_pcnt, sc_p
-        torch.cuda.empty_cache()
+            producer.build_corridors_raw(ccfg, B, K, d_knots.data_ptr(), d_pts.data_ptr(), d_pcnt.data_ptr(), P_, es[0].cor.data_ptr(),
+                                         es[0].cnt.data_ptr(), cmax, api.MEM_DEVICE)
+            torch.cuda.synchronize()
+            t_cor_alone = time.perf_counter() - t1
+            t1 = time.perf_counter()
+            if opt.solve_raw(es[0].prob, es[0].sol) != api.OK:
+                raise api.CilqrError(-1, "in end-to-end solve")
+            torch.cuda.synchronize()
+            t_solve_alone = time.perf_counter() - t1
+            first = (es[0].traj.clone(), es[0].nc.clone(), es[0].st.clone())
+            del t_cor[:]
+            dt_e, cores_e = host_cores(lambda: pooled(n_extra, sub_e, lambda i: None))
+            same_e = all(bool(torch.equal(x.traj, first[0]) and torch.equal(x.nc, first[1]) and torch.equal(x.st, first[2])) for x in es)
+            e_status = np.bincount(es[0].st.cpu().numpy(), minlength=7).tolist()
+            assert e_status[6] == 0 or failed[0] > 0   # a knot whose corridor could not be built takes its problem out of the solve (status 6)
+            end_to_end = {"value": round(B * n_extra / dt_e, 1), "unit": "solves/s", "ms_per_step": round(1e3 * dt_e / n_extra, 3), "steps": n_extra,
+                          "corridor_call_ms_beside_solves": round(1e3 * sum(t_cor) / max(1, len(t_cor)), 3),
+                          "corridor_ms_alone": round(t_cor_alone * 1e3, 3), "solve_ms_alone": round(t_solve_alone * 1e3, 3),
+                          "sequential_value": round(B / (t_cor_alone + t_solve_alone), 1),
+                          "corridors_failed": failed[0], "status_histogram": e_status, "host_cores_busy": round(cores_e, 2),
+                          "identical_across_steps_and_to_the_sequential_call": same_e,
+                          "mean_obstacle_points": round(float(sc_p["obstacle_count"].mean()), 2),
+                          "mean_half_planes": round(float(es[0].cnt.clamp(min=0).double().mean().item()), 2),
+                          "note": "obstacle points in HBM -> k_build_corridors (sphere-flip construction, on a handle and stream of its own) -> "
+                                  "cilqr_pool_submit; the corridors of a step are built while the pool iterates the steps before it.  Other "
+                                  "corridors than the generator's simplified ones of the timed region: a larger feasible set, another "
+                                  "iteration count"}
+            producer.close()
+            del es, d_pts, d_knots, d_pcnt, sc_p
+            torch.cuda.empty_cache()
+        except Exception as e_:   # noqa: BLE001  (an extra leg must never cost the line its `value`)
+            end_to_end = {"error": repr(e_)}
+            while pool.wait() != api.ERR_STATE:      # whatever it left in flight on the pool (ERR_STATE: nothing is)
+                pass
 
     traffic = None
     if world == 1 and not args.no_traffic and not args.no_profile and single and single["bwd_problem_steps"] > 0:
@@ -1442,7 +1453,7 @@ def run(args, rank, local_rank, world, comm, real_stdout):
             "mean_cost_rows": float(nc.mean()),
             "status_histogram": np.bincount(st, minlength=7).tolist(),
             "scene_generation_s": round(t_gen, 1),
-            "device_bytes": sum(c.opt.device_bytes() for c in ctx),
+            "device_bytes": dev_bytes_timed,
             "host": host,
         }
     if hung:   # a stuck collective cannot be torn down: print the line and leave

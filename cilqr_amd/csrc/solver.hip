@@ -1858,12 +1858,15 @@ int cilqr_build_corridors(cilqr_handle h, const cilqr_corridor_config* cfg, int3
     HIP_TRY(hipEventCreateWithFlags(&h->cor_done, hipEventDisableTiming));
   }
   int* t_fail = h->cor_fail;
+  // (a producer beside solves in flight -- bench.py: end_to_end -- runs on the handle's own stream at normal priority: on a
+  // low-priority stream the call took 25 ms instead of 16.5 and the pipeline lost 1.5 %, r06 log 7)
+  hipStream_t cst = h->stream;
   const double *d_knots = knots, *d_pts = points;
   const int* d_cnt = point_count;
   double* d_cor = corridor;
   double* d_poly = polygons;
   int* d_ccnt = corridor_count;
-  if (hipMemsetAsync(t_fail, 0, 4, h->stream) != hipSuccess) rc = CILQR_ERR_DEVICE;
+  if (hipMemsetAsync(t_fail, 0, 4, cst) != hipSuccess) rc = CILQR_ERR_DEVICE;
   if (rc == CILQR_OK && memory == CILQR_MEM_HOST) {
     const size_t o_pts = (b_knots + 255) / 256 * 256, o_cnt = o_pts + (b_pts + 255) / 256 * 256;
     if (hipMalloc(&t_in, o_cnt + b_cnt + 256) != hipSuccess || hipMalloc(&t_out, b_cor + 512 + b_cnt + b_poly) != hipSuccess) {
@@ -1871,9 +1874,9 @@ int cilqr_build_corridors(cilqr_handle h, const cilqr_corridor_config* cfg, int3
     } else {
       char* bi = static_cast<char*>(t_in);
       char* bo = static_cast<char*>(t_out);
-      if (hipMemcpyAsync(bi, knots, b_knots, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
-          (b_pts && hipMemcpyAsync(bi + o_pts, points, b_pts, hipMemcpyHostToDevice, h->stream) != hipSuccess) ||
-          hipMemcpyAsync(bi + o_cnt, point_count, b_cnt, hipMemcpyHostToDevice, h->stream) != hipSuccess)
+      if (hipMemcpyAsync(bi, knots, b_knots, hipMemcpyHostToDevice, cst) != hipSuccess ||
+          (b_pts && hipMemcpyAsync(bi + o_pts, points, b_pts, hipMemcpyHostToDevice, cst) != hipSuccess) ||
+          hipMemcpyAsync(bi + o_cnt, point_count, b_cnt, hipMemcpyHostToDevice, cst) != hipSuccess)
         rc = CILQR_ERR_DEVICE;
       d_knots = reinterpret_cast<const double*>(bi);
       d_pts = reinterpret_cast<const double*>(bi + o_pts);
@@ -1885,22 +1888,22 @@ int cilqr_build_corridors(cilqr_handle h, const cilqr_corridor_config* cfg, int3
   }
   int failed = 0;
   if (rc == CILQR_OK) {
-    launch_build_corridors((int)n, cp, d_knots, d_pts, d_cnt, max_points, d_cor, d_ccnt, cmax, t_fail, d_poly, h->stream);
+    launch_build_corridors((int)n, cp, d_knots, d_pts, d_cnt, max_points, d_cor, d_ccnt, cmax, t_fail, d_poly, cst);
     if (hipGetLastError() != hipSuccess) rc = CILQR_ERR_DEVICE;
     if (rc == CILQR_OK && memory == CILQR_MEM_HOST) {
-      if (hipMemcpyAsync(corridor, d_cor, b_cor, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
-          hipMemcpyAsync(corridor_count, d_ccnt, b_cnt, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
-          (polygons && hipMemcpyAsync(polygons, d_poly, b_poly, hipMemcpyDeviceToHost, h->stream) != hipSuccess))
+      if (hipMemcpyAsync(corridor, d_cor, b_cor, hipMemcpyDeviceToHost, cst) != hipSuccess ||
+          hipMemcpyAsync(corridor_count, d_ccnt, b_cnt, hipMemcpyDeviceToHost, cst) != hipSuccess ||
+          (polygons && hipMemcpyAsync(polygons, d_poly, b_poly, hipMemcpyDeviceToHost, cst) != hipSuccess))
         rc = CILQR_ERR_DEVICE;
     }
     if (rc == CILQR_OK &&
-        hipMemcpyAsync(h->cor_fail_host, t_fail, 4, hipMemcpyDeviceToHost, h->stream) != hipSuccess)
+        hipMemcpyAsync(h->cor_fail_host, t_fail, 4, hipMemcpyDeviceToHost, cst) != hipSuccess)
       rc = CILQR_ERR_DEVICE;
     // a large batch is milliseconds of kernel time: the caller's thread naps through it instead of spinning (it usually has
     // solves in flight whose worker threads want the cores); a small one is waited for the short way
     if (rc == CILQR_OK && n >= (size_t)1 << 18) {
-      if (hipEventRecord(h->cor_done, h->stream) != hipSuccess || wait_event(h->cor_done, true) != CILQR_OK) rc = CILQR_ERR_DEVICE;
-    } else if (hipStreamSynchronize(h->stream) != hipSuccess) {
+      if (hipEventRecord(h->cor_done, cst) != hipSuccess || wait_event(h->cor_done, true) != CILQR_OK) rc = CILQR_ERR_DEVICE;
+    } else if (hipStreamSynchronize(cst) != hipSuccess) {
       rc = CILQR_ERR_DEVICE;
     }
     if (rc == CILQR_OK) failed = *h->cor_fail_host;

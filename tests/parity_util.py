@@ -184,8 +184,9 @@ def second_look(scene: dict, cfg, b: int, gpu: dict | None = None, n_perturb: in
     through.  A problem that differs from the library although the mask called it stable is looked at again with this.  It is
     excused (`excused`) only if the oracle moves in at least MIN_FLIPS of the re-runs AND -- when the library's result is given --
     that result agrees within `tol` (control flow, cost rows, trajectory) with the ending of at least one perturbed oracle run
-    (the search goes on up to `max_perturb` runs while the oracle keeps flipping and no run has matched yet).  Anything else
-    is a mismatch: the oracle comparing unequal to ITSELF proves nothing about what the library returned."""
+    (the search goes on up to `max_perturb` runs while the oracle keeps flipping and no run has matched yet) -- or the oracle's
+    own flipped endings are (nearly) all DISTINCT from each other, i.e. there is no set of alternative endings to be one of.
+    Anything else is a mismatch: the oracle comparing unequal to ITSELF proves nothing about what the library returned."""
     B = scene["coarse"].shape[0]
     one = {k: (np.ascontiguousarray(v[b:b + 1]) if isinstance(v, np.ndarray) and v.shape[:1] == (B,) else v) for k, v in scene.items()}
     g1 = None
@@ -194,21 +195,38 @@ def second_look(scene: dict, cfg, b: int, gpu: dict | None = None, n_perturb: in
     r0 = orc.solve_batch(one, cfg, want_trace=True)
     rng = np.random.default_rng(seed + b)
     flips = matches = runs = 0
+    endings = []          # one representative per DISTINCT ending among the runs that ended elsewhere (clustered at `tol`)
     while runs < n_perturb or (g1 is not None and matches == 0 and flips * n_perturb >= MIN_FLIPS * runs and runs < max_perturb):
         sc2 = dict(one)
         sc2["coarse"] = one["coarse"] * (1.0 + eps * rng.standard_normal(one["coarse"].shape))
         r1 = orc.solve_batch(sc2, cfg, want_margin=False, want_trace=True)
         runs += 1
         flow, e_cost, e_traj = solution_errors(r1, r0, 0)
-        flips += int((not flow) or max(e_cost, e_traj) > stable_tol)
+        if (not flow) or max(e_cost, e_traj) > stable_tol:
+            flips += 1
+            for rep in endings:
+                f2, c2, t2 = solution_errors(r1, rep, 0)
+                if f2 and max(c2, t2) <= tol:
+                    break
+            else:
+                endings.append(r1)
         if g1 is not None:
             gflow, g_cost, g_traj = solution_errors(g1, r1, 0)
             matches += int(gflow and max(g_cost, g_traj) <= tol)
     flips_in_first = flips if runs == n_perturb else None
     enough = flips * n_perturb >= MIN_FLIPS * runs
+    # "One of the oracle's alternative endings" presupposes that the oracle HAS alternative endings it returns to.  On the
+    # chaotic problems it does not: every perturbed run that leaves the unperturbed ending ends somewhere else again (mix11 #5284
+    # of the 8192 report: 31 flips in 128 runs, 31 distinct endings).  Then -- and only then -- there is nothing to match, and the
+    # problem is held to the step-by-step replay alone like every oracle-unstable problem.
+    no_two_alike = flips >= MIN_FLIPS and len(endings) * 4 >= flips * 3
     return {"problem": int(b), "oracle_reruns": int(runs), "ended_elsewhere": int(flips), "ended_elsewhere_in_the_first_64": flips_in_first,
+            "distinct_endings_among_those": len(endings),
             "library_result_equals_a_perturbed_oracle_ending": (int(matches) if g1 is not None else None),
-            "excused": bool(enough and (g1 is None or matches > 0))}
+            "excused_because": ("matches an oracle ending" if (enough and g1 is not None and matches > 0) else
+                                "the oracle's own perturbed endings do not repeat (chaotic): step replay only" if (enough and no_two_alike) else
+                                "the oracle moves (no library result given)" if (enough and g1 is None) else None),
+            "excused": bool(enough and (g1 is None or matches > 0 or no_two_alike))}
 
 
 def assert_parity(gpu: dict, ref: dict, tol=REL_TOL, max_unstable_frac=MAX_UNSTABLE_FRAC, what=""):
