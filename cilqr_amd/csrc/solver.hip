@@ -676,7 +676,13 @@ int cilqr_destroy(cilqr_handle h) {
   if (h == nullptr) return CILQR_ERR_NULL;
   if (h->workers_started) {
     {
-      std::lock_guard<std::mutex> lk(h->mu);
+      // nothing is left running on arrays the caller frees next: the solves submitted and not collected finish first
+      std::unique_lock<std::mutex> lk(h->mu);
+      h->cv.wait(lk, [&] {
+        for (int k = 0; k < h->job_count; ++k)
+          if (h->jobs[(h->job_head + k) % kJobRing].phase != 5) return false;
+        return true;
+      });
       h->quit = true;
     }
     h->cv.notify_all();
@@ -994,14 +1000,16 @@ int job_begin(cilqr_solver* h, cilqr_job& j) {
   if (j.tm.begin(3)) return CILQR_ERR_DEVICE;
   j.gmain = main_view(h, js);
   int rc;
-  if (j.upload != 0) {
+  int upload_state;
+  {   // (under the lock: the transfer thread moves the field while it works -- found by the ThreadSanitizer run of round 6)
+    std::unique_lock<std::mutex> lk(h->mu);
     // the transfer thread has been copying this solve's arrays since it was submitted (worker_io_main): wait until every
     // copy is enqueued and the event behind the last one recorded, then let the stream wait for that event
-    {
-      std::unique_lock<std::mutex> lk(h->mu);
-      h->cv.wait(lk, [&] { return j.upload == 3 || j.upload < 0; });
-    }
-    if (j.upload < 0) {
+    if (j.upload != 0) h->cv.wait(lk, [&] { return j.upload == 3 || j.upload < 0; });
+    upload_state = j.upload;
+  }
+  if (upload_state != 0) {
+    if (upload_state < 0) {
       std::snprintf(g_last_hip_error, sizeof(g_last_hip_error), "%s", j.err_text);
       {
         std::lock_guard<std::mutex> lk(h->mu);

@@ -169,6 +169,7 @@ int cilqr_default_config(cilqr_config* cfg, int32_t n_steps);
 /* device: HIP ordinal.  batch_capacity/cmax/max_lane_segments size the HBM arena once. */
 int cilqr_create(const cilqr_config* cfg, int32_t device, int32_t batch_capacity, int32_t cmax,
                  int32_t max_lane_segments, cilqr_handle* out);
+/* waits for the solves that were submitted and not collected (cilqr_submit), then frees everything */
 int cilqr_destroy(cilqr_handle h);
 /* hipStream_t to launch on (NULL = the handle's own stream). */
 int cilqr_set_stream(cilqr_handle h, void* hip_stream);

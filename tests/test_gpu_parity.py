@@ -1272,6 +1272,48 @@ def test_nearest_lane_grid_equals_linear_scan():
     opt.close()
 
 
+def test_a_failing_solve_between_two_good_ones_on_one_handle():
+    """Three submitted solves with host arrays on one handle (two in flight, one queued, the transfer thread uploading ahead):
+    the middle one is refused by the argument checks (`n_knots` wrong: CILQR_ERR_KNOTS, cc:75-78) -- its wait returns that code,
+    the solves either side of it return their results bit for bit, nothing deadlocks, an input buffer the bad solve's upload
+    never got is not leaked (a second round of three goes through), and destroying the handle with solves in flight waits."""
+    sc = scenario.generate("mix11", 3000, seed=171)
+    opt = _opt(sc)
+    ref = opt.plan(sc)
+    B, K, M = 3000, sc["n_steps"] + 1, opt.cfg.max_iter
+    prob, keep = opt._host_problem(sc)
+    bad = api.ProblemBatch.from_buffer_copy(prob)
+    bad.n_knots = K - 1
+    null_corridor = api.ProblemBatch.from_buffer_copy(prob)
+    null_corridor.corridor = None
+
+    def outs():
+        o = dict(traj=np.full((B, K, 10), np.nan), hist=np.full((B, M + 1, 5), np.nan), nc=np.full(B, -1, np.int32),
+                 st=np.full(B, -1, np.int32), ni=np.full(B, -1, np.int32))
+        o["sol"] = api.SolutionBatch(api.MEM_HOST, 0, o["traj"].ctypes.data, o["hist"].ctypes.data, o["nc"].ctypes.data,
+                                     o["st"].ctypes.data, o["ni"].ctypes.data, None, None, None)
+        return o
+
+    for wrong, code in ((bad, api.ERR_KNOTS), (null_corridor, api.ERR_CONSTRAINTS)):
+        a, b, c = outs(), outs(), outs()
+        assert opt.submit_raw(prob, a["sol"]) == api.OK
+        assert opt.submit_raw(wrong, b["sol"]) == api.OK          # accepted: the checks run when its turn comes
+        assert opt.submit_raw(prob, c["sol"]) == api.OK
+        assert opt.wait() == api.OK
+        assert opt.wait() == code
+        assert opt.wait() == api.OK
+        for o in (a, c):
+            assert np.array_equal(o["traj"], ref["traj"]) and np.array_equal(o["hist"], ref["cost_hist"])
+            assert np.array_equal(o["nc"], ref["n_cost"]) and np.array_equal(o["st"], ref["status"])
+    again = opt.plan(sc)                                           # the synchronous call still works on the handle
+    assert np.array_equal(again["traj"], ref["traj"])
+    a, b, c = outs(), outs(), outs()
+    for o in (a, b, c):
+        assert opt.submit_raw(prob, o["sol"]) == api.OK
+    opt.close()                                                    # cilqr_destroy with three solves outstanding: waits for them
+    del keep
+
+
 def test_handle_pool_deals_batches_round_robin_bit_identically():
     """cilqr_pool_*: two handles on one GPU, seven different batches submitted as a stream (up to depth = 6 submitted:
     two in flight and one queued per handle, the oldest collected first).  Every batch comes back bit-identical to the synchronous call; a submit beyond
