@@ -114,7 +114,7 @@ int main(int argc, char** argv) {
   if (opt.native_handle() != nullptr) cilqr_set_profiling(opt.native_handle(), 0);
 
   // ---- cilqr_solve_batch, `batch` scenes per call, host arrays ----
-  std::vector<double> t_batch;
+  std::vector<double> t_batch, t_submit;
   if (batch > 1 && n >= batch) {
     cilqr_config cfg;
     cilqr_default_config(&cfg, K - 1);
@@ -138,6 +138,14 @@ int main(int argc, char** argv) {
         const auto t1 = clk::now();
         if (rc != CILQR_OK) return 8;
         if (pass == 1) t_batch.push_back(std::chrono::duration<double, std::milli>(t1 - t0).count());
+        // the same batch through cilqr_submit + cilqr_wait (a worker thread drives it and its host waits nap between polls:
+        // ADVICE r05 -- what that costs a small batch, whose iterations are ~100 us)
+        const auto t2 = clk::now();
+        const int rs = cilqr_submit(h, &in, &out);
+        const int rw = rs == CILQR_OK ? cilqr_wait(h) : rs;
+        const auto t3 = clk::now();
+        if (rw != CILQR_OK) return 9;
+        if (pass == 1) t_submit.push_back(std::chrono::duration<double, std::milli>(t3 - t2).count());
       }
     cilqr_destroy(h);
   }
@@ -158,6 +166,8 @@ int main(int argc, char** argv) {
   if (!t_batch.empty()) {
     std::printf(", \"batch\": %d, ", batch);
     stats(t_batch, "solve_batch");
+    std::printf(", ");
+    stats(t_submit, "submit_wait");
   }
   std::printf("}\n");
   return 0;
