@@ -128,8 +128,9 @@ int grow_pinned(void** p, size_t* have, size_t need) {
 
 // Host arrays travel on two streams of the handle's own, created when the first large host batch shows up: HIP maps streams
 // onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 unless the environment says otherwise) in the order they are created, and a
-// handle that only ever sees device arrays should not spend queues on streams it never uses (a pool of two handles with four
-// streams each put both first stages on one queue: 2.00 -> 1.84 M solves/s, measured).
+// handle that only ever sees device arrays should not spend queues on streams it never uses (round 3 measured what two
+// handles on one queue cost: they run like one; with the copy streams created at cilqr_create one run of round 6 gave 1.84
+// instead of 2.00 M solves/s -- not reproduced once they existed lazily, r06 log 2).
 int io_streams(cilqr_solver* h) {
   std::lock_guard<std::mutex> lk(h->io_mu);
   if (h->stream_in == nullptr) HIP_TRY(hipStreamCreateWithFlags(&h->stream_in, hipStreamNonBlocking));
