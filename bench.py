@@ -18,12 +18,19 @@ shrunk, exactly where another handle's cost kernels fit).  Every step is a compl
 the batch; `value` = problems solved / wall time of the K steps.  `one_handle` reports the same steps
 through one handle (half the memory), `single_batch` the strictly sequential call.
 
+Two extra legs on rank 0 at N = 1 (never `value`; `--no-extras` skips them): `pcie_inclusive` -- the same stream of batches with
+every input and output array in pageable HOST memory (CILQR_MEM_HOST through the pool: the library uploads the queued solve's
+arrays beside the solves and downloads the results ragged), compared bit for bit with the device-resident result -- and
+`end_to_end` -- obstacle points in HBM -> cilqr_build_corridors on a handle and stream of its own -> cilqr_pool_submit.
+Multi-rank runs carry `per_rank`, `host.cores_busy_per_rank` and `gather_verified_ranks` (a checksum check of what rank 0
+gathered); `--gather c_abi` lets cilqr_gather_results carry the per-step gather instead of torch.distributed.
+
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     backward-pass kernel, every launch of the timed region (time-weighted) and the launches
                that cover the whole batch: algorithmic bytes ((N*110+44)*8 B per problem
-               per launch) / HIP-event time, against the 8 TB/s HBM peak; `frac` is quoted on the
-               HBM bytes the kernel really moves (PMC-recorded per problem-step, profiles/), which is
-               <= 1 by construction; `frac_algorithmic` on the dense figure
+               per launch) / HIP-event time, against the 8 TB/s HBM peak; `achieved` and `frac` are quoted on the
+               HBM bytes the kernel really moves (PMC-counted per problem-step), which is
+               <= 1 by construction; `achieved_algorithmic` / `frac_algorithmic` on the dense figure
   cpu_baseline the CPU oracle (single thread) on a bounded sample of the same scenes, plus
                mean / median / p95 per solve for each BASELINE config's scene family
 """
