@@ -32,6 +32,7 @@ constexpr double kEps = 1e-10;  // algorithm/math/vec2d.h:33
 struct P2f {
   float x, y;
 };
+typedef __attribute__((address_space(3))) unsigned long long lds_float2;   // a pointer to it is an LDS address: ds_read / ds_write, never a flat access
 
 // Order-preserving image of a float32: as unsigned integers the images compare exactly as the floats do (-0 folded onto
 // +0 first; NaNs have no place in that order -- waves that hold one sort by float comparisons).
@@ -93,8 +94,8 @@ __device__ __forceinline__ void rank_sort_in_registers(const P2f* p, int n, int 
 // entries (exact predicates keep at most n + 1 on the stack; with float32 rounding a nearly
 // collinear point can survive in both chains, and 2n - 1 pushes is the hard bound).  Returns the
 // number of hull vertices.  CAP > 0: the register sort above for waves whose counts all fit CAP.
-template <int CAP, typename Idx>
-__device__ int hull_indices(const P2f* p, int n, Idx* order, Idx* h) {
+template <int CAP, typename Idx, int WIN>
+__device__ __forceinline__ int hull_indices(const P2f* p, int n, Idx* order, Idx* h, lds_float2* win) {
   bool in_registers = false;
   if (CAP > 0) {
     bool plain = n <= CAP;
@@ -130,20 +131,75 @@ __device__ int hull_indices(const P2f* p, int n, Idx* order, Idx* h) {
       order[rank] = (Idx)i;
     }
   }
-  auto cross = [&](int o, int a, int b) {
-    const float ax = p[a].x - p[o].x, ay = p[a].y - p[o].y;
-    const float bx = p[b].x - p[o].x, by = p[b].y - p[o].y;
+  // The monotone chain.  The two topmost stack points stay in registers (a = p[h[k-2]], b = p[h[k-1]]): the test of a
+  // new point reads nothing.  A pop needs the point two below the new top: the points of the topmost WIN levels are
+  // kept in LDS as well (a ring: level l in row l % WIN, column = lane, so any per-lane level is conflict-free), written
+  // at every push; `lo` is the lowest level whose row has not been overwritten by a push WIN levels higher -- below it
+  // (a run of more than WIN - 2 pops) the point comes from the lane's arrays, two dependent trips to memory, as every
+  // pop did before.  The next point of the chain is requested one trip ahead.
+  auto turn = [](const P2f& o, const P2f& m, const P2f& q) {
+    const float ax = m.x - o.x, ay = m.y - o.y;
+    const float bx = q.x - o.x, by = q.y - o.y;
     const float t1 = ax * by, t2 = ay * bx;
     return t1 - t2;
   };
-  int k = 0;
+  const int lane = threadIdx.x & 63;
+  int k = 0, lo = 0;
+  P2f a = P2f{0.0f, 0.0f}, b = P2f{0.0f, 0.0f};
+  auto level_point = [&](int l) -> P2f {
+    if (WIN > 0 && l >= lo) {
+      const unsigned long long v = win[(l % (WIN > 0 ? WIN : 1)) * 64 + lane];
+      return P2f{__uint_as_float((uint32_t)v), __uint_as_float((uint32_t)(v >> 32))};
+    }
+    return p[h[l]];
+  };
+  auto push = [&](Idx oi, const P2f& q) {
+    h[k] = oi;
+    if (WIN > 0) {
+      win[(k % (WIN > 0 ? WIN : 1)) * 64 + lane] = ((unsigned long long)__float_as_uint(q.y) << 32) | __float_as_uint(q.x);
+      lo = max(lo, k - WIN + 1);
+    }
+    ++k;
+    a = b;
+    b = q;
+  };
+  Idx on = (Idx)0;
+  P2f qn = P2f{0.0f, 0.0f};
+  if (n > 0) {
+    on = order[0];
+    qn = p[on];
+  }
   for (int i = 0; i < n; ++i) {
-    while (k >= 2 && cross(h[k - 2], h[k - 1], order[i]) <= 0.0f) --k;
-    h[k++] = order[i];
+    const Idx oi = on;
+    const P2f q = qn;
+    if (i + 1 < n) {
+      on = order[i + 1];
+      qn = p[on];
+    }
+    while (k >= 2 && turn(a, b, q) <= 0.0f) {
+      --k;
+      b = a;
+      if (k >= 2) a = level_point(k - 2);
+    }
+    push(oi, q);
+  }
+  if (n >= 2) {
+    on = order[n - 2];
+    qn = p[on];
   }
   for (int i = n - 2, t = k + 1; i >= 0; --i) {
-    while (k >= t && cross(h[k - 2], h[k - 1], order[i]) <= 0.0f) --k;
-    h[k++] = order[i];
+    const Idx oi = on;
+    const P2f q = qn;
+    if (i >= 1) {
+      on = order[i - 1];
+      qn = p[on];
+    }
+    while (k >= t && turn(a, b, q) <= 0.0f) {
+      --k;
+      b = a;
+      if (k >= 2) a = level_point(k - 2);
+    }
+    push(oi, q);
   }
   if (k > 1) --k;
   if (k == 2 && p[h[0]].x == p[h[1]].x && p[h[0]].y == p[h[1]].y) k = 1;
@@ -164,7 +220,7 @@ __device__ void make_clockwise(Idx* h, int k) {
 // the count zeroed), ccount [n]
 // (m >= 3 half-planes, or -1 no points, -2 fewer than 4 flipped points, -3 more than cmax
 // half-planes, -4 degenerate hull); *n_failed counts the knots with a negative code.
-template <int MAXP, typename Idx, int BIG, int SMALL>
+template <int MAXP, typename Idx, int BIG, int SMALL, int WIN>
 __global__ __launch_bounds__(64) void k_build_corridors(int n, CorridorParams cp, const double* __restrict__ knots,
                                                         const double* __restrict__ points,
                                                         const int* __restrict__ count, int pmax,
@@ -173,6 +229,8 @@ __global__ __launch_bounds__(64) void k_build_corridors(int n, CorridorParams cp
                                                         double* __restrict__ polygons) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
+  __shared__ unsigned long long win_rows[(WIN > 0 ? WIN : 1) * 64];
+  lds_float2* win = (lds_float2*)win_rows;
   const double ox = knots[3 * t], oy = knots[3 * t + 1], theta = knots[3 * t + 2];
   // private working set (scratch), kept small: it is what the kernel's memory traffic consists of.
   // `flip` is dead once the first hull is known and is reused for the dual points; the kept points
@@ -230,7 +288,7 @@ __global__ __launch_bounds__(64) void k_build_corridors(int n, CorridorParams cp
     code = -2;
   } else {
     flip[nf] = P2f{0.0f, 0.0f};
-    const int n1 = hull_indices<BIG, Idx>(flip, nf + 1, order, hull);  // cc:184
+    const int n1 = hull_indices<BIG, Idx, WIN>(flip, nf + 1, order, hull, win);  // cc:184
     if (n1 < 3 || n1 > nf + 1) {   // more vertices than points: float32 predicates disagreed (degenerate)
       code = -4;
     } else {
@@ -261,7 +319,7 @@ __global__ __launch_bounds__(64) void k_build_corridors(int n, CorridorParams cp
         ix = 0.99 * safe_radius * dx / d + ox;
         iy = 0.99 * safe_radius * dy / d + oy;
       }
-      const int n2 = hull_indices<SMALL, Idx>(vd, n1, order, hull);  // cc:218
+      const int n2 = hull_indices<SMALL, Idx, WIN>(vd, n1, order, hull, win);  // cc:218
       if (n2 < 3 || n2 > n1) {
         code = -4;
       } else {
@@ -289,7 +347,7 @@ __global__ __launch_bounds__(64) void k_build_corridors(int n, CorridorParams cp
             idx = (idx + 1 == n1) ? 0 : idx + 1;
           }
         }
-        const int n3 = hull_indices<SMALL, Idx>(dual, nt, order, hull);  // cc:241-242
+        const int n3 = hull_indices<SMALL, Idx, WIN>(dual, nt, order, hull, win);  // cc:241-242
         if (n3 < 3 || n3 > nt) {
           code = -4;
         } else if (n3 > cmax) {
@@ -346,22 +404,24 @@ __global__ __launch_bounds__(64) void k_build_corridors(int n, CorridorParams cp
 void launch_build_corridors(int n, const CorridorParams& cp, const double* knots, const double* points,
                             const int* count, int pmax, double* corridor, int* ccount, int cmax, int* n_failed,
                             double* polygons, hipStream_t st) {
-  // Unused dynamic LDS caps the kernel at 16 waves per CU.  A lane's working set lives in scratch
-  // memory; with every wave slot filled (32 per CU) the scratch of the waves in flight (1.2 GB)
-  // streams through HBM on every access, at half that the kernel is 20 % faster (measured).
-  constexpr int lds_pad = 10000;
+  // Occupancy.  The two kernels with the LDS window run as many waves as their registers allow (11-12 per CU at 142
+  // VGPRs): a wave waits on memory for most of its life and, with the pops of the chains served from LDS, another
+  // wave in flight is time gained (65536 x 51 knots: 10.0 / 8.9 / 8.4 ms at 8 / 10 / 12 waves per CU).  The generic
+  // kernel, every access of which goes to scratch memory, is capped at 16 waves per CU by unused dynamic LDS:
+  // with more, the scratch of the waves in flight streams through HBM on every access (20 % slower, measured).
+  constexpr int lds_pad_generic = 10000;
   // three capacities: a lane's scratch working set scales with it
   const int need = pmax + 4 * cp.per_edge;
   const dim3 grid((n + 63) / 64), block(64);
   if (need <= 56)
-    hipLaunchKernelGGL((k_build_corridors<56, unsigned char, 57, 16>), grid, block, lds_pad, st, n, cp, knots,
+    hipLaunchKernelGGL((k_build_corridors<56, unsigned char, 57, 40, 16>), grid, block, 0, st, n, cp, knots,
                        points, count, pmax, corridor, ccount, cmax, n_failed, polygons);
   else if (need <= 96)
-    hipLaunchKernelGGL((k_build_corridors<96, unsigned char, 0, 16>), grid, block, lds_pad, st, n, cp, knots,
+    hipLaunchKernelGGL((k_build_corridors<96, unsigned char, 0, 40, 16>), grid, block, 0, st, n, cp, knots,
                        points, count, pmax, corridor, ccount, cmax, n_failed, polygons);
   else   // is_multiple_sample scenes: six samples per obstacle edge and per box edge (every sort on the generic path: the
          // kernel the two above are held against bit for bit, tests/test_corridor.py)
-    hipLaunchKernelGGL((k_build_corridors<kCorMaxPts, unsigned short, 0, 0>), grid, block, lds_pad, st, n, cp,
+    hipLaunchKernelGGL((k_build_corridors<kCorMaxPts, unsigned short, 0, 0, 0>), grid, block, lds_pad_generic, st, n, cp,
                        knots, points, count, pmax, corridor, ccount, cmax, n_failed, polygons);
 }
 
