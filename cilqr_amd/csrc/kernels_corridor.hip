@@ -61,16 +61,19 @@ __device__ __forceinline__ void static_for(F&& f) {
 // lane's count are all-ones (they sort behind everything and are never stored); `nmax`, the largest count of the wave, ends
 // the unrolled loops early with scalar branches.
 template <int CAP, typename Idx>
-__device__ __forceinline__ void rank_sort_in_registers(const P2f* p, int n, int nmax, Idx* order) {
+__device__ __forceinline__ bool rank_sort_in_registers(const P2f* p, int n, int nmax, Idx* order) {
   uint64_t key[CAP];
+  bool plain = true;
   static_for<0, CAP>([&](auto C) {
     constexpr int c = decltype(C)::value;
     key[c] = ~0ull;
     if (c < nmax && c < n) {
       const P2f q = p[c];
+      plain = plain && (q.x == q.x) && (q.y == q.y);
       key[c] = ((uint64_t)ordered_bits(q.x) << 32) | ordered_bits(q.y);
     }
   });
+  if (__all(plain ? 1 : 0) == 0) return false;   // a NaN somewhere in the wave: nothing written, the caller sorts by float comparisons
   static_for<0, CAP>([&](auto I) {
     constexpr int i = decltype(I)::value;
     if (i < nmax) {      // (wave-uniform: a scalar branch around the rest of the body)
@@ -87,6 +90,7 @@ __device__ __forceinline__ void rank_sort_in_registers(const P2f* p, int n, int 
       if (i < n) order[rank] = (Idx)i;
     }
   });
+  return true;
 }
 
 // strictly convex hull of p[0..n): indices into p, counter-clockwise (y up) from the
@@ -98,10 +102,7 @@ template <int CAP, typename Idx, int WIN>
 __device__ __forceinline__ int hull_indices(const P2f* p, int n, Idx* order, Idx* h, lds_float2* win) {
   bool in_registers = false;
   if (CAP > 0) {
-    bool plain = n <= CAP;
-    for (int i = 0; i < n && plain; ++i) plain = (p[i].x == p[i].x) && (p[i].y == p[i].y);   // (n loads; a NaN ends the scan)
-    in_registers = __all(plain ? 1 : 0) != 0;
-    if (in_registers) {
+    if (__all(n <= CAP ? 1 : 0) != 0) {
       // largest count among the lanes that are HERE (the call sits inside divergent branches: a butterfly of shuffles would
       // read lanes that are not), bit by bit through votes -- the result is the same scalar in every lane
       int nmax = 0;
@@ -111,7 +112,7 @@ __device__ __forceinline__ int hull_indices(const P2f* p, int n, Idx* order, Idx
         if (__any(n >= cand ? 1 : 0)) nmax = cand;
       }
       nmax = __builtin_amdgcn_readfirstlane(nmax);
-      rank_sort_in_registers<(CAP > 0 ? CAP : 1), Idx>(p, n, nmax, order);
+      in_registers = rank_sort_in_registers<(CAP > 0 ? CAP : 1), Idx>(p, n, nmax, order);
     }
   }
   if (!in_registers) {
