@@ -32,7 +32,8 @@ constexpr double kEps = 1e-10;  // algorithm/math/vec2d.h:33
 struct P2f {
   float x, y;
 };
-typedef __attribute__((address_space(3))) unsigned long long lds_float2;   // a pointer to it is an LDS address: ds_read / ds_write, never a flat access
+typedef __attribute__((address_space(3))) unsigned long long lds_float2;
+typedef __attribute__((address_space(3))) unsigned char lds_u8;   // a pointer to it is an LDS address: ds_read / ds_write, never a flat access
 
 // Order-preserving image of a float32: as unsigned integers the images compare exactly as the floats do (-0 folded onto
 // +0 first; NaNs have no place in that order -- waves that hold one sort by float comparisons).
@@ -60,8 +61,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 // by the front end (static_for), so every key is a register the compiler names: no load in it at all.  Lanes hold different counts: keys past a
 // lane's count are all-ones (they sort behind everything and are never stored); `nmax`, the largest count of the wave, ends
 // the unrolled loops early with scalar branches.
-template <int CAP, typename Idx>
-__device__ __forceinline__ bool rank_sort_in_registers(const P2f* p, int n, int nmax, Idx* order) {
+template <int CAP, typename SetOrder>
+__device__ __forceinline__ bool rank_sort_in_registers(const P2f* p, int n, int nmax, const SetOrder& set_order) {
   uint64_t key[CAP];
   bool plain = true;
   static_for<0, CAP>([&](auto C) {
@@ -87,7 +88,7 @@ __device__ __forceinline__ bool rank_sort_in_registers(const P2f* p, int n, int 
           });
         }
       });
-      if (i < n) order[rank] = (Idx)i;
+      if (i < n) set_order(rank, i);
     }
   });
   return true;
@@ -98,8 +99,19 @@ __device__ __forceinline__ bool rank_sort_in_registers(const P2f* p, int n, int 
 // entries (exact predicates keep at most n + 1 on the stack; with float32 rounding a nearly
 // collinear point can survive in both chains, and 2n - 1 pushes is the hard bound).  Returns the
 // number of hull vertices.  CAP > 0: the register sort above for waves whose counts all fit CAP.
-template <int CAP, typename Idx, int WIN>
-__device__ __forceinline__ int hull_indices(const P2f* p, int n, Idx* order, Idx* h, lds_float2* win) {
+template <int CAP, typename Idx, int WIN, bool ORD>
+__device__ __forceinline__ int hull_indices(const P2f* p, int n, Idx* order, Idx* h, lds_float2* win, lds_u8* order_rows) {
+  const int lane = threadIdx.x & 63;
+  // the sorted order: with the window, rows of LDS as well (row = rank, column = lane: what a wave reads with its
+  // uniform loop index is one 64-byte row); without, the lane's private array
+  auto set_order = [&](int r, int v) {
+    if constexpr (ORD) order_rows[r * 64 + lane] = (unsigned char)v;
+    else order[r] = (Idx)v;
+  };
+  auto get_order = [&](int r) -> Idx {
+    if constexpr (ORD) return (Idx)order_rows[r * 64 + lane];
+    else return order[r];
+  };
   bool in_registers = false;
   if (CAP > 0) {
     if (__all(n <= CAP ? 1 : 0) != 0) {
@@ -112,7 +124,7 @@ __device__ __forceinline__ int hull_indices(const P2f* p, int n, Idx* order, Idx
         if (__any(n >= cand ? 1 : 0)) nmax = cand;
       }
       nmax = __builtin_amdgcn_readfirstlane(nmax);
-      in_registers = rank_sort_in_registers<(CAP > 0 ? CAP : 1), Idx>(p, n, nmax, order);
+      in_registers = rank_sort_in_registers<(CAP > 0 ? CAP : 1)>(p, n, nmax, set_order);
     }
   }
   if (!in_registers) {
@@ -121,7 +133,7 @@ __device__ __forceinline__ int hull_indices(const P2f* p, int n, Idx* order, Idx
     // false with everything, so two points can land on one rank and leave another rank without a point: every entry is set
     // first, so that what the scans read for such a rank is a point of this lane (what the reference's cv::convexHull makes of
     // a NaN is undefined; here it is at least the same corridor on every run and in every instantiation)
-    for (int i = 0; i < n; ++i) order[i] = (Idx)0;
+    for (int i = 0; i < n; ++i) set_order(i, 0);
     for (int i = 0; i < n; ++i) {
       const P2f q = p[i];
       int rank = 0;
@@ -129,7 +141,7 @@ __device__ __forceinline__ int hull_indices(const P2f* p, int n, Idx* order, Idx
         const P2f r = p[j];
         rank += (r.x < q.x || (r.x == q.x && (r.y < q.y || (r.y == q.y && j < i)))) ? 1 : 0;
       }
-      order[rank] = (Idx)i;
+      set_order(rank, i);
     }
   }
   // The monotone chain.  The two topmost stack points stay in registers (a = p[h[k-2]], b = p[h[k-1]]): the test of a
@@ -144,7 +156,6 @@ __device__ __forceinline__ int hull_indices(const P2f* p, int n, Idx* order, Idx
     const float t1 = ax * by, t2 = ay * bx;
     return t1 - t2;
   };
-  const int lane = threadIdx.x & 63;
   int k = 0, lo = 0;
   P2f a = P2f{0.0f, 0.0f}, b = P2f{0.0f, 0.0f};
   auto level_point = [&](int l) -> P2f {
@@ -167,14 +178,14 @@ __device__ __forceinline__ int hull_indices(const P2f* p, int n, Idx* order, Idx
   Idx on = (Idx)0;
   P2f qn = P2f{0.0f, 0.0f};
   if (n > 0) {
-    on = order[0];
+    on = get_order(0);
     qn = p[on];
   }
   for (int i = 0; i < n; ++i) {
     const Idx oi = on;
     const P2f q = qn;
     if (i + 1 < n) {
-      on = order[i + 1];
+      on = get_order(i + 1);
       qn = p[on];
     }
     while (k >= 2 && turn(a, b, q) <= 0.0f) {
@@ -185,14 +196,14 @@ __device__ __forceinline__ int hull_indices(const P2f* p, int n, Idx* order, Idx
     push(oi, q);
   }
   if (n >= 2) {
-    on = order[n - 2];
+    on = get_order(n - 2);
     qn = p[on];
   }
   for (int i = n - 2, t = k + 1; i >= 0; --i) {
     const Idx oi = on;
     const P2f q = qn;
     if (i >= 1) {
-      on = order[i - 1];
+      on = get_order(i - 1);
       qn = p[on];
     }
     while (k >= t && turn(a, b, q) <= 0.0f) {
@@ -221,7 +232,7 @@ __device__ void make_clockwise(Idx* h, int k) {
 // the count zeroed), ccount [n]
 // (m >= 3 half-planes, or -1 no points, -2 fewer than 4 flipped points, -3 more than cmax
 // half-planes, -4 degenerate hull); *n_failed counts the knots with a negative code.
-template <int MAXP, typename Idx, int BIG, int SMALL, int WIN>
+template <int MAXP, typename Idx, int BIG, int SMALL, int WIN, bool ORD>
 __global__ __launch_bounds__(64) void k_build_corridors(int n, CorridorParams cp, const double* __restrict__ knots,
                                                         const double* __restrict__ points,
                                                         const int* __restrict__ count, int pmax,
@@ -232,6 +243,9 @@ __global__ __launch_bounds__(64) void k_build_corridors(int n, CorridorParams cp
   if (t >= n) return;
   __shared__ unsigned long long win_rows[(WIN > 0 ? WIN : 1) * 64];
   lds_float2* win = (lds_float2*)win_rows;
+  __shared__ unsigned char order_bytes[ORD ? (MAXP + 1) * 64 : 64];
+  lds_u8* order_rows = (lds_u8*)order_bytes;
+  static_assert(!ORD || sizeof(Idx) == 1, "the LDS rows of the sorted order hold bytes");
   const double ox = knots[3 * t], oy = knots[3 * t + 1], theta = knots[3 * t + 2];
   // private working set (scratch), kept small: it is what the kernel's memory traffic consists of.
   // `flip` is dead once the first hull is known and is reused for the dual points; the kept points
@@ -289,7 +303,7 @@ __global__ __launch_bounds__(64) void k_build_corridors(int n, CorridorParams cp
     code = -2;
   } else {
     flip[nf] = P2f{0.0f, 0.0f};
-    const int n1 = hull_indices<BIG, Idx, WIN>(flip, nf + 1, order, hull, win);  // cc:184
+    const int n1 = hull_indices<BIG, Idx, WIN, ORD>(flip, nf + 1, order, hull, win, order_rows);  // cc:184
     if (n1 < 3 || n1 > nf + 1) {   // more vertices than points: float32 predicates disagreed (degenerate)
       code = -4;
     } else {
@@ -320,7 +334,7 @@ __global__ __launch_bounds__(64) void k_build_corridors(int n, CorridorParams cp
         ix = 0.99 * safe_radius * dx / d + ox;
         iy = 0.99 * safe_radius * dy / d + oy;
       }
-      const int n2 = hull_indices<SMALL, Idx, WIN>(vd, n1, order, hull, win);  // cc:218
+      const int n2 = hull_indices<SMALL, Idx, WIN, ORD>(vd, n1, order, hull, win, order_rows);  // cc:218
       if (n2 < 3 || n2 > n1) {
         code = -4;
       } else {
@@ -348,7 +362,7 @@ __global__ __launch_bounds__(64) void k_build_corridors(int n, CorridorParams cp
             idx = (idx + 1 == n1) ? 0 : idx + 1;
           }
         }
-        const int n3 = hull_indices<SMALL, Idx, WIN>(dual, nt, order, hull, win);  // cc:241-242
+        const int n3 = hull_indices<SMALL, Idx, WIN, ORD>(dual, nt, order, hull, win, order_rows);  // cc:241-242
         if (n3 < 3 || n3 > nt) {
           code = -4;
         } else if (n3 > cmax) {
@@ -415,14 +429,14 @@ void launch_build_corridors(int n, const CorridorParams& cp, const double* knots
   const int need = pmax + 4 * cp.per_edge;
   const dim3 grid((n + 63) / 64), block(64);
   if (need <= 56)
-    hipLaunchKernelGGL((k_build_corridors<56, unsigned char, 57, 40, 16>), grid, block, 0, st, n, cp, knots,
+    hipLaunchKernelGGL((k_build_corridors<56, unsigned char, 57, 40, 16, true>), grid, block, 0, st, n, cp, knots,
                        points, count, pmax, corridor, ccount, cmax, n_failed, polygons);
   else if (need <= 96)
-    hipLaunchKernelGGL((k_build_corridors<96, unsigned char, 0, 40, 16>), grid, block, 0, st, n, cp, knots,
+    hipLaunchKernelGGL((k_build_corridors<96, unsigned char, 0, 40, 16, false>), grid, block, 0, st, n, cp, knots,
                        points, count, pmax, corridor, ccount, cmax, n_failed, polygons);
   else   // is_multiple_sample scenes: six samples per obstacle edge and per box edge (every sort on the generic path: the
          // kernel the two above are held against bit for bit, tests/test_corridor.py)
-    hipLaunchKernelGGL((k_build_corridors<kCorMaxPts, unsigned short, 0, 0, 0>), grid, block, lds_pad_generic, st, n, cp,
+    hipLaunchKernelGGL((k_build_corridors<kCorMaxPts, unsigned short, 0, 0, 0, false>), grid, block, lds_pad_generic, st, n, cp,
                        knots, points, count, pmax, corridor, ccount, cmax, n_failed, polygons);
 }
 
