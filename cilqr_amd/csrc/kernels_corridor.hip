@@ -35,6 +35,27 @@ struct P2f {
 typedef __attribute__((address_space(3))) unsigned long long lds_float2;
 typedef __attribute__((address_space(3))) unsigned char lds_u8;   // a pointer to it is an LDS address: ds_read / ds_write, never a flat access
 
+// A lane's small index arrays (the sorted order, the chain's stack) in one of two homes.  In the lane's private segment an
+// access is a trip to scratch memory, and a write with a per-lane index scatters over 64 cache lines.  As rows of LDS
+// (row = index, column = lane: a wave reading with its uniform loop index reads one 64-byte row; per-lane indices
+// collide only on equal (row mod 4, lane / 4)) it is an LDS access; indices past the rows go to a private array.
+template <typename Idx>
+struct PrivateIdx {
+  Idx* a;
+  __device__ __forceinline__ int get(int i) const { return (int)a[i]; }
+  __device__ __forceinline__ void set(int i, int v) const { a[i] = (Idx)v; }
+};
+template <typename Idx, int ROWS>
+struct LdsIdx {
+  lds_u8* rows;   // + lane
+  Idx* past;      // entries ROWS, ROWS + 1, ... (nullptr: there are none)
+  __device__ __forceinline__ int get(int i) const { return (i < ROWS || past == nullptr) ? (int)rows[i * 64] : (int)past[i]; }
+  __device__ __forceinline__ void set(int i, int v) const {
+    if (i < ROWS || past == nullptr) rows[i * 64] = (unsigned char)v;
+    else past[i] = (Idx)v;
+  }
+};
+
 // Order-preserving image of a float32: as unsigned integers the images compare exactly as the floats do (-0 folded onto
 // +0 first; NaNs have no place in that order -- waves that hold one sort by float comparisons).
 __device__ inline uint32_t ordered_bits(float v) {
@@ -99,19 +120,10 @@ __device__ __forceinline__ bool rank_sort_in_registers(const P2f* p, int n, int 
 // entries (exact predicates keep at most n + 1 on the stack; with float32 rounding a nearly
 // collinear point can survive in both chains, and 2n - 1 pushes is the hard bound).  Returns the
 // number of hull vertices.  CAP > 0: the register sort above for waves whose counts all fit CAP.
-template <int CAP, typename Idx, int WIN, bool ORD>
-__device__ __forceinline__ int hull_indices(const P2f* p, int n, Idx* order, Idx* h, lds_float2* win, lds_u8* order_rows) {
+template <int CAP, int WIN, typename Ord, typename Stk>
+__device__ __forceinline__ int hull_indices(const P2f* p, int n, const Ord& order, const Stk& h, lds_float2* win) {
   const int lane = threadIdx.x & 63;
-  // the sorted order: with the window, rows of LDS as well (row = rank, column = lane: what a wave reads with its
-  // uniform loop index is one 64-byte row); without, the lane's private array
-  auto set_order = [&](int r, int v) {
-    if constexpr (ORD) order_rows[r * 64 + lane] = (unsigned char)v;
-    else order[r] = (Idx)v;
-  };
-  auto get_order = [&](int r) -> Idx {
-    if constexpr (ORD) return (Idx)order_rows[r * 64 + lane];
-    else return order[r];
-  };
+  auto set_order = [&](int r, int v) { order.set(r, v); };
   bool in_registers = false;
   if (CAP > 0) {
     if (__all(n <= CAP ? 1 : 0) != 0) {
@@ -163,10 +175,10 @@ __device__ __forceinline__ int hull_indices(const P2f* p, int n, Idx* order, Idx
       const unsigned long long v = win[(l % (WIN > 0 ? WIN : 1)) * 64 + lane];
       return P2f{__uint_as_float((uint32_t)v), __uint_as_float((uint32_t)(v >> 32))};
     }
-    return p[h[l]];
+    return p[h.get(l)];
   };
-  auto push = [&](Idx oi, const P2f& q) {
-    h[k] = oi;
+  auto push = [&](int oi, const P2f& q) {
+    h.set(k, oi);
     if (WIN > 0) {
       win[(k % (WIN > 0 ? WIN : 1)) * 64 + lane] = ((unsigned long long)__float_as_uint(q.y) << 32) | __float_as_uint(q.x);
       lo = max(lo, k - WIN + 1);
@@ -175,17 +187,17 @@ __device__ __forceinline__ int hull_indices(const P2f* p, int n, Idx* order, Idx
     a = b;
     b = q;
   };
-  Idx on = (Idx)0;
+  int on = 0;
   P2f qn = P2f{0.0f, 0.0f};
   if (n > 0) {
-    on = get_order(0);
+    on = order.get(0);
     qn = p[on];
   }
   for (int i = 0; i < n; ++i) {
-    const Idx oi = on;
+    const int oi = on;
     const P2f q = qn;
     if (i + 1 < n) {
-      on = get_order(i + 1);
+      on = order.get(i + 1);
       qn = p[on];
     }
     while (k >= 2 && turn(a, b, q) <= 0.0f) {
@@ -196,14 +208,14 @@ __device__ __forceinline__ int hull_indices(const P2f* p, int n, Idx* order, Idx
     push(oi, q);
   }
   if (n >= 2) {
-    on = get_order(n - 2);
+    on = order.get(n - 2);
     qn = p[on];
   }
   for (int i = n - 2, t = k + 1; i >= 0; --i) {
-    const Idx oi = on;
+    const int oi = on;
     const P2f q = qn;
     if (i >= 1) {
-      on = get_order(i - 1);
+      on = order.get(i - 1);
       qn = p[on];
     }
     while (k >= t && turn(a, b, q) <= 0.0f) {
@@ -214,15 +226,18 @@ __device__ __forceinline__ int hull_indices(const P2f* p, int n, Idx* order, Idx
     push(oi, q);
   }
   if (k > 1) --k;
-  if (k == 2 && p[h[0]].x == p[h[1]].x && p[h[0]].y == p[h[1]].y) k = 1;
+  if (k == 2) {
+    const P2f h0 = p[h.get(0)], h1 = p[h.get(1)];
+    if (h0.x == h1.x && h0.y == h1.y) k = 1;
+  }
   return k;
 }
-template <typename Idx>
-__device__ void make_clockwise(Idx* h, int k) {
+template <typename Stk>
+__device__ __forceinline__ void make_clockwise(const Stk& h, int k) {
   for (int a = 1, b = k - 1; a < b; ++a, --b) {
-    const Idx t = h[a];
-    h[a] = h[b];
-    h[b] = t;
+    const int t = h.get(a);
+    h.set(a, h.get(b));
+    h.set(b, t);
   }
 }
 
@@ -243,8 +258,9 @@ __global__ __launch_bounds__(64) void k_build_corridors(int n, CorridorParams cp
   if (t >= n) return;
   __shared__ unsigned long long win_rows[(WIN > 0 ? WIN : 1) * 64];
   lds_float2* win = (lds_float2*)win_rows;
-  __shared__ unsigned char order_bytes[ORD ? (MAXP + 1) * 64 : 64];
-  lds_u8* order_rows = (lds_u8*)order_bytes;
+  constexpr int kOrdRows = MAXP + 1, kStkRows = MAXP + 2;   // a chain's stack holds at most n + 1 entries unless float32 rounding keeps a point in both chains
+  __shared__ unsigned char order_bytes[ORD ? kOrdRows * 64 : 64];
+  __shared__ unsigned char stack_bytes[ORD ? kStkRows * 64 : 64];
   static_assert(!ORD || sizeof(Idx) == 1, "the LDS rows of the sorted order hold bytes");
   const double ox = knots[3 * t], oy = knots[3 * t + 1], theta = knots[3 * t + 2];
   // private working set (scratch), kept small: it is what the kernel's memory traffic consists of.
@@ -252,7 +268,22 @@ __global__ __launch_bounds__(64) void k_build_corridors(int n, CorridorParams cp
   // are remembered by their index in the input list and re-read (or re-derived) when needed.
   P2f flip[MAXP + 1], vd[MAXP + 1];
   P2f* dual = flip;
-  Idx src[MAXP], order[MAXP + 1], hull[2 * (MAXP + 1)], v2[MAXP + 1];
+  Idx src[MAXP], order_priv[ORD ? 1 : MAXP + 1], hull_priv[2 * (MAXP + 1)], v2_priv[ORD ? 1 : MAXP + 1];
+  // the sorted order, the chain's stack = the hull, and the second hull's copy (v2: alive only between two hulls, in the
+  // rows of the sorted order): LDS rows in the kernels that have them, private arrays in the others
+  using OrdT = typename std::conditional<ORD, LdsIdx<Idx, kOrdRows>, PrivateIdx<Idx>>::type;
+  using StkT = typename std::conditional<ORD, LdsIdx<Idx, kStkRows>, PrivateIdx<Idx>>::type;
+  OrdT order, v2;
+  StkT hull;
+  if constexpr (ORD) {
+    order = OrdT{(lds_u8*)order_bytes + (threadIdx.x & 63), nullptr};
+    v2 = order;
+    hull = StkT{(lds_u8*)stack_bytes + (threadIdx.x & 63), hull_priv};
+  } else {
+    order = OrdT{order_priv};
+    v2 = OrdT{v2_priv};
+    hull = StkT{hull_priv};
+  }
   int code = 0;
   int nf = 0;
   double safe_radius = cp.radius;
@@ -303,19 +334,19 @@ __global__ __launch_bounds__(64) void k_build_corridors(int n, CorridorParams cp
     code = -2;
   } else {
     flip[nf] = P2f{0.0f, 0.0f};
-    const int n1 = hull_indices<BIG, Idx, WIN, ORD>(flip, nf + 1, order, hull, win, order_rows);  // cc:184
+    const int n1 = hull_indices<BIG, WIN>(flip, nf + 1, order, hull, win);  // cc:184
     if (n1 < 3 || n1 > nf + 1) {   // more vertices than points: float32 predicates disagreed (degenerate)
       code = -4;
     } else {
       // star-shaped polygon through the visible points cc:186-198
       int origin_index = -1;
       for (int i = 0; i < n1; ++i) {
-        if (hull[i] == nf) {
+        if (hull.get(i) == nf) {
           origin_index = i;
           vd[i] = P2f{(float)ox, (float)oy};
         } else {
           double x, y;
-          input_point(src[hull[i]], x, y);
+          input_point(src[hull.get(i)], x, y);
           vd[i] = P2f{(float)x, (float)y};
         }
       }
@@ -324,7 +355,7 @@ __global__ __launch_bounds__(64) void k_build_corridors(int n, CorridorParams cp
         const uint64_t sz = (uint64_t)n1;
         const int last = (int)(((uint64_t)(int64_t)(origin_index - 1)) % sz);
         const int next = (int)(((uint64_t)(int64_t)(origin_index + 1)) % sz);
-        const int vl = hull[last], vn = hull[next];
+        const int vl = hull.get(last), vn = hull.get(next);
         double lx = ox, ly = oy, nx = ox, ny = oy;
         if (vl != nf) input_point(src[vl], lx, ly);
         if (vn != nf) input_point(src[vn], nx, ny);
@@ -334,16 +365,17 @@ __global__ __launch_bounds__(64) void k_build_corridors(int n, CorridorParams cp
         ix = 0.99 * safe_radius * dx / d + ox;
         iy = 0.99 * safe_radius * dy / d + oy;
       }
-      const int n2 = hull_indices<SMALL, Idx, WIN, ORD>(vd, n1, order, hull, win, order_rows);  // cc:218
+      const int n2 = hull_indices<SMALL, WIN>(vd, n1, order, hull, win);  // cc:218
       if (n2 < 3 || n2 > n1) {
         code = -4;
       } else {
-        for (int j = 0; j < n2; ++j) v2[j] = hull[j];
+        for (int j = 0; j < n2; ++j) v2.set(j, hull.get(j));
         // one half-plane per star vertex, normal of the hull edge it hides behind  cc:220-239
         int nt = 0;
         for (int j = 0; j < n2; ++j) {
           const int j1 = (j + 1 == n2) ? 0 : j + 1;
-          const float rx = vd[v2[j1]].x - vd[v2[j]].x, ry = vd[v2[j1]].y - vd[v2[j]].y;
+          const int vj = v2.get(j), vj1 = v2.get(j1);
+          const float rx = vd[vj1].x - vd[vj].x, ry = vd[vj1].y - vd[vj].y;
           float n0 = ry, nn1 = -rx;
           const float z = n0 * n0 + nn1 * nn1;
           if (z > 0.0f) {
@@ -351,9 +383,9 @@ __global__ __launch_bounds__(64) void k_build_corridors(int n, CorridorParams cp
             n0 = n0 / s;
             nn1 = nn1 / s;
           }
-          int idx = v2[j];
+          int idx = vj;
           int guard = 0;
-          while (idx != v2[j1] && guard++ <= n1 && nt < MAXP + 1) {
+          while (idx != vj1 && guard++ <= n1 && nt < MAXP + 1) {
             const double c = (vd[idx].x - ix) * n0 + (vd[idx].y - iy) * nn1;
             const float cf = (float)c;
             dual[nt].x = n0 / cf;
@@ -362,7 +394,7 @@ __global__ __launch_bounds__(64) void k_build_corridors(int n, CorridorParams cp
             idx = (idx + 1 == n1) ? 0 : idx + 1;
           }
         }
-        const int n3 = hull_indices<SMALL, Idx, WIN, ORD>(dual, nt, order, hull, win, order_rows);  // cc:241-242
+        const int n3 = hull_indices<SMALL, WIN>(dual, nt, order, hull, win);  // cc:241-242
         if (n3 < 3 || n3 > nt) {
           code = -4;
         } else if (n3 > cmax) {
@@ -375,7 +407,7 @@ __global__ __launch_bounds__(64) void k_build_corridors(int n, CorridorParams cp
           for (int i = 0; i <= m; ++i) {  // polygon vertices cc:244-249, half-planes cc:251-261
             double qx, qy;
             if (i < m) {
-              const P2f a = dual[hull[i]], b = dual[hull[(i + 1 == m) ? 0 : i + 1]];
+              const P2f a = dual[hull.get(i)], b = dual[hull.get((i + 1 == m) ? 0 : i + 1)];
               const float rx = b.x - a.x, ry = b.y - a.y;
               const float t1 = ry * a.x, t2 = rx * a.y;
               const double c = t1 - t2;
@@ -429,7 +461,7 @@ void launch_build_corridors(int n, const CorridorParams& cp, const double* knots
   const int need = pmax + 4 * cp.per_edge;
   const dim3 grid((n + 63) / 64), block(64);
   if (need <= 56)
-    hipLaunchKernelGGL((k_build_corridors<56, unsigned char, 57, 40, 16, true>), grid, block, 0, st, n, cp, knots,
+    hipLaunchKernelGGL((k_build_corridors<56, unsigned char, 57, 40, 8, true>), grid, block, 0, st, n, cp, knots,
                        points, count, pmax, corridor, ccount, cmax, n_failed, polygons);
   else if (need <= 96)
     hipLaunchKernelGGL((k_build_corridors<96, unsigned char, 0, 40, 16, false>), grid, block, 0, st, n, cp, knots,
