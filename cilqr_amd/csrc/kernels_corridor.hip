@@ -314,19 +314,37 @@ __global__ __launch_bounds__(64) void k_build_corridors(int n, CorridorParams cp
     }
   };
   {
-    for (int i = 0; i < np + nbox; ++i) {
-      double x, y;
-      input_point(i, x, y);
-      // filter cc:136-149 and sphere flip cc:154-177
+    // filter cc:136-149 and sphere flip cc:154-177
+    auto consider = [&](int i, double x, double y) {
       const double dx = x - ox, dy = y - oy;
-      if (fabs(dx) > cp.max_diff_x || fabs(dy) > cp.max_diff_y) continue;
+      if (fabs(dx) > cp.max_diff_x || fabs(dy) > cp.max_diff_y) return;
       const double norm2 = sqrt(dx * dx + dy * dy);
-      if (fabs(norm2) < kEps) continue;
+      if (fabs(norm2) < kEps) return;
       if (norm2 < cp.radius) safe_radius = norm2;
       src[nf] = (Idx)i;
       flip[nf].x = (float)(dx + 2 * (cp.radius - norm2) * dx / norm2);
       flip[nf].y = (float)(dy + 2 * (cp.radius - norm2) * dy / norm2);
       ++nf;
+    };
+    // the obstacle points (lanes hold different counts; the next point is requested while this one is worked on), then
+    // the box points, the same number in every lane: two loops, so that no trip of the first carries the box arithmetic
+    double xn = 0.0, yn = 0.0;
+    if (np > 0) {
+      xn = pp[0];
+      yn = pp[1];
+    }
+    for (int i = 0; i < np; ++i) {
+      const double x = xn, y = yn;
+      if (i + 1 < np) {
+        xn = pp[2 * i + 2];
+        yn = pp[2 * i + 3];
+      }
+      consider(i, x, y);
+    }
+    for (int i = np; i < np + nbox; ++i) {
+      double x, y;
+      input_point(i, x, y);
+      consider(i, x, y);
     }
   }
   int m = 0;
