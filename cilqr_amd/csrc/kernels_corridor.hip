@@ -11,10 +11,19 @@
 //
 // Mapping: every knot of every problem is independent, so one lane builds one corridor (64 corridors
 // share one instruction stream; spreading a corridor over a wave would cost ~10x the instructions,
-// the hull scans being sequential).  The working set of a lane (<= MAXP points, three small hulls)
-// lives in its private segment: the arrays are indexed with data-dependent indices, which means
-// scratch memory (built with -disable-promote-alloca-to-vector, see the Makefile).  That scratch
-// traffic is the kernel's cost, so the arrays are kept minimal and the occupancy is capped.
+// the hull scans being sequential).  A lane's working set (<= MAXP points, three small hulls) is indexed with
+// data-dependent indices.  What decides the kernel's time is the number of DEPENDENT trips to memory a wave makes and
+// how many cache lines a trip touches (round 6 counters: a wave waits on s_waitcnt for 87 % of its life; an access with a
+// per-lane index into the private segment touches 64 lines, and the L1 of a CU holds a fraction of one wave's arrays):
+//   * the point arrays (flip / vd / dual, 8 B x 57) stay in the private segment (scratch memory; built with
+//     -disable-promote-alloca-to-vector, see the Makefile): they are read with per-lane indices only where a chain pops
+//     past its LDS window and where a stage gathers hull vertices;
+//   * the rank sorts run on keys in registers (no load in the n^2 loop, NaN test on the key loads);
+//   * the monotone chains keep their two topmost points in registers and the next WIN levels in an LDS ring, so a pop is an
+//     LDS read; the next point of a chain is requested a step ahead;
+//   * the small index arrays (sorted order, chain stack = hull, second hull's copy) are LDS rows [index][lane];
+//   * occupancy is whatever the registers allow (the LDS of a wave is 11.4 KB: 14 fit a CU, 12 run at 159 VGPRs).
+// 65536 x 51 knots (28.5 obstacle points + 8 box points each): 23.4 ms in round 5, 15.7 with the register sort, 6.4 now.
 // The kernel is a once-per-solve prologue (3.3 M corridors for 65536 x 51 knots).
 #include <hip/hip_runtime.h>
 #include <stdint.h>

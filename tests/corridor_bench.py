@@ -39,7 +39,7 @@ for it in range(4):
                                      ccnt.data_ptr(), cmax, api.MEM_DEVICE)
     torch.cuda.synchronize()
     times.append(time.perf_counter() - t0)
-    assert rc == api.OK and nf == 0
+    assert (rc == api.OK and nf == 0) or os.environ.get("CORRIDOR_BENCH_NO_ASSERT")   # (the stage-ablation variant returns garbage)
 t = min(times[1:])
 # CPU oracle on the first problems
 n_cpu = 0
