@@ -275,7 +275,8 @@ def test_build_corridors_failure_codes_and_arguments(built):
 def test_register_rank_sort_equals_the_generic_sort_bit_for_bit(built):
     """The three instantiations of k_build_corridors sort the points of a hull three ways: capacity 56 ranks all three hulls
     with 64-bit integer keys held in registers, capacity 96 the first hull by float comparisons on points in scratch memory and
-    the two small hulls in registers, capacity 320 everything by float comparisons.  The capacity follows max_points, so the same
+    the two small hulls in registers, capacity 320 everything by float comparisons; the first two run their chains on
+    registers + an LDS window (the first with its index arrays in LDS rows), the third on the lane's private arrays alone.  The capacity follows max_points, so the same
     corridors are built with the point array padded to 44, 60 and 120 columns (same counts): every output bit must agree --
     including knots with duplicated points, points exactly on the knot's axes (a flipped coordinate of +-0), and NaN / Inf
     points, on which a wave falls back to the float comparisons."""
@@ -328,6 +329,83 @@ def test_register_rank_sort_equals_the_generic_sort_bit_for_bit(built):
         assert np.array_equal(o[0][ok], outs[0][0][ok]) and np.array_equal(o[3][ok], outs[0][3][ok])
         assert ((o[1] >= 3) | (o[1] <= -2)).all() and (o[1] <= sc["cmax"]).all()
     assert (outs[0][1] >= 3).mean() > 0.9
+    opt.close()
+
+
+def _longest_pop_run(ox, oy, pts, radius=150.0):
+    """Longest run of pops one new point causes in the monotone chain over the sphere-flipped points (+ the knot itself), in
+    float64: how far below its top a chain of the first hull has to look."""
+    d = pts - [ox, oy]
+    n = np.hypot(d[:, 0], d[:, 1])
+    f = d + 2 * (radius - n)[:, None] * d / n[:, None]
+    f = np.vstack([f, [0.0, 0.0]])
+    f = f[np.lexsort((f[:, 1], f[:, 0]))]
+    best = 0
+    for chain in (f, f[::-1]):
+        h = []
+        for q in chain:
+            run = 0
+            while len(h) >= 2 and ((h[-1][0] - h[-2][0]) * (q[1] - h[-2][1]) - (h[-1][1] - h[-2][1]) * (q[0] - h[-2][0])) <= 0:
+                h.pop()
+                run += 1
+            best = max(best, run)
+            h.append(q)
+    return best
+
+
+@pytest.mark.gpu
+def test_long_pop_runs_leave_the_lds_window(built):
+    """The chains of the 56- and 96-point kernels keep the two topmost stack points in registers and the 8 / 16 levels below
+    them in an LDS ring; a new point that pops more than that goes back to the lane's arrays.  Knots built for it: 20-30
+    obstacle points on an arc 24 m from the knot (flipped: an arc of radius 276 m, all of them hull vertices until ...) and
+    one point half a metre from the knot in the middle of the arc's directions (flipped: 299.5 m out, behind all of them in
+    x, it pops the arc's half facing it in one step).  The same corridors from the three instantiations (the third has no
+    window and no LDS rows) and from the oracle."""
+    sc = scenario.generate("mix11", 64, seed=9, obstacle_points=True)
+    pts, cnt = sc["obstacle_points"].copy(), sc["obstacle_count"].copy()
+    knots = np.ascontiguousarray(sc["coarse"][:, :, :3])
+    B, K, P = cnt.shape[0], cnt.shape[1], pts.shape[2]
+    rng = np.random.default_rng(12)
+    crafted = []
+    for _ in range(160):
+        b, k = int(rng.integers(0, B)), int(rng.integers(0, K))
+        ox, oy = knots[b, k, 0], knots[b, k, 1]
+        m = int(rng.integers(20, 31))
+        mid = rng.uniform(-np.pi, np.pi)
+        ang = mid + np.linspace(-0.45, 0.45, m) + rng.uniform(-0.004, 0.004, m)
+        arc = np.stack([ox + 24.0 * np.cos(ang), oy + 24.0 * np.sin(ang)], 1)
+        popper = [ox + 0.5 * np.cos(mid), oy + 0.5 * np.sin(mid)]
+        p = np.vstack([arc[rng.permutation(m)], popper])
+        pts[b, k, :m + 1] = p
+        cnt[b, k] = m + 1
+        crafted.append((b, k))
+    runs = [_longest_pop_run(knots[b, k, 0], knots[b, k, 1], pts[b, k, :cnt[b, k]]) for b, k in set(crafted)]
+    assert sum(r > 8 for r in runs) >= 40 and sum(r > 16 for r in runs) >= 5, sorted(runs)[-10:]
+    opt = _opt(sc)
+    cmax = 64   # (an arc of 30 points can give 30 half-planes: room for them, so that the crafted knots are compared as corridors)
+    outs = []
+    for width in (P, 60, 120):
+        wide = np.zeros((B, K, width, 2))
+        wide[:, :, :P] = pts
+        wide[:, :, P:] = 1e9
+        outs.append(opt.build_corridors(knots, wide, cnt, cmax=cmax, want_polygons=True))
+    for o in outs[1:]:
+        assert np.array_equal(o[1], outs[0][1]) and np.array_equal(o[0], outs[0][0]) and np.array_equal(o[3], outs[0][3])
+    got, got_cnt = outs[0][0], outs[0][1]
+    built_ok = 0
+    for b, k in sorted(set(crafted)):
+        th = knots[b, k, 2]
+        trig = (float(opt.device_math(7, [th])[0]), float(opt.device_math(8, [th])[0]))
+        try:
+            cons, _ = orc.build_corridor(*knots[b, k], pts[b, k, :cnt[b, k]], max_out=cmax, trig=trig)
+        except ValueError as e:
+            assert got_cnt[b, k] == int(e.args[0]), (b, k, got_cnt[b, k], e.args)
+            continue
+        assert got_cnt[b, k] == len(cons), (b, k, got_cnt[b, k], len(cons))
+        g = got[b, k, :len(cons)]
+        assert (np.abs(g - cons) / np.abs(cons).max(axis=1, keepdims=True)).max() < 1e-5, (b, k)
+        built_ok += 1
+    assert built_ok >= len(set(crafted)) // 2, built_ok
     opt.close()
 
 
