@@ -154,15 +154,28 @@ __device__ __forceinline__ int hull_indices(const P2f* p, int n, const Ord& orde
     // false with everything, so two points can land on one rank and leave another rank without a point: every entry is set
     // first, so that what the scans read for such a rank is a point of this lane (what the reference's cv::convexHull makes of
     // a NaN is undefined; here it is at least the same corridor on every run and in every instantiation)
+    // Eight points are ranked per pass over the others: one load of p[j] serves eight comparisons.
     for (int i = 0; i < n; ++i) set_order(i, 0);
-    for (int i = 0; i < n; ++i) {
-      const P2f q = p[i];
-      int rank = 0;
+    constexpr int R = CAP > 0 ? 1 : 8;   // (behind a register sort this path is the rare fallback: kept narrow, its registers count towards the kernel's)
+    for (int i0 = 0; i0 < n; i0 += R) {
+      P2f q[R];
+      int rank[R];
+      static_for<0, R>([&](auto U) {
+        constexpr int u = decltype(U)::value;
+        q[u] = p[min(i0 + u, n - 1)];
+        rank[u] = 0;
+      });
       for (int j = 0; j < n; ++j) {
         const P2f r = p[j];
-        rank += (r.x < q.x || (r.x == q.x && (r.y < q.y || (r.y == q.y && j < i)))) ? 1 : 0;
+        static_for<0, R>([&](auto U) {
+          constexpr int u = decltype(U)::value;
+          rank[u] += (r.x < q[u].x || (r.x == q[u].x && (r.y < q[u].y || (r.y == q[u].y && j < i0 + u)))) ? 1 : 0;
+        });
       }
-      set_order(rank, i);
+      static_for<0, R>([&](auto U) {
+        constexpr int u = decltype(U)::value;
+        if (i0 + u < n) set_order(rank[u], i0 + u);
+      });
     }
   }
   // The monotone chain.  The two topmost stack points stay in registers (a = p[h[k-2]], b = p[h[k-1]]): the test of a
