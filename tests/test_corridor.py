@@ -5,6 +5,8 @@ the construction guarantees -- the reference holds no vectors for this path and 
 OpenCV, so parity with the reference is UNPINNED here (see the oracle's header).  GPU tests compare
 the HIP kernel (cilqr_build_corridors) with the oracle knot by knot and run the full
 obstacle points -> corridors -> CILQR solve chain on the device."""
+import os
+
 import numpy as np
 import pytest
 
@@ -329,6 +331,80 @@ def test_register_rank_sort_equals_the_generic_sort_bit_for_bit(built):
         assert np.array_equal(o[0][ok], outs[0][0][ok]) and np.array_equal(o[3][ok], outs[0][3][ok])
         assert ((o[1] >= 3) | (o[1] <= -2)).all() and (o[1] <= sc["cmax"]).all()
     assert (outs[0][1] >= 3).mean() > 0.9
+    opt.close()
+
+
+@pytest.mark.gpu
+def test_full_size_batch_of_distinct_knots_corridor_properties_and_oracle_sample(built):
+    """65536 DIFFERENT scenes x 51 knots (3.3 M corridors, the end-to-end leg's size) through one cilqr_build_corridors call:
+      * every knot gets a corridor (>= 3 half-planes, none fails), rows past the count are zero;
+      * the size-independent properties of _check_corridor on all of them, evaluated on the device: the knot strictly inside
+        every half-plane, no obstacle point inside all of them by more than 1 mm;
+      * a second call returns the same bits, and the call on device-resident arrays the same as on host arrays;
+      * a seeded sample of 3000 knots against the oracle (with the device's cos / sin of the heading, see
+        test_build_corridors_matches_oracle): same number of half-planes, the same half-planes to 1e-5."""
+    import torch
+    B = 65536
+    sc = scenario.generate("mix11", B, seed=707, obstacle_points=True, workers=min(16, os.cpu_count() or 4))
+    knots = np.ascontiguousarray(sc["coarse"][:, :, :3])
+    pts, cnt, cmax = sc["obstacle_points"], sc["obstacle_count"], sc["cmax"]
+    K, P = cnt.shape[1], pts.shape[2]
+    opt = api.BatchIlqrOptimizer(api.default_config(sc["n_steps"]), batch_capacity=256, cmax=cmax)
+    cor, ccnt, n_failed = opt.build_corridors(knots, pts, cnt, cmax=cmax)
+    assert n_failed == 0 and (ccnt >= 3).all() and (ccnt <= cmax).all()
+    live = np.arange(cmax)[None, None, :] < ccnt[:, :, None]
+    assert (cor[~live] == 0).all()
+    dev = torch.device("cuda", 0)
+    d_knots, d_pts, d_cnt = (torch.from_numpy(a).to(dev) for a in (knots, pts, cnt))
+    d_cor = torch.zeros((B, K, cmax, 3), dtype=torch.float64, device=dev)
+    d_ccnt = torch.zeros((B, K), dtype=torch.int32, device=dev)
+    opt.set_stream(torch.cuda.current_stream().cuda_stream)
+    for _ in range(2):   # device-resident arrays, twice
+        d_cor.fill_(7.0)
+        rc, nf = opt.build_corridors_raw(api.default_corridor_config(), B, K, d_knots.data_ptr(), d_pts.data_ptr(),
+                                         d_cnt.data_ptr(), P, d_cor.data_ptr(), d_ccnt.data_ptr(), cmax, api.MEM_DEVICE)
+        torch.cuda.synchronize()
+        assert rc == api.OK and nf == 0
+        assert np.array_equal(d_cor.cpu().numpy(), cor) and np.array_equal(d_ccnt.cpu().numpy(), ccnt)
+    # "the knot strictly inside every half-plane" holds for every edge of the corridor polygon that HAS a direction.  Where
+    # two consecutive polygon vertices coincide to float32 precision (they come from a float32 hull of the dual points,
+    # corridor.cc:244-261) the edge between them is rounding noise of length ~1e-6, and where an edge of that hull passes the
+    # origin of the dual plane within rounding the vertex it maps to lies ~1e9 m away: the half-planes built on such edges are
+    # noise too -- about one row in 1e5, in the oracle exactly as on the device (a sample of them is compared below).
+    inside, n_rows, degenerate = 0, 0, []
+    for b0 in range(0, B, 2048):
+        c, n = d_cor[b0:b0 + 2048], d_ccnt[b0:b0 + 2048]
+        lv = torch.arange(cmax, device=dev)[None, None, :] < n[:, :, None]
+        nrm = torch.hypot(c[..., 0], c[..., 1])
+        assert bool((nrm[lv] > 0).all())
+        o = d_knots[b0:b0 + 2048]
+        g0 = c[..., 0] * o[:, :, None, 0] + c[..., 1] * o[:, :, None, 1] - c[..., 2]
+        wrong = lv & (g0 >= 0)
+        assert bool(((nrm[wrong] < 1e-3) | (nrm[wrong] > 1e6)).all()), nrm[wrong]
+        degenerate += [(b0 + int(b), int(k), int(r)) for b, k, r in torch.nonzero(wrong).cpu().numpy()]
+        n_rows += int(lv.sum())
+        p = d_pts[b0:b0 + 2048]                                              # [b, K, P, 2]
+        g = (torch.einsum("bkpi,bkci->bkpc", p, c[..., :2]) - c[:, :, None, :, 2]) / nrm[:, :, None, :].clamp_min(1e-300)
+        g = torch.where((lv & ~wrong)[:, :, None, :], g, torch.full_like(g, -1.0))   # rows past the count (and noise rows) exclude no point
+        pv = torch.arange(P, device=dev)[None, None, :] < d_cnt[b0:b0 + 2048][:, :, None]
+        inside += int(((g < -1e-3).all(dim=3) & pv).sum())
+    assert inside == 0 and len(degenerate) < 1e-4 * n_rows, (inside, len(degenerate), n_rows)
+    for b, k, r in degenerate[:40]:
+        th = knots[b, k, 2]
+        trig = (float(opt.device_math(7, [th])[0]), float(opt.device_math(8, [th])[0]))
+        cons, _ = orc.build_corridor(*knots[b, k], pts[b, k, :cnt[b, k]], max_out=cmax, trig=trig)
+        assert len(cons) == ccnt[b, k] and np.allclose(cor[b, k, r], cons[r], rtol=1e-5, atol=0.0), (b, k, r, cor[b, k, r], cons[r])
+    print(f"\n{n_rows} half-planes, {len(degenerate)} on an edge of rounding noise (the same rows in the oracle)")
+    rng = np.random.default_rng(23)
+    worst = 0.0
+    for _ in range(3000):
+        b, k = int(rng.integers(0, B)), int(rng.integers(0, K))
+        th = knots[b, k, 2]
+        trig = (float(opt.device_math(7, [th])[0]), float(opt.device_math(8, [th])[0]))
+        cons, _ = orc.build_corridor(*knots[b, k], pts[b, k, :cnt[b, k]], max_out=cmax, trig=trig)
+        assert len(cons) == ccnt[b, k], (b, k, len(cons), ccnt[b, k])
+        worst = max(worst, float((np.abs(cor[b, k, :len(cons)] - cons) / np.abs(cons).max(axis=1, keepdims=True)).max()))
+    assert worst < 1e-5, worst
     opt.close()
 
 
